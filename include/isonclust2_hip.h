@@ -1,0 +1,220 @@
+/*
+ * isonclust2_hip.h — C ABI of the MI355X-native read->cluster assignment path of isONclust2.
+ *
+ * The reference has no plugin/FFI interface; its seam for this path is the C++ call
+ *     StrandedCluster getBestCluster(rightId, leftBatch, rightBatch, sharedMinTab)   src/cluster.h:18-20
+ * made once per read inside ClusterSortedReads (src/cluster.cpp:166), plus the index mutators
+ * AddMinimizers (src/cluster.cpp:180, src/minimizer.cpp:31-42) and the sort-stage feeders
+ * (src/qualscore.cpp:39-136).  This header is what a C++ maintainer binds instead: plain pointers
+ * and sizes, no C++/torch types, every call returns 0 or a negative ioc_status and never throws.
+ *
+ * One context per GPU; a context is used by one host thread at a time (the reference `cluster`
+ * is single-threaded and non-reentrant: globals at src/cluster.cpp:21-23, src/minimizer.cpp:15).
+ *
+ * Data model on the device (all SoA, 32-bit):
+ *   queries   = the right batch's clusterable entries in loop order (src/cluster.cpp:115), each with
+ *               forward and reverse minimizer lists (value, position; Index == ordinal,
+ *               src/minimizer.cpp:78-123), HPC length, error-rate cell and integer pass threshold;
+ *   targets   = L existing left clusters (ids 0..L-1, from the persisted MinDB) followed by the
+ *               queries themselves as tentative new clusters (id L+j) — with consensus off a
+ *               representative never changes (src/cluster.cpp:263-265), so (Size, totalMapped) of
+ *               (query j, target t) is independent of every clustering decision;
+ *   index     = open-addressed hash  minimizer value -> posting list of target ids.
+ */
+#ifndef ISONCLUST2_HIP_H
+#define ISONCLUST2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ioc_ctx ioc_ctx;
+
+typedef enum {
+    IOC_OK = 0,
+    IOC_ERR_ARG = -1,       /* bad argument / shape */
+    IOC_ERR_HIP = -2,       /* HIP runtime error (ioc_last_error has the text) */
+    IOC_ERR_STATE = -3,     /* call order violated */
+    IOC_ERR_CAPACITY = -4,  /* a documented device-side limit was exceeded */
+    IOC_ERR_TABLE = -5,     /* empirical probability table lookup failure (p_emp_prob.cpp:87-89) */
+    IOC_ERR_NO_DEVICE = -6,
+    IOC_ERR_INPUT = -7      /* input the reference would exit(1)/throw on */
+} ioc_status;
+
+/* ClsMode, src/args.h:7 */
+enum { IOC_MODE_SAHLIN = 0, IOC_MODE_FAST = 1, IOC_MODE_FURIOUS = 2, IOC_MODE_NONE = 3 };
+
+/* The clustering parameters frozen at sort time (CmdArgs, src/args.h:9-37) that the path reads
+ * (src/cluster.cpp:366-369, 534-536). */
+typedef struct {
+    int32_t k;                /* KmerSize */
+    int32_t w;                /* WindowSize */
+    int32_t min_shared;       /* MinShared */
+    int32_t mode;             /* IOC_MODE_* */
+    double min_fraction;      /* MinFraction */
+    double mapped_threshold;  /* MappedThreshold */
+    double min_prob_no_hits;  /* MinProbNoHits */
+    double aligned_threshold; /* AlignedThreshold (host fallback only) */
+} ioc_params;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int ioc_ctx_create(int device, ioc_ctx** out);
+void ioc_ctx_destroy(ioc_ctx* ctx);
+const char* ioc_last_error(const ioc_ctx* ctx);
+/* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
+int ioc_set_stream(ioc_ctx* ctx, void* hip_stream);
+int ioc_synchronize(ioc_ctx* ctx);
+
+/* Parameters + the 15x15 integer gap-limit table, gap_limit[e_cl-1][e_rd-1] =
+ * max{ n : pow(1 - P(e_cl, e_rd), n) >= MinProbNoHits }: the monotone predicate of
+ * getMappedRatio (src/cluster.cpp:333-347) evaluated ONCE on the host with the host libm,
+ * compared as integers on the device.  ioc_host_gap_limits() fills it from the table file. */
+int ioc_set_params(ioc_ctx* ctx, const ioc_params* p, const int32_t gap_limit[225]);
+
+/* ---- queries (right batch) ------------------------------------------------------------------- */
+/* Host -> device upload of the query SoA.  off_fwd/off_rev: [n+1] element offsets into
+ * min_val/min_pos (total = number of minimizers, fwd and rev, of all queries).  err_cell in 1..15 =
+ * clamp(round(100 * HpcSeq.ErrorRate)) (src/p_emp_prob.cpp:66-84).  min_total[j] = smallest integer
+ * T with float(double(T)/double(hpc_len[j])) >= MappedThreshold (src/cluster.cpp:390-400). */
+int ioc_queries_upload(ioc_ctx* ctx, int32_t n, const int64_t* off_fwd, const int64_t* off_rev,
+                       const uint32_t* min_val, const uint32_t* min_pos, int64_t total,
+                       const uint32_t* hpc_len, const uint8_t* err_cell, const uint32_t* min_total);
+/* Same, with every pointer already a device pointer on ctx's device (inputs resident in HBM,
+ * e.g. produced by ioc_extract_minimizers); the context borrows them until the next upload/bind. */
+int ioc_queries_bind_device(ioc_ctx* ctx, int32_t n, const int64_t* d_off_fwd, const int64_t* d_off_rev,
+                            const uint32_t* d_min_val, const uint32_t* d_min_pos, int64_t total,
+                            const uint32_t* d_hpc_len, const uint8_t* d_err_cell,
+                            const uint32_t* d_min_total, const int64_t* h_off_fwd,
+                            const int64_t* h_off_rev);
+
+/* ---- left state (merge: `cluster -l L -r R`, src/main.cpp:247-261) ----------------------------- */
+/* The persisted MinDB (src/minimizer.h:60-61) as CSR: n_keys distinct values, offs[n_keys+1],
+ * postings = ascending cluster ids < n_clusters.  n_clusters = 0 resets to initial clustering. */
+int ioc_left_load(ioc_ctx* ctx, int32_t n_clusters, const uint8_t* cls_err_cell, int64_t n_keys,
+                  const uint32_t* keys, const int64_t* offs, const uint32_t* postings);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* AddMinimizers for every tentative representative at once (src/minimizer.cpp:31-42): per-query
+ * sorted distinct forward values, hash insert, posting lists. */
+int ioc_index_build(ioc_ctx* ctx);
+/* GetMinimizerHits + ConsolidateMinimizerHits + the Size part of SortMinimizerHits
+ * (src/minimizer.cpp:44-76, src/cluster.cpp:609-636) for every query against every earlier
+ * target: per-query candidate lists (target, strand, Size). */
+int ioc_score(ioc_ctx* ctx);
+/* getBestClusterMapping + getMappedRatio (src/cluster.cpp:324-406) for all queries, iterated to the
+ * unique fixed point of the greedy loop (src/cluster.cpp:115-310).  Queries listed in
+ * forced_* (host decisions: alignment fallback results in sahlin mode) are taken as given.
+ * n_iter (optional) receives the number of parallel sweeps. */
+int ioc_resolve(ioc_ctx* ctx, int32_t* n_iter);
+/* Per query: target >= 0 joined target id (left cluster id, or L + index of the query that opened
+ * the cluster), -1 = opens a new cluster; strand +1/-1 (0 for new); flags bit0 = order-dependent tie
+ * (>= 2 passing candidates at the winning Size: host replays the libstdc++ order), bit1 = no
+ * mapping hit but top >= MinShared (sahlin/furious: host alignment fallback, cluster.cpp:553-566). */
+int ioc_get_decisions(ioc_ctx* ctx, int32_t* target, int8_t* strand, uint8_t* flags);
+/* Host override of one query's decision (tie replay / alignment fallback); takes effect in the
+ * next ioc_resolve. target -1 = new cluster. */
+int ioc_force_decision(ioc_ctx* ctx, int32_t query, int32_t target, int32_t strand);
+int ioc_clear_forced(ioc_ctx* ctx);
+
+/* Full candidate table of one query against the targets that are clusters under the current
+ * decisions, in the fields the reference's hit map holds (src/minimizer.cpp:44-76): target id,
+ * strand, Size, Index of the first hitting read minimizer, and totalMapped (0xFFFFFFFF if not
+ * evaluated).  Returns the count (<= cap) or a negative status. */
+int ioc_query_candidates(ioc_ctx* ctx, int32_t query, int32_t cap, int32_t* target, int8_t* strand,
+                         uint32_t* size, uint32_t* first_index, uint32_t* total_mapped);
+
+/* MinDB after clustering (AddMinimizers applied for every query that opened a cluster): CSR with
+ * final cluster ids.  Call with keys == NULL to size (n_keys, n_postings). */
+int ioc_index_export(ioc_ctx* ctx, int64_t* n_keys, int64_t* n_postings, uint32_t* keys,
+                     int64_t* offs, uint32_t* postings);
+
+/* ---- sort-stage feeders (src/qualscore.cpp:39-136, src/hpc.cpp:4-32, src/kmer_index.cpp:5-17,
+ *      src/minimizer.cpp:78-123) ------------------------------------------------------------------ */
+/* CalcQualScore / CalcErrorRate for n reads (host pointers; offs[n+1] into qual).  score[i] < 0
+ * mirrors FillQualScores' -1 (src/qualscore.cpp:22-34). */
+int ioc_qual_scores(ioc_ctx* ctx, int32_t n, const int64_t* offs, const uint8_t* qual, int32_t k,
+                    double* score, double* err_rate);
+/* HomopolymerCompress + RevComp + KmerEncodeSeq x2 + GetKmerMinimizers x2 + CalcErrorRate(hpc quals)
+ * for n reads.  Outputs stay on the device in the layout ioc_queries_bind_device takes; the host
+ * receives lengths/offsets/error rates.  status[i]: 0 ok, 1 HPC length < 2k or < w
+ * (src/qualscore.cpp:65-73), 2 non-ACGT base (RevComp throws, src/util.cpp:31-33). */
+int ioc_extract_minimizers(ioc_ctx* ctx, int32_t n, const int64_t* offs, const uint8_t* seq,
+                           const uint8_t* qual, int32_t k, int32_t w, uint32_t* hpc_len,
+                           double* hpc_err, int64_t* off_fwd, int64_t* off_rev, int32_t* status);
+/* Device->host copy of the minimizers produced by the last ioc_extract_minimizers. */
+int ioc_extracted_download(ioc_ctx* ctx, uint32_t* min_val, uint32_t* min_pos, int64_t cap);
+/* Make the extracted minimizers the current queries (no host round trip of the 8 B/minimizer SoA).
+ * keep[i] != 0 selects read i (gates of src/cluster.cpp:116-160 applied by the caller). */
+int ioc_queries_from_extracted(ioc_ctx* ctx, const uint8_t* keep, const uint8_t* err_cell,
+                               const uint32_t* min_total);
+
+/* ---- instrumentation ------------------------------------------------------------------------ */
+typedef struct {
+    float ms_build;    /* ioc_index_build, HIP events on the launch stream */
+    float ms_score;    /* ioc_score (the dominant kernel)                  */
+    float ms_resolve;  /* ioc_resolve                                      */
+    int32_t resolve_iters;
+    int32_t n_queries;
+    int64_t n_minimizers;      /* probes M                                  */
+    int64_t n_index_postings;  /* postings stored in the device index       */
+    int64_t n_candidates;      /* candidate entries written by ioc_score    */
+    int64_t n_mapped_evals;    /* (query,target,strand) mapped-ratio evaluations */
+    int64_t postings_traversed;/* postings read by ioc_score (if counted)   */
+} ioc_timings;
+int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
+
+/* ---- host-side helpers (pure host code, no GPU needed) ----------------------------------------- */
+/* Fill gap_limit[225] and p_shared[225] for (k, w) from the table file (isonclust2_amd/data/
+ * pmin_shared.bin; rows selected as src/p_emp_prob.cpp:22-47).  Returns IOC_ERR_TABLE if no row
+ * matches (k outside 10..30 etc.). */
+int ioc_host_gap_limits(const char* table_path, int32_t k, int32_t w, double min_prob_no_hits,
+                        int32_t* gap_limit, double* p_shared);
+/* clamp(round(100*e)) in 1..15, src/p_emp_prob.cpp:66-84 + src/util.cpp:6-10 */
+uint8_t ioc_host_err_cell(double err_rate);
+/* smallest T with float(double(T)/double(hpc_len)) >= mapped_threshold (src/cluster.cpp:390-400) */
+uint32_t ioc_host_min_total(uint32_t hpc_len, double mapped_threshold);
+
+/* ---- host driver: ClusterSortedReads on flat arrays (src/cluster.cpp:67-322, consensus off) ------ */
+typedef struct {
+    /* right batch, one record per entry in loop order */
+    int32_t n;
+    const int64_t* off_fwd;    /* [n+1] */
+    const int64_t* off_rev;    /* [n+1] */
+    const uint32_t* min_val;
+    const uint32_t* min_pos;
+    int64_t total;
+    const uint32_t* raw_len;   /* RawSeq length        */
+    const uint32_t* hpc_len;   /* HpcSeq length        */
+    const double* score;       /* RawSeq Score()       */
+    const double* raw_err;     /* RawSeq ErrorRate()   */
+    const double* hpc_err;     /* HpcSeq ErrorRate()   */
+    const uint8_t* state;      /* 0 clusterable, 1 null placeholder (skipped, cluster.cpp:125) */
+    double min_qual;           /* CmdArgs::MinQual     */
+} ioc_batch_view;
+
+typedef struct {
+    int64_t n_clusters;
+    int64_t n_joined;
+    int64_t n_gated;
+    int64_t n_tie_replays;
+    int64_t n_aln_invoked;
+    int32_t resolve_iters;
+} ioc_cluster_stats;
+
+/* Initial clustering of one sorted batch (`cluster -l batch.cer`, src/main.cpp:262-275):
+ * out_cls[i] = final cluster id of entry i (-1 if gated), out_strand[i] = MatchStrand after the
+ * flips of src/cluster.cpp:235-246 (+1 for entries that open a cluster). */
+int ioc_cluster_batch(ioc_ctx* ctx, const ioc_params* p, const char* table_path,
+                      const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
+                      ioc_cluster_stats* stats);
+/* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries
+ * must all be clusterable. */
+int ioc_cluster_resident(ioc_ctx* ctx, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISONCLUST2_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes loader of libisonclust2_hip.so (the C ABI of include/isonclust2_hip.h).
+
+There is no CPU fallback: if the HIP library is missing, cannot be loaded, or no GPU is visible,
+every compute entry point raises.  The library is built in-tree by `__graft_entry__.build()` /
+`make -C isonclust2_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libisonclust2_hip.so")
+TABLE_PATH = os.path.join(HERE, "data", "pmin_shared.bin")
+
+
+class IocError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"isonclust2_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("min_shared", C.c_int32), ("mode", C.c_int32),
+                ("min_fraction", C.c_double), ("mapped_threshold", C.c_double),
+                ("min_prob_no_hits", C.c_double), ("aligned_threshold", C.c_double)]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("off_fwd", C.POINTER(C.c_int64)), ("off_rev", C.POINTER(C.c_int64)),
+                ("min_val", C.POINTER(C.c_uint32)), ("min_pos", C.POINTER(C.c_uint32)),
+                ("total", C.c_int64), ("raw_len", C.POINTER(C.c_uint32)),
+                ("hpc_len", C.POINTER(C.c_uint32)), ("score", C.POINTER(C.c_double)),
+                ("raw_err", C.POINTER(C.c_double)), ("hpc_err", C.POINTER(C.c_double)),
+                ("state", C.POINTER(C.c_uint8)), ("min_qual", C.c_double)]
+
+
+class ClusterStats(C.Structure):
+    _fields_ = [("n_clusters", C.c_int64), ("n_joined", C.c_int64), ("n_gated", C.c_int64),
+                ("n_tie_replays", C.c_int64), ("n_aln_invoked", C.c_int64),
+                ("resolve_iters", C.c_int32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_build", C.c_float), ("ms_score", C.c_float), ("ms_resolve", C.c_float),
+                ("resolve_iters", C.c_int32), ("n_queries", C.c_int32), ("n_minimizers", C.c_int64),
+                ("n_index_postings", C.c_int64), ("n_candidates", C.c_int64),
+                ("n_mapped_evals", C.c_int64), ("postings_traversed", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/isonclust2_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "ioc_ctx_create", "ioc_ctx_destroy", "ioc_last_error", "ioc_set_stream", "ioc_synchronize",
+    "ioc_set_params", "ioc_queries_upload", "ioc_queries_bind_device", "ioc_left_load",
+    "ioc_index_build", "ioc_score", "ioc_resolve", "ioc_get_decisions", "ioc_force_decision",
+    "ioc_clear_forced", "ioc_query_candidates", "ioc_index_export", "ioc_qual_scores",
+    "ioc_extract_minimizers", "ioc_extracted_download", "ioc_queries_from_extracted",
+    "ioc_get_timings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
+    "ioc_cluster_batch", "ioc_cluster_resident",
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or raise (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IocError(-100, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    pi64, pu32, pu8 = C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    pi32, pi8, pd = C.POINTER(C.c_int32), C.POINTER(C.c_int8), C.POINTER(C.c_double)
+    L.ioc_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.ioc_ctx_destroy.argtypes = [vp]
+    L.ioc_ctx_destroy.restype = None
+    L.ioc_last_error.argtypes = [vp]
+    L.ioc_last_error.restype = C.c_char_p
+    L.ioc_set_stream.argtypes = [vp, vp]
+    L.ioc_synchronize.argtypes = [vp]
+    L.ioc_set_params.argtypes = [vp, C.POINTER(Params), pi32]
+    L.ioc_queries_upload.argtypes = [vp, i32, pi64, pi64, pu32, pu32, i64, pu32, pu8, pu32]
+    L.ioc_queries_bind_device.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, pi64, pi64]
+    L.ioc_left_load.argtypes = [vp, i32, pu8, i64, pu32, pi64, pu32]
+    L.ioc_index_build.argtypes = [vp]
+    L.ioc_score.argtypes = [vp]
+    L.ioc_resolve.argtypes = [vp, pi32]
+    L.ioc_get_decisions.argtypes = [vp, pi32, pi8, pu8]
+    L.ioc_force_decision.argtypes = [vp, i32, i32, i32]
+    L.ioc_clear_forced.argtypes = [vp]
+    L.ioc_query_candidates.argtypes = [vp, i32, i32, pi32, pi8, pu32, pu32, pu32]
+    L.ioc_index_export.argtypes = [vp, pi64, pi64, pu32, pi64, pu32]
+    L.ioc_qual_scores.argtypes = [vp, i32, pi64, pu8, i32, pd, pd]
+    L.ioc_extract_minimizers.argtypes = [vp, i32, pi64, pu8, pu8, i32, i32, pu32, pd, pi64, pi64, pi32]
+    L.ioc_extracted_download.argtypes = [vp, pu32, pu32, i64]
+    L.ioc_queries_from_extracted.argtypes = [vp, pu8, pu8, pu32]
+    L.ioc_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.ioc_host_gap_limits.argtypes = [C.c_char_p, i32, i32, C.c_double, pi32, pd]
+    L.ioc_host_err_cell.argtypes = [C.c_double]
+    L.ioc_host_err_cell.restype = C.c_uint8
+    L.ioc_host_min_total.argtypes = [C.c_uint32, C.c_double]
+    L.ioc_host_min_total.restype = C.c_uint32
+    L.ioc_cluster_batch.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(BatchView), pi32, pi8,
+                                    C.POINTER(ClusterStats)]
+    L.ioc_cluster_resident.argtypes = [vp, pi32, pi8, C.POINTER(ClusterStats)]
+    _lib = L
+    return L

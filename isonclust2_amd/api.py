@@ -1,0 +1,183 @@
+"""Python mirror of the host interface of the path (names follow the reference's C++ seam).
+
+Everything here calls the C ABI of libisonclust2_hip.so; numpy arrays are only the carriers of
+the flat SoA the ABI takes.  No compute happens in Python and nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchView, ClusterStats, IocError, Params, Timings
+
+MODE = {"sahlin": 0, "fast": 1, "furious": 2, "none": 3}
+
+
+def default_params(k=11, w=15, mode="fast"):
+    """CmdArgs defaults (src/args.h:9-37) restricted to what the path reads."""
+    return Params(k=k, w=w, min_shared=5, mode=MODE[mode], min_fraction=0.8, mapped_threshold=0.65,
+                  min_prob_no_hits=0.1, aligned_threshold=0.2)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def host_gap_limits(k, w, min_prob_no_hits=0.1, table=_lib.TABLE_PATH):
+    L = _lib.load()
+    g = np.zeros(225, np.int32)
+    p = np.zeros(225, np.float64)
+    rc = L.ioc_host_gap_limits(table.encode(), k, w, min_prob_no_hits, _p(g, C.c_int32), _p(p, C.c_double))
+    if rc != 0:
+        raise IocError(rc, f"no table rows for k={k}, w={w}")
+    return g.reshape(15, 15), p.reshape(15, 15)
+
+
+def host_err_cell(e):
+    return int(_lib.load().ioc_host_err_cell(float(e)))
+
+
+def host_min_total(hpc_len, thr=0.65):
+    return int(_lib.load().ioc_host_min_total(int(hpc_len), float(thr)))
+
+
+class Context:
+    """One context per GPU (ioc_ctx)."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.ioc_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise IocError(rc, "ioc_ctx_create failed (no MI355X visible?)")
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ioc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise IocError(rc, self.L.ioc_last_error(self.h).decode(errors="replace"))
+        return rc
+
+    # ---- low level -------------------------------------------------------------------------
+    def set_params(self, params: Params, table=_lib.TABLE_PATH):
+        g, _ = host_gap_limits(params.k, params.w, params.min_prob_no_hits, table)
+        g = np.ascontiguousarray(g.reshape(-1))
+        self._chk(self.L.ioc_set_params(self.h, C.byref(params), _p(g, C.c_int32)))
+        self.params = params
+
+    def queries_upload(self, off_fwd, off_rev, min_val, min_pos, hpc_len, err_cell, min_total):
+        off_fwd = np.ascontiguousarray(off_fwd, np.int64)
+        off_rev = np.ascontiguousarray(off_rev, np.int64)
+        min_val = np.ascontiguousarray(min_val, np.uint32)
+        min_pos = np.ascontiguousarray(min_pos, np.uint32)
+        hpc_len = np.ascontiguousarray(hpc_len, np.uint32)
+        err_cell = np.ascontiguousarray(err_cell, np.uint8)
+        min_total = np.ascontiguousarray(min_total, np.uint32)
+        n = len(off_fwd) - 1
+        self._chk(self.L.ioc_queries_upload(self.h, n, _p(off_fwd, C.c_int64), _p(off_rev, C.c_int64),
+                                            _p(min_val, C.c_uint32), _p(min_pos, C.c_uint32), len(min_val),
+                                            _p(hpc_len, C.c_uint32), _p(err_cell, C.c_uint8),
+                                            _p(min_total, C.c_uint32)))
+        self.n = n
+
+    def left_load(self, n_clusters, cls_err_cell, keys, offs, postings):
+        if n_clusters == 0:
+            self._chk(self.L.ioc_left_load(self.h, 0, None, 0, None, None, None))
+            return
+        cls_err_cell = np.ascontiguousarray(cls_err_cell, np.uint8)
+        keys = np.ascontiguousarray(keys, np.uint32)
+        offs = np.ascontiguousarray(offs, np.int64)
+        postings = np.ascontiguousarray(postings, np.uint32)
+        self._chk(self.L.ioc_left_load(self.h, n_clusters, _p(cls_err_cell, C.c_uint8), len(keys),
+                                       _p(keys, C.c_uint32), _p(offs, C.c_int64), _p(postings, C.c_uint32)))
+
+    def index_build(self):
+        self._chk(self.L.ioc_index_build(self.h))
+
+    def score(self):
+        self._chk(self.L.ioc_score(self.h))
+
+    def resolve(self):
+        it = C.c_int32(0)
+        self._chk(self.L.ioc_resolve(self.h, C.byref(it)))
+        return it.value
+
+    def decisions(self):
+        n = self.n
+        t, s, f = np.zeros(n, np.int32), np.zeros(n, np.int8), np.zeros(n, np.uint8)
+        self._chk(self.L.ioc_get_decisions(self.h, _p(t, C.c_int32), _p(s, C.c_int8), _p(f, C.c_uint8)))
+        return t, s, f
+
+    def force_decision(self, q, target, strand=1):
+        self._chk(self.L.ioc_force_decision(self.h, q, target, strand))
+
+    def query_candidates(self, q, cap):
+        t, s = np.zeros(cap, np.int32), np.zeros(cap, np.int8)
+        sz, fi, tm = (np.zeros(cap, np.uint32) for _ in range(3))
+        n = self._chk(self.L.ioc_query_candidates(self.h, q, cap, _p(t, C.c_int32), _p(s, C.c_int8),
+                                                  _p(sz, C.c_uint32), _p(fi, C.c_uint32), _p(tm, C.c_uint32)))
+        return t[:n], s[:n], sz[:n], fi[:n], tm[:n]
+
+    def index_export(self):
+        nk, npost = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.ioc_index_export(self.h, C.byref(nk), C.byref(npost), None, None, None))
+        keys = np.zeros(max(nk.value, 1), np.uint32)
+        offs = np.zeros(nk.value + 1, np.int64)
+        post = np.zeros(max(npost.value, 1), np.uint32)
+        self._chk(self.L.ioc_index_export(self.h, C.byref(nk), C.byref(npost), _p(keys, C.c_uint32),
+                                          _p(offs, C.c_int64), _p(post, C.c_uint32)))
+        return keys[:nk.value], offs, post[:npost.value]
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.L.ioc_get_timings(self.h, C.byref(t)))
+        return t.as_dict()
+
+    def synchronize(self):
+        self._chk(self.L.ioc_synchronize(self.h))
+
+    # ---- ClusterSortedReads on one sorted batch (src/cluster.cpp:67-322) -------------------------
+    def cluster_batch(self, params: Params, batch: dict, table=_lib.TABLE_PATH):
+        """batch: dict with off_fwd, off_rev, min_val, min_pos, raw_len, hpc_len, score, raw_err,
+        hpc_err, state, min_qual (the fields of ioc_batch_view).  Returns (cls, strand, stats)."""
+        arrs = {
+            "off_fwd": np.ascontiguousarray(batch["off_fwd"], np.int64),
+            "off_rev": np.ascontiguousarray(batch["off_rev"], np.int64),
+            "min_val": np.ascontiguousarray(batch["min_val"], np.uint32),
+            "min_pos": np.ascontiguousarray(batch["min_pos"], np.uint32),
+            "raw_len": np.ascontiguousarray(batch["raw_len"], np.uint32),
+            "hpc_len": np.ascontiguousarray(batch["hpc_len"], np.uint32),
+            "score": np.ascontiguousarray(batch["score"], np.float64),
+            "raw_err": np.ascontiguousarray(batch["raw_err"], np.float64),
+            "hpc_err": np.ascontiguousarray(batch["hpc_err"], np.float64),
+            "state": np.ascontiguousarray(batch["state"], np.uint8),
+        }
+        n = len(arrs["off_fwd"]) - 1
+        v = BatchView(n=n, off_fwd=_p(arrs["off_fwd"], C.c_int64), off_rev=_p(arrs["off_rev"], C.c_int64),
+                      min_val=_p(arrs["min_val"], C.c_uint32), min_pos=_p(arrs["min_pos"], C.c_uint32),
+                      total=len(arrs["min_val"]), raw_len=_p(arrs["raw_len"], C.c_uint32),
+                      hpc_len=_p(arrs["hpc_len"], C.c_uint32), score=_p(arrs["score"], C.c_double),
+                      raw_err=_p(arrs["raw_err"], C.c_double), hpc_err=_p(arrs["hpc_err"], C.c_double),
+                      state=_p(arrs["state"], C.c_uint8), min_qual=float(batch.get("min_qual", 7.0)))
+        cls, strand = np.zeros(n, np.int32), np.zeros(n, np.int8)
+        st = ClusterStats()
+        self._chk(self.L.ioc_cluster_batch(self.h, C.byref(params), table.encode(), C.byref(v),
+                                           _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
+        self.n = n
+        self.params = params
+        return cls, strand, st.as_dict()
+
+    def cluster_resident(self):
+        n = self.n
+        cls, strand = np.zeros(n, np.int32), np.zeros(n, np.int8)
+        st = ClusterStats()
+        self._chk(self.L.ioc_cluster_resident(self.h, _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
+        return cls, strand, st.as_dict()

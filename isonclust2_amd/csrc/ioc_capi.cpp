@@ -1,0 +1,744 @@
+// ioc_capi.cpp — context management and the device-facing half of the C ABI
+// (include/isonclust2_hip.h).  Host code only; kernels live in ioc_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "ioc_internal.h"
+#include "ioc_kernels.h"
+
+int ioc_fail(ioc_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return ioc_fail((c), IOC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+static int dev_reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return IOC_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return ioc_fail(c, IOC_ERR_CAPACITY,
+                        "hipMalloc(" + std::to_string(want) + " B) failed: " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return IOC_OK;
+}
+#define RESERVE(c, b, bytes)                     \
+    do {                                         \
+        int r__ = dev_reserve((c), (b), (bytes)); \
+        if (r__ != IOC_OK) return r__;           \
+    } while (0)
+
+static void dev_free(DevBuf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+template <class T>
+static T* P(DevBuf& b)
+{
+    return static_cast<T*>(b.p);
+}
+
+extern "C" {
+
+int ioc_ctx_create(int device, ioc_ctx** out)
+{
+    if (!out) return IOC_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IOC_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return IOC_ERR_ARG;
+    ioc_ctx* c = new (std::nothrow) ioc_ctx;
+    if (!c) return IOC_ERR_CAPACITY;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        return IOC_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return IOC_ERR_HIP;
+        }
+    *out = c;
+    return IOC_OK;
+}
+
+void ioc_ctx_destroy(ioc_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->b_off_fwd, &c->b_off_rev, &c->b_min, &c->b_pos, &c->b_hpc_len, &c->b_err_cell,
+                      &c->b_min_total, &c->b_doff, &c->b_left_err, &c->b_lkeys, &c->b_loffs, &c->b_lpost,
+                      &c->b_lslot, &c->b_lset_off, &c->b_lset_val, &c->b_keys, &c->b_cnt, &c->b_off, &c->b_fill,
+                      &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
+                      &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
+                      &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->x_hpc_len};
+    for (auto b : bufs) dev_free(*b);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* ioc_last_error(const ioc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int ioc_set_stream(ioc_ctx* c, void* s)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    return IOC_OK;
+}
+
+int ioc_synchronize(ioc_ctx* c)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IOC_OK;
+}
+
+int ioc_set_params(ioc_ctx* c, const ioc_params* p, const int32_t gap_limit[225])
+{
+    if (!c || !p || !gap_limit) return IOC_ERR_ARG;
+    if (p->k < 1 || p->k > 32 || p->w < p->k) return ioc_fail(c, IOC_ERR_ARG, "bad k/w");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->params = *p;
+    memcpy(c->h_glim, gap_limit, sizeof(c->h_glim));
+    for (int i = 0; i < 225; ++i)
+        if (gap_limit[i] < -1) return ioc_fail(c, IOC_ERR_ARG, "gap_limit < -1");
+    // Candidates with Size < keep can never be walked: top >= MinShared is required
+    // (cluster.cpp:376-379) and then cut = int(top * MinFraction) >= int(MinShared * MinFraction).
+    int keep = 1;
+    if (p->min_fraction >= 0.0 && p->min_fraction <= 1.0 && p->min_shared > 0) {
+        keep = int(double(p->min_shared) * p->min_fraction);
+        if (keep > p->min_shared) keep = p->min_shared;
+        if (keep < 1) keep = 1;
+    }
+    c->keep = keep;
+    RESERVE(c, c->b_glim, 225 * 4);
+    HIPCHK(c, hipMemcpyAsync(c->b_glim.p, c->h_glim, 225 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_params = true;
+    c->scored = c->resolved = false;
+    return IOC_OK;
+}
+
+static int queries_common(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int64_t* off_rev, int64_t total)
+{
+    if (n < 0 || total < 0 || (n > 0 && (!off_fwd || !off_rev))) return ioc_fail(c, IOC_ERR_ARG, "bad query shape");
+    c->h_off_fwd.assign(off_fwd, off_fwd + n + 1);
+    c->h_off_rev.assign(off_rev, off_rev + n + 1);
+    c->h_doff.assign(size_t(n) + 1, 0);
+    c->max_fwd = c->max_rev = 0;
+    for (int i = 0; i < n; ++i) {
+        int64_t a = off_fwd[i + 1] - off_fwd[i], b = off_rev[i + 1] - off_rev[i];
+        if (a < 0 || b < 0 || off_fwd[i] < 0 || off_rev[i] < 0 || off_fwd[i + 1] > total || off_rev[i + 1] > total)
+            return ioc_fail(c, IOC_ERR_ARG, "minimizer offsets out of range at query " + std::to_string(i));
+        if (a > INT32_MAX / 4 || b > INT32_MAX / 4) return ioc_fail(c, IOC_ERR_CAPACITY, "query too long");
+        c->max_fwd = std::max<int32_t>(c->max_fwd, int32_t(a));
+        c->max_rev = std::max<int32_t>(c->max_rev, int32_t(b));
+        c->h_doff[size_t(i) + 1] = c->h_doff[size_t(i)] + a;
+    }
+    c->n = n;
+    c->total = total;
+    c->built = c->scored = c->resolved = false;
+    c->h_forced_t.assign(size_t(n), INT32_MIN);
+    c->h_forced_s.assign(size_t(n), 0);
+    c->forced_dirty = true;
+    RESERVE(c, c->b_doff, size_t(n + 1) * 8);
+    HIPCHK(c, hipMemcpyAsync(c->b_doff.p, c->h_doff.data(), size_t(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    return IOC_OK;
+}
+
+int ioc_queries_upload(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int64_t* off_rev,
+                       const uint32_t* min_val, const uint32_t* min_pos, int64_t total, const uint32_t* hpc_len,
+                       const uint8_t* err_cell, const uint32_t* min_total)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0 && (!hpc_len || !err_cell || !min_total || (total > 0 && (!min_val || !min_pos))))
+        return ioc_fail(c, IOC_ERR_ARG, "null query array");
+    for (int i = 0; i < n; ++i)
+        if (err_cell[i] < 1 || err_cell[i] > 15) return ioc_fail(c, IOC_ERR_ARG, "err_cell outside 1..15");
+    int r = queries_common(c, n, off_fwd, off_rev, total);
+    if (r != IOC_OK) return r;
+    RESERVE(c, c->b_off_fwd, size_t(n + 1) * 8);
+    RESERVE(c, c->b_off_rev, size_t(n + 1) * 8);
+    RESERVE(c, c->b_min, size_t(total) * 4);
+    RESERVE(c, c->b_pos, size_t(total) * 4);
+    RESERVE(c, c->b_hpc_len, size_t(n) * 4);
+    RESERVE(c, c->b_err_cell, size_t(n));
+    RESERVE(c, c->b_min_total, size_t(n) * 4);
+    hipStream_t s = c->stream;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->b_off_fwd.p, off_fwd, size_t(n + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_off_rev.p, off_rev, size_t(n + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_hpc_len.p, hpc_len, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_err_cell.p, err_cell, size_t(n), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_min_total.p, min_total, size_t(n) * 4, hipMemcpyHostToDevice, s));
+    }
+    if (total > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->b_min.p, min_val, size_t(total) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_pos.p, min_pos, size_t(total) * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->d_off_fwd = P<int64_t>(c->b_off_fwd);
+    c->d_off_rev = P<int64_t>(c->b_off_rev);
+    c->d_min = P<uint32_t>(c->b_min);
+    c->d_pos = P<uint32_t>(c->b_pos);
+    c->d_hpc_len = P<uint32_t>(c->b_hpc_len);
+    c->d_err_cell = P<uint8_t>(c->b_err_cell);
+    c->d_min_total = P<uint32_t>(c->b_min_total);
+    c->borrowed = false;
+    return IOC_OK;
+}
+
+int ioc_queries_bind_device(ioc_ctx* c, int32_t n, const int64_t* d_off_fwd, const int64_t* d_off_rev,
+                            const uint32_t* d_min_val, const uint32_t* d_min_pos, int64_t total,
+                            const uint32_t* d_hpc_len, const uint8_t* d_err_cell, const uint32_t* d_min_total,
+                            const int64_t* h_off_fwd, const int64_t* h_off_rev)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0 && (!d_off_fwd || !d_off_rev || !d_hpc_len || !d_err_cell || !d_min_total ||
+                  (total > 0 && (!d_min_val || !d_min_pos))))
+        return ioc_fail(c, IOC_ERR_ARG, "null device array");
+    int r = queries_common(c, n, h_off_fwd, h_off_rev, total);
+    if (r != IOC_OK) return r;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->d_off_fwd = d_off_fwd;
+    c->d_off_rev = d_off_rev;
+    c->d_min = d_min_val;
+    c->d_pos = d_min_pos;
+    c->d_hpc_len = d_hpc_len;
+    c->d_err_cell = d_err_cell;
+    c->d_min_total = d_min_total;
+    c->borrowed = true;
+    return IOC_OK;
+}
+
+int ioc_left_load(ioc_ctx* c, int32_t L, const uint8_t* cls_err_cell, int64_t n_keys, const uint32_t* keys,
+                  const int64_t* offs, const uint32_t* postings)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (L < 0 || n_keys < 0) return ioc_fail(c, IOC_ERR_ARG, "negative size");
+    c->built = c->scored = c->resolved = false;
+    if (L == 0) n_keys = 0;  // a MinDB without clusters has nothing to match (cluster.cpp:92-94)
+    if (n_keys > 0 && (!keys || !offs || !postings || !cls_err_cell)) return ioc_fail(c, IOC_ERR_ARG, "null left array");
+    int64_t np = n_keys > 0 ? offs[n_keys] : 0;
+    // validate + transpose: cluster -> sorted distinct values (the membership sets of getMappedRatio)
+    std::vector<int64_t> soff(size_t(L) + 1, 0);
+    for (int64_t i = 0; i < n_keys; ++i) {
+        if (offs[i + 1] < offs[i]) return ioc_fail(c, IOC_ERR_ARG, "left offsets not monotone");
+        if (i > 0 && keys[i] <= keys[i - 1]) return ioc_fail(c, IOC_ERR_ARG, "left keys must be strictly ascending");
+        for (int64_t p = offs[i]; p < offs[i + 1]; ++p) {
+            if (postings[p] >= uint32_t(L)) return ioc_fail(c, IOC_ERR_ARG, "left posting >= n_clusters");
+            if (p > offs[i] && postings[p] <= postings[p - 1])
+                return ioc_fail(c, IOC_ERR_ARG, "left posting lists must be strictly ascending");
+            soff[postings[p] + 1]++;
+        }
+    }
+    for (int i = 0; i < L; ++i) soff[size_t(i) + 1] += soff[size_t(i)];
+    std::vector<uint32_t> sval(size_t(np > 0 ? np : 1));
+    {
+        std::vector<int64_t> cur(soff.begin(), soff.end() - 1);
+        for (int64_t i = 0; i < n_keys; ++i)  // keys ascending -> each cluster's set comes out sorted
+            for (int64_t p = offs[i]; p < offs[i + 1]; ++p) sval[size_t(cur[postings[p]]++)] = keys[i];
+    }
+    c->L = L;
+    c->n_left_keys = n_keys;
+    c->n_left_post = np;
+    c->h_lkeys.assign(keys, keys + n_keys);
+    c->h_loffs.assign(offs, offs + (n_keys > 0 ? n_keys + 1 : 0));
+    c->h_lpost.assign(postings, postings + np);
+    RESERVE(c, c->b_left_err, size_t(L));
+    RESERVE(c, c->b_lkeys, size_t(n_keys) * 4);
+    RESERVE(c, c->b_loffs, size_t(n_keys + 1) * 8);
+    RESERVE(c, c->b_lpost, size_t(np) * 4);
+    RESERVE(c, c->b_lslot, size_t(n_keys) * 4);
+    RESERVE(c, c->b_lset_off, size_t(L + 1) * 8);
+    RESERVE(c, c->b_lset_val, size_t(np) * 4);
+    hipStream_t s = c->stream;
+    if (L > 0) {
+        for (int i = 0; i < L; ++i)
+            if (cls_err_cell[i] < 1 || cls_err_cell[i] > 15) return ioc_fail(c, IOC_ERR_ARG, "left err_cell outside 1..15");
+        HIPCHK(c, hipMemcpyAsync(c->b_left_err.p, cls_err_cell, size_t(L), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_lset_off.p, soff.data(), size_t(L + 1) * 8, hipMemcpyHostToDevice, s));
+    }
+    if (n_keys > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->b_lkeys.p, keys, size_t(n_keys) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_loffs.p, offs, size_t(n_keys + 1) * 8, hipMemcpyHostToDevice, s));
+    }
+    if (np > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->b_lpost.p, postings, size_t(np) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_lset_val.p, sval.data(), size_t(np) * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return IOC_OK;
+}
+
+static uint32_t env_u32(const char* name, uint32_t dflt)
+{
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    long x = strtol(v, nullptr, 10);
+    return x > 0 ? uint32_t(x) : dflt;
+}
+
+int ioc_index_build(ioc_ctx* c)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_params) return ioc_fail(c, IOC_ERR_STATE, "ioc_set_params first");
+    const int n = c->n;
+    const int64_t nfwd_total = c->h_doff.empty() ? 0 : c->h_doff[size_t(n)];
+    const int64_t ub_entries = nfwd_total + c->n_left_post;
+    if (ub_entries >= (int64_t(1) << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 index postings");
+    if (uint64_t(c->L) + uint64_t(n) >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "too many targets");
+    if (uint32_t(n) > 131072u) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 131072 queries per call");
+    uint32_t pmax = 1;
+    while (pmax < uint32_t(c->max_fwd)) pmax <<= 1;
+    if (pmax > 32768) return ioc_fail(c, IOC_ERR_CAPACITY, "a query has more than 32768 forward minimizers");
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+
+    RESERVE(c, c->b_dvals, size_t(nfwd_total) * 4);
+    RESERVE(c, c->b_dslot, size_t(nfwd_total) * 4);
+    RESERVE(c, c->b_dcount, size_t(n) * 4);
+    RESERVE(c, c->b_misc, 256);
+    HIPCHK(c, iock_distinct(s, n, c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals),
+                            P<uint32_t>(c->b_dcount), pmax));
+
+    // ---- hash table sizing: distinct keys <= min(entries, 4^k); HPC sequences have no equal
+    // neighbours, so at most 4*3^(k-1) distinct k-mers occur — used as the first guess only.
+    const int k = c->params.k;
+    double ub = double(nfwd_total + c->n_left_keys);
+    if (k <= 15) ub = std::min(ub, std::pow(4.0, k));
+    double guess = ub;
+    if (k <= 20) guess = std::min(guess, 4.0 * std::pow(3.0, k - 1));
+    auto pow2_at_least = [](double x) {
+        uint32_t cap = 1024;
+        while (double(cap) < x && cap < (1u << 30)) cap <<= 1;
+        return cap;
+    };
+    uint32_t cap = pow2_at_least(2.0 * guess);
+    const uint32_t cap_safe = pow2_at_least(2.0 * ub);
+    for (;;) {
+        const uint32_t nslots = cap + 1;
+        uint32_t bits = 0;
+        while ((1u << bits) < cap) bits++;
+        const uint32_t shift = 32 - bits;
+        RESERVE(c, c->b_keys, size_t(nslots) * 4);
+        RESERVE(c, c->b_cnt, size_t(nslots + 1) * 4);
+        RESERVE(c, c->b_off, size_t(nslots + 1) * 4);
+        RESERVE(c, c->b_fill, size_t(nslots + 1) * 4);
+        RESERVE(c, c->b_rows, size_t(nslots) * 16);
+        RESERVE(c, c->b_scan, (size_t(nslots) / 1024 + 4) * 4);
+        HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(nslots) * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(nslots + 1) * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_fill.p, 0, size_t(nslots + 1) * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
+        uint32_t* d_err = P<uint32_t>(c->b_misc);
+        HIPCHK(c, iock_hash_insert_left(s, c->n_left_keys, P<uint32_t>(c->b_lkeys), P<int64_t>(c->b_loffs),
+                                        P<uint32_t>(c->b_keys), cap, shift, P<uint32_t>(c->b_cnt),
+                                        P<uint32_t>(c->b_lslot), d_err));
+        HIPCHK(c, iock_hash_insert_queries(s, n, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals),
+                                           P<uint32_t>(c->b_dcount), P<uint32_t>(c->b_keys), cap, shift,
+                                           P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_dslot), d_err));
+        HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan)));
+        uint32_t h_err = 0, h_total = 0;
+        HIPCHK(c, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&h_total, P<uint32_t>(c->b_off) + nslots, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (h_err != 0) {
+            if (cap >= cap_safe) return ioc_fail(c, IOC_ERR_CAPACITY, "hash table overflow at safe capacity");
+            cap = std::min<uint64_t>(uint64_t(cap) * 4, cap_safe);
+            continue;
+        }
+        c->cap = cap;
+        c->n_post = h_total;
+        RESERVE(c, c->b_post, size_t(h_total) * 4 + 256);
+        HIPCHK(c, iock_fill_left(s, c->n_left_keys, P<int64_t>(c->b_loffs), P<uint32_t>(c->b_lpost),
+                                 P<uint32_t>(c->b_lslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_fill),
+                                 P<uint32_t>(c->b_post)));
+        HIPCHK(c, iock_fill_queries(s, n, uint32_t(c->L), P<int64_t>(c->b_doff), P<uint32_t>(c->b_dcount),
+                                    P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_fill),
+                                    P<uint32_t>(c->b_post)));
+        HIPCHK(c, iock_sort_lists(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_post),
+                                  uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048));
+        HIPCHK(c, iock_pack_rows(s, nslots, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt),
+                                 c->b_rows.p));
+        break;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    c->built = true;
+    c->scored = c->resolved = false;
+    c->tm.n_queries = n;
+    c->tm.n_minimizers = 0;
+    for (int i = 0; i < n; ++i)
+        c->tm.n_minimizers += (c->h_off_fwd[size_t(i) + 1] - c->h_off_fwd[size_t(i)]) +
+                              (c->h_off_rev[size_t(i) + 1] - c->h_off_rev[size_t(i)]);
+    c->tm.n_index_postings = c->n_post;
+    return IOC_OK;
+}
+
+static uint32_t hash_shift(uint32_t cap)
+{
+    uint32_t bits = 0;
+    while ((1u << bits) < cap) bits++;
+    return 32 - bits;
+}
+
+int ioc_score(ioc_ctx* c)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->built) return ioc_fail(c, IOC_ERR_STATE, "ioc_index_build first");
+    const int n = c->n;
+    const uint64_t L = uint64_t(c->L);
+    const uint64_t capacity = 2ull * L * uint64_t(n) + uint64_t(n) * uint64_t(n > 0 ? n - 1 : 0);
+    size_t freeB = 0, totalB = 0;
+    HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+    const uint64_t need = capacity * 12ull;
+    const uint64_t have = uint64_t(freeB) + c->b_cand_key.cap + c->b_cand_size.cap + c->b_cand_mapped.cap;
+    if (need + (1ull << 28) > have)
+        return ioc_fail(c, IOC_ERR_CAPACITY, "candidate tables need " + std::to_string(need >> 20) + " MiB of HBM");
+    RESERVE(c, c->b_cand_key, size_t(capacity) * 4);
+    RESERVE(c, c->b_cand_size, size_t(capacity) * 4);
+    RESERVE(c, c->b_cand_mapped, size_t(capacity) * 4);
+    RESERVE(c, c->b_cand_count, size_t(n) * 4);
+    RESERVE(c, c->b_misc, 256);
+    c->cand_capacity = int64_t(capacity);
+    hipStream_t s = c->stream;
+    const bool count_trav = getenv("IOC_COUNT_TRAVERSED") != nullptr;
+    unsigned long long* d_trav = reinterpret_cast<unsigned long long*>(P<uint8_t>(c->b_misc) + 64);
+    HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
+    HIPCHK(c, hipMemsetAsync(c->b_cand_mapped.p, 0xFF, size_t(capacity) * 4, s));
+    const uint32_t range = env_u32("IOC_SCORE_RANGE", 8192);
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    HIPCHK(c, iock_score(s, n, uint32_t(L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
+                         hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
+                         P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
+                         count_trav ? d_trav : nullptr));
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (count_trav) {
+        unsigned long long t = 0;
+        HIPCHK(c, hipMemcpyAsync(&t, d_trav, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->tm.postings_traversed = int64_t(t);
+    }
+    c->scored = true;
+    c->resolved = false;
+    return IOC_OK;
+}
+
+int ioc_force_decision(ioc_ctx* c, int32_t q, int32_t target, int32_t strand)
+{
+    if (!c || q < 0 || q >= c->n) return IOC_ERR_ARG;
+    if (target >= 0 && strand != 1 && strand != -1) return ioc_fail(c, IOC_ERR_ARG, "strand must be +1/-1");
+    if (target >= c->L + q) return ioc_fail(c, IOC_ERR_ARG, "forced target is not an earlier target");
+    c->h_forced_t[size_t(q)] = target < 0 ? (target == -2 ? -2 : -1) : target;  // -2: excluded (gated) entry
+    c->h_forced_s[size_t(q)] = int8_t(target < 0 ? 0 : strand);
+    c->forced_dirty = true;
+    return IOC_OK;
+}
+
+int ioc_clear_forced(ioc_ctx* c)
+{
+    if (!c) return IOC_ERR_ARG;
+    std::fill(c->h_forced_t.begin(), c->h_forced_t.end(), INT32_MIN);
+    std::fill(c->h_forced_s.begin(), c->h_forced_s.end(), 0);
+    c->forced_dirty = true;
+    return IOC_OK;
+}
+
+int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->scored) return ioc_fail(c, IOC_ERR_STATE, "ioc_score first");
+    const int n = c->n;
+    hipStream_t s = c->stream;
+    RESERVE(c, c->b_valid0, size_t(n));
+    RESERVE(c, c->b_valid1, size_t(n));
+    RESERVE(c, c->b_dec_target, size_t(n) * 4);
+    RESERVE(c, c->b_dec_strand, size_t(n));
+    RESERVE(c, c->b_flags, size_t(n));
+    RESERVE(c, c->b_forced_t, size_t(n) * 4);
+    RESERVE(c, c->b_forced_s, size_t(n));
+    RESERVE(c, c->b_misc, 256);
+    if (c->forced_dirty && n > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->b_forced_t.p, c->h_forced_t.data(), size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_forced_s.p, c->h_forced_s.data(), size_t(n), hipMemcpyHostToDevice, s));
+        c->forced_dirty = false;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    // initial guess: every query opens a cluster (any guess converges to the same fixed point)
+    if (n > 0) HIPCHK(c, hipMemsetAsync(c->b_valid0.p, 1, size_t(n), s));
+    c->cur_valid = 0;
+    uint32_t* d_first_changed = P<uint32_t>(c->b_misc) + 8;
+    unsigned long long* d_evals = reinterpret_cast<unsigned long long*>(P<uint8_t>(c->b_misc) + 128);
+    HIPCHK(c, hipMemsetAsync(d_evals, 0, 8, s));
+    DecideArgs a{};
+    a.n = n;
+    a.L = uint32_t(c->L);
+    a.off_fwd = c->d_off_fwd;
+    a.off_rev = c->d_off_rev;
+    a.mins = c->d_min;
+    a.pos = c->d_pos;
+    a.hpc_len = c->d_hpc_len;
+    a.err_cell = c->d_err_cell;
+    a.min_total = c->d_min_total;
+    a.left_err = P<uint8_t>(c->b_left_err);
+    a.doff = P<int64_t>(c->b_doff);
+    a.dvals = P<uint32_t>(c->b_dvals);
+    a.dcount = P<uint32_t>(c->b_dcount);
+    a.lset_off = P<int64_t>(c->b_lset_off);
+    a.lset_val = P<uint32_t>(c->b_lset_val);
+    a.cand_key = P<uint32_t>(c->b_cand_key);
+    a.cand_size = P<uint32_t>(c->b_cand_size);
+    a.cand_mapped = P<uint32_t>(c->b_cand_mapped);
+    a.cand_count = P<uint32_t>(c->b_cand_count);
+    a.glim = P<int32_t>(c->b_glim);
+    a.dec_target = P<int32_t>(c->b_dec_target);
+    a.dec_strand = P<int8_t>(c->b_dec_strand);
+    a.flags = P<uint8_t>(c->b_flags);
+    a.forced_t = P<int32_t>(c->b_forced_t);
+    a.forced_s = P<int8_t>(c->b_forced_s);
+    a.first_changed = d_first_changed;
+    a.n_evals = d_evals;
+    a.min_shared = c->params.min_shared;
+    a.min_fraction = c->params.min_fraction;
+    int first = 0, iters = 0;
+    while (first < n) {
+        uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
+        uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
+        HIPCHK(c, hipMemsetAsync(d_first_changed, 0xFF, 4, s));
+        HIPCHK(c, iock_copy_prefix_valid(s, first, vin, vout));
+        a.first = first;
+        a.valid_in = vin;
+        a.valid_out = vout;
+        HIPCHK(c, iock_decide(s, &a, n - first));
+        uint32_t fc = 0;
+        HIPCHK(c, hipMemcpyAsync(&fc, d_first_changed, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        iters++;
+        c->cur_valid ^= 1;
+        if (fc == 0xFFFFFFFFu) break;  // fixed point: valid_out == valid_in
+        // queries <= fc are final: fc was computed from a correct prefix, everything before it
+        // did not change ("fixed point of the greedy loop")
+        first = int(fc) + 1;
+        if (iters > n + 2) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    unsigned long long ev = 0;
+    HIPCHK(c, hipMemcpyAsync(&ev, d_evals, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->tm.n_mapped_evals = int64_t(ev);
+    c->tm.resolve_iters = iters;
+    if (n_iter) *n_iter = iters;
+    c->resolved = true;
+    return IOC_OK;
+}
+
+int ioc_get_decisions(ioc_ctx* c, int32_t* target, int8_t* strand, uint8_t* flags)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    const size_t n = size_t(c->n);
+    hipStream_t s = c->stream;
+    if (n == 0) return IOC_OK;
+    if (target) HIPCHK(c, hipMemcpyAsync(target, c->b_dec_target.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (strand) HIPCHK(c, hipMemcpyAsync(strand, c->b_dec_strand.p, n, hipMemcpyDeviceToHost, s));
+    if (flags) HIPCHK(c, hipMemcpyAsync(flags, c->b_flags.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return IOC_OK;
+}
+
+int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, int8_t* strand, uint32_t* size,
+                         uint32_t* first_index, uint32_t* total_mapped)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    if (q < 0 || q >= c->n || cap < 0) return ioc_fail(c, IOC_ERR_ARG, "bad query index");
+    hipStream_t s = c->stream;
+    const uint32_t L = uint32_t(c->L);
+    const uint32_t T = L + uint32_t(q);
+    if (T == 0) return 0;
+    DevBuf hist, first;
+    int rc = dev_reserve(c, hist, size_t(2) * T * 4);
+    if (rc != IOC_OK) return rc;
+    rc = dev_reserve(c, first, size_t(2) * T * 4);
+    if (rc != IOC_OK) {
+        dev_free(hist);
+        return rc;
+    }
+    auto cleanup = [&]() {
+        dev_free(hist);
+        dev_free(first);
+    };
+    const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
+    std::vector<uint32_t> hh(size_t(2) * T), hf(size_t(2) * T);
+    uint32_t cc = 0;
+    hipError_t e = hipMemsetAsync(hist.p, 0, size_t(2) * T * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(first.p, 0xFF, size_t(2) * T * 4, s);
+    if (e == hipSuccess)
+        e = iock_query_table(s, q, L, c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap, hash_shift(c->cap),
+                             P<uint32_t>(c->b_post), valid, P<uint32_t>(hist), P<uint32_t>(first));
+    if (e == hipSuccess) e = hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), first.p, hf.size() * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&cc, P<uint32_t>(c->b_cand_count) + q, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        cleanup();
+        return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
+    }
+    // cached totalMapped values of this query's candidate list
+    const uint64_t cbase = 2ull * L * uint64_t(q) + uint64_t(q) * uint64_t(q > 0 ? q - 1 : 0);
+    std::vector<uint32_t> ck(cc), cm(cc);
+    if (cc) {
+        e = hipMemcpyAsync(ck.data(), P<uint32_t>(c->b_cand_key) + cbase, size_t(cc) * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(cm.data(), P<uint32_t>(c->b_cand_mapped) + cbase, size_t(cc) * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            cleanup();
+            return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
+        }
+    }
+    cleanup();
+    std::vector<uint32_t> mapped(size_t(2) * T, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < cc; ++i) {
+        uint32_t tg = ck[i] >> 1, sb = ck[i] & 1u;
+        if (tg < T) mapped[size_t(sb) * T + tg] = cm[i];
+    }
+    int out = 0;
+    for (uint32_t sb = 0; sb < 2; ++sb)
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t sz = hh[size_t(sb) * T + t];
+            if (!sz) continue;
+            if (out < cap) {
+                if (target) target[out] = int32_t(t);
+                if (strand) strand[out] = sb ? -1 : 1;
+                if (size) size[out] = sz;
+                if (first_index) first_index[out] = hf[size_t(sb) * T + t];
+                if (total_mapped) total_mapped[out] = mapped[size_t(sb) * T + t];
+            }
+            out++;
+        }
+    if (out > cap) return ioc_fail(c, IOC_ERR_CAPACITY, "candidate buffer too small: need " + std::to_string(out));
+    return out;
+}
+
+int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t* keys, int64_t* offs,
+                     uint32_t* postings)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    hipStream_t s = c->stream;
+    const uint32_t nslots = c->cap + 1;
+    std::vector<uint32_t> hk(nslots), ho(size_t(nslots) + 1), hc(nslots), hp(size_t(c->n_post) + 1);
+    std::vector<uint8_t> valid(size_t(c->n) + 1);
+    HIPCHK(c, hipMemcpyAsync(hk.data(), c->b_keys.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(ho.data(), c->b_off.p, size_t(nslots + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(hc.data(), c->b_cnt.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
+    if (c->n_post) HIPCHK(c, hipMemcpyAsync(hp.data(), c->b_post.p, size_t(c->n_post) * 4, hipMemcpyDeviceToHost, s));
+    const void* v = c->cur_valid == 0 ? c->b_valid0.p : c->b_valid1.p;
+    if (c->n) HIPCHK(c, hipMemcpyAsync(valid.data(), v, size_t(c->n), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // final cluster id of query i that opened a cluster = L + rank among such queries (cluster.cpp:178)
+    std::vector<int32_t> cid(size_t(c->n) + 1, -1);
+    int32_t next = c->L;
+    for (int i = 0; i < c->n; ++i)
+        if (valid[size_t(i)]) cid[size_t(i)] = next++;
+    struct Row {
+        uint32_t key, slot;
+    };
+    std::vector<Row> rows;
+    for (uint32_t sl = 0; sl < nslots; ++sl) {
+        if (hc[sl] == 0) continue;
+        uint32_t key = (sl == c->cap) ? 0xFFFFFFFFu : hk[sl];
+        rows.push_back(Row{key, sl});
+    }
+    std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.key < b.key; });
+    int64_t nk = 0, np = 0;
+    const uint32_t L = uint32_t(c->L);
+    for (auto& r : rows) {
+        int64_t start = np;
+        for (uint32_t p = 0; p < hc[r.slot]; ++p) {
+            uint32_t t = hp[size_t(ho[r.slot]) + p];
+            int32_t id = t < L ? int32_t(t) : cid[size_t(t - L)];
+            if (id < 0) continue;
+            if (postings) postings[np] = uint32_t(id);
+            np++;
+        }
+        // the reference keeps keys with emptied lists only through UpdateMinDB (consensus); a key
+        // whose every contributor joined another cluster was never inserted by AddMinimizers.
+        if (np == start) continue;
+        if (keys) keys[nk] = r.key;
+        if (offs) offs[nk] = start;
+        nk++;
+    }
+    if (offs) offs[nk] = np;
+    if (n_keys) *n_keys = nk;
+    if (n_postings) *n_postings = np;
+    return IOC_OK;
+}
+
+int ioc_get_timings(ioc_ctx* c, ioc_timings* out)
+{
+    if (!c || !out) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    if (c->built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_build = ms;
+    if (c->scored && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->tm.ms_score = ms;
+    if (c->resolved && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->tm.ms_resolve = ms;
+    if (c->scored) {
+        std::vector<uint32_t> cc(size_t(c->n) + 1);
+        if (c->n) HIPCHK(c, hipMemcpy(cc.data(), c->b_cand_count.p, size_t(c->n) * 4, hipMemcpyDeviceToHost));
+        int64_t t = 0;
+        for (int i = 0; i < c->n; ++i) t += cc[size_t(i)];
+        c->tm.n_candidates = t;
+    }
+    *out = c->tm;
+    return IOC_OK;
+}
+
+}  // extern "C"

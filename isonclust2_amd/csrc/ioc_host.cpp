@@ -1,0 +1,383 @@
+// ioc_host.cpp — host side of the path: the empirical-probability table, the scalar
+// thresholds the device compares against, and the ClusterSortedReads driver on flat arrays.
+//
+// Mirrors (does not copy) the reference's host logic:
+//   InitMinSharedMap / GetPMinShared     src/p_emp_prob.cpp:22-94
+//   round(number, 2)                     src/util.cpp:6-10
+//   gates + new-cluster / join logic     src/cluster.cpp:115-261
+//   candidate order of equal Size        src/minimizer.cpp:44-76 + src/cluster.cpp:609-636
+//     (libstdc++ unordered_map iteration order + std::sort) — replayed here with the very same
+//     container types for the rare queries whose winner depends on it.
+// All arithmetic of the hot path itself (hits, Sizes, mapped totals, candidate walk) runs on the
+// GPU; there is no CPU fallback: without a device every entry point fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "ioc_internal.h"
+
+namespace {
+
+struct PTable {
+    double p[225];
+    int filled = 0;
+};
+
+int load_table(const char* path, int K, int W, PTable& t)
+{
+    for (auto& x : t.p) x = std::nan("");
+    t.filled = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return IOC_ERR_TABLE;
+    char magic[8];
+    uint32_t n = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "IOCPMIN1", 8) == 0 && fread(&n, 4, 1, f) == 1;
+    for (uint32_t c = 0; ok && c < n; ++c) {
+        int32_t kw[2];
+        double cells[225];
+        ok = fread(kw, 4, 2, f) == 2 && fread(cells, 8, 225, f) == 225;
+        // rows with k == K and |w_row - W| <= 2; later rows overwrite (p_emp_prob.cpp:37-43)
+        if (ok && kw[0] == K && std::abs(kw[1] - W) <= 2)
+            for (int i = 0; i < 225; ++i)
+                if (!std::isnan(cells[i])) t.p[i] = cells[i];
+    }
+    fclose(f);
+    if (!ok) return IOC_ERR_TABLE;
+    for (auto x : t.p)
+        if (!std::isnan(x)) t.filled++;
+    return IOC_OK;
+}
+
+// ---- candidate order replay (only for order-dependent ties) ---------------------------------------
+typedef std::pair<int, int> StrandedCluster;
+struct StrandedClsHash {  // src/minimizer.h:52-58
+    std::size_t operator()(const StrandedCluster& u) const { return size_t(int(u.first * u.second)); }
+};
+struct HitInfo {
+    unsigned Size = 0;
+    unsigned Mapped = 0;
+};
+struct SortedHit {  // src/minimizer.h:84-91
+    unsigned Size, Cls;
+    int Strand;
+};
+bool by_size_desc(const std::unique_ptr<SortedHit>& a, const std::unique_ptr<SortedHit>& b)
+{
+    return a->Size > b->Size;
+}
+
+struct Cand {
+    int32_t cls;  // final cluster id
+    int8_t strand;
+    uint32_t size, first, mapped;
+    int32_t target;
+};
+
+}  // namespace
+
+extern "C" {
+
+int ioc_host_gap_limits(const char* table_path, int32_t k, int32_t w, double min_prob_no_hits, int32_t* gap_limit,
+                        double* p_shared)
+{
+    if (!table_path || !gap_limit) return IOC_ERR_ARG;
+    PTable t;
+    int r = load_table(table_path, k, w, t);
+    if (r != IOC_OK) return r;
+    if (t.filled != 225) return IOC_ERR_TABLE;  // GetPMinShared would throw (p_emp_prob.cpp:87-89)
+    for (int i = 0; i < 225; ++i) {
+        const double pe = 1.0 - t.p[i];
+        if (p_shared) p_shared[i] = t.p[i];
+        // predicate of cluster.cpp:333-347: pow(pError, double(n)) >= MinProbNoHits, monotone in n
+        int32_t lim = -1;
+        if (pow(pe, 0.0) >= min_prob_no_hits) {
+            lim = 0;
+            while (lim < INT32_MAX - 2 && pow(pe, double(lim + 1)) >= min_prob_no_hits) {
+                lim++;
+                if (lim > (1 << 22)) {  // pError == 1 (or p0 <= 0): every gap passes
+                    lim = INT32_MAX - 2;
+                    break;
+                }
+            }
+        }
+        gap_limit[i] = lim;
+    }
+    return IOC_OK;
+}
+
+uint8_t ioc_host_err_cell(double e)
+{
+    // round(e, 2) = std::round(e * int(pow(10,2))) / 100, then clamp to [0.01, 0.15]; the map keys
+    // are c/100 for c = 1..15, so the cell is the clamped integer numerator.
+    int decimals = int(std::pow(10, 2));
+    double m = std::round(e * decimals);
+    if (std::isnan(m)) return 0;
+    double r = m / decimals;
+    if (r > 0.15) return 15;
+    if (r < 0.01) return 1;
+    for (int c = 1; c <= 15; ++c)
+        if (double(c) / 100 == r) return uint8_t(c);
+    return 0;
+}
+
+uint32_t ioc_host_min_total(uint32_t hpc_len, double thr)
+{
+    if (hpc_len == 0) return 0xFFFFFFFEu;
+    auto pass = [&](uint32_t T) {
+        float mr = float(double(T) / double(hpc_len));  // cluster.cpp:390-399 narrows to float
+        return mr >= thr;
+    };
+    if (!pass(hpc_len)) return 0xFFFFFFFEu;
+    uint32_t lo = 0, hi = hpc_len;  // pass(hi) true
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (pass(mid))
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+// ---- tie replay ---------------------------------------------------------------------------------------
+// Rebuilds the reference's `order` for one query from the device-computed hit table and returns
+// the first passing candidate in that order (cluster.cpp:381-403).
+static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint32_t need, int32_t& out_target,
+                        int8_t& out_strand)
+{
+    const int T = c->L + q;
+    std::vector<int32_t> tg(size_t(2) * T + 1);
+    std::vector<int8_t> st(size_t(2) * T + 1);
+    std::vector<uint32_t> sz(size_t(2) * T + 1), fi(size_t(2) * T + 1), tm(size_t(2) * T + 1);
+    int nc = ioc_query_candidates(c, q, 2 * T, tg.data(), st.data(), sz.data(), fi.data(), tm.data());
+    if (nc < 0) return nc;
+    std::vector<Cand> cs;
+    cs.reserve(size_t(nc));
+    for (int i = 0; i < nc; ++i) {
+        int32_t id = tg[size_t(i)] < c->L ? tg[size_t(i)] : cid[size_t(tg[size_t(i)] - c->L)];
+        if (id < 0) continue;
+        cs.push_back(Cand{id, st[size_t(i)], sz[size_t(i)], fi[size_t(i)], tm[size_t(i)], tg[size_t(i)]});
+    }
+    // insertion order of the reference: +1 strand raw hits first, in read-minimizer order, posting
+    // lists ascending in cluster id (minimizer.cpp:52-73) => by (first hitting Index, cluster id)
+    std::stable_sort(cs.begin(), cs.end(), [](const Cand& a, const Cand& b) {
+        if (a.strand != b.strand) return a.strand > b.strand;
+        if (a.first != b.first) return a.first < b.first;
+        return a.cls < b.cls;
+    });
+    const size_t nm = size_t(c->h_off_fwd[size_t(q) + 1] - c->h_off_fwd[size_t(q)]) +
+                      size_t(c->h_off_rev[size_t(q) + 1] - c->h_off_rev[size_t(q)]);
+    std::unordered_map<StrandedCluster, HitInfo, StrandedClsHash> res(20 * nm, StrandedClsHash());
+    for (auto& x : cs) {
+        HitInfo& h = res[std::make_pair(int(x.cls), int(x.strand))];
+        h.Size = x.size;
+        h.Mapped = x.mapped;
+    }
+    std::vector<std::unique_ptr<SortedHit>> order;
+    order.reserve(res.size());
+    for (auto& kv : res) {
+        auto p = new SortedHit;
+        p->Size = kv.second.Size;
+        p->Cls = unsigned(kv.first.first);
+        p->Strand = kv.first.second;
+        order.push_back(std::unique_ptr<SortedHit>(p));
+    }
+    std::sort(order.begin(), order.end(), by_size_desc);
+    out_target = -1;
+    out_strand = 0;
+    if (order.empty()) return IOC_OK;
+    const unsigned top = order[0]->Size;
+    if (top < unsigned(c->params.min_shared)) return IOC_OK;
+    for (auto& o : order) {
+        if (int(o->Size) < int(double(top) * c->params.min_fraction)) break;
+        const HitInfo& h = res.at(std::make_pair(int(o->Cls), o->Strand));
+        if (h.Mapped == 0xFFFFFFFFu)
+            return ioc_fail(c, IOC_ERR_STATE, "tie replay met a candidate the device did not evaluate");
+        if (h.Mapped >= need) {
+            out_target = int32_t(o->Cls);  // a final cluster id
+            out_strand = int8_t(o->Strand);
+            return IOC_OK;
+        }
+    }
+    return IOC_OK;
+}
+
+static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std::vector<uint32_t>& need,
+                        int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+{
+    const int n = c->n;
+    int r;
+    if ((r = ioc_index_build(c)) != IOC_OK) return r;
+    if ((r = ioc_score(c)) != IOC_OK) return r;
+    if ((r = ioc_clear_forced(c)) != IOC_OK) return r;
+    // gated entries never become clusters: force them out of the target set
+    for (int i = 0; i < n; ++i)
+        if (gated[size_t(i)] && (r = ioc_force_decision(c, i, -2, 0)) != IOC_OK) return r;
+    int32_t iters = 0;
+    if ((r = ioc_resolve(c, &iters)) != IOC_OK) return r;
+    if (c->params.mode != IOC_MODE_FAST && c->params.mode != IOC_MODE_NONE) {
+        return ioc_fail(c, IOC_ERR_STATE,
+                        "sahlin/furious need the host alignment fallback (cluster.cpp:461-515): not wired yet");
+    }
+    std::vector<int32_t> tgt(size_t(n) + 1);
+    std::vector<int8_t> str(size_t(n) + 1);
+    std::vector<uint8_t> flg(size_t(n) + 1);
+    if ((r = ioc_get_decisions(c, tgt.data(), str.data(), flg.data())) != IOC_OK) return r;
+    // final cluster ids in creation order (newId = cls.size(), cluster.cpp:178)
+    std::vector<int32_t> cid(size_t(n) + 1, -1);
+    int32_t next = c->L;
+    for (int i = 0; i < n; ++i)
+        if (!gated[size_t(i)] && tgt[size_t(i)] < 0) cid[size_t(i)] = next++;
+    int64_t joined = 0, ngated = 0, ties = 0;
+    for (int i = 0; i < n; ++i) {
+        if (gated[size_t(i)]) {
+            out_cls[i] = -1;
+            out_strand[i] = 0;
+            ngated++;
+            continue;
+        }
+        if (tgt[size_t(i)] < 0) {
+            out_cls[i] = cid[size_t(i)];
+            out_strand[i] = 1;
+            continue;
+        }
+        int32_t t = tgt[size_t(i)];
+        int8_t s = str[size_t(i)];
+        int32_t cls = t < c->L ? t : cid[size_t(t - c->L)];
+        if (flg[size_t(i)] & 1) {
+            int32_t rt = -1;
+            int8_t rs = 0;
+            if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs)) != IOC_OK) return r;
+            if (rt < 0) return ioc_fail(c, IOC_ERR_STATE, "tie replay found no passing candidate");
+            cls = rt;
+            s = rs;
+            ties++;
+        }
+        if (cls < 0) return ioc_fail(c, IOC_ERR_STATE, "joined target is not a cluster");
+        out_cls[i] = cls;
+        out_strand[i] = s;
+        joined++;
+    }
+    if (stats) {
+        stats->n_clusters = next;
+        stats->n_joined = joined;
+        stats->n_gated = ngated;
+        stats->n_tie_replays = ties;
+        stats->n_aln_invoked = 0;
+        stats->resolve_iters = iters;
+    }
+    return IOC_OK;
+}
+
+int ioc_cluster_batch(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_batch_view* rb,
+                      int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+{
+    if (!c || !p || !table_path || !rb || !out_cls || !out_strand) return IOC_ERR_ARG;
+    const int n = rb->n;
+    if (n < 0) return ioc_fail(c, IOC_ERR_ARG, "negative batch size");
+    int32_t glim[225];
+    int r = ioc_host_gap_limits(table_path, p->k, p->w, p->min_prob_no_hits, glim, nullptr);
+    if (r != IOC_OK) return ioc_fail(c, r, "empirical probability lookup failure (k, w outside the table)");
+    if ((r = ioc_set_params(c, p, glim)) != IOC_OK) return r;
+    if (p->mode == IOC_MODE_NONE) {
+        // no branch of getBestCluster fires for None (cluster.cpp:545-567): every clusterable entry
+        // opens its own cluster.  Same gates, no device work needed — but keep the contract that
+        // nothing runs without a device: the context exists, so a device is present.
+    }
+    // ---- gates of the loop, in the reference's order (cluster.cpp:116-160) ----
+    std::vector<uint8_t> gated(size_t(n) + 1, 0), cell(size_t(n) + 1, 1);
+    std::vector<uint32_t> need(size_t(n) + 1, 0xFFFFFFFEu);
+    bool compact = false;
+    for (int i = 0; i < n; ++i) {
+        bool g = false;
+        if (rb->state && rb->state[i] == 1) g = true;                               // null rep
+        else if (rb->state && rb->state[i] == 2)
+            return ioc_fail(c, IOC_ERR_INPUT, "entry without HpcSeq (the reference dereferences null here)");
+        else if (rb->score[i] < 0) g = true;                                       // :145
+        else if (rb->raw_len[i] < uint32_t(2 * p->k)) g = true;                    // :148
+        else if (rb->hpc_len[i] < uint32_t(2 * p->k)) g = true;                    // :152
+        else if ((-10 * log10(rb->raw_err[i])) <= rb->min_qual) g = true;          // :157
+        gated[size_t(i)] = g;
+        int64_t nf = rb->off_fwd[i + 1] - rb->off_fwd[i], nr = rb->off_rev[i + 1] - rb->off_rev[i];
+        if (g && (nf || nr)) compact = true;
+        if (!g) {
+            uint8_t cl = ioc_host_err_cell(rb->hpc_err[i]);
+            if (cl == 0) return ioc_fail(c, IOC_ERR_TABLE, "error rate is NaN");
+            cell[size_t(i)] = cl;
+            need[size_t(i)] = ioc_host_min_total(rb->hpc_len[i], p->mapped_threshold);
+        }
+    }
+    if (p->mode == IOC_MODE_NONE) {
+        int32_t next = 0;
+        int64_t ng = 0;
+        for (int i = 0; i < n; ++i) {
+            out_cls[i] = gated[size_t(i)] ? -1 : next++;
+            out_strand[i] = gated[size_t(i)] ? 0 : 1;
+            ng += gated[size_t(i)];
+        }
+        if (stats) *stats = ioc_cluster_stats{next, 0, ng, 0, 0, 0};
+        return IOC_OK;
+    }
+    if (!compact) {
+        r = ioc_queries_upload(c, n, rb->off_fwd, rb->off_rev, rb->min_val, rb->min_pos, rb->total, rb->hpc_len,
+                               cell.data(), need.data());
+    } else {
+        // slow path: gated entries that still carry minimizers are given empty lists
+        std::vector<int64_t> of(size_t(n) + 1, 0), orv(size_t(n) + 1, 0);
+        std::vector<uint32_t> mv, mp;
+        int64_t tot = 0;
+        for (int i = 0; i < n; ++i) {
+            of[size_t(i)] = tot;
+            if (!gated[size_t(i)]) tot += rb->off_fwd[i + 1] - rb->off_fwd[i];
+        }
+        of[size_t(n)] = tot;
+        for (int i = 0; i < n; ++i) {
+            orv[size_t(i)] = tot;
+            if (!gated[size_t(i)]) tot += rb->off_rev[i + 1] - rb->off_rev[i];
+        }
+        orv[size_t(n)] = tot;
+        mv.resize(size_t(tot) + 1);
+        mp.resize(size_t(tot) + 1);
+        for (int i = 0; i < n; ++i) {
+            if (gated[size_t(i)]) continue;
+            size_t a = size_t(rb->off_fwd[i]), b = size_t(rb->off_fwd[i + 1]);
+            std::copy(rb->min_val + a, rb->min_val + b, mv.begin() + of[size_t(i)]);
+            std::copy(rb->min_pos + a, rb->min_pos + b, mp.begin() + of[size_t(i)]);
+            a = size_t(rb->off_rev[i]);
+            b = size_t(rb->off_rev[i + 1]);
+            std::copy(rb->min_val + a, rb->min_val + b, mv.begin() + orv[size_t(i)]);
+            std::copy(rb->min_pos + a, rb->min_pos + b, mp.begin() + orv[size_t(i)]);
+        }
+        // the fwd block must precede... offsets are absolute, any layout is valid
+        std::vector<int64_t> of2(of), or2(orv);
+        // CSR needs off[i+1] as the end of entry i: with gated entries skipped the arrays above
+        // already satisfy that (gated entries have zero length).
+        r = ioc_queries_upload(c, n, of2.data(), or2.data(), mv.data(), mp.data(), tot, rb->hpc_len, cell.data(),
+                               need.data());
+    }
+    if (r != IOC_OK) return r;
+    if ((r = ioc_left_load(c, 0, nullptr, 0, nullptr, nullptr, nullptr)) != IOC_OK) return r;
+    return run_pipeline(c, gated, need, out_cls, out_strand, stats);
+}
+
+int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+{
+    if (!c || !out_cls || !out_strand) return IOC_ERR_ARG;
+    if (!c->have_params) return ioc_fail(c, IOC_ERR_STATE, "ioc_set_params first");
+    const int n = c->n;
+    std::vector<uint8_t> gated(size_t(n) + 1, 0);
+    std::vector<uint32_t> need(size_t(n) + 1, 0);
+    // thresholds live on the device; the tie replay needs them on the host
+    if (n > 0) {
+        hipError_t e = hipMemcpy(need.data(), c->d_min_total, size_t(n) * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
+    }
+    return run_pipeline(c, gated, need, out_cls, out_strand, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// ioc_internal.h — context layout shared by the device TU (ioc_device.hip) and the host driver
+// (ioc_host.cpp).  Not part of the public C ABI (include/isonclust2_hip.h).
+#ifndef IOC_INTERNAL_H
+#define IOC_INTERNAL_H
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "isonclust2_hip.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct ioc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+
+    bool have_params = false;
+    ioc_params params{};
+    int32_t h_glim[225]{};
+    int32_t keep = 1;  // candidates with Size < keep can never be evaluated (cluster.cpp:376-389)
+
+    // ---- queries ----
+    int32_t n = 0;
+    int64_t total = 0;
+    bool borrowed = false;
+    std::vector<int64_t> h_off_fwd, h_off_rev, h_doff;
+    const int64_t* d_off_fwd = nullptr;
+    const int64_t* d_off_rev = nullptr;
+    const uint32_t* d_min = nullptr;
+    const uint32_t* d_pos = nullptr;
+    const uint32_t* d_hpc_len = nullptr;
+    const uint8_t* d_err_cell = nullptr;
+    const uint32_t* d_min_total = nullptr;
+    DevBuf b_off_fwd, b_off_rev, b_min, b_pos, b_hpc_len, b_err_cell, b_min_total, b_doff;
+    int32_t max_fwd = 0, max_rev = 0;
+
+    // ---- left state ----
+    int32_t L = 0;
+    int64_t n_left_keys = 0, n_left_post = 0;
+    DevBuf b_left_err, b_lkeys, b_loffs, b_lpost, b_lslot;
+    // left clusters' value sets (transposed MinDB), built by ioc_left_load
+    DevBuf b_lset_off, b_lset_val;
+    std::vector<uint32_t> h_lkeys;
+    std::vector<int64_t> h_loffs;
+    std::vector<uint32_t> h_lpost;
+
+    // ---- index ----
+    bool built = false;
+    uint32_t cap = 0;  // power of two; slot `cap` is reserved for the key 0xFFFFFFFF
+    DevBuf b_keys, b_cnt, b_off, b_fill, b_rows, b_post, b_dvals, b_dcount, b_dslot, b_scan;
+    int64_t n_post = 0;
+
+    // ---- scoring ----
+    bool scored = false;
+    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count;
+    int64_t cand_capacity = 0;
+
+    // ---- resolve ----
+    bool resolved = false;
+    DevBuf b_valid0, b_valid1, b_dec_target, b_dec_strand, b_flags, b_forced_t, b_forced_s, b_misc,
+        b_glim;
+    int cur_valid = 0;
+    std::vector<int32_t> h_forced_t;
+    std::vector<int8_t> h_forced_s;
+    bool forced_dirty = false;
+
+    // ---- extraction (K1) outputs ----
+    DevBuf x_min, x_pos, x_off_fwd, x_off_rev, x_hpc_len;
+    int32_t x_n = 0;
+    int64_t x_total = 0;
+    std::vector<int64_t> xh_off_fwd, xh_off_rev;
+    std::vector<uint32_t> xh_hpc_len;
+    std::vector<int32_t> xh_status;
+
+    // ---- instrumentation ----
+    hipEvent_t ev[6]{};
+    ioc_timings tm{};
+};
+
+int ioc_fail(ioc_ctx* c, int code, const std::string& msg);
+
+#endif

@@ -1,0 +1,89 @@
+// ioc_kernels.h — launcher prototypes of ioc_kernels.hip / ioc_extract.hip (internal).
+#ifndef IOC_KERNELS_H
+#define IOC_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+
+#include <climits>
+#include <cstddef>
+#include <cstdint>
+
+// Arguments of k_decide (getBestClusterMapping + getMappedRatio, src/cluster.cpp:324-406).
+struct DecideArgs {
+    int n;
+    uint32_t L;
+    int first;  // queries < first are final
+    const int64_t* off_fwd;
+    const int64_t* off_rev;
+    const uint32_t* mins;
+    const uint32_t* pos;
+    const uint32_t* hpc_len;
+    const uint8_t* err_cell;
+    const uint32_t* min_total;
+    const uint8_t* left_err;
+    const int64_t* doff;
+    const uint32_t* dvals;
+    const uint32_t* dcount;
+    const int64_t* lset_off;
+    const uint32_t* lset_val;
+    const uint32_t* cand_key;
+    const uint32_t* cand_size;
+    uint32_t* cand_mapped;
+    const uint32_t* cand_count;
+    const int32_t* glim;  // [15][15]
+    const uint8_t* valid_in;
+    uint8_t* valid_out;
+    int32_t* dec_target;
+    int8_t* dec_strand;
+    uint8_t* flags;
+    const int32_t* forced_t;  // INT32_MIN = not forced
+    const int8_t* forced_s;
+    uint32_t* first_changed;  // atomicMin
+    unsigned long long* n_evals;
+    int min_shared;
+    double min_fraction;
+};
+
+extern "C" {
+hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
+                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax);
+hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
+                                    const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
+                                    uint32_t* cnt, uint32_t* dslot, uint32_t* err);
+hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* lkeys, const int64_t* loffs,
+                                 uint32_t* keys, uint32_t cap, uint32_t shift, uint32_t* cnt, uint32_t* lslot,
+                                 uint32_t* err);
+hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch);
+hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
+                          const uint32_t* lslot, const uint32_t* off, uint32_t* fill, uint32_t* post);
+hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
+                             const uint32_t* dslot, const uint32_t* off, uint32_t* fill, uint32_t* post);
+hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
+                           uint32_t L, uint32_t n, uint32_t nblocks);
+hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
+                          const uint32_t* cnt, void* rows);
+hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
+                      const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
+                      uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
+                      unsigned long long* traversed);
+hipError_t iock_decide(hipStream_t st, const void* args, int nblocks);
+hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout);
+hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
+                            const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
+                            const uint8_t* valid, uint32_t* hist, uint32_t* first);
+size_t iock_decide_args_size();
+
+// ---- sort-stage kernels (ioc_extract.hip) ----
+hipError_t iock_qual_scores(hipStream_t st, int n, const int64_t* offs, const uint8_t* qual, int k,
+                            const double* tab_capped, const double* tab_nomin, double* score, double* err);
+hipError_t iock_hpc(hipStream_t st, int n, const int64_t* offs, const uint8_t* seq, const uint8_t* qual,
+                    uint8_t* hseq, uint8_t* hqual, uint32_t* hlen, int32_t* status);
+hipError_t iock_hpc_error(hipStream_t st, int n, const int64_t* offs, const uint8_t* hqual, const uint32_t* hlen,
+                          const double* tab_nomin, double* err);
+hipError_t iock_minimizers(hipStream_t st, int n, const int64_t* offs, const uint8_t* hseq, const uint32_t* hlen,
+                           const int32_t* status, int k, int w, int pass, const int64_t* off_fwd,
+                           const int64_t* off_rev, uint32_t* cnt_fwd, uint32_t* cnt_rev, uint32_t* omin,
+                           uint32_t* opos);
+}
+
+#endif

@@ -1,0 +1,912 @@
+// ioc_kernels.hip — CDNA4 (gfx950) kernels of the read->cluster assignment path.
+//
+// No MFMA anywhere: the path is integer hashing / gather / histogram work bounded by HBM + LDS
+// (SURVEY.md §8(d)).  Wavefront = 64 lanes throughout; every kernel uses 256-thread workgroups
+// (4 waves) so that LDS histograms of several queries are co-resident on one CU.
+//
+// Kernel            replaces (reference file:line)
+// k_distinct        the dedupe of AddMinimizers (`cls > back()`), src/minimizer.cpp:31-42
+// k_hash_insert*    MinimizerDB insert (unordered_map<unsigned, RepSet>), src/minimizer.h:60-61
+// k_scan_*          (posting-list offsets: CSR instead of vector<unsigned> per key)
+// k_fill_*          RepSet::emplace_back, src/minimizer.cpp:38-40
+// k_score           GetMinimizerHits + ConsolidateMinimizerHits + Size of SortMinimizerHits,
+//                   src/minimizer.cpp:44-76, src/cluster.cpp:609-636
+// k_decide          getBestClusterMapping + getMappedRatio, src/cluster.cpp:324-406
+// k_query_table     the full hit map of one query (tie replay), src/minimizer.cpp:44-76
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ioc_kernels.h"
+
+#define IOC_BLOCK 256
+#define IOC_WAVES (IOC_BLOCK / 64)
+#define IOC_EMPTY 0xFFFFFFFFu
+
+namespace {
+
+__device__ __forceinline__ int lane_id() { return int(threadIdx.x) & 63; }
+__device__ __forceinline__ int wave_id() { return int(threadIdx.x) >> 6; }
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t v, uint32_t shift)
+{
+    return (v * 0x9E3779B1u) >> shift;
+}
+
+// Lookup in the packed rows (key, off, cnt, -) — one 16-byte load per probe step.
+__device__ __forceinline__ bool index_lookup(const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
+                                             uint32_t v, uint32_t& off, uint32_t& cnt)
+{
+    if (v == IOC_EMPTY) {
+        uint4 r = rows[cap];
+        off = r.y;
+        cnt = r.z;
+        return cnt != 0;
+    }
+    uint32_t h = hash_slot(v, shift);
+    for (uint32_t step = 0; step < cap; ++step) {
+        uint4 r = rows[h];
+        if (r.x == v) {
+            off = r.y;
+            cnt = r.z;
+            return true;
+        }
+        if (r.x == IOC_EMPTY) return false;
+        h = (h + 1) & (cap - 1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the block; sh must hold IOC_WAVES words; two barriers.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* sh)
+{
+    uint32_t incl = wave_incl_scan(v);
+    if (lane_id() == 63) sh[wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < IOC_WAVES; ++w) {
+        uint32_t s = sh[w];
+        if (w < wave_id()) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+// lower_bound style membership test in a sorted array
+__device__ __forceinline__ bool sorted_contains(const uint32_t* __restrict__ a, uint32_t n, uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        uint32_t x = a[mid];
+        if (x < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < n && a[lo] == v;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// k_distinct: one workgroup per query; forward minimizer values -> LDS bitonic sort -> unique.
+// dvals segment of query j starts at doff[j] (capacity nFwd[j]); dcount[j] = #distinct.
+// =====================================================================================================
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_distinct(int n, const int64_t* __restrict__ off_fwd, const uint32_t* __restrict__ mins,
+           const int64_t* __restrict__ doff, uint32_t* __restrict__ dvals, uint32_t* __restrict__ dcount,
+           uint32_t pmax)
+{
+    extern __shared__ uint32_t s[];  // pmax words
+    __shared__ uint32_t sh[IOC_WAVES];
+    int j = blockIdx.x;
+    if (j >= n) return;
+    int64_t b = off_fwd[j];
+    uint32_t m = uint32_t(off_fwd[j + 1] - b);
+    if (m == 0) {
+        if (threadIdx.x == 0) dcount[j] = 0;
+        return;
+    }
+    uint32_t P = 1;
+    while (P < m) P <<= 1;
+    if (P > pmax) P = pmax;  // host guarantees m <= pmax
+    for (uint32_t i = threadIdx.x; i < P; i += IOC_BLOCK) s[i] = (i < m) ? mins[b + i] : IOC_EMPTY;
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += IOC_BLOCK) {
+                uint32_t x = i ^ j2;
+                if (x > i) {
+                    uint32_t a = s[i], c = s[x];
+                    bool asc = (i & k2) == 0;
+                    if ((a > c) == asc) {
+                        s[i] = c;
+                        s[x] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // unique over the first m sorted entries (padding sorts to the end; equal-to-padding real
+    // values are indistinguishable from it but then identical, so the prefix is the multiset).
+    uint32_t base = 0;
+    uint32_t* out = dvals + doff[j];
+    for (uint32_t c = 0; c < m; c += IOC_BLOCK) {
+        uint32_t i = c + threadIdx.x;
+        uint32_t flag = (i < m) && (i == 0 || s[i] != s[i - 1]);
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(flag, tot, sh);
+        if (flag) out[base + ex] = s[i];
+        base += tot;
+    }
+    if (threadIdx.x == 0) dcount[j] = base;
+}
+
+// =====================================================================================================
+// hash build
+// =====================================================================================================
+__device__ __forceinline__ uint32_t hash_insert(uint32_t* __restrict__ keys, uint32_t cap, uint32_t shift,
+                                                uint32_t v)
+{
+    if (v == IOC_EMPTY) return cap;
+    uint32_t h = hash_slot(v, shift);
+    for (uint32_t step = 0; step < cap; ++step) {
+        uint32_t k = keys[h];
+        if (k == v) return h;
+        if (k == IOC_EMPTY) {
+            uint32_t old = atomicCAS(&keys[h], IOC_EMPTY, v);
+            if (old == IOC_EMPTY || old == v) return h;
+        }
+        h = (h + 1) & (cap - 1);
+    }
+    return cap + 1;  // table full (host sizes the table so that this cannot happen)
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_hash_insert_queries(int n, const int64_t* __restrict__ doff, const uint32_t* __restrict__ dvals,
+                      const uint32_t* __restrict__ dcount, uint32_t* __restrict__ keys, uint32_t cap,
+                      uint32_t shift, uint32_t* __restrict__ cnt, uint32_t* __restrict__ dslot,
+                      uint32_t* __restrict__ err)
+{
+    int j = blockIdx.x;
+    if (j >= n) return;
+    int64_t b = doff[j];
+    uint32_t m = dcount[j];
+    for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) {
+        uint32_t slot = hash_insert(keys, cap, shift, dvals[b + d]);
+        if (slot > cap) {
+            atomicAdd(err, 1u);
+            slot = cap;
+        } else {
+            atomicAdd(&cnt[slot], 1u);
+        }
+        dslot[b + d] = slot;
+    }
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_hash_insert_left(int64_t nkeys, const uint32_t* __restrict__ lkeys, const int64_t* __restrict__ loffs,
+                   uint32_t* __restrict__ keys, uint32_t cap, uint32_t shift, uint32_t* __restrict__ cnt,
+                   uint32_t* __restrict__ lslot, uint32_t* __restrict__ err)
+{
+    int64_t i = int64_t(blockIdx.x) * IOC_BLOCK + threadIdx.x;
+    if (i >= nkeys) return;
+    uint32_t slot = hash_insert(keys, cap, shift, lkeys[i]);
+    if (slot > cap) {
+        atomicAdd(err, 1u);
+        slot = cap;
+    } else {
+        atomicAdd(&cnt[slot], uint32_t(loffs[i + 1] - loffs[i]));
+    }
+    lslot[i] = slot;
+}
+
+// ---- 3-phase exclusive scan over u32 (n up to 2^31): block = 1024 elements -------------------------
+#define IOC_SCAN_ELEMS 1024
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_scan_reduce(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t sh[IOC_WAVES];
+    int64_t base = int64_t(blockIdx.x) * IOC_SCAN_ELEMS;
+    uint32_t v = 0;
+#pragma unroll
+    for (int r = 0; r < IOC_SCAN_ELEMS / IOC_BLOCK; ++r) {
+        int64_t i = base + r * IOC_BLOCK + threadIdx.x;
+        if (i < n) v += in[i];
+    }
+    uint32_t tot;
+    block_excl_scan(v, tot, sh);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block_sums in place, total -> block_sums[nb]
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_scan_sums(uint32_t* __restrict__ block_sums, int64_t nb)
+{
+    __shared__ uint32_t sh[IOC_WAVES];
+    uint32_t carry = 0;
+    for (int64_t c = 0; c < nb; c += IOC_BLOCK) {
+        int64_t i = c + threadIdx.x;
+        uint32_t v = (i < nb) ? block_sums[i] : 0;
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(v, tot, sh);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_scan_apply(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restrict__ block_sums,
+             uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t sh[IOC_WAVES];
+    int64_t base = int64_t(blockIdx.x) * IOC_SCAN_ELEMS;
+    uint32_t carry = block_sums[blockIdx.x];
+    // each thread owns 4 consecutive elements so that the scan order is the element order
+    int64_t i0 = base + int64_t(threadIdx.x) * (IOC_SCAN_ELEMS / IOC_BLOCK);
+    uint32_t v[IOC_SCAN_ELEMS / IOC_BLOCK];
+    uint32_t s = 0;
+#pragma unroll
+    for (int r = 0; r < IOC_SCAN_ELEMS / IOC_BLOCK; ++r) {
+        v[r] = (i0 + r < n) ? in[i0 + r] : 0;
+        s += v[r];
+    }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(s, tot, sh) + carry;
+#pragma unroll
+    for (int r = 0; r < IOC_SCAN_ELEMS / IOC_BLOCK; ++r) {
+        if (i0 + r < n) out[i0 + r] = ex;
+        ex += v[r];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == IOC_BLOCK - 1) {
+        // total goes to out[n]: last thread's running value covers every element < n
+        out[n] = ex;
+    }
+}
+
+// ---- fill ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_fill_left(int64_t nkeys, const int64_t* __restrict__ loffs, const uint32_t* __restrict__ lpost,
+            const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ off, uint32_t* __restrict__ fill,
+            uint32_t* __restrict__ post)
+{
+    // one wave per key
+    int64_t key = (int64_t(blockIdx.x) * IOC_BLOCK + threadIdx.x) >> 6;
+    if (key >= nkeys) return;
+    uint32_t slot = lslot[key];
+    int64_t b = loffs[key];
+    uint32_t m = uint32_t(loffs[key + 1] - b);
+    uint32_t o = off[slot];
+    for (uint32_t t = lane_id(); t < m; t += 64) post[o + t] = lpost[b + t];
+    if (lane_id() == 0) fill[slot] = m;
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32_t* __restrict__ dcount,
+               const uint32_t* __restrict__ dslot, const uint32_t* __restrict__ off,
+               uint32_t* __restrict__ fill, uint32_t* __restrict__ post)
+{
+    int j = blockIdx.x;
+    if (j >= n) return;
+    int64_t b = doff[j];
+    uint32_t m = dcount[j];
+    for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) {
+        uint32_t slot = dslot[b + d];
+        uint32_t p = atomicAdd(&fill[slot], 1u);
+        post[off[slot] + p] = L + uint32_t(j);
+    }
+}
+
+// Posting lists must be ascending in target id (the reference keeps RepSet ascending,
+// src/minimizer.cpp:38-40); the atomic fill leaves the query part of each list unordered.
+// One wave per slot: rank-by-counting for lists <= 64; longer lists go through a per-wave LDS bitmap
+// (the query part holds distinct integers in [L, L+n)).
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
+             uint32_t* __restrict__ post, uint32_t L, uint32_t words_per_wave)
+{
+    extern __shared__ uint32_t sbits[];  // IOC_WAVES * words_per_wave
+    const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6;  // global wave id
+    const uint32_t nw = (gridDim.x * IOC_BLOCK) >> 6;
+    const int lane = lane_id();
+    uint32_t* bits = sbits + size_t(wave_id()) * words_per_wave;
+    for (uint32_t slot = gw; slot < nslots; slot += nw) {
+        const uint32_t c = cnt[slot];
+        if (c < 2) continue;
+        const uint32_t o = off[slot];
+        // the left part (values < L) was copied first and is already ascending: it is a prefix by position
+        uint32_t a = 0, b2 = c;
+        while (a < b2) {
+            uint32_t mid = (a + b2) >> 1;
+            if (post[o + mid] < L) a = mid + 1; else b2 = mid;
+        }
+        const uint32_t m = c - a;
+        if (m < 2) continue;
+        uint32_t* p = post + o + a;
+        if (m <= 64) {
+            uint32_t x = (uint32_t(lane) < m) ? p[lane] : IOC_EMPTY;
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t < m; ++t) {
+                uint32_t y = __shfl(x, int(t));
+                rank += (y < x);
+            }
+            if (uint32_t(lane) < m) p[rank] = x;
+        } else {
+            for (uint32_t wd = lane; wd < words_per_wave; wd += 64) bits[wd] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (uint32_t t = lane; t < m; t += 64) {
+                uint32_t id = p[t] - L;
+                atomicOr(&bits[id >> 5], 1u << (id & 31));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            uint32_t base = 0;
+            for (uint32_t w0 = 0; w0 < words_per_wave; w0 += 64) {
+                uint32_t wd = w0 + lane;
+                uint32_t bw = (wd < words_per_wave) ? bits[wd] : 0;
+                uint32_t pc = __popc(bw);
+                uint32_t incl = wave_incl_scan(pc);
+                uint32_t ex = base + incl - pc;
+                while (bw) {
+                    uint32_t bit = __ffs(bw) - 1;
+                    bw &= bw - 1;
+                    p[ex++] = L + wd * 32 + bit;
+                }
+                base += __shfl(incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_pack_rows(uint32_t nslots, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off,
+            const uint32_t* __restrict__ cnt, uint4* __restrict__ rows)
+{
+    uint32_t s = blockIdx.x * IOC_BLOCK + threadIdx.x;
+    if (s >= nslots) return;
+    rows[s] = make_uint4(keys[s], off[s], cnt[s], 0u);
+}
+
+// =====================================================================================================
+// k_score — the dominant kernel.  One workgroup per query j (heaviest first).  LDS holds the dense
+// histogram Size[strand][target] over the visible targets t < L + j (in passes of `range` targets);
+// each wave probes 64 minimizer occurrences at a time (one per lane) and then walks the 64 posting
+// lists cooperatively (64 postings per step, coalesced), counting with LDS atomics.  Lists are
+// ascending, so a walk stops at the first step whose lowest lane is already >= L + j.
+// Output: compacted candidate list (target<<1|strandbit, Size) for Size >= keep, ordered by
+// (strand, target) — deterministic.
+// =====================================================================================================
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+        const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
+        const uint32_t* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
+        uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
+        unsigned long long* __restrict__ traversed)
+{
+    extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
+    __shared__ uint32_t wcount[IOC_WAVES];
+    const int j = n - 1 - int(blockIdx.x);
+    if (j < 0) return;
+    const uint32_t T = L + uint32_t(j);  // visible targets: [0, T)
+    const int lane = lane_id(), wave = wave_id();
+    const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
+    uint32_t written = 0;
+    unsigned long long trav = 0;
+
+    for (uint32_t rbase = 0; rbase < T; rbase += range) {
+        const uint32_t Tr = (T - rbase < range) ? (T - rbase) : range;
+        for (uint32_t i = threadIdx.x; i < 2 * Tr; i += IOC_BLOCK) hist[i] = 0;
+        __syncthreads();
+        const uint32_t hi = rbase + Tr;  // count targets in [rbase, hi)
+        for (int s = 0; s < 2; ++s) {
+            const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
+            const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
+            uint32_t* h = hist + uint32_t(s) * Tr;
+            for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
+                int64_t t = c0 + lane;
+                uint32_t o = 0, c = 0;
+                if (t < e) index_lookup(rows, cap, shift, mins[t], o, c);
+                unsigned long long mask = __ballot(c != 0);
+                while (mask) {
+                    int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    uint32_t lo = __builtin_amdgcn_readlane(o, l);
+                    uint32_t lc = __builtin_amdgcn_readlane(c, l);
+                    for (uint32_t p = 0; p < lc; p += 64) {
+                        uint32_t q = p + lane;
+                        uint32_t tg = (q < lc) ? post[lo + q] : IOC_EMPTY;
+                        if (tg >= rbase && tg < hi) atomicAdd(&h[tg - rbase], 1u);
+                        trav += (q < lc);
+                        // ascending list: once the first lane of this step is past the window, stop
+                        uint32_t first = __builtin_amdgcn_readfirstlane(tg);
+                        if (first >= hi) break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- ordered compaction of hist[0 .. 2*Tr) --------------------------------------------
+        const uint32_t tot = 2 * Tr;
+        const uint32_t per = (tot + IOC_WAVES - 1) / IOC_WAVES;
+        const uint32_t w0 = wave * per;
+        const uint32_t w1 = (w0 + per < tot) ? (w0 + per) : tot;
+        uint32_t my = 0;
+        for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+            uint32_t i = i0 + lane;
+            bool f = (i < w1) && (hist[i] >= keep);
+            my += __popcll(__ballot(f));
+        }
+        if (lane == 0) wcount[wave] = my;
+        __syncthreads();
+        uint32_t wbase = written, all = 0;
+        for (int w = 0; w < IOC_WAVES; ++w) {
+            if (w < wave) wbase += wcount[w];
+            all += wcount[w];
+        }
+        for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+            uint32_t i = i0 + lane;
+            uint32_t v = (i < w1) ? hist[i] : 0;
+            bool f = (i < w1) && (v >= keep);
+            unsigned long long bm = __ballot(f);
+            if (f) {
+                uint32_t pos = wbase + __popcll(bm & ((1ull << lane) - 1ull));
+                uint32_t strandbit = (i >= Tr) ? 1u : 0u;
+                uint32_t tg = rbase + (strandbit ? i - Tr : i);
+                cand_key[cbase + pos] = (tg << 1) | strandbit;
+                cand_size[cbase + pos] = v;
+            }
+            wbase += __popcll(bm);
+        }
+        written += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cand_count[j] = written;
+    if (traversed) {
+        for (int o = 32; o > 0; o >>= 1) trav += __shfl_down(trav, o);
+        if (lane == 0) atomicAdd(traversed, trav);
+    }
+}
+
+// =====================================================================================================
+// k_decide — one workgroup per query.  Given the current guess of which queries open clusters
+// (valid_in), walk the query's candidate list exactly as getBestClusterMapping does:
+//   top = max Size over candidates that ARE clusters;  top < MinShared -> new cluster;
+//   cut = int(double(top) * MinFraction);  evaluate every candidate with int(Size) >= cut;
+//   winner = passing candidate of maximal Size (the first passing one in descending-Size order).
+// totalMapped of a (query, target, strand) is decision-independent and cached in cand_mapped.
+// =====================================================================================================
+#define IOC_MAX_SURV IOC_BLOCK
+#define IOC_BITWORDS 1024  // 65536 minimizers per strand per pass
+
+// totalMapped of query minimizers (qmin,qpos)[0..M) against the sorted value set `set`
+// (src/cluster.cpp:324-353 with the pow() predicate replaced by the integer gap limit).
+__device__ uint32_t eval_total_mapped(const uint32_t* __restrict__ qmin, const uint32_t* __restrict__ qpos,
+                                      uint32_t M, const uint32_t* __restrict__ set, uint32_t setN, uint32_t limEx,
+                                      uint32_t hpcLen, unsigned long long* bits, uint32_t* red)
+{
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t total = 0;
+    // carry across passes of 65536 minimizers: index of the last hit so far (or none)
+    __shared__ uint32_t carry_last;
+    __shared__ uint32_t carry_any;
+    if (threadIdx.x == 0) {
+        carry_any = 0;
+        carry_last = 0;
+    }
+    __syncthreads();
+    for (uint32_t pbase = 0; pbase < M; pbase += IOC_BITWORDS * 64) {
+        uint32_t Mp = (M - pbase < IOC_BITWORDS * 64) ? (M - pbase) : IOC_BITWORDS * 64;
+        uint32_t nwords = (Mp + 63) >> 6;
+        // phase A: hit bitmap, one 64-bit word per wave step (coalesced reads of qmin)
+        for (uint32_t wd = wave; wd < nwords; wd += IOC_WAVES) {
+            uint32_t i = pbase + wd * 64 + lane;
+            bool hit = (i < M) && sorted_contains(set, setN, qmin[i]);
+            unsigned long long m = __ballot(hit);
+            if (lane == 0) bits[wd] = m;
+        }
+        __syncthreads();
+        // phase B: one thread per word; gaps between consecutive hits
+        uint32_t local = 0;
+        uint32_t had_any = carry_any, had_last = carry_last;
+        for (uint32_t wd = threadIdx.x; wd < nwords; wd += IOC_BLOCK) {
+            unsigned long long m = bits[wd];
+            if (!m) continue;
+            // previous hit: look back through earlier words, then the carry
+            bool pany = false;
+            uint32_t pidx = 0;
+            for (int x = int(wd) - 1; x >= 0; --x) {
+                unsigned long long pm = bits[x];
+                if (pm) {
+                    pany = true;
+                    pidx = pbase + uint32_t(x) * 64 + (63 - __builtin_clzll(pm));
+                    break;
+                }
+            }
+            if (!pany && had_any) {
+                pany = true;
+                pidx = had_last;
+            }
+            while (m) {
+                uint32_t bit = __builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t i = pbase + wd * 64 + bit;
+                if (!pany) {
+                    if (i < limEx) local += qpos[i];  // pow(pError, hits[0].Index) >= p0
+                } else {
+                    if (i - pidx - 1 < limEx) local += qpos[i] - qpos[pidx];
+                }
+                pany = true;
+                pidx = i;
+            }
+        }
+        // block reduce of `local`
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+        if (lane == 0) red[wave] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) sum += red[w];
+            red[IOC_WAVES] = sum;
+            // update carry: last hit of this pass
+            for (int x = int(nwords) - 1; x >= 0; --x) {
+                unsigned long long pm = bits[x];
+                if (pm) {
+                    carry_any = 1;
+                    carry_last = pbase + uint32_t(x) * 64 + (63 - __builtin_clzll(pm));
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        total += red[IOC_WAVES];
+        __syncthreads();
+    }
+    // tail: pow(pError, nMins - (lastIdx + 1)) >= p0
+    uint32_t any = carry_any, last = carry_last;
+    if (any && (M - last - 1 < limEx)) total += hpcLen - qpos[last];
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_decide(DecideArgs a)
+{
+    __shared__ unsigned long long bits[IOC_BITWORDS];
+    __shared__ uint32_t red[IOC_WAVES + 1];
+    __shared__ uint32_t surv[IOC_MAX_SURV];
+    __shared__ uint32_t wsum[IOC_WAVES];
+    __shared__ uint32_t s_top;
+    __shared__ uint32_t bestSize, bestEntry, bestCount;
+    const int j = a.first + int(blockIdx.x);
+    if (j >= a.n) return;
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t L = a.L;
+    const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
+    const uint32_t C = a.cand_count[j];
+
+    int32_t ft = a.forced_t ? a.forced_t[j] : INT32_MIN;
+    if (ft != INT32_MIN) {
+        if (threadIdx.x == 0) {
+            uint8_t nv = (ft == -1) ? 1 : 0;  // -1 opens a cluster; -2 = excluded entry (gated)
+            a.dec_target[j] = ft;
+            a.dec_strand[j] = (ft < 0) ? 0 : a.forced_s[j];
+            a.flags[j] = 0;
+            a.valid_out[j] = nv;
+            if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
+        }
+        return;
+    }
+
+    // ---- top over candidates that are clusters --------------------------------------------------
+    uint32_t top = 0;
+    for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
+        uint32_t tg = a.cand_key[cbase + c] >> 1;
+        bool ok = (tg < L) || a.valid_in[tg - L];
+        uint32_t sz = a.cand_size[cbase + c];
+        if (ok && sz > top) top = sz;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_down(top, o);
+        top = t > top ? t : top;
+    }
+    if (lane == 0) red[wave] = top;
+    if (threadIdx.x == 0) {
+        bestSize = 0;
+        bestEntry = 0xFFFFFFFFu;
+        bestCount = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < IOC_WAVES; ++w) t = red[w] > t ? red[w] : t;
+        s_top = t;
+    }
+    __syncthreads();
+    top = s_top;
+    int32_t out_t = -1;
+    int8_t out_s = 0;
+    uint8_t out_f = 0;
+    if (top >= uint32_t(a.min_shared)) {
+        const int cut = int(double(top) * a.min_fraction);
+        const uint32_t nf = uint32_t(a.off_fwd[j + 1] - a.off_fwd[j]);
+        const uint32_t nr = uint32_t(a.off_rev[j + 1] - a.off_rev[j]);
+        const uint32_t hl = a.hpc_len[j];
+        const uint32_t need = a.min_total[j];
+        const int ecr = int(a.err_cell[j]) - 1;
+        // candidates are visited in slices of IOC_BLOCK (one per thread); the survivors of a slice
+        // (clusters with int(Size) >= cut) are evaluated one after the other by the whole block
+        for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
+            const uint32_t cc = c0 + threadIdx.x;
+            bool f = false;
+            if (cc < C) {
+                uint32_t tg = a.cand_key[cbase + cc] >> 1;
+                bool ok = (tg < L) || a.valid_in[tg - L];
+                f = ok && (int(a.cand_size[cbase + cc]) >= cut);
+            }
+            unsigned long long bm = __ballot(f);
+            if (lane == 0) wsum[wave] = uint32_t(__popcll(bm));
+            __syncthreads();
+            uint32_t wb = 0, ns = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) {
+                if (w < wave) wb += wsum[w];
+                ns += wsum[w];
+            }
+            if (f) surv[wb + uint32_t(__popcll(bm & ((1ull << lane) - 1ull)))] = cc;
+            __syncthreads();
+            for (uint32_t sidx = 0; sidx < ns; ++sidx) {
+                const uint32_t c = surv[sidx];
+                const uint32_t key = a.cand_key[cbase + c];
+                const uint32_t tg = key >> 1;
+                const int strandbit = int(key & 1u);
+                uint32_t tm = a.cand_mapped[cbase + c];
+                if (tm == 0xFFFFFFFFu) {
+                    const uint32_t* set;
+                    uint32_t setN;
+                    int ecl;
+                    if (tg < L) {
+                        set = a.lset_val + a.lset_off[tg];
+                        setN = uint32_t(a.lset_off[tg + 1] - a.lset_off[tg]);
+                        ecl = int(a.left_err[tg]) - 1;
+                    } else {
+                        set = a.dvals + a.doff[tg - L];
+                        setN = a.dcount[tg - L];
+                        ecl = int(a.err_cell[tg - L]) - 1;
+                    }
+                    const uint32_t limEx = uint32_t(a.glim[ecl * 15 + ecr] + 1);  // gap n passes iff n < limEx
+                    const int64_t qb = strandbit ? a.off_rev[j] : a.off_fwd[j];
+                    const uint32_t M = strandbit ? nr : nf;
+                    tm = eval_total_mapped(a.mins + qb, a.pos + qb, M, set, setN, limEx, hl, bits, red);
+                    if (threadIdx.x == 0) {
+                        a.cand_mapped[cbase + c] = tm;
+                        if (a.n_evals) atomicAdd(a.n_evals, 1ull);
+                    }
+                }
+                if (threadIdx.x == 0 && tm >= need) {
+                    uint32_t sz = a.cand_size[cbase + c];
+                    if (sz > bestSize) {
+                        bestSize = sz;
+                        bestEntry = c;
+                        bestCount = 1;
+                    } else if (sz == bestSize) {
+                        bestCount++;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (bestEntry != 0xFFFFFFFFu) {
+            uint32_t key = a.cand_key[cbase + bestEntry];
+            out_t = int32_t(key >> 1);
+            out_s = (key & 1u) ? -1 : 1;
+            if (bestCount > 1) out_f |= 1;
+        } else {
+            out_f |= 2;  // no mapping hit although top >= MinShared (cluster.cpp:553-566)
+        }
+    }
+    if (threadIdx.x == 0) {
+        uint8_t nv = (out_t < 0) ? 1 : 0;
+        a.dec_target[j] = out_t;
+        a.dec_strand[j] = out_s;
+        a.flags[j] = out_f;
+        a.valid_out[j] = nv;
+        if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
+    }
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_copy_prefix_valid(int first, const uint8_t* __restrict__ vin, uint8_t* __restrict__ vout)
+{
+    int i = blockIdx.x * IOC_BLOCK + threadIdx.x;
+    if (i < first) vout[i] = vin[i];
+}
+
+// =====================================================================================================
+// k_query_table — full hit table of ONE query against the targets that are clusters (tie replay on
+// the host): Size and the Index of the first hitting read minimizer per (target, strand).
+// hist/first live in global scratch (2 * T words each), zeroed / set to 0xFFFFFFFF by the host.
+// =====================================================================================================
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+              const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
+              const uint32_t* __restrict__ post, const uint8_t* __restrict__ valid, uint32_t* __restrict__ hist,
+              uint32_t* __restrict__ first)
+{
+    const uint32_t T = L + uint32_t(j);
+    const int lane = lane_id();
+    const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6;
+    const uint32_t nw = (gridDim.x * IOC_BLOCK) >> 6;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
+        const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
+        for (int64_t c0 = b + int64_t(gw) * 64; c0 < e; c0 += int64_t(nw) * 64) {
+            int64_t t = c0 + lane;
+            uint32_t o = 0, c = 0;
+            if (t < e) index_lookup(rows, cap, shift, mins[t], o, c);
+            unsigned long long mask = __ballot(c != 0);
+            while (mask) {
+                int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                uint32_t lo = __builtin_amdgcn_readlane(o, l);
+                uint32_t lc = __builtin_amdgcn_readlane(c, l);
+                uint32_t idx = uint32_t(c0 + l - b);
+                for (uint32_t p = lane; p < lc; p += 64) {
+                    uint32_t tg = post[lo + p];
+                    if (tg < T && (tg < L || valid[tg - L])) {
+                        atomicAdd(&hist[uint32_t(s) * T + tg], 1u);
+                        atomicMin(&first[uint32_t(s) * T + tg], idx);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+#define CK(x)                     \
+    do {                          \
+        hipError_t e_ = (x);      \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+
+extern "C" {
+
+hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
+                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax)
+{
+    if (n <= 0) return hipSuccess;
+    size_t lds = size_t(pmax) * 4;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_distinct, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_distinct, dim3(n), dim3(IOC_BLOCK), lds, st, n, off_fwd, mins, doff, dvals, dcount, pmax);
+    return hipGetLastError();
+}
+
+hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
+                                    const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
+                                    uint32_t* cnt, uint32_t* dslot, uint32_t* err)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hash_insert_queries, dim3(n), dim3(IOC_BLOCK), 0, st, n, doff, dvals, dcount, keys, cap,
+                       shift, cnt, dslot, err);
+    return hipGetLastError();
+}
+
+hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* lkeys, const int64_t* loffs,
+                                 uint32_t* keys, uint32_t cap, uint32_t shift, uint32_t* cnt, uint32_t* lslot,
+                                 uint32_t* err)
+{
+    if (nkeys <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hash_insert_left, dim3((unsigned)((nkeys + IOC_BLOCK - 1) / IOC_BLOCK)), dim3(IOC_BLOCK), 0,
+                       st, nkeys, lkeys, loffs, keys, cap, shift, cnt, lslot, err);
+    return hipGetLastError();
+}
+
+// exclusive scan of in[0..n) into out[0..n], out[n] = total. scratch: ceil(n/1024)+1 words.
+hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch)
+{
+    if (n <= 0) return hipSuccess;
+    int64_t nb = (n + IOC_SCAN_ELEMS - 1) / IOC_SCAN_ELEMS;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(IOC_BLOCK), 0, st, in, n, scratch);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(IOC_BLOCK), 0, st, scratch, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(IOC_BLOCK), 0, st, in, n, scratch, out);
+    return hipGetLastError();
+}
+
+hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
+                          const uint32_t* lslot, const uint32_t* off, uint32_t* fill, uint32_t* post)
+{
+    if (nkeys <= 0) return hipSuccess;
+    int64_t threads = nkeys * 64;
+    hipLaunchKernelGGL(k_fill_left, dim3((unsigned)((threads + IOC_BLOCK - 1) / IOC_BLOCK)), dim3(IOC_BLOCK), 0, st,
+                       nkeys, loffs, lpost, lslot, off, fill, post);
+    return hipGetLastError();
+}
+
+hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
+                             const uint32_t* dslot, const uint32_t* off, uint32_t* fill, uint32_t* post)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_queries, dim3(n), dim3(IOC_BLOCK), 0, st, n, L, doff, dcount, dslot, off, fill, post);
+    return hipGetLastError();
+}
+
+hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
+                           uint32_t L, uint32_t n, uint32_t nblocks)
+{
+    uint32_t words = (n + 31) / 32;
+    if (words == 0) words = 1;
+    size_t lds = size_t(IOC_WAVES) * words * 4;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_sort_lists, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_sort_lists, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt, post, L, words);
+    return hipGetLastError();
+}
+
+hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
+                          const uint32_t* cnt, void* rows)
+{
+    hipLaunchKernelGGL(k_pack_rows, dim3((nslots + IOC_BLOCK - 1) / IOC_BLOCK), dim3(IOC_BLOCK), 0, st, nslots, keys,
+                       off, cnt, (uint4*)rows);
+    return hipGetLastError();
+}
+
+hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
+                      const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
+                      uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
+                      unsigned long long* traversed)
+{
+    if (n <= 0) return hipSuccess;
+    uint32_t tmax = L + uint32_t(n - 1);
+    uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
+    size_t lds = size_t(2) * r * 4;
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(k_score, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins, (const uint4*)rows,
+                       cap, shift, post, range, keep, cand_key, cand_size, cand_count, traversed);
+    return hipGetLastError();
+}
+
+hipError_t iock_decide(hipStream_t st, const void* args_, int nblocks)
+{
+    if (nblocks <= 0) return hipSuccess;
+    DecideArgs a = *reinterpret_cast<const DecideArgs*>(args_);
+    hipLaunchKernelGGL(k_decide, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout)
+{
+    if (first <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_prefix_valid, dim3((first + IOC_BLOCK - 1) / IOC_BLOCK), dim3(IOC_BLOCK), 0, st, first,
+                       vin, vout);
+    return hipGetLastError();
+}
+
+hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
+                            const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
+                            const uint8_t* valid, uint32_t* hist, uint32_t* first)
+{
+    hipLaunchKernelGGL(k_query_table, dim3(64), dim3(IOC_BLOCK), 0, st, j, L, off_fwd, off_rev, mins,
+                       (const uint4*)rows, cap, shift, post, valid, hist, first);
+    return hipGetLastError();
+}
+
+size_t iock_decide_args_size() { return sizeof(DecideArgs); }
+
+}  // extern "C"

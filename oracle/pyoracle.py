@@ -1,0 +1,327 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so) and of oracle/_ref.
+
+TEST INFRASTRUCTURE: importable only from tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke().  Nothing under isonclust2_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PMIN_BIN = os.path.join(os.path.dirname(HERE), "isonclust2_amd", "data", "pmin_shared.bin")
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("min_shared", C.c_int32),
+                ("min_cls_size", C.c_int32), ("mode", C.c_int32), ("cons_max_size", C.c_int32),
+                ("min_qual", C.c_double), ("mapped_threshold", C.c_double),
+                ("aligned_threshold", C.c_double), ("min_fraction", C.c_double),
+                ("min_prob_no_hits", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("probes", "postings", "mapped_calls", "queries",
+                                          "new_clusters", "joins", "index_appends", "aln_invoked",
+                                          "tie_reads")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+MODE = {"sahlin": 0, "fast": 1, "furious": 2, "none": 3}
+
+
+def default_params(k=11, w=15, mode="fast"):
+    """Defaults of CmdArgs (src/args.h:9-37)."""
+    return Params(k=k, w=w, min_shared=5, min_cls_size=3, mode=MODE[mode], cons_max_size=-150,
+                  min_qual=7.0, mapped_threshold=0.65, aligned_threshold=0.2, min_fraction=0.8,
+                  min_prob_no_hits=0.1)
+
+
+def build(force=False):
+    so = os.path.join(HERE, "liboracle.so")
+    src = os.path.join(HERE, "oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
+    u32p, i32p, dp, cp = C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_char_p
+    L.orc_hpc.argtypes = [cp, cp, i32, cp, cp]
+    L.orc_revcomp.argtypes = [cp, i32, cp]
+    L.orc_kmer_encode.argtypes = [cp, i32, i32, u32p]
+    L.orc_minimizers.argtypes = [u32p, i32, i32, i32, u32p, u32p, u32p]
+    L.orc_qual_tab.argtypes = [i32, dp]
+    L.orc_qual_score.argtypes = [cp, i32, i32]
+    L.orc_qual_score.restype = C.c_double
+    L.orc_error_rate.argtypes = [cp, i32, i32]
+    L.orc_error_rate.restype = C.c_double
+    L.orc_round.argtypes = [C.c_double, i32]
+    L.orc_round.restype = C.c_double
+    L.orc_pmin_table.argtypes = [cp, i32, i32, dp]
+    L.orc_pmin_lookup.argtypes = [dp, C.c_double, C.c_double, i32p]
+    L.orc_pmin_lookup.restype = C.c_double
+    L.orc_gap_limit.argtypes = [C.c_double, C.c_double]
+    L.orc_kmer_to_index.argtypes = [cp, i32]
+    L.orc_kmer_to_index.restype = C.c_uint32
+    L.orc_index_to_kmer.argtypes = [C.c_uint32, i32, cp]
+    L.orc_minmatch.argtypes = [cp, cp, i32, cp, cp, i32, i32, i32, cp, C.c_double, u32p, dp, dp]
+    L.orc_reads_new.argtypes = [cp, cp, i64p, i32]
+    L.orc_reads_new.restype = vp
+    L.orc_reads_free.argtypes = [vp]
+    L.orc_reads_score_sort.argtypes = [vp, i32, i32]
+    L.orc_reads_n.argtypes = [vp]
+    L.orc_reads_order.argtypes = [vp, i32p, dp, dp]
+    L.orc_batch_prepare.argtypes = [vp, i32, i32, C.POINTER(Params), i32]
+    L.orc_batch_prepare.restype = vp
+    L.orc_batch_free.argtypes = [vp]
+    L.orc_batch_n_entries.argtypes = [vp]
+    L.orc_batch_entry_info.argtypes = [vp, i32p, i32p, i32p, i32p, dp, dp, dp, i32p, i32p]
+    L.orc_batch_entry_mins.argtypes = [vp, i32, i32, u32p, u32p, u32p]
+    L.orc_batch_entry_hpc.argtypes = [vp, i32, cp, cp]
+    L.orc_cluster.argtypes = [vp, vp, C.POINTER(Params), cp, C.POINTER(Stats)]
+    L.orc_batch_n_clusters.argtypes = [vp]
+    L.orc_batch_n_members.argtypes = [vp]
+    L.orc_batch_members.argtypes = [vp, i32p, i32p, i32p, i32p]
+    L.orc_batch_index.argtypes = [vp, u32p, i64p, u32p, i64p]
+    L.orc_batch_index.restype = C.c_int64
+    L.orc_set_aligner.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ---- thin numpy-level helpers -------------------------------------------------------------
+def hpc(seq: bytes, qual: bytes):
+    o1, o2 = C.create_string_buffer(len(seq) + 1), C.create_string_buffer(len(seq) + 1)
+    n = lib().orc_hpc(seq, qual, len(seq), o1, o2)
+    return o1.raw[:n], o2.raw[:n]
+
+
+def revcomp(seq: bytes):
+    o = C.create_string_buffer(len(seq) + 1)
+    if lib().orc_revcomp(seq, len(seq), o) != 0:
+        raise ValueError("invalid base")
+    return o.raw[:len(seq)]
+
+
+def kmer_encode(seq: bytes, k: int):
+    out = np.zeros(max(len(seq), 1), np.uint32)
+    n = lib().orc_kmer_encode(seq, len(seq), k, _p(out, C.c_uint32))
+    return out[:n].copy()
+
+
+def minimizers(kmers: np.ndarray, k: int, w: int):
+    kmers = np.ascontiguousarray(kmers, np.uint32)
+    n = len(kmers)
+    a, b, c = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+    m = lib().orc_minimizers(_p(kmers, C.c_uint32), n, k, w, _p(a, C.c_uint32), _p(b, C.c_uint32),
+                             _p(c, C.c_uint32))
+    return a[:m].copy(), b[:m].copy(), c[:m].copy()
+
+
+def qual_score(qual: bytes, k: int):
+    return lib().orc_qual_score(qual, len(qual), k)
+
+
+def error_rate(qual: bytes, nomin=True):
+    return lib().orc_error_rate(qual, len(qual), 1 if nomin else 0)
+
+
+def pmin_table(k, w, path=PMIN_BIN):
+    t = np.zeros(225, np.float64)
+    n = lib().orc_pmin_table(path.encode(), k, w, _p(t, C.c_double))
+    if n < 0:
+        raise IOError(path)
+    return t.reshape(15, 15), n
+
+
+def pmin_lookup(tab, e1, e2):
+    tab = np.ascontiguousarray(tab, np.float64).reshape(-1)
+    err = C.c_int32(0)
+    r = lib().orc_pmin_lookup(_p(tab, C.c_double), e1, e2, C.byref(err))
+    if err.value:
+        raise KeyError((e1, e2))
+    return r
+
+
+class ReadSet:
+    """FillQualScores + SortByQualScores over a list of (seq, qual) byte strings."""
+
+    def __init__(self, seqs, quals):
+        offs = np.zeros(len(seqs) + 1, np.int64)
+        offs[1:] = np.cumsum([len(s) for s in seqs])
+        self._s, self._q = b"".join(seqs), b"".join(quals)
+        self._offs = offs
+        self.h = lib().orc_reads_new(self._s, self._q, _p(offs, C.c_int64), len(seqs))
+
+    @classmethod
+    def from_flat(cls, seq_flat: np.ndarray, qual_flat: np.ndarray, offs: np.ndarray):
+        self = cls.__new__(cls)
+        self._s, self._q = seq_flat.tobytes(), qual_flat.tobytes()
+        self._offs = np.ascontiguousarray(offs, np.int64)
+        self.h = lib().orc_reads_new(self._s, self._q, _p(self._offs, C.c_int64), len(offs) - 1)
+        return self
+
+    def score_sort(self, k, w):
+        lib().orc_reads_score_sort(self.h, k, w)
+
+    def order(self):
+        n = lib().orc_reads_n(self.h)
+        o, s, e = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.float64)
+        lib().orc_reads_order(self.h, _p(o, C.c_int32), _p(s, C.c_double), _p(e, C.c_double))
+        return o, s, e
+
+    def __len__(self):
+        return lib().orc_reads_n(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_reads_free(self.h)
+            self.h = None
+
+
+class Batch:
+    def __init__(self, reads: ReadSet, start, end, params: Params, batch_nr=0):
+        self.params = params
+        self.h = lib().orc_batch_prepare(reads.h, start, end, C.byref(params), batch_nr)
+        if not self.h:
+            raise ValueError("PrepareSortedBatch failed (non-ACGT base)")
+
+    def n_entries(self):
+        return lib().orc_batch_n_entries(self.h)
+
+    def entry_info(self):
+        n = self.n_entries()
+        i32 = lambda: np.zeros(n, np.int32)
+        f64 = lambda: np.zeros(n, np.float64)
+        d = dict(state=i32(), orig=i32(), raw_len=i32(), hpc_len=i32(), score=f64(), raw_err=f64(),
+                 hpc_err=f64(), n_fwd=i32(), n_rev=i32())
+        lib().orc_batch_entry_info(self.h, _p(d["state"], C.c_int32), _p(d["orig"], C.c_int32),
+                                   _p(d["raw_len"], C.c_int32), _p(d["hpc_len"], C.c_int32),
+                                   _p(d["score"], C.c_double), _p(d["raw_err"], C.c_double),
+                                   _p(d["hpc_err"], C.c_double), _p(d["n_fwd"], C.c_int32),
+                                   _p(d["n_rev"], C.c_int32))
+        return d
+
+    def entry_mins(self, i, strand, n):
+        a, b, c = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+        m = lib().orc_batch_entry_mins(self.h, i, strand, _p(a, C.c_uint32), _p(b, C.c_uint32),
+                                       _p(c, C.c_uint32))
+        return a[:m], b[:m], c[:m]
+
+    def entry_hpc(self, i, n):
+        a, b = C.create_string_buffer(n + 1), C.create_string_buffer(n + 1)
+        m = lib().orc_batch_entry_hpc(self.h, i, a, b)
+        return a.raw[:m], b.raw[:m]
+
+    def minimizer_soa(self):
+        """Flat SoA of all entries' minimizers: (info, off_fwd, off_rev, min, pos); fwd lists first."""
+        info = self.entry_info()
+        n = self.n_entries()
+        nf, nr = info["n_fwd"].astype(np.int64), info["n_rev"].astype(np.int64)
+        off_f = np.zeros(n + 1, np.int64)
+        off_f[1:] = np.cumsum(nf)
+        off_r = np.zeros(n + 1, np.int64)
+        off_r[1:] = np.cumsum(nr)
+        off_r += off_f[-1]
+        tot = int(off_r[-1])
+        mn, ps = np.zeros(tot, np.uint32), np.zeros(tot, np.uint32)
+        for i in range(n):
+            for s, off, cnt in ((0, off_f, nf), (1, off_r, nr)):
+                if cnt[i]:
+                    a, b, c = self.entry_mins(i, s, int(cnt[i]))
+                    assert np.array_equal(c, np.arange(len(c), dtype=np.uint32))
+                    mn[off[i]:off[i] + cnt[i]] = a
+                    ps[off[i]:off[i] + cnt[i]] = b
+        return info, off_f, off_r, mn, ps
+
+    def cluster(self, right=None, mode="fast", min_cls_size=-1, stats=True, path=PMIN_BIN):
+        p = Params.from_buffer_copy(self.params)
+        p.mode = MODE[mode]
+        p.min_cls_size = min_cls_size
+        st = Stats()
+        rc = lib().orc_cluster(self.h, right.h if right is not None else None, C.byref(p),
+                               path.encode(), C.byref(st) if stats else None)
+        if rc != 0:
+            raise RuntimeError(f"orc_cluster failed: {rc}")
+        return st.as_dict()
+
+    def members(self):
+        n = lib().orc_batch_n_members(self.h)
+        a, b, c, d = (np.zeros(max(n, 1), np.int32) for _ in range(4))
+        m = lib().orc_batch_members(self.h, _p(a, C.c_int32), _p(b, C.c_int32), _p(c, C.c_int32),
+                                    _p(d, C.c_int32))
+        return a[:m], b[:m], c[:m], d[:m]
+
+    def n_clusters(self):
+        return lib().orc_batch_n_clusters(self.h)
+
+    def assignments(self, n_reads):
+        """(cls, strand) per original read index; -1/0 for reads in no cluster."""
+        cls, orig, strand, is_rep = self.members()
+        acl = np.full(n_reads, -1, np.int32)
+        ast = np.zeros(n_reads, np.int32)
+        keep = is_rep == 0
+        acl[orig[keep]] = cls[keep]
+        ast[orig[keep]] = strand[keep]
+        return acl, ast
+
+    def index(self):
+        np_ = C.c_int64(0)
+        nk = lib().orc_batch_index(self.h, None, None, None, C.byref(np_))
+        keys = np.zeros(max(nk, 1), np.uint32)
+        offs = np.zeros(nk + 1, np.int64)
+        post = np.zeros(max(np_.value, 1), np.uint32)
+        lib().orc_batch_index(self.h, _p(keys, C.c_uint32), _p(offs, C.c_int64), _p(post, C.c_uint32),
+                              C.byref(np_))
+        return keys[:nk], offs, post[:np_.value]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_batch_free(self.h)
+            self.h = None
+
+
+# ---- oracle/_ref (reference TUs compiled where they lie; build container only) ------------------------
+_ref = None
+
+
+def ref():
+    """Returns the ctypes handle of oracle/_ref/libisonref.so, or None if it was never built."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    so = os.path.join(HERE, "_ref", "libisonref.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    R.ref_kmer_encode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    R.ref_kmer_to_index.argtypes = [C.c_char_p, C.c_int]
+    R.ref_kmer_to_index.restype = C.c_uint32
+    R.ref_index_to_kmer.argtypes = [C.c_uint32, C.c_int, C.c_char_p]
+    R.ref_revcomp.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    R.ref_round.argtypes = [C.c_double, C.c_int]
+    R.ref_round.restype = C.c_double
+    R.ref_pmin_init.argtypes = [C.c_int, C.c_int]
+    R.ref_pmin_init.restype = C.c_void_p
+    R.ref_pmin_size.argtypes = [C.c_void_p]
+    R.ref_pmin_free.argtypes = [C.c_void_p]
+    R.ref_pmin_lookup.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    R.ref_pmin_lookup.restype = C.c_double
+    _ref = R
+    return R
