@@ -136,6 +136,46 @@ class Context:
                                           _p(offs, C.c_int64), _p(post, C.c_uint32)))
         return keys[:nk.value], offs, post[:npost.value]
 
+    # ---- sort-stage feeders --------------------------------------------------------------------
+    def qual_scores(self, offs, qual, k):
+        """CalcQualScore / CalcErrorRate per read (src/qualscore.cpp:14-37, 107-154)."""
+        offs = np.ascontiguousarray(offs, np.int64)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        n = len(offs) - 1
+        score, err = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        self._chk(self.L.ioc_qual_scores(self.h, n, _p(offs, C.c_int64), _p(qual, C.c_uint8), k,
+                                         _p(score, C.c_double), _p(err, C.c_double)))
+        return score, err
+
+    def extract_minimizers(self, offs, seq, qual, k, w):
+        """HomopolymerCompress + KmerEncodeSeq + GetKmerMinimizers on both strands
+        (src/qualscore.cpp:39-105); the minimizers stay on the device."""
+        offs = np.ascontiguousarray(offs, np.int64)
+        seq = np.ascontiguousarray(seq, np.uint8)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        n = len(offs) - 1
+        hpc_len, hpc_err = np.zeros(n, np.uint32), np.zeros(n, np.float64)
+        off_fwd, off_rev = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        status = np.zeros(n, np.int32)
+        self._chk(self.L.ioc_extract_minimizers(self.h, n, _p(offs, C.c_int64), _p(seq, C.c_uint8),
+                                                _p(qual, C.c_uint8), k, w, _p(hpc_len, C.c_uint32),
+                                                _p(hpc_err, C.c_double), _p(off_fwd, C.c_int64),
+                                                _p(off_rev, C.c_int64), _p(status, C.c_int32)))
+        return dict(hpc_len=hpc_len, hpc_err=hpc_err, off_fwd=off_fwd, off_rev=off_rev, status=status)
+
+    def extracted_download(self, total):
+        mn, ps = np.zeros(max(total, 1), np.uint32), np.zeros(max(total, 1), np.uint32)
+        self._chk(self.L.ioc_extracted_download(self.h, _p(mn, C.c_uint32), _p(ps, C.c_uint32), len(mn)))
+        return mn[:total], ps[:total]
+
+    def queries_from_extracted(self, keep, err_cell, min_total):
+        keep = np.ascontiguousarray(keep, np.uint8)
+        err_cell = np.ascontiguousarray(err_cell, np.uint8)
+        min_total = np.ascontiguousarray(min_total, np.uint32)
+        self._chk(self.L.ioc_queries_from_extracted(self.h, _p(keep, C.c_uint8), _p(err_cell, C.c_uint8),
+                                                    _p(min_total, C.c_uint32)))
+        self.n = len(keep)
+
     def timings(self):
         t = Timings()
         self._chk(self.L.ioc_get_timings(self.h, C.byref(t)))

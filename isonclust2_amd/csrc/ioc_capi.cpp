@@ -102,7 +102,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -337,6 +337,7 @@ int ioc_index_build(ioc_ctx* c)
 
     RESERVE(c, c->b_dvals, size_t(nfwd_total) * 4);
     RESERVE(c, c->b_dslot, size_t(nfwd_total) * 4);
+    RESERVE(c, c->b_fill, size_t(nfwd_total) * 4);  // position of each distinct value inside its posting list
     RESERVE(c, c->b_dcount, size_t(n) * 4);
     RESERVE(c, c->b_misc, 256);
     HIPCHK(c, iock_distinct(s, n, c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals),
@@ -364,12 +365,11 @@ int ioc_index_build(ioc_ctx* c)
         RESERVE(c, c->b_keys, size_t(nslots) * 4);
         RESERVE(c, c->b_cnt, size_t(nslots + 1) * 4);
         RESERVE(c, c->b_off, size_t(nslots + 1) * 4);
-        RESERVE(c, c->b_fill, size_t(nslots + 1) * 4);
         RESERVE(c, c->b_rows, size_t(nslots) * 16);
+        RESERVE(c, c->b_qinfo, size_t(nslots) * 4);
         RESERVE(c, c->b_scan, (size_t(nslots) / 1024 + 4) * 4);
         HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(nslots) * 4, s));
         HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(nslots + 1) * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->b_fill.p, 0, size_t(nslots + 1) * 4, s));
         HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
         uint32_t* d_err = P<uint32_t>(c->b_misc);
         HIPCHK(c, iock_hash_insert_left(s, c->n_left_keys, P<uint32_t>(c->b_lkeys), P<int64_t>(c->b_loffs),
@@ -377,7 +377,8 @@ int ioc_index_build(ioc_ctx* c)
                                         P<uint32_t>(c->b_lslot), d_err));
         HIPCHK(c, iock_hash_insert_queries(s, n, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals),
                                            P<uint32_t>(c->b_dcount), P<uint32_t>(c->b_keys), cap, shift,
-                                           P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_dslot), d_err));
+                                           P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_fill),
+                                           d_err));
         HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan)));
         uint32_t h_err = 0, h_total = 0;
         HIPCHK(c, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s));
@@ -392,15 +393,14 @@ int ioc_index_build(ioc_ctx* c)
         c->n_post = h_total;
         RESERVE(c, c->b_post, size_t(h_total) * 4 + 256);
         HIPCHK(c, iock_fill_left(s, c->n_left_keys, P<int64_t>(c->b_loffs), P<uint32_t>(c->b_lpost),
-                                 P<uint32_t>(c->b_lslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_fill),
-                                 P<uint32_t>(c->b_post)));
+                                 P<uint32_t>(c->b_lslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_post)));
         HIPCHK(c, iock_fill_queries(s, n, uint32_t(c->L), P<int64_t>(c->b_doff), P<uint32_t>(c->b_dcount),
-                                    P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_fill),
+                                    P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_fill), P<uint32_t>(c->b_off),
                                     P<uint32_t>(c->b_post)));
         HIPCHK(c, iock_sort_lists(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_post),
-                                  uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048));
+                                  uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048, P<uint32_t>(c->b_qinfo)));
         HIPCHK(c, iock_pack_rows(s, nslots, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt),
-                                 c->b_rows.p));
+                                 P<uint32_t>(c->b_qinfo), c->b_rows.p));
         break;
     }
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -542,26 +542,40 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.n_evals = d_evals;
     a.min_shared = c->params.min_shared;
     a.min_fraction = c->params.min_fraction;
-    int first = 0, iters = 0;
+    // misc layout (uint32 words): [8] first_changed, [9] q_count, [10] incomplete
+    const uint32_t q_cap = env_u32("IOC_QUEUE_CAP", 1u << 20);
+    RESERVE(c, c->b_queue, size_t(q_cap) * 8);
+    RESERVE(c, c->b_cut, size_t(n) * 4);
+    a.cut = P<int32_t>(c->b_cut);
+    a.q_items = P<uint32_t>(c->b_queue);
+    a.q_count = P<uint32_t>(c->b_misc) + 9;
+    a.q_cap = q_cap;
+    a.incomplete = P<uint32_t>(c->b_misc) + 10;
+    const int eval_blocks = int(env_u32("IOC_EVAL_BLOCKS", 256 * 4));
+    int first = 0, iters = 0, sweeps = 0;
     while (first < n) {
         uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
         uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
-        HIPCHK(c, hipMemsetAsync(d_first_changed, 0xFF, 4, s));
+        const uint32_t init[3] = {0xFFFFFFFFu, 0u, 0u};
+        HIPCHK(c, hipMemcpyAsync(d_first_changed, init, 12, hipMemcpyHostToDevice, s));
         HIPCHK(c, iock_copy_prefix_valid(s, first, vin, vout));
         a.first = first;
         a.valid_in = vin;
         a.valid_out = vout;
-        HIPCHK(c, iock_decide(s, &a, n - first));
-        uint32_t fc = 0;
-        HIPCHK(c, hipMemcpyAsync(&fc, d_first_changed, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, iock_decide_sweep(s, &a, n - first, eval_blocks));
+        uint32_t res[3] = {0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(res, d_first_changed, 12, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        sweeps++;
+        if (sweeps > 4 * n + 64) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
+        if (res[2] != 0) continue;  // work queue overflowed: same sweep again, the cache is fuller now
         iters++;
         c->cur_valid ^= 1;
+        const uint32_t fc = res[0];
         if (fc == 0xFFFFFFFFu) break;  // fixed point: valid_out == valid_in
         // queries <= fc are final: fc was computed from a correct prefix, everything before it
         // did not change ("fixed point of the greedy loop")
         first = int(fc) + 1;
-        if (iters > n + 2) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
     }
     HIPCHK(c, hipEventRecord(c->ev[5], s));
     unsigned long long ev = 0;

@@ -60,13 +60,13 @@ struct ioc_ctx {
 
     // ---- scoring ----
     bool scored = false;
-    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count;
+    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo;
     int64_t cand_capacity = 0;
 
     // ---- resolve ----
     bool resolved = false;
     DevBuf b_valid0, b_valid1, b_dec_target, b_dec_strand, b_flags, b_forced_t, b_forced_s, b_misc,
-        b_glim;
+        b_glim, b_queue, b_cut;
     int cur_valid = 0;
     std::vector<int32_t> h_forced_t;
     std::vector<int8_t> h_forced_s;
@@ -79,6 +79,7 @@ struct ioc_ctx {
     std::vector<int64_t> xh_off_fwd, xh_off_rev;
     std::vector<uint32_t> xh_hpc_len;
     std::vector<int32_t> xh_status;
+    std::vector<uint8_t> x_keep;
 
     // ---- instrumentation ----
     hipEvent_t ev[6]{};

@@ -42,6 +42,11 @@ struct DecideArgs {
     unsigned long long* n_evals;
     int min_shared;
     double min_fraction;
+    int32_t* cut;           // per query: cut of the candidate walk, INT32_MAX = no walk
+    uint32_t* q_items;      // work queue of (query, candidate index) pairs awaiting k_eval
+    uint32_t* q_count;
+    uint32_t q_cap;
+    uint32_t* incomplete;   // queries whose walk met a candidate that is not evaluated yet
 };
 
 extern "C" {
@@ -49,24 +54,24 @@ hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const ui
                          uint32_t* dvals, uint32_t* dcount, uint32_t pmax);
 hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
                                     const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
-                                    uint32_t* cnt, uint32_t* dslot, uint32_t* err);
+                                    uint32_t* cnt, uint32_t* dslot, uint32_t* dpos, uint32_t* err);
 hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* lkeys, const int64_t* loffs,
                                  uint32_t* keys, uint32_t cap, uint32_t shift, uint32_t* cnt, uint32_t* lslot,
                                  uint32_t* err);
 hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch);
 hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
-                          const uint32_t* lslot, const uint32_t* off, uint32_t* fill, uint32_t* post);
+                          const uint32_t* lslot, const uint32_t* off, uint32_t* post);
 hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
-                             const uint32_t* dslot, const uint32_t* off, uint32_t* fill, uint32_t* post);
+                             const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, uint32_t* post);
 hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
-                           uint32_t L, uint32_t n, uint32_t nblocks);
+                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo);
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
-                          const uint32_t* cnt, void* rows);
+                          const uint32_t* cnt, const uint32_t* qinfo, void* rows);
 hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                       const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
                       unsigned long long* traversed);
-hipError_t iock_decide(hipStream_t st, const void* args, int nblocks);
+hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks);
 hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout);
 hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
@@ -83,7 +88,7 @@ hipError_t iock_hpc_error(hipStream_t st, int n, const int64_t* offs, const uint
 hipError_t iock_minimizers(hipStream_t st, int n, const int64_t* offs, const uint8_t* hseq, const uint32_t* hlen,
                            const int32_t* status, int k, int w, int pass, const int64_t* off_fwd,
                            const int64_t* off_rev, uint32_t* cnt_fwd, uint32_t* cnt_rev, uint32_t* omin,
-                           uint32_t* opos);
+                           uint32_t* opos, uint32_t max_hlen);
 }
 
 #endif

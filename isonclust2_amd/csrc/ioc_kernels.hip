@@ -11,7 +11,8 @@
 // k_fill_*          RepSet::emplace_back, src/minimizer.cpp:38-40
 // k_score           GetMinimizerHits + ConsolidateMinimizerHits + Size of SortMinimizerHits,
 //                   src/minimizer.cpp:44-76, src/cluster.cpp:609-636
-// k_decide          getBestClusterMapping + getMappedRatio, src/cluster.cpp:324-406
+// k_decide_scan / k_eval / k_decide_pick
+//                   getBestClusterMapping + getMappedRatio, src/cluster.cpp:324-406
 // k_query_table     the full hit map of one query (tie replay), src/minimizer.cpp:44-76
 #include <hip/hip_runtime.h>
 
@@ -22,6 +23,8 @@
 #define IOC_BLOCK 256
 #define IOC_WAVES (IOC_BLOCK / 64)
 #define IOC_EMPTY 0xFFFFFFFFu
+#define IOC_FLAT_UNROLL 8
+#define IOC_SHORT_LIST 192
 
 namespace {
 
@@ -35,12 +38,13 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t v, uint32_t shift)
 
 // Lookup in the packed rows (key, off, cnt, -) — one 16-byte load per probe step.
 __device__ __forceinline__ bool index_lookup(const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
-                                             uint32_t v, uint32_t& off, uint32_t& cnt)
+                                             uint32_t v, uint32_t& off, uint32_t& cnt, uint32_t& info)
 {
     if (v == IOC_EMPTY) {
         uint4 r = rows[cap];
         off = r.y;
         cnt = r.z;
+        info = r.w;
         return cnt != 0;
     }
     uint32_t h = hash_slot(v, shift);
@@ -49,6 +53,7 @@ __device__ __forceinline__ bool index_lookup(const uint4* __restrict__ rows, uin
         if (r.x == v) {
             off = r.y;
             cnt = r.z;
+            info = r.w;
             return true;
         }
         if (r.x == IOC_EMPTY) return false;
@@ -182,7 +187,7 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_hash_insert_queries(int n, const int64_t* __restrict__ doff, const uint32_t* __restrict__ dvals,
                       const uint32_t* __restrict__ dcount, uint32_t* __restrict__ keys, uint32_t cap,
                       uint32_t shift, uint32_t* __restrict__ cnt, uint32_t* __restrict__ dslot,
-                      uint32_t* __restrict__ err)
+                      uint32_t* __restrict__ dpos, uint32_t* __restrict__ err)
 {
     int j = blockIdx.x;
     if (j >= n) return;
@@ -190,13 +195,15 @@ k_hash_insert_queries(int n, const int64_t* __restrict__ doff, const uint32_t* _
     uint32_t m = dcount[j];
     for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) {
         uint32_t slot = hash_insert(keys, cap, shift, dvals[b + d]);
+        uint32_t pos = 0;
         if (slot > cap) {
             atomicAdd(err, 1u);
             slot = cap;
         } else {
-            atomicAdd(&cnt[slot], 1u);
+            pos = atomicAdd(&cnt[slot], 1u);  // position inside the posting list (after the left part)
         }
         dslot[b + d] = slot;
+        dpos[b + d] = pos;
     }
 }
 
@@ -284,8 +291,7 @@ k_scan_apply(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restr
 // ---- fill ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_fill_left(int64_t nkeys, const int64_t* __restrict__ loffs, const uint32_t* __restrict__ lpost,
-            const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ off, uint32_t* __restrict__ fill,
-            uint32_t* __restrict__ post)
+            const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ off, uint32_t* __restrict__ post)
 {
     // one wave per key
     int64_t key = (int64_t(blockIdx.x) * IOC_BLOCK + threadIdx.x) >> 6;
@@ -295,22 +301,19 @@ k_fill_left(int64_t nkeys, const int64_t* __restrict__ loffs, const uint32_t* __
     uint32_t m = uint32_t(loffs[key + 1] - b);
     uint32_t o = off[slot];
     for (uint32_t t = lane_id(); t < m; t += 64) post[o + t] = lpost[b + t];
-    if (lane_id() == 0) fill[slot] = m;
 }
 
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32_t* __restrict__ dcount,
-               const uint32_t* __restrict__ dslot, const uint32_t* __restrict__ off,
-               uint32_t* __restrict__ fill, uint32_t* __restrict__ post)
+               const uint32_t* __restrict__ dslot, const uint32_t* __restrict__ dpos,
+               const uint32_t* __restrict__ off, uint32_t* __restrict__ post)
 {
     int j = blockIdx.x;
     if (j >= n) return;
     int64_t b = doff[j];
     uint32_t m = dcount[j];
     for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) {
-        uint32_t slot = dslot[b + d];
-        uint32_t p = atomicAdd(&fill[slot], 1u);
-        post[off[slot] + p] = L + uint32_t(j);
+        post[off[dslot[b + d]] + dpos[b + d]] = L + uint32_t(j);
     }
 }
 
@@ -320,7 +323,8 @@ k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32
 // (the query part holds distinct integers in [L, L+n)).
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-             uint32_t* __restrict__ post, uint32_t L, uint32_t words_per_wave)
+             uint32_t* __restrict__ post, uint32_t L, uint32_t words_per_wave, uint32_t e1, uint32_t e2,
+             uint32_t e3, uint32_t* __restrict__ qinfo)
 {
     extern __shared__ uint32_t sbits[];  // IOC_WAVES * words_per_wave
     const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6;  // global wave id
@@ -329,6 +333,28 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
     uint32_t* bits = sbits + size_t(wave_id()) * words_per_wave;
     for (uint32_t slot = gw; slot < nslots; slot += nw) {
         const uint32_t c = cnt[slot];
+        // epoch boundaries: number of entries below the target ids e1 < e2 < e3, 10 bits each
+        // (lists of >= 1024 entries get 0x80000000: k_score falls back to a binary search)
+        {
+            uint32_t info = 0x80000000u;
+            if (c < 1024) {
+                const uint32_t o0 = off[slot];
+                uint32_t b1 = 0, b2 = 0, b3 = 0;
+                for (uint32_t t = lane; t < c; t += 64) {
+                    const uint32_t v = post[o0 + t];
+                    b1 += v < e1;
+                    b2 += v < e2;
+                    b3 += v < e3;
+                }
+                for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                    b1 += __shfl_down(b1, o2);
+                    b2 += __shfl_down(b2, o2);
+                    b3 += __shfl_down(b3, o2);
+                }
+                info = b1 | (b2 << 10) | (b3 << 20);
+            }
+            if (lane == 0) qinfo[slot] = info;
+        }
         if (c < 2) continue;
         const uint32_t o = off[slot];
         // the left part (values < L) was copied first and is already ascending: it is a prefix by position
@@ -377,38 +403,62 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
 
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_pack_rows(uint32_t nslots, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off,
-            const uint32_t* __restrict__ cnt, uint4* __restrict__ rows)
+            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ qinfo, uint4* __restrict__ rows)
 {
     uint32_t s = blockIdx.x * IOC_BLOCK + threadIdx.x;
     if (s >= nslots) return;
-    rows[s] = make_uint4(keys[s], off[s], cnt[s], 0u);
+    rows[s] = make_uint4(keys[s], off[s], cnt[s], qinfo[s]);
 }
 
 // =====================================================================================================
 // k_score — the dominant kernel.  One workgroup per query j (heaviest first).  LDS holds the dense
-// histogram Size[strand][target] over the visible targets t < L + j (in passes of `range` targets);
-// each wave probes 64 minimizer occurrences at a time (one per lane) and then walks the 64 posting
-// lists cooperatively (64 postings per step, coalesced), counting with LDS atomics.  Lists are
-// ascending, so a walk stops at the first step whose lowest lane is already >= L + j.
+// histogram Size[strand][target] over the visible targets t < L + j (in passes of `range` targets).
+// Each wave takes 64 minimizer occurrences at a time, one per lane:
+//   (1) hash probe  -> posting list (off, cnt)                        [64 independent loads in flight]
+//   (2) lower_bound -> the part of the ascending list inside the visible window
+//   (3) wave prefix sum of the 64 effective lengths, lists compacted into per-wave LDS scratch
+//   (4) flattened traversal: lane x of step s owns posting s*64+x of the concatenation, finds its
+//       list by a 6-step search over the prefix sums, loads the posting (independent of every other
+//       step -> deep memory-level parallelism, all lanes busy) and counts it with an LDS atomic.
 // Output: compacted candidate list (target<<1|strandbit, Size) for Size >= keep, ordered by
 // (strand, target) — deterministic.
 // =====================================================================================================
+__device__ __forceinline__ uint32_t list_lower_bound(const uint32_t* __restrict__ p, uint32_t n, uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (p[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
         const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
         const uint32_t* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
-        unsigned long long* __restrict__ traversed)
+        unsigned long long* __restrict__ traversed, uint32_t e1, uint32_t e2, uint32_t e3)
 {
     extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
+    __shared__ uint32_t sx[IOC_WAVES][64];  // exclusive prefix of effective lengths (compacted lists)
+    __shared__ uint32_t so[IOC_WAVES][64];  // start offset in post[] of each compacted list
     const int j = n - 1 - int(blockIdx.x);
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);  // visible targets: [0, T)
+    // first epoch boundary >= T: its position field in the row info (30 = none: whole list)
+    const uint32_t eshift = T <= e1 ? 0u : T <= e2 ? 10u : T <= e3 ? 20u : 30u;
     const int lane = lane_id(), wave = wave_id();
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     uint32_t written = 0;
     unsigned long long trav = 0;
+    uint32_t* const wx = sx[wave];
+    uint32_t* const wo = so[wave];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (uint32_t rbase = 0; rbase < T; rbase += range) {
         const uint32_t Tr = (T - rbase < range) ? (T - rbase) : range;
@@ -419,26 +469,73 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
             const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
             const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
             uint32_t* h = hist + uint32_t(s) * Tr;
+            // software pipelining: the hash probe of the next chunk is issued before this chunk's
+            // postings are traversed
+            uint32_t o_nx = 0, c_nx = 0, q_nx = 0;
+            {
+                const int64_t t = b + wave * 64 + lane;
+                if (t < e) index_lookup(rows, cap, shift, mins[t], o_nx, c_nx, q_nx);
+            }
             for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
-                int64_t t = c0 + lane;
-                uint32_t o = 0, c = 0;
-                if (t < e) index_lookup(rows, cap, shift, mins[t], o, c);
-                unsigned long long mask = __ballot(c != 0);
-                while (mask) {
-                    int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    uint32_t lo = __builtin_amdgcn_readlane(o, l);
-                    uint32_t lc = __builtin_amdgcn_readlane(c, l);
-                    for (uint32_t p = 0; p < lc; p += 64) {
-                        uint32_t q = p + lane;
-                        uint32_t tg = (q < lc) ? post[lo + q] : IOC_EMPTY;
-                        if (tg >= rbase && tg < hi) atomicAdd(&h[tg - rbase], 1u);
-                        trav += (q < lc);
-                        // ascending list: once the first lane of this step is past the window, stop
-                        uint32_t first = __builtin_amdgcn_readfirstlane(tg);
-                        if (first >= hi) break;
+                uint32_t o = o_nx, len = c_nx;
+                const uint32_t qi = q_nx;
+                {
+                    const int64_t t = c0 + IOC_WAVES * 64 + lane;
+                    o_nx = 0;
+                    c_nx = 0;
+                    q_nx = 0;
+                    if (t < e) index_lookup(rows, cap, shift, mins[t], o_nx, c_nx, q_nx);
+                }
+                // Visible part of the ascending list.  Single pass (the common case): the row carries
+                // the list positions of three epoch boundaries, so the list is cut at the first
+                // boundary >= T without touching it; the few entries in [T, boundary) are rejected by
+                // the window test below.  Long lists and range passes pay a binary search.
+                if (len) {
+                    if (rbase == 0 && hi == T && !(qi & 0x80000000u)) {
+                        if (eshift < 30) len = (qi >> eshift) & 1023u;
+                    } else {
+                        const uint32_t* pl = post + o;
+                        const uint32_t i0 = rbase ? list_lower_bound(pl, len, rbase) : 0u;
+                        const uint32_t i1 = list_lower_bound(pl, len, hi);
+                        len = i1 - i0;
+                        o += i0;
                     }
                 }
+                const unsigned long long nz = __ballot(len != 0);
+                const uint32_t nl = uint32_t(__popcll(nz));
+                if (nl == 0) continue;
+                const uint32_t incl = wave_incl_scan(len);
+                const uint32_t total = __shfl(incl, 63);
+                if (len) {
+                    const uint32_t r = uint32_t(__popcll(nz & lt_mask));
+                    wx[r] = incl - len;
+                    wo[r] = o;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t p0 = lane; p0 < total; p0 += 64 * IOC_FLAT_UNROLL) {
+                    uint32_t r[IOC_FLAT_UNROLL], tg[IOC_FLAT_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < IOC_FLAT_UNROLL; ++u) r[u] = 0;
+#pragma unroll
+                    for (uint32_t hh = 32; hh > 0; hh >>= 1) {
+#pragma unroll
+                        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+                            const uint32_t r2 = r[u] + hh;
+                            if (r2 < nl && wx[r2] <= p0 + 64u * u) r[u] = r2;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+                        const uint32_t p = p0 + 64u * u;
+                        tg[u] = (p < total) ? post[wo[r[u]] + (p - wx[r[u]])] : IOC_EMPTY;
+                    }
+#pragma unroll
+                    for (int u = 0; u < IOC_FLAT_UNROLL; ++u)
+                        if (tg[u] < hi) atomicAdd(&h[tg[u] - rbase], 1u);  // ascending list: entries >= hi are not visible
+                }
+                trav += total;
+                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
@@ -466,7 +563,7 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
             bool f = (i < w1) && (v >= keep);
             unsigned long long bm = __ballot(f);
             if (f) {
-                uint32_t pos = wbase + __popcll(bm & ((1ull << lane) - 1ull));
+                uint32_t pos = wbase + __popcll(bm & lt_mask);
                 uint32_t strandbit = (i >= Tr) ? 1u : 0u;
                 uint32_t tg = rbase + (strandbit ? i - Tr : i);
                 cand_key[cbase + pos] = (tg << 1) | strandbit;
@@ -478,143 +575,40 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
         __syncthreads();
     }
     if (threadIdx.x == 0) cand_count[j] = written;
-    if (traversed) {
-        for (int o = 32; o > 0; o >>= 1) trav += __shfl_down(trav, o);
-        if (lane == 0) atomicAdd(traversed, trav);
-    }
+    if (traversed && lane == 0) atomicAdd(traversed, trav);
 }
 
 // =====================================================================================================
-// k_decide — one workgroup per query.  Given the current guess of which queries open clusters
-// (valid_in), walk the query's candidate list exactly as getBestClusterMapping does:
-//   top = max Size over candidates that ARE clusters;  top < MinShared -> new cluster;
-//   cut = int(double(top) * MinFraction);  evaluate every candidate with int(Size) >= cut;
-//   winner = passing candidate of maximal Size (the first passing one in descending-Size order).
-// totalMapped of a (query, target, strand) is decision-independent and cached in cand_mapped.
+// Resolve: getBestClusterMapping + getMappedRatio (src/cluster.cpp:324-406) for every query, given
+// the current guess of which queries open clusters (valid_in).  Three wide kernels per sweep:
+//   k_decide_scan  per query: top = max Size over candidates that ARE clusters; top < MinShared ->
+//                  new cluster; cut = int(double(top) * MinFraction); every cluster candidate with
+//                  int(Size) >= cut whose totalMapped is not cached yet goes to a global work queue;
+//   k_eval         one workgroup per queued (query, candidate): totalMapped (decision-independent,
+//                  cached in cand_mapped);
+//   k_decide_pick  per query: winner = passing candidate of maximal Size (= the first passing one
+//                  in descending-Size order); >= 2 passing at that Size -> order-dependent tie flag.
 // =====================================================================================================
-#define IOC_MAX_SURV IOC_BLOCK
-#define IOC_BITWORDS 1024  // 65536 minimizers per strand per pass
-
-// totalMapped of query minimizers (qmin,qpos)[0..M) against the sorted value set `set`
-// (src/cluster.cpp:324-353 with the pow() predicate replaced by the integer gap limit).
-__device__ uint32_t eval_total_mapped(const uint32_t* __restrict__ qmin, const uint32_t* __restrict__ qpos,
-                                      uint32_t M, const uint32_t* __restrict__ set, uint32_t setN, uint32_t limEx,
-                                      uint32_t hpcLen, unsigned long long* bits, uint32_t* red)
-{
-    const int lane = lane_id(), wave = wave_id();
-    uint32_t total = 0;
-    // carry across passes of 65536 minimizers: index of the last hit so far (or none)
-    __shared__ uint32_t carry_last;
-    __shared__ uint32_t carry_any;
-    if (threadIdx.x == 0) {
-        carry_any = 0;
-        carry_last = 0;
-    }
-    __syncthreads();
-    for (uint32_t pbase = 0; pbase < M; pbase += IOC_BITWORDS * 64) {
-        uint32_t Mp = (M - pbase < IOC_BITWORDS * 64) ? (M - pbase) : IOC_BITWORDS * 64;
-        uint32_t nwords = (Mp + 63) >> 6;
-        // phase A: hit bitmap, one 64-bit word per wave step (coalesced reads of qmin)
-        for (uint32_t wd = wave; wd < nwords; wd += IOC_WAVES) {
-            uint32_t i = pbase + wd * 64 + lane;
-            bool hit = (i < M) && sorted_contains(set, setN, qmin[i]);
-            unsigned long long m = __ballot(hit);
-            if (lane == 0) bits[wd] = m;
-        }
-        __syncthreads();
-        // phase B: one thread per word; gaps between consecutive hits
-        uint32_t local = 0;
-        uint32_t had_any = carry_any, had_last = carry_last;
-        for (uint32_t wd = threadIdx.x; wd < nwords; wd += IOC_BLOCK) {
-            unsigned long long m = bits[wd];
-            if (!m) continue;
-            // previous hit: look back through earlier words, then the carry
-            bool pany = false;
-            uint32_t pidx = 0;
-            for (int x = int(wd) - 1; x >= 0; --x) {
-                unsigned long long pm = bits[x];
-                if (pm) {
-                    pany = true;
-                    pidx = pbase + uint32_t(x) * 64 + (63 - __builtin_clzll(pm));
-                    break;
-                }
-            }
-            if (!pany && had_any) {
-                pany = true;
-                pidx = had_last;
-            }
-            while (m) {
-                uint32_t bit = __builtin_ctzll(m);
-                m &= m - 1;
-                uint32_t i = pbase + wd * 64 + bit;
-                if (!pany) {
-                    if (i < limEx) local += qpos[i];  // pow(pError, hits[0].Index) >= p0
-                } else {
-                    if (i - pidx - 1 < limEx) local += qpos[i] - qpos[pidx];
-                }
-                pany = true;
-                pidx = i;
-            }
-        }
-        // block reduce of `local`
-        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
-        if (lane == 0) red[wave] = local;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t sum = 0;
-            for (int w = 0; w < IOC_WAVES; ++w) sum += red[w];
-            red[IOC_WAVES] = sum;
-            // update carry: last hit of this pass
-            for (int x = int(nwords) - 1; x >= 0; --x) {
-                unsigned long long pm = bits[x];
-                if (pm) {
-                    carry_any = 1;
-                    carry_last = pbase + uint32_t(x) * 64 + (63 - __builtin_clzll(pm));
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        total += red[IOC_WAVES];
-        __syncthreads();
-    }
-    // tail: pow(pError, nMins - (lastIdx + 1)) >= p0
-    uint32_t any = carry_any, last = carry_last;
-    if (any && (M - last - 1 < limEx)) total += hpcLen - qpos[last];
-    __syncthreads();
-    return total;
-}
+#define IOC_CUT_NEG INT32_MAX
+#define IOC_BITWORDS 1024   // 65536 minimizers per strand per pass
+#define IOC_SET_LDS 8192    // target value sets up to this size are staged in LDS (32 KiB)
+#define IOC_EVAL_ILP 4
 
 __global__ void __launch_bounds__(IOC_BLOCK)
-k_decide(DecideArgs a)
+k_decide_scan(DecideArgs a)
 {
-    __shared__ unsigned long long bits[IOC_BITWORDS];
-    __shared__ uint32_t red[IOC_WAVES + 1];
-    __shared__ uint32_t surv[IOC_MAX_SURV];
-    __shared__ uint32_t wsum[IOC_WAVES];
+    __shared__ uint32_t red[IOC_WAVES];
     __shared__ uint32_t s_top;
-    __shared__ uint32_t bestSize, bestEntry, bestCount;
     const int j = a.first + int(blockIdx.x);
     if (j >= a.n) return;
     const int lane = lane_id(), wave = wave_id();
     const uint32_t L = a.L;
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     const uint32_t C = a.cand_count[j];
-
-    int32_t ft = a.forced_t ? a.forced_t[j] : INT32_MIN;
-    if (ft != INT32_MIN) {
-        if (threadIdx.x == 0) {
-            uint8_t nv = (ft == -1) ? 1 : 0;  // -1 opens a cluster; -2 = excluded entry (gated)
-            a.dec_target[j] = ft;
-            a.dec_strand[j] = (ft < 0) ? 0 : a.forced_s[j];
-            a.flags[j] = 0;
-            a.valid_out[j] = nv;
-            if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
-        }
+    if (a.forced_t[j] != INT32_MIN) {
+        if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
         return;
     }
-
-    // ---- top over candidates that are clusters --------------------------------------------------
     uint32_t top = 0;
     for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
         uint32_t tg = a.cand_key[cbase + c] >> 1;
@@ -627,11 +621,6 @@ k_decide(DecideArgs a)
         top = t > top ? t : top;
     }
     if (lane == 0) red[wave] = top;
-    if (threadIdx.x == 0) {
-        bestSize = 0;
-        bestEntry = 0xFFFFFFFFu;
-        bestCount = 0;
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
@@ -640,88 +629,300 @@ k_decide(DecideArgs a)
     }
     __syncthreads();
     top = s_top;
+    if (top < uint32_t(a.min_shared)) {
+        if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
+        return;
+    }
+    const int cut = int(double(top) * a.min_fraction);
+    if (threadIdx.x == 0) a.cut[j] = cut;
+    for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
+        const uint32_t c = c0 + threadIdx.x;
+        bool f = false;
+        if (c < C) {
+            uint32_t tg = a.cand_key[cbase + c] >> 1;
+            bool ok = (tg < L) || a.valid_in[tg - L];
+            f = ok && (int(a.cand_size[cbase + c]) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
+        }
+        const unsigned long long bm = __ballot(f);
+        if (bm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.q_count, uint32_t(__popcll(bm)));
+            base = __shfl(base, 0);
+            if (f) {
+                uint32_t slot = base + uint32_t(__popcll(bm & ((1ull << lane) - 1ull)));
+                if (slot < a.q_cap) {
+                    a.q_items[2 * size_t(slot)] = uint32_t(j);
+                    a.q_items[2 * size_t(slot) + 1] = c;
+                }
+            }
+        }
+    }
+}
+
+// totalMapped of one (query, target, strand): src/cluster.cpp:324-353 with the pow() predicate
+// replaced by the integer gap limit (a gap of n missing minimizers passes iff n < limEx).
+// LDS copy of a sorted set is stored skewed (one pad word per 32) so that the power-of-two strides of
+// the binary search do not land on one bank.
+#define IOC_SKEW(i) ((i) + ((i) >> 5))
+template <bool SET_IN_LDS>
+__device__ __forceinline__ uint32_t set_at(const uint32_t* set, uint32_t i)
+{
+    return SET_IN_LDS ? set[IOC_SKEW(i)] : set[i];
+}
+
+template <bool SET_IN_LDS>
+__device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict__ qmin,
+                                                      const uint32_t* __restrict__ qpos, uint32_t M,
+                                                      const uint32_t* set, uint32_t setN, uint32_t limEx,
+                                                      uint32_t hpcLen, unsigned long long* bits, uint32_t* red,
+                                                      uint32_t* carry)
+{
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t total = 0;
+    if (threadIdx.x == 0) {
+        carry[0] = 0;  // any hit so far
+        carry[1] = 0;  // index of the last hit so far
+    }
+    uint32_t hp2 = 1;
+    while ((hp2 << 1) <= setN) hp2 <<= 1;
+    if (setN == 0) hp2 = 0;
+    __syncthreads();
+    for (uint32_t pbase = 0; pbase < M; pbase += IOC_BITWORDS * 64) {
+        const uint32_t Mp = (M - pbase < IOC_BITWORDS * 64) ? (M - pbase) : IOC_BITWORDS * 64;
+        const uint32_t nwords = (Mp + 63) >> 6;
+        // phase A: hit bitmap; IOC_EVAL_ILP independent branchless searches per lane
+        for (uint32_t wd0 = wave * IOC_EVAL_ILP; wd0 < nwords; wd0 += IOC_WAVES * IOC_EVAL_ILP) {
+            uint32_t v[IOC_EVAL_ILP], pos[IOC_EVAL_ILP];
+            bool in[IOC_EVAL_ILP];
+#pragma unroll
+            for (int u = 0; u < IOC_EVAL_ILP; ++u) {
+                const uint32_t i = pbase + (wd0 + u) * 64 + lane;
+                in[u] = (wd0 + u < nwords) && (i < M);
+                v[u] = in[u] ? qmin[i] : 0u;
+                pos[u] = 0;
+            }
+            for (uint32_t h = hp2; h > 0; h >>= 1) {
+#pragma unroll
+                for (int u = 0; u < IOC_EVAL_ILP; ++u) {
+                    const uint32_t q = pos[u] + h;
+                    if (q <= setN && set_at<SET_IN_LDS>(set, q - 1) < v[u]) pos[u] = q;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IOC_EVAL_ILP; ++u) {
+                const bool hit = in[u] && pos[u] < setN && set_at<SET_IN_LDS>(set, pos[u]) == v[u];
+                const unsigned long long m = __ballot(hit);
+                if (lane == 0 && wd0 + u < nwords) bits[wd0 + u] = m;
+            }
+        }
+        __syncthreads();
+        // phase B: one thread per minimizer index (coalesced reads of qpos); the previous hit is
+        // the highest set bit below i: same word, else an earlier word, else the carry of the
+        // previous pass.
+        uint32_t local = 0;
+        const uint32_t had_any = carry[0], had_last = carry[1];
+        for (uint32_t ii = threadIdx.x; ii < Mp; ii += IOC_BLOCK) {
+            const uint32_t wd = ii >> 6, bit = ii & 63u;
+            const unsigned long long m = bits[wd];
+            if (!((m >> bit) & 1ull)) continue;
+            const uint32_t i = pbase + ii;
+            bool pany = false;
+            uint32_t pidx = 0;
+            const unsigned long long below = m & ((1ull << bit) - 1ull);
+            if (below) {
+                pany = true;
+                pidx = pbase + wd * 64 + uint32_t(63 - __builtin_clzll(below));
+            } else {
+                for (int x = int(wd) - 1; x >= 0; --x) {
+                    const unsigned long long pm = bits[x];
+                    if (pm) {
+                        pany = true;
+                        pidx = pbase + uint32_t(x) * 64 + uint32_t(63 - __builtin_clzll(pm));
+                        break;
+                    }
+                }
+                if (!pany && had_any) {
+                    pany = true;
+                    pidx = had_last;
+                }
+            }
+            if (!pany) {
+                if (i < limEx) local += qpos[i];  // pow(pError, hits[0].Index) >= p0
+            } else if (i - pidx - 1 < limEx) {
+                local += qpos[i] - qpos[pidx];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+        if (lane == 0) red[wave] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) sum += red[w];
+            red[IOC_WAVES] = sum;
+            for (int x = int(nwords) - 1; x >= 0; --x) {
+                const unsigned long long pm = bits[x];
+                if (pm) {
+                    carry[0] = 1;
+                    carry[1] = pbase + uint32_t(x) * 64 + uint32_t(63 - __builtin_clzll(pm));
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        total += red[IOC_WAVES];
+        __syncthreads();
+    }
+    // tail: pow(pError, nMins - (lastIdx + 1)) >= p0
+    const uint32_t any = carry[0], last = carry[1];
+    if (any && (M - last - 1 < limEx)) total += hpcLen - qpos[last];
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_eval(DecideArgs a)
+{
+    __shared__ unsigned long long bits[IOC_BITWORDS];
+    __shared__ uint32_t sset[IOC_SET_LDS + IOC_SET_LDS / 32 + 1];
+    __shared__ uint32_t red[IOC_WAVES + 1];
+    __shared__ uint32_t carry[2];
+    uint32_t count = *a.q_count;
+    if (count > a.q_cap) count = a.q_cap;
+    const uint32_t L = a.L;
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint32_t j = a.q_items[2 * size_t(w)];
+        const uint32_t c = a.q_items[2 * size_t(w) + 1];
+        const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
+        const uint32_t key = a.cand_key[cbase + c];
+        const uint32_t tg = key >> 1;
+        const int strandbit = int(key & 1u);
+        const uint32_t* set;
+        uint32_t setN;
+        int ecl;
+        if (tg < L) {
+            set = a.lset_val + a.lset_off[tg];
+            setN = uint32_t(a.lset_off[tg + 1] - a.lset_off[tg]);
+            ecl = int(a.left_err[tg]) - 1;
+        } else {
+            set = a.dvals + a.doff[tg - L];
+            setN = a.dcount[tg - L];
+            ecl = int(a.err_cell[tg - L]) - 1;
+        }
+        const int ecr = int(a.err_cell[j]) - 1;
+        const uint32_t limEx = uint32_t(a.glim[ecl * 15 + ecr] + 1);  // gap n passes iff n < limEx
+        const int64_t qb = strandbit ? a.off_rev[j] : a.off_fwd[j];
+        const uint32_t M = uint32_t((strandbit ? a.off_rev[j + 1] : a.off_fwd[j + 1]) - qb);
+        uint32_t tm;
+        if (setN <= IOC_SET_LDS) {
+            for (uint32_t i = threadIdx.x; i < setN; i += IOC_BLOCK) sset[IOC_SKEW(i)] = set[i];
+            __syncthreads();
+            tm = eval_total_mapped<true>(a.mins + qb, a.pos + qb, M, sset, setN, limEx, a.hpc_len[j], bits, red, carry);
+        } else {
+            tm = eval_total_mapped<false>(a.mins + qb, a.pos + qb, M, set, setN, limEx, a.hpc_len[j], bits, red, carry);
+        }
+        if (threadIdx.x == 0) {
+            a.cand_mapped[cbase + c] = tm;
+            if (a.n_evals) atomicAdd(a.n_evals, 1ull);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_decide_pick(DecideArgs a)
+{
+    __shared__ uint32_t rs[IOC_WAVES], re[IOC_WAVES], rc[IOC_WAVES];
+    const int j = a.first + int(blockIdx.x);
+    if (j >= a.n) return;
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t L = a.L;
+    const int32_t ft = a.forced_t[j];
+    if (ft != INT32_MIN) {
+        if (threadIdx.x == 0) {
+            uint8_t nv = (ft == -1) ? 1 : 0;  // -1 opens a cluster; -2 = excluded entry (gated)
+            a.dec_target[j] = ft;
+            a.dec_strand[j] = (ft < 0) ? 0 : a.forced_s[j];
+            a.flags[j] = 0;
+            a.valid_out[j] = nv;
+            if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
+        }
+        return;
+    }
+    const int cut = a.cut[j];
     int32_t out_t = -1;
     int8_t out_s = 0;
     uint8_t out_f = 0;
-    if (top >= uint32_t(a.min_shared)) {
-        const int cut = int(double(top) * a.min_fraction);
-        const uint32_t nf = uint32_t(a.off_fwd[j + 1] - a.off_fwd[j]);
-        const uint32_t nr = uint32_t(a.off_rev[j + 1] - a.off_rev[j]);
-        const uint32_t hl = a.hpc_len[j];
+    if (cut != IOC_CUT_NEG) {
+        const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
+        const uint32_t C = a.cand_count[j];
         const uint32_t need = a.min_total[j];
-        const int ecr = int(a.err_cell[j]) - 1;
-        // candidates are visited in slices of IOC_BLOCK (one per thread); the survivors of a slice
-        // (clusters with int(Size) >= cut) are evaluated one after the other by the whole block
-        for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
-            const uint32_t cc = c0 + threadIdx.x;
-            bool f = false;
-            if (cc < C) {
-                uint32_t tg = a.cand_key[cbase + cc] >> 1;
-                bool ok = (tg < L) || a.valid_in[tg - L];
-                f = ok && (int(a.cand_size[cbase + cc]) >= cut);
+        uint32_t bs = 0, be = 0xFFFFFFFFu, bc = 0;
+        bool missing = false;
+        for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
+            const uint32_t tg = a.cand_key[cbase + c] >> 1;
+            const bool ok = (tg < L) || a.valid_in[tg - L];
+            const uint32_t sz = a.cand_size[cbase + c];
+            if (!ok || int(sz) < cut) continue;
+            const uint32_t tm = a.cand_mapped[cbase + c];
+            if (tm == 0xFFFFFFFFu) {
+                missing = true;
+                continue;
             }
-            unsigned long long bm = __ballot(f);
-            if (lane == 0) wsum[wave] = uint32_t(__popcll(bm));
-            __syncthreads();
-            uint32_t wb = 0, ns = 0;
-            for (int w = 0; w < IOC_WAVES; ++w) {
-                if (w < wave) wb += wsum[w];
-                ns += wsum[w];
-            }
-            if (f) surv[wb + uint32_t(__popcll(bm & ((1ull << lane) - 1ull)))] = cc;
-            __syncthreads();
-            for (uint32_t sidx = 0; sidx < ns; ++sidx) {
-                const uint32_t c = surv[sidx];
-                const uint32_t key = a.cand_key[cbase + c];
-                const uint32_t tg = key >> 1;
-                const int strandbit = int(key & 1u);
-                uint32_t tm = a.cand_mapped[cbase + c];
-                if (tm == 0xFFFFFFFFu) {
-                    const uint32_t* set;
-                    uint32_t setN;
-                    int ecl;
-                    if (tg < L) {
-                        set = a.lset_val + a.lset_off[tg];
-                        setN = uint32_t(a.lset_off[tg + 1] - a.lset_off[tg]);
-                        ecl = int(a.left_err[tg]) - 1;
-                    } else {
-                        set = a.dvals + a.doff[tg - L];
-                        setN = a.dcount[tg - L];
-                        ecl = int(a.err_cell[tg - L]) - 1;
-                    }
-                    const uint32_t limEx = uint32_t(a.glim[ecl * 15 + ecr] + 1);  // gap n passes iff n < limEx
-                    const int64_t qb = strandbit ? a.off_rev[j] : a.off_fwd[j];
-                    const uint32_t M = strandbit ? nr : nf;
-                    tm = eval_total_mapped(a.mins + qb, a.pos + qb, M, set, setN, limEx, hl, bits, red);
-                    if (threadIdx.x == 0) {
-                        a.cand_mapped[cbase + c] = tm;
-                        if (a.n_evals) atomicAdd(a.n_evals, 1ull);
-                    }
-                }
-                if (threadIdx.x == 0 && tm >= need) {
-                    uint32_t sz = a.cand_size[cbase + c];
-                    if (sz > bestSize) {
-                        bestSize = sz;
-                        bestEntry = c;
-                        bestCount = 1;
-                    } else if (sz == bestSize) {
-                        bestCount++;
-                    }
+            if (tm >= need) {
+                if (sz > bs) {
+                    bs = sz;
+                    be = c;
+                    bc = 1;
+                } else if (sz == bs) {
+                    bc++;
+                    be = c < be ? c : be;
                 }
             }
-            __syncthreads();
         }
-        if (bestEntry != 0xFFFFFFFFu) {
-            uint32_t key = a.cand_key[cbase + bestEntry];
-            out_t = int32_t(key >> 1);
-            out_s = (key & 1u) ? -1 : 1;
-            if (bestCount > 1) out_f |= 1;
-        } else {
-            out_f |= 2;  // no mapping hit although top >= MinShared (cluster.cpp:553-566)
+        if (__ballot(missing) && lane == 0) atomicAdd(a.incomplete, 1u);
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t os = __shfl_down(bs, o), oe = __shfl_down(be, o), oc = __shfl_down(bc, o);
+            if (os > bs) {
+                bs = os;
+                be = oe;
+                bc = oc;
+            } else if (os == bs) {
+                bc += oc;
+                be = oe < be ? oe : be;
+            }
+        }
+        if (lane == 0) {
+            rs[wave] = bs;
+            re[wave] = be;
+            rc[wave] = bc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bs = 0;
+            be = 0xFFFFFFFFu;
+            bc = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) {
+                if (rs[w] > bs) {
+                    bs = rs[w];
+                    be = re[w];
+                    bc = rc[w];
+                } else if (rs[w] == bs) {
+                    bc += rc[w];
+                    be = re[w] < be ? re[w] : be;
+                }
+            }
+            if (bs > 0 && be != 0xFFFFFFFFu) {
+                const uint32_t key = a.cand_key[cbase + be];
+                out_t = int32_t(key >> 1);
+                out_s = (key & 1u) ? -1 : 1;
+                if (bc > 1) out_f |= 1;
+            } else {
+                out_f |= 2;  // no mapping hit although top >= MinShared (cluster.cpp:553-566)
+            }
         }
     }
     if (threadIdx.x == 0) {
-        uint8_t nv = (out_t < 0) ? 1 : 0;
+        const uint8_t nv = (out_t < 0) ? 1 : 0;
         a.dec_target[j] = out_t;
         a.dec_strand[j] = out_s;
         a.flags[j] = out_f;
@@ -757,8 +958,8 @@ k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int6
         const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
         for (int64_t c0 = b + int64_t(gw) * 64; c0 < e; c0 += int64_t(nw) * 64) {
             int64_t t = c0 + lane;
-            uint32_t o = 0, c = 0;
-            if (t < e) index_lookup(rows, cap, shift, mins[t], o, c);
+            uint32_t o = 0, c = 0, qi_ = 0;
+            if (t < e) index_lookup(rows, cap, shift, mins[t], o, c, qi_);
             unsigned long long mask = __ballot(c != 0);
             while (mask) {
                 int l = __builtin_ctzll(mask);
@@ -801,11 +1002,11 @@ hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const ui
 
 hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
                                     const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
-                                    uint32_t* cnt, uint32_t* dslot, uint32_t* err)
+                                    uint32_t* cnt, uint32_t* dslot, uint32_t* dpos, uint32_t* err)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_hash_insert_queries, dim3(n), dim3(IOC_BLOCK), 0, st, n, doff, dvals, dcount, keys, cap,
-                       shift, cnt, dslot, err);
+                       shift, cnt, dslot, dpos, err);
     return hipGetLastError();
 }
 
@@ -831,39 +1032,49 @@ hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, ui
 }
 
 hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
-                          const uint32_t* lslot, const uint32_t* off, uint32_t* fill, uint32_t* post)
+                          const uint32_t* lslot, const uint32_t* off, uint32_t* post)
 {
     if (nkeys <= 0) return hipSuccess;
     int64_t threads = nkeys * 64;
     hipLaunchKernelGGL(k_fill_left, dim3((unsigned)((threads + IOC_BLOCK - 1) / IOC_BLOCK)), dim3(IOC_BLOCK), 0, st,
-                       nkeys, loffs, lpost, lslot, off, fill, post);
+                       nkeys, loffs, lpost, lslot, off, post);
     return hipGetLastError();
 }
 
 hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
-                             const uint32_t* dslot, const uint32_t* off, uint32_t* fill, uint32_t* post)
+                             const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, uint32_t* post)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_queries, dim3(n), dim3(IOC_BLOCK), 0, st, n, L, doff, dcount, dslot, off, fill, post);
+    hipLaunchKernelGGL(k_fill_queries, dim3(n), dim3(IOC_BLOCK), 0, st, n, L, doff, dcount, dslot, dpos, off, post);
     return hipGetLastError();
 }
 
-hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
-                           uint32_t L, uint32_t n, uint32_t nblocks)
+static void epoch_bounds(uint32_t L, uint32_t n, uint32_t& e1, uint32_t& e2, uint32_t& e3)
 {
+    e1 = L + (n + 3) / 4;
+    e2 = L + (n + 1) / 2;
+    e3 = L + uint32_t((3ull * n + 3) / 4);
+}
+
+hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
+                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo)
+{
+    uint32_t e1, e2, e3;
+    epoch_bounds(L, n, e1, e2, e3);
     uint32_t words = (n + 31) / 32;
     if (words == 0) words = 1;
     size_t lds = size_t(IOC_WAVES) * words * 4;
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_sort_lists, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(k_sort_lists, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt, post, L, words);
+    hipLaunchKernelGGL(k_sort_lists, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt, post, L, words, e1, e2,
+                       e3, qinfo);
     return hipGetLastError();
 }
 
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
-                          const uint32_t* cnt, void* rows)
+                          const uint32_t* cnt, const uint32_t* qinfo, void* rows)
 {
     hipLaunchKernelGGL(k_pack_rows, dim3((nslots + IOC_BLOCK - 1) / IOC_BLOCK), dim3(IOC_BLOCK), 0, st, nslots, keys,
-                       off, cnt, (uint4*)rows);
+                       off, cnt, qinfo, (uint4*)rows);
     return hipGetLastError();
 }
 
@@ -877,16 +1088,20 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
     size_t lds = size_t(2) * r * 4;
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    uint32_t e1, e2, e3;
+    epoch_bounds(L, uint32_t(n), e1, e2, e3);
     hipLaunchKernelGGL(k_score, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins, (const uint4*)rows,
-                       cap, shift, post, range, keep, cand_key, cand_size, cand_count, traversed);
+                       cap, shift, post, range, keep, cand_key, cand_size, cand_count, traversed, e1, e2, e3);
     return hipGetLastError();
 }
 
-hipError_t iock_decide(hipStream_t st, const void* args_, int nblocks)
+hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int eval_blocks)
 {
     if (nblocks <= 0) return hipSuccess;
     DecideArgs a = *reinterpret_cast<const DecideArgs*>(args_);
-    hipLaunchKernelGGL(k_decide, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     return hipGetLastError();
 }
 
