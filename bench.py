@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s clustered on the BASELINE.json config-2 workload (3000 reads / 50 Mb, k=11 w=15,
+fast mode) on N MI355X GPUs of one node.
+
+One "step" = one pass of the hot path over one sorted batch whose minimizer SoA is already resident
+in HBM: index build + shared-minimizer scoring + mapped-ratio resolve + decisions back on the host
+(ioc_cluster_resident).  Batches shard one per GPU with no data-path collective (weak scaling); ranks
+only meet at the timing barrier.  Inputs are synthetic (isonclust2_amd/synth.py, seed = 1 + rank) and
+are prepared by the product's own GPU sort stage (ioc_qual_scores / ioc_extract_minimizers), never by
+the oracle.  The oracle appears only in the cpu_baseline leg (rank 0, N=1): it is timed on the same
+batch on one host core and doubles as a full-size parity check.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def prepare_resident_batch(ctx, api, synth, config, seed, k, w):
+    """raw reads -> GPU quality scores -> stable sort -> GPU HPC/minimizers -> resident queries."""
+    rs = synth.generate_config(config, seed=seed)
+    score, err = ctx.qual_scores(rs.offs, rs.qual, k)                       # FillQualScores
+    order = np.argsort(-score, kind="stable")                               # SortByQualScores
+    lens = np.diff(rs.offs)[order]
+    so = np.zeros(rs.n + 1, np.int64)
+    so[1:] = np.cumsum(lens)
+    starts = rs.offs[:-1][order]
+    idx = np.repeat(starts - so[:-1], lens) + np.arange(so[-1])
+    ex = ctx.extract_minimizers(so, rs.seq[idx], rs.qual[idx], k, w)        # PrepareSortedBatch
+    p = api.default_params(k, w, "fast")
+    ctx.set_params(p)
+    # gates of the clustering loop (src/cluster.cpp:116-160); MinQual default 7.0
+    keep = (ex["status"] == 0) & (score[order] >= 0) & (-10 * np.log10(err[order]) > 7.0)
+    cell = np.array([api.host_err_cell(e) if kp else 1 for e, kp in zip(ex["hpc_err"], keep)], np.uint8)
+    need = np.array([api.host_min_total(h, p.mapped_threshold) if kp else 0xFFFFFFFE
+                     for h, kp in zip(ex["hpc_len"], keep)], np.uint32)
+    ctx.queries_from_extracted(keep, cell, need)
+    ctx.left_load(0, None, None, None, None)
+    return rs, order, int(ex["off_rev"][-1])
+
+
+def cpu_baseline_and_parity(rs, order, cls, strand, k, w):
+    """Oracle (CPU restatement, 1 core) on the SAME batch: timing of the ClusterSortedReads region,
+    exact M/H/C_s counts for the roofline, and a full-size parity check of the GPU result."""
+    from oracle import pyoracle as po
+    from tests.helpers import oracle_sorted_batch
+    B, view = oracle_sorted_batch(rs, k, w)
+    assert np.array_equal(view["orig"], order), "sort order differs from the oracle's"
+    t0 = time.perf_counter()
+    st = B.cluster(mode="fast", stats=True)
+    dt = time.perf_counter() - t0
+    acl, ast = B.assignments(rs.n)
+    ocl, ost = acl[view["orig"]], ast[view["orig"]]
+    mism = int(np.count_nonzero((ocl != cls) | (ost != strand)))
+    return dt, st, mism
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="config2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    k, w = 11, 15
+
+    import torch
+    from isonclust2_amd import api, synth
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ctx = api.Context(local_rank)
+    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(a.warmup):
+        cls, strand, st = ctx.cluster_resident()
+    barrier()
+    ms_score = ms_build = ms_resolve = 0.0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cls, strand, st = ctx.cluster_resident()
+        tm = ctx.timings()          # HIP events recorded on the launch stream around each phase
+        ms_score += tm["ms_score"]
+        ms_build += tm["ms_build"]
+        ms_resolve += tm["ms_resolve"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nreads = torch.tensor([rs.n], dtype=torch.int64, device=dev)
+        dist.all_reduce(nreads, op=dist.ReduceOp.SUM)
+        total_reads = int(nreads.item())
+    else:
+        total_reads = rs.n
+    ms_score /= a.steps
+    ms_build /= a.steps
+    ms_resolve /= a.steps
+
+    if rank == 0:
+        value = total_reads * a.steps / elapsed
+        cpu = None
+        parity = None
+        M = tm["n_minimizers"]
+        # H = postings the reference's GetMinimizerHits traverses on this batch, counted on the device
+        # from the final clustering (instrumentation launch, untimed); C_s = survivor candidates
+        H = ctx.count_reference_postings()
+        Cs = tm["n_mapped_evals"]
+        h_source = "device count (ioc_count_reference_postings)"
+        if world == 1 and not a.no_cpu_baseline:
+            dt, ost, mism = cpu_baseline_and_parity(rs, order, cls, strand, k, w)
+            cpu = {"value": rs.n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                   "sample": f"the full {a.config} batch ({rs.n} reads), ClusterSortedReads region, oracle -O3 -msse3, 1 run"}
+            parity = {"entries": rs.n, "mismatches": mism, "clusters": st["n_clusters"],
+                      "tie_replays": st["n_tie_replays"], "oracle_postings": ost["postings"],
+                      "device_postings": H}
+            Cs = ost["mapped_calls"]
+            h_source += "; equals the oracle's count" if H == ost["postings"] else "; DIFFERS from the oracle's count"
+        # algorithmic bytes of one scoring launch: 12 B per minimizer probed +
+        # 8 B index row per probe + 4 B per posting traversed + 16 B per surviving candidate
+        alg_bytes = None
+        roof = None
+        if H:
+            alg_bytes = 12 * M + 8 * M + 4 * H + 16 * Cs
+            ach = alg_bytes / (ms_score * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_score", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                    "kernel_ms": ms_score, "counts": {"M": M, "H": H, "C_s": Cs, "H_source": h_source}}
+            tfile = os.path.join(ROOT, "profiles", "k_score_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    roof["traffic"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        out = {
+            "metric": "reads/s clustered (fast mode, k=11 w=15, 3000-read / 50 Mb batch per GPU)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {rs.tag}; one sorted batch per GPU, minimizer SoA resident in HBM",
+                       "mode": "fast", "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
+                       "parallelism": f"batch-shard x{world}, no data-path collective"},
+            "phase_ms": {"index_build": ms_build, "score": ms_score, "resolve": ms_resolve,
+                         "resolve_sweeps": tm["resolve_iters"]},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,10 @@ typedef struct {
     int64_t postings_traversed;/* postings read by ioc_score (if counted)   */
 } ioc_timings;
 int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
+/* Instrumentation (one extra scoring launch, outside any timed region): the number of postings the
+ * reference's GetMinimizerHits would traverse on this batch = sum over queries of Size over the
+ * targets that are clusters — the H of the algorithmic-bytes figure. */
+int ioc_count_reference_postings(ioc_ctx* ctx, int64_t* n_postings);
 
 /* ---- host-side helpers (pure host code, no GPU needed) ----------------------------------------- */
 /* Fill gap_limit[225] and p_shared[225] for (k, w) from the table file (isonclust2_amd/data/
@@ -193,7 +197,23 @@ typedef struct {
     const double* hpc_err;     /* HpcSeq ErrorRate()   */
     const uint8_t* state;      /* 0 clusterable, 1 null placeholder (skipped, cluster.cpp:125) */
     double min_qual;           /* CmdArgs::MinQual     */
+    /* merge only (right batch already clustered: one record per right cluster, the arrays above
+     * describe its representative, cluster.cpp:537): */
+    const int32_t* n_members;  /* reads[i]->size() - 1; NULL = fresh reads */
+    int32_t depth;             /* right Batch::Depth; the MinClsSize filter applies when > 0 (:119-123) */
+    int32_t min_cls_size;      /* left SortArgs.MinClsSize after the -A override (main.cpp:329-331) */
 } ioc_batch_view;
+
+/* Left batch of a merge (`cluster -l L -r R`): its clusters' representative HPC error rates and the
+ * persisted MinDB as CSR (keys strictly ascending, posting lists strictly ascending cluster ids). */
+typedef struct {
+    int32_t n_clusters;
+    const double* cls_hpc_err; /* [n_clusters] HpcSeq->ErrorRate() of each representative */
+    int64_t n_keys;
+    const uint32_t* keys;
+    const int64_t* offs;       /* [n_keys+1] */
+    const uint32_t* postings;
+} ioc_left_view;
 
 typedef struct {
     int64_t n_clusters;
@@ -208,6 +228,14 @@ typedef struct {
  * out_cls[i] = final cluster id of entry i (-1 if gated), out_strand[i] = MatchStrand after the
  * flips of src/cluster.cpp:235-246 (+1 for entries that open a cluster). */
 int ioc_cluster_batch(ioc_ctx* ctx, const ioc_params* p, const char* table_path,
+                      const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
+                      ioc_cluster_stats* stats);
+/* Merge (`cluster -l L -r R`, src/cluster.cpp:67-322 with both batches real): every right cluster's
+ * representative is a query against the left MinDB; out_cls[i] = left cluster the right cluster i
+ * ends up in (existing id, or a new id >= left->n_clusters in creation order, or -1 if filtered),
+ * out_strand[i] = +1 / -1 (-1: every member's MatchStrand flips, :235-246).  left == NULL is
+ * ioc_cluster_batch.  ioc_index_export afterwards returns the merged MinDB. */
+int ioc_cluster_merge(ioc_ctx* ctx, const ioc_params* p, const char* table_path, const ioc_left_view* left,
                       const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
                       ioc_cluster_stats* stats);
 /* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries

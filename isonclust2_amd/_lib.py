@@ -30,7 +30,14 @@ class BatchView(C.Structure):
                 ("total", C.c_int64), ("raw_len", C.POINTER(C.c_uint32)),
                 ("hpc_len", C.POINTER(C.c_uint32)), ("score", C.POINTER(C.c_double)),
                 ("raw_err", C.POINTER(C.c_double)), ("hpc_err", C.POINTER(C.c_double)),
-                ("state", C.POINTER(C.c_uint8)), ("min_qual", C.c_double)]
+                ("state", C.POINTER(C.c_uint8)), ("min_qual", C.c_double),
+                ("n_members", C.POINTER(C.c_int32)), ("depth", C.c_int32), ("min_cls_size", C.c_int32)]
+
+
+class LeftView(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("cls_hpc_err", C.POINTER(C.c_double)), ("n_keys", C.c_int64),
+                ("keys", C.POINTER(C.c_uint32)), ("offs", C.POINTER(C.c_int64)),
+                ("postings", C.POINTER(C.c_uint32))]
 
 
 class ClusterStats(C.Structure):
@@ -59,8 +66,8 @@ SYMBOLS = [
     "ioc_index_build", "ioc_score", "ioc_resolve", "ioc_get_decisions", "ioc_force_decision",
     "ioc_clear_forced", "ioc_query_candidates", "ioc_index_export", "ioc_qual_scores",
     "ioc_extract_minimizers", "ioc_extracted_download", "ioc_queries_from_extracted",
-    "ioc_get_timings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
-    "ioc_cluster_batch", "ioc_cluster_resident",
+    "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
+    "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident",
 ]
 
 _lib = None
@@ -102,6 +109,7 @@ def load():
     L.ioc_extracted_download.argtypes = [vp, pu32, pu32, i64]
     L.ioc_queries_from_extracted.argtypes = [vp, pu8, pu8, pu32]
     L.ioc_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.ioc_count_reference_postings.argtypes = [vp, pi64]
     L.ioc_host_gap_limits.argtypes = [C.c_char_p, i32, i32, C.c_double, pi32, pd]
     L.ioc_host_err_cell.argtypes = [C.c_double]
     L.ioc_host_err_cell.restype = C.c_uint8
@@ -109,6 +117,8 @@ def load():
     L.ioc_host_min_total.restype = C.c_uint32
     L.ioc_cluster_batch.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(BatchView), pi32, pi8,
                                     C.POINTER(ClusterStats)]
+    L.ioc_cluster_merge.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(LeftView), C.POINTER(BatchView),
+                                    pi32, pi8, C.POINTER(ClusterStats)]
     L.ioc_cluster_resident.argtypes = [vp, pi32, pi8, C.POINTER(ClusterStats)]
     _lib = L
     return L

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import BatchView, ClusterStats, IocError, Params, Timings
+from ._lib import BatchView, ClusterStats, IocError, LeftView, Params, Timings
 
 MODE = {"sahlin": 0, "fast": 1, "furious": 2, "none": 3}
 
@@ -181,6 +181,11 @@ class Context:
         self._chk(self.L.ioc_get_timings(self.h, C.byref(t)))
         return t.as_dict()
 
+    def count_reference_postings(self):
+        h = C.c_int64(0)
+        self._chk(self.L.ioc_count_reference_postings(self.h, C.byref(h)))
+        return h.value
+
     def synchronize(self):
         self._chk(self.L.ioc_synchronize(self.h))
 
@@ -188,6 +193,13 @@ class Context:
     def cluster_batch(self, params: Params, batch: dict, table=_lib.TABLE_PATH):
         """batch: dict with off_fwd, off_rev, min_val, min_pos, raw_len, hpc_len, score, raw_err,
         hpc_err, state, min_qual (the fields of ioc_batch_view).  Returns (cls, strand, stats)."""
+        return self.cluster_merge(params, None, batch, table)
+
+    def cluster_merge(self, params: Params, left, batch: dict, table=_lib.TABLE_PATH):
+        """ClusterSortedReads(left, right).  left: None (initial clustering) or dict with cls_hpc_err,
+        keys, offs, postings (the left clusters' representative error rates + MinDB as CSR).
+        batch: the right batch (ioc_batch_view fields; for a clustered right batch one record per
+        right cluster = its representative, plus n_members / depth / min_cls_size)."""
         arrs = {
             "off_fwd": np.ascontiguousarray(batch["off_fwd"], np.int64),
             "off_rev": np.ascontiguousarray(batch["off_rev"], np.int64),
@@ -201,15 +213,29 @@ class Context:
             "state": np.ascontiguousarray(batch["state"], np.uint8),
         }
         n = len(arrs["off_fwd"]) - 1
+        nm = None
+        if batch.get("n_members") is not None:
+            nm = np.ascontiguousarray(batch["n_members"], np.int32)
         v = BatchView(n=n, off_fwd=_p(arrs["off_fwd"], C.c_int64), off_rev=_p(arrs["off_rev"], C.c_int64),
                       min_val=_p(arrs["min_val"], C.c_uint32), min_pos=_p(arrs["min_pos"], C.c_uint32),
                       total=len(arrs["min_val"]), raw_len=_p(arrs["raw_len"], C.c_uint32),
                       hpc_len=_p(arrs["hpc_len"], C.c_uint32), score=_p(arrs["score"], C.c_double),
                       raw_err=_p(arrs["raw_err"], C.c_double), hpc_err=_p(arrs["hpc_err"], C.c_double),
-                      state=_p(arrs["state"], C.c_uint8), min_qual=float(batch.get("min_qual", 7.0)))
+                      state=_p(arrs["state"], C.c_uint8), min_qual=float(batch.get("min_qual", 7.0)),
+                      n_members=_p(nm, C.c_int32) if nm is not None else None,
+                      depth=int(batch.get("depth", -1)), min_cls_size=int(batch.get("min_cls_size", 3)))
+        lv = None
+        if left is not None:
+            le = np.ascontiguousarray(left["cls_hpc_err"], np.float64)
+            lk = np.ascontiguousarray(left["keys"], np.uint32)
+            lo = np.ascontiguousarray(left["offs"], np.int64)
+            lp = np.ascontiguousarray(left["postings"], np.uint32)
+            lv = LeftView(n_clusters=len(le), cls_hpc_err=_p(le, C.c_double), n_keys=len(lk),
+                          keys=_p(lk, C.c_uint32), offs=_p(lo, C.c_int64), postings=_p(lp, C.c_uint32))
         cls, strand = np.zeros(n, np.int32), np.zeros(n, np.int8)
         st = ClusterStats()
-        self._chk(self.L.ioc_cluster_batch(self.h, C.byref(params), table.encode(), C.byref(v),
+        self._chk(self.L.ioc_cluster_merge(self.h, C.byref(params), table.encode(),
+                                           C.byref(lv) if lv is not None else None, C.byref(v),
                                            _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
         self.n = n
         self.params = params

@@ -452,7 +452,7 @@ int ioc_score(ioc_ctx* c)
     HIPCHK(c, iock_score(s, n, uint32_t(L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         count_trav ? d_trav : nullptr));
+                         count_trav ? d_trav : nullptr, nullptr, nullptr));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
         unsigned long long t = 0;
@@ -735,6 +735,28 @@ int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t*
     return IOC_OK;
 }
 
+int ioc_count_reference_postings(ioc_ctx* c, int64_t* n_postings)
+{
+    if (!c || !n_postings) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    hipStream_t s = c->stream;
+    RESERVE(c, c->b_misc, 256);
+    unsigned long long* d_sum = reinterpret_cast<unsigned long long*>(P<uint8_t>(c->b_misc) + 192);
+    HIPCHK(c, hipMemsetAsync(d_sum, 0, 8, s));
+    const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
+    const uint32_t range = env_u32("IOC_SCORE_RANGE", 8192);
+    HIPCHK(c, iock_score(s, c->n, uint32_t(c->L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
+                         hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
+                         P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
+                         nullptr, valid, d_sum));
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *n_postings = int64_t(h);
+    return IOC_OK;
+}
+
 int ioc_get_timings(ioc_ctx* c, ioc_timings* out)
 {
     if (!c || !out) return IOC_ERR_ARG;
@@ -744,7 +766,7 @@ int ioc_get_timings(ioc_ctx* c, ioc_timings* out)
     if (c->built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_build = ms;
     if (c->scored && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->tm.ms_score = ms;
     if (c->resolved && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->tm.ms_resolve = ms;
-    if (c->scored) {
+    if (c->scored && getenv("IOC_COUNT_CANDIDATES")) {
         std::vector<uint32_t> cc(size_t(c->n) + 1);
         if (c->n) HIPCHK(c, hipMemcpy(cc.data(), c->b_cand_count.p, size_t(c->n) * 4, hipMemcpyDeviceToHost));
         int64_t t = 0;

@@ -277,7 +277,15 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
 int ioc_cluster_batch(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_batch_view* rb,
                       int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
 {
+    return ioc_cluster_merge(c, p, table_path, nullptr, rb, out_cls, out_strand, stats);
+}
+
+int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_left_view* left,
+                      const ioc_batch_view* rb, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+{
     if (!c || !p || !table_path || !rb || !out_cls || !out_strand) return IOC_ERR_ARG;
+    const int32_t L = left ? left->n_clusters : 0;
+    if (L < 0) return ioc_fail(c, IOC_ERR_ARG, "negative left cluster count");
     const int n = rb->n;
     if (n < 0) return ioc_fail(c, IOC_ERR_ARG, "negative batch size");
     int32_t glim[225];
@@ -295,7 +303,9 @@ int ioc_cluster_batch(ioc_ctx* c, const ioc_params* p, const char* table_path, c
     bool compact = false;
     for (int i = 0; i < n; ++i) {
         bool g = false;
-        if (rb->state && rb->state[i] == 1) g = true;                               // null rep
+        if (rb->n_members && rb->depth > 0 && rb->min_cls_size > 1 && rb->n_members[i] < rb->min_cls_size)
+            g = true;                                                               // :119-123
+        else if (rb->state && rb->state[i] == 1) g = true;                          // null rep
         else if (rb->state && rb->state[i] == 2)
             return ioc_fail(c, IOC_ERR_INPUT, "entry without HpcSeq (the reference dereferences null here)");
         else if (rb->score[i] < 0) g = true;                                       // :145
@@ -313,7 +323,7 @@ int ioc_cluster_batch(ioc_ctx* c, const ioc_params* p, const char* table_path, c
         }
     }
     if (p->mode == IOC_MODE_NONE) {
-        int32_t next = 0;
+        int32_t next = L;
         int64_t ng = 0;
         for (int i = 0; i < n; ++i) {
             out_cls[i] = gated[size_t(i)] ? -1 : next++;
@@ -361,7 +371,17 @@ int ioc_cluster_batch(ioc_ctx* c, const ioc_params* p, const char* table_path, c
                                need.data());
     }
     if (r != IOC_OK) return r;
-    if ((r = ioc_left_load(c, 0, nullptr, 0, nullptr, nullptr, nullptr)) != IOC_OK) return r;
+    if (L > 0) {
+        std::vector<uint8_t> lcell(size_t(L), 1);
+        for (int i = 0; i < L; ++i) {
+            lcell[size_t(i)] = ioc_host_err_cell(left->cls_hpc_err[i]);
+            if (lcell[size_t(i)] == 0) return ioc_fail(c, IOC_ERR_TABLE, "left error rate is NaN");
+        }
+        r = ioc_left_load(c, L, lcell.data(), left->n_keys, left->keys, left->offs, left->postings);
+    } else {
+        r = ioc_left_load(c, 0, nullptr, 0, nullptr, nullptr, nullptr);
+    }
+    if (r != IOC_OK) return r;
     return run_pipeline(c, gated, need, out_cls, out_strand, stats);
 }
 

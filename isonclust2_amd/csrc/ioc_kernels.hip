@@ -441,7 +441,8 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
         const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
         const uint32_t* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
-        unsigned long long* __restrict__ traversed, uint32_t e1, uint32_t e2, uint32_t e3)
+        unsigned long long* __restrict__ traversed, uint32_t e1, uint32_t e2, uint32_t e3,
+        const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum)
 {
     extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
@@ -539,6 +540,19 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
             }
         }
         __syncthreads();
+        if (audit_valid) {
+            // instrumentation launch: number of postings the reference would traverse for this query =
+            // sum of Size over the targets that are clusters (GetMinimizerHits raw hits)
+            unsigned long long sum = 0;
+            for (uint32_t i = threadIdx.x; i < 2 * Tr; i += IOC_BLOCK) {
+                const uint32_t tg = rbase + (i >= Tr ? i - Tr : i);
+                if (tg < L || audit_valid[tg - L]) sum += hist[i];
+            }
+            for (int o2 = 32; o2 > 0; o2 >>= 1) sum += __shfl_down(sum, o2);
+            if (lane == 0 && sum) atomicAdd(audit_sum, sum);
+            __syncthreads();
+            continue;
+        }
         // ---- ordered compaction of hist[0 .. 2*Tr) --------------------------------------------
         const uint32_t tot = 2 * Tr;
         const uint32_t per = (tot + IOC_WAVES - 1) / IOC_WAVES;
@@ -574,7 +588,7 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
         written += all;
         __syncthreads();
     }
-    if (threadIdx.x == 0) cand_count[j] = written;
+    if (threadIdx.x == 0 && !audit_valid) cand_count[j] = written;
     if (traversed && lane == 0) atomicAdd(traversed, trav);
 }
 
@@ -1081,7 +1095,7 @@ hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys,
 hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                       const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
-                      unsigned long long* traversed)
+                      unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum)
 {
     if (n <= 0) return hipSuccess;
     uint32_t tmax = L + uint32_t(n - 1);
@@ -1091,7 +1105,8 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     uint32_t e1, e2, e3;
     epoch_bounds(L, uint32_t(n), e1, e2, e3);
     hipLaunchKernelGGL(k_score, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins, (const uint4*)rows,
-                       cap, shift, post, range, keep, cand_key, cand_size, cand_count, traversed, e1, e2, e3);
+                       cap, shift, post, range, keep, cand_key, cand_size, cand_count, traversed, e1, e2, e3,
+                       audit_valid, audit_sum);
     return hipGetLastError();
 }
 

@@ -1,0 +1,158 @@
+"""Host-side mirror of `isONclust2 cluster` on in-memory batches (src/main.cpp:238-382).
+
+Only bookkeeping lives here (which read sits in which cluster with which strand, the batch
+metadata, the representative records a later merge needs); every hot-path computation is a call
+into the C ABI (api.Context).  The data layout is the flat SoA of ioc_batch_view, not the
+reference's pointer graph.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+VIEW_KEYS = ("raw_len", "hpc_len", "score", "raw_err", "hpc_err", "state")
+
+
+@dataclass
+class SortedBatch:
+    """What PrepareSortedBatch produces: one record per read of the batch, in sorted order."""
+    view: dict               # fields of ioc_batch_view
+    read_ids: np.ndarray     # global id of each entry's read
+    batch_nr: int = 0
+    batch_start: int = 0
+    batch_end: int = 0
+    depth: int = -1
+
+
+@dataclass
+class ClusteredBatch:
+    """A batch after ClusterSortedReads: clusters with their representative records + MinDB."""
+    rep_view: dict           # one ioc_batch_view record per cluster (its representative)
+    member_cls: np.ndarray   # flat membership: cluster id,
+    member_read: np.ndarray  # global read id,
+    member_strand: np.ndarray  # MatchStrand
+    mindb: tuple             # (keys, offs, postings) CSR
+    depth: int = 0
+    batch_start: int = 0
+    batch_end: int = 0
+    stats: dict = field(default_factory=dict)
+
+    @property
+    def n_clusters(self):
+        return len(self.rep_view["hpc_len"])
+
+    def assignments(self, n_reads):
+        cls = np.full(n_reads, -1, np.int32)
+        strand = np.zeros(n_reads, np.int32)
+        cls[self.member_read] = self.member_cls
+        strand[self.member_read] = self.member_strand
+        return cls, strand
+
+
+def gather_records(view, idx):
+    """Compact copy of the records `idx` of a view (CSR minimizer lists re-packed, fwd lists first)."""
+    idx = np.asarray(idx, np.int64)
+    of, orv = np.asarray(view["off_fwd"], np.int64), np.asarray(view["off_rev"], np.int64)
+    nf, nr = (of[1:] - of[:-1])[idx], (orv[1:] - orv[:-1])[idx]
+    n = len(idx)
+    off_f = np.zeros(n + 1, np.int64)
+    off_f[1:] = np.cumsum(nf)
+    off_r = np.zeros(n + 1, np.int64)
+    off_r[1:] = np.cumsum(nr)
+    off_r += off_f[-1]
+
+    def take(starts, lens):
+        tot = int(lens.sum())
+        if tot == 0:
+            return np.zeros(0, np.int64)
+        base = np.repeat(starts - (np.cumsum(lens) - lens), lens)
+        return base + np.arange(tot)
+
+    sel = np.concatenate([take(of[:-1][idx], nf), take(orv[:-1][idx], nr)])
+    out = dict(off_fwd=off_f, off_rev=off_r, min_val=np.asarray(view["min_val"])[sel],
+               min_pos=np.asarray(view["min_pos"])[sel], min_qual=view.get("min_qual", 7.0))
+    for k in VIEW_KEYS:
+        out[k] = np.asarray(view[k])[idx]
+    return out
+
+
+def concat_records(a, b):
+    """Concatenate two record sets (both compact, fwd lists first)."""
+    na, nb = len(a["hpc_len"]), len(b["hpc_len"])
+    fa, fb = int(a["off_fwd"][-1]), int(b["off_fwd"][-1])
+    ta, tb = len(a["min_val"]), len(b["min_val"])
+    off_f = np.concatenate([a["off_fwd"][:-1], b["off_fwd"] + fa])
+    rev_a = a["off_rev"] - fa          # relative to start of a's rev block
+    rev_b = b["off_rev"] - fb
+    rbase = fa + fb
+    off_r = np.concatenate([rev_a[:-1] + rbase, rev_b + rbase + (ta - fa)])
+    mv = np.concatenate([a["min_val"][:fa], b["min_val"][:fb], a["min_val"][fa:], b["min_val"][fb:]])
+    mp = np.concatenate([a["min_pos"][:fa], b["min_pos"][:fb], a["min_pos"][fa:], b["min_pos"][fb:]])
+    out = dict(off_fwd=off_f, off_rev=off_r, min_val=mv, min_pos=mp, min_qual=a.get("min_qual", 7.0))
+    for k in VIEW_KEYS:
+        out[k] = np.concatenate([a[k], b[k]])
+    assert len(off_f) == na + nb + 1 and len(off_r) == na + nb + 1
+    return out
+
+
+def cluster_single(ctx, params, sb: SortedBatch) -> ClusteredBatch:
+    """`cluster -l batch.cer`: initial clustering of one sorted batch (src/main.cpp:262-275)."""
+    cls, strand, st = ctx.cluster_batch(params, sb.view)
+    keys, offs, post = ctx.index_export()
+    ok = cls >= 0
+    # the entry that opened cluster c is its representative (cluster.cpp:178-206)
+    n_cls = int(st["n_clusters"])
+    rep_entry = np.full(n_cls, -1, np.int64)
+    first = np.nonzero(ok)[0]
+    # entries are in loop order: the first entry assigned to a NEW id is the one that created it
+    seen = np.zeros(n_cls, bool)
+    for i in first:
+        c = cls[i]
+        if not seen[c]:
+            seen[c] = True
+            rep_entry[c] = i
+    rep_view = gather_records(sb.view, rep_entry)
+    return ClusteredBatch(rep_view=rep_view, member_cls=cls[ok].astype(np.int32),
+                          member_read=np.asarray(sb.read_ids)[ok].astype(np.int64),
+                          member_strand=strand[ok].astype(np.int32), mindb=(keys, offs, post),
+                          depth=sb.depth + 1 if sb.depth < 0 else sb.depth + 1,
+                          batch_start=sb.batch_start, batch_end=sb.batch_end, stats=st)
+
+
+def cluster_merge(ctx, params, left: ClusteredBatch, right: ClusteredBatch, min_cls_size=3) -> ClusteredBatch:
+    """`cluster -l L -r R` (src/main.cpp:247-261 + src/cluster.cpp:67-322): every right cluster's
+    representative is matched against the left MinDB; members move with their strands flipped on a
+    reverse-strand match; unmatched right clusters are appended to the left."""
+    if right.depth > 0 and right.batch_start != left.batch_end + 1:
+        raise ValueError("Trying to merge non-consecutive batches! Giving up!")          # cluster.cpp:81-85
+    if left.depth > 0 and right.depth > left.depth:
+        raise ValueError("The left input batch must have higher depth!")                  # cluster.cpp:87-90
+    nR = right.n_clusters
+    counts = np.bincount(right.member_cls, minlength=nR).astype(np.int32)
+    rv = dict(right.rep_view)
+    rv.update(n_members=counts, depth=right.depth, min_cls_size=min_cls_size)
+    lv = dict(cls_hpc_err=left.rep_view["hpc_err"], keys=left.mindb[0], offs=left.mindb[1],
+              postings=left.mindb[2])
+    cls, strand, st = ctx.cluster_merge(params, lv, rv)
+    keys, offs, post = ctx.index_export()
+    L = left.n_clusters
+    kept = cls >= 0
+    new = np.nonzero(kept & (cls >= L))[0]
+    # new left clusters appear in creation order; a right cluster is "new" iff its id is its own
+    created = []
+    seen = set()
+    for i in new:
+        if cls[i] not in seen:
+            seen.add(int(cls[i]))
+            created.append(i)
+    rep_view = left.rep_view
+    if created:
+        rep_view = concat_records(left.rep_view, gather_records(right.rep_view, np.array(created)))
+    mcl = cls[right.member_cls]
+    mst = strand[right.member_cls].astype(np.int32) * right.member_strand
+    keep = mcl >= 0
+    return ClusteredBatch(rep_view=rep_view,
+                          member_cls=np.concatenate([left.member_cls, mcl[keep].astype(np.int32)]),
+                          member_read=np.concatenate([left.member_read, right.member_read[keep]]),
+                          member_strand=np.concatenate([left.member_strand, mst[keep]]),
+                          mindb=(keys, offs, post), depth=left.depth + 1, batch_start=left.batch_start,
+                          batch_end=right.batch_end, stats=st)
