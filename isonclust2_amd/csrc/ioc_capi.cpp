@@ -102,7 +102,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -315,7 +315,7 @@ static uint32_t env_u32(const char* name, uint32_t dflt)
     const char* v = getenv(name);
     if (!v || !*v) return dflt;
     long x = strtol(v, nullptr, 10);
-    return x > 0 ? uint32_t(x) : dflt;
+    return x >= 0 ? uint32_t(x) : dflt;
 }
 
 int ioc_index_build(ioc_ctx* c)
@@ -379,7 +379,8 @@ int ioc_index_build(ioc_ctx* c)
                                            P<uint32_t>(c->b_dcount), P<uint32_t>(c->b_keys), cap, shift,
                                            P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_fill),
                                            d_err));
-        HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan)));
+        // posting lists start 16-byte aligned and are padded to a multiple of 4 entries (0xFFFFFFFF)
+        HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan), 3u));
         uint32_t h_err = 0, h_total = 0;
         HIPCHK(c, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&h_total, P<uint32_t>(c->b_off) + nslots, 4, hipMemcpyDeviceToHost, s));
@@ -391,7 +392,9 @@ int ioc_index_build(ioc_ctx* c)
         }
         c->cap = cap;
         c->n_post = h_total;
+        if (uint64_t(h_total) >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 padded index postings");
         RESERVE(c, c->b_post, size_t(h_total) * 4 + 256);
+        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, size_t(h_total) * 4 + 256, s));
         HIPCHK(c, iock_fill_left(s, c->n_left_keys, P<int64_t>(c->b_loffs), P<uint32_t>(c->b_lpost),
                                  P<uint32_t>(c->b_lslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_post)));
         HIPCHK(c, iock_fill_queries(s, n, uint32_t(c->L), P<int64_t>(c->b_doff), P<uint32_t>(c->b_dcount),
@@ -448,11 +451,21 @@ int ioc_score(ioc_ctx* c)
     HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
     HIPCHK(c, hipMemsetAsync(c->b_cand_mapped.p, 0xFF, size_t(capacity) * 4, s));
     const uint32_t range = env_u32("IOC_SCORE_RANGE", 8192);
+    // XCD-partitioned scoring keeps 8 partial histograms per query (single-pass case only)
+    uint32_t* d_part = nullptr;
+    iock_set_score_variant(int(env_u32("IOC_SCORE_VARIANT", 0)));
+    if (env_u32("IOC_SCORE_PARTS", 1) == 1 && L + uint64_t(n) <= range && capacity * 8 * 4 + (1ull << 28) < have - need) {
+        RESERVE(c, c->b_part, size_t(capacity) * 8 * 4);
+        d_part = P<uint32_t>(c->b_part);
+    } else if (c->b_part.p) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        dev_free(c->b_part);
+    }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     HIPCHK(c, iock_score(s, n, uint32_t(L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         count_trav ? d_trav : nullptr, nullptr, nullptr));
+                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part));
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
         unsigned long long t = 0;
@@ -749,7 +762,7 @@ int ioc_count_reference_postings(ioc_ctx* c, int64_t* n_postings)
     HIPCHK(c, iock_score(s, c->n, uint32_t(c->L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         nullptr, valid, d_sum));
+                         nullptr, valid, d_sum, P<uint32_t>(c->b_part)));
     unsigned long long h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

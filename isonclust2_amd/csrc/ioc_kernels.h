@@ -58,7 +58,8 @@ hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, 
 hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* lkeys, const int64_t* loffs,
                                  uint32_t* keys, uint32_t cap, uint32_t shift, uint32_t* cnt, uint32_t* lslot,
                                  uint32_t* err);
-hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch);
+hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch,
+                               uint32_t round_mask);
 hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
                           const uint32_t* lslot, const uint32_t* off, uint32_t* post);
 hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
@@ -70,13 +71,15 @@ hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys,
 hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                       const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
-                      unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum);
+                      unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
+                      uint32_t* part);
 hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks);
 hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout);
 hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
                             const uint8_t* valid, uint32_t* hist, uint32_t* first);
 size_t iock_decide_args_size();
+void iock_set_score_variant(int v);
 
 // ---- sort-stage kernels (ioc_extract.hip) ----
 hipError_t iock_qual_scores(hipStream_t st, int n, const int64_t* offs, const uint8_t* qual, int k,

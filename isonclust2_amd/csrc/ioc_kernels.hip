@@ -227,7 +227,7 @@ k_hash_insert_left(int64_t nkeys, const uint32_t* __restrict__ lkeys, const int6
 // ---- 3-phase exclusive scan over u32 (n up to 2^31): block = 1024 elements -------------------------
 #define IOC_SCAN_ELEMS 1024
 __global__ void __launch_bounds__(IOC_BLOCK)
-k_scan_reduce(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ block_sums)
+k_scan_reduce(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__ block_sums, uint32_t rmask)
 {
     __shared__ uint32_t sh[IOC_WAVES];
     int64_t base = int64_t(blockIdx.x) * IOC_SCAN_ELEMS;
@@ -235,7 +235,7 @@ k_scan_reduce(const uint32_t* __restrict__ in, int64_t n, uint32_t* __restrict__
 #pragma unroll
     for (int r = 0; r < IOC_SCAN_ELEMS / IOC_BLOCK; ++r) {
         int64_t i = base + r * IOC_BLOCK + threadIdx.x;
-        if (i < n) v += in[i];
+        if (i < n) v += (in[i] + rmask) & ~rmask;
     }
     uint32_t tot;
     block_excl_scan(v, tot, sh);
@@ -261,7 +261,7 @@ k_scan_sums(uint32_t* __restrict__ block_sums, int64_t nb)
 
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_scan_apply(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restrict__ block_sums,
-             uint32_t* __restrict__ out)
+             uint32_t* __restrict__ out, uint32_t rmask)
 {
     __shared__ uint32_t sh[IOC_WAVES];
     int64_t base = int64_t(blockIdx.x) * IOC_SCAN_ELEMS;
@@ -272,7 +272,7 @@ k_scan_apply(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restr
     uint32_t s = 0;
 #pragma unroll
     for (int r = 0; r < IOC_SCAN_ELEMS / IOC_BLOCK; ++r) {
-        v[r] = (i0 + r < n) ? in[i0 + r] : 0;
+        v[r] = (i0 + r < n) ? ((in[i0 + r] + rmask) & ~rmask) : 0;
         s += v[r];
     }
     uint32_t tot;
@@ -436,8 +436,122 @@ __device__ __forceinline__ uint32_t list_lower_bound(const uint32_t* __restrict_
     return lo;
 }
 
+// Flattened traversal of the (compacted) posting lists of one wave chunk, in 16-byte units.
+// Every posting list starts 16-byte aligned and is padded to a multiple of 4 entries with
+// 0xFFFFFFFF, so a lane fetches 4 postings per load (1 KiB per wave instruction).  The concatenation
+// of the nl lists has `total` units; lane x of step s owns unit p = 64*s + x.  Which list p belongs to
+// is read off a bitmap of list starts over the concatenation (one 64-bit word per step, built with
+// one ds_or per list): list(p) = #starts <= p, a running popcount — two LDS reads per UNIT instead of
+// a 6-step search per posting.  The kernel is VALU-issue bound, so instructions per posting are what
+// counts: the list bookkeeping is amortised over 4 postings.
+#define IOC_BM_WORDS 128  // + IOC_FLAT_UNROLL words of slack are allocated
+template <int V>
+__device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post, uint32_t o, uint32_t len,
+                                              uint32_t* __restrict__ wb, unsigned long long* __restrict__ bm,
+                                              uint32_t* __restrict__ h, uint32_t rbase, uint32_t hi,
+                                              unsigned long long& trav, uint32_t& abl)
+{
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long le_mask = lt_mask | (1ull << lane);
+    const uint32_t lenU = (len + 3u) >> 2;  // units of 4 postings
+    const unsigned long long nz = __ballot(lenU != 0);
+    const uint32_t nl = uint32_t(__popcll(nz));
+    if (nl == 0) return;
+    const uint32_t incl = wave_incl_scan(lenU);
+    const uint32_t total = __shfl(incl, 63);
+    const uint32_t excl = incl - lenU;
+    const uint32_t nwords = (total + 63) >> 6;
+    const uint4* __restrict__ post4 = reinterpret_cast<const uint4*>(post);
+    trav += 4ull * total;
+    if (nwords <= IOC_BM_WORDS) {
+        // (zero IOC_FLAT_UNROLL words past the end so that the unrolled loop reads unconditionally)
+        for (uint32_t w = lane; w < nwords + IOC_FLAT_UNROLL; w += 64) bm[w] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lenU) {
+            wb[__popcll(nz & lt_mask)] = (o >> 2) - excl;  // unit address = wb[list] + p
+            atomicOr(&bm[excl >> 6], 1ull << (excl & 63u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t c0 = 0;  // lists started before the current word (same in every lane)
+        for (uint32_t w0 = 0; w0 < nwords; w0 += IOC_FLAT_UNROLL) {
+            // branch-free body: all LDS reads, then all posting loads, then all LDS atomics are issued
+            // back to back
+            unsigned long long B[IOC_FLAT_UNROLL];
+            uint32_t r[IOC_FLAT_UNROLL], base[IOC_FLAT_UNROLL];
+            uint4 tg[IOC_FLAT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < IOC_FLAT_UNROLL; ++u) B[u] = bm[w0 + u];
+#pragma unroll
+            for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+                const uint32_t rr = c0 + uint32_t(__popcll(B[u] & le_mask)) - 1u;
+                r[u] = rr < 64u ? rr : 63u;
+                c0 += uint32_t(__popcll(B[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < IOC_FLAT_UNROLL; ++u) base[u] = wb[r[u]];
+#pragma unroll
+            for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+                const uint32_t p = (w0 + u) * 64u + uint32_t(lane);
+                const bool in = p < total;
+                const uint32_t a = in ? base[u] + p : 0u;
+                if (V == 2 || V == 6 || V == 7) {  // ablation: no posting loads
+                    tg[u] = make_uint4(a & 2047u, (a + 1) & 2047u, (a + 2) & 2047u, (a + 3) & 2047u);
+                } else {
+                    tg[u] = post4[a];
+                }
+                if (!in) tg[u] = make_uint4(IOC_EMPTY, IOC_EMPTY, IOC_EMPTY, IOC_EMPTY);
+            }
+#pragma unroll
+            for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+                const uint32_t t4[4] = {tg[u].x, tg[u].y, tg[u].z, tg[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (V == 1 || V == 6) {  // ablation: no LDS atomics
+                        if (t4[e] < hi) abl += t4[e];
+                    } else if (V == 7) {  // ablation: plain LDS stores instead of atomics
+                        if (t4[e] < hi) h[t4[e] - rbase] = t4[e];
+                    } else {
+                        // ascending list: entries >= hi (later targets, padding) are not visible;
+                        // t - rbase wraps for entries below a range pass's window
+                        if (t4[e] - rbase < hi - rbase) atomicAdd(&h[t4[e] - rbase], 1u);
+                    }
+                }
+            }
+        }
+    } else {
+        // very long chunk (> 32768 postings): 6-step search over the prefix sums kept in wb / bm storage
+        uint32_t* wx = reinterpret_cast<uint32_t*>(bm);  // 64 words used
+        __builtin_amdgcn_wave_barrier();
+        if (lenU) {
+            const uint32_t r = uint32_t(__popcll(nz & lt_mask));
+            wx[r] = excl;
+            wb[r] = o >> 2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t p = lane; p < total; p += 64) {
+            uint32_t r = 0;
+#pragma unroll
+            for (uint32_t hh = 32; hh > 0; hh >>= 1) {
+                const uint32_t r2 = r + hh;
+                if (r2 < nl && wx[r2] <= p) r = r2;
+            }
+            const uint4 t = post4[wb[r] + (p - wx[r])];
+            if (t.x - rbase < hi - rbase) atomicAdd(&h[t.x - rbase], 1u);
+            if (t.y - rbase < hi - rbase) atomicAdd(&h[t.y - rbase], 1u);
+            if (t.z - rbase < hi - rbase) atomicAdd(&h[t.z - rbase], 1u);
+            if (t.w - rbase < hi - rbase) atomicAdd(&h[t.w - rbase], 1u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int V>
 __global__ void __launch_bounds__(IOC_BLOCK)
-k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
         const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
         const uint32_t* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
@@ -446,8 +560,8 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
 {
     extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
-    __shared__ uint32_t sx[IOC_WAVES][64];  // exclusive prefix of effective lengths (compacted lists)
-    __shared__ uint32_t so[IOC_WAVES][64];  // start offset in post[] of each compacted list
+    __shared__ uint32_t s_wb[IOC_WAVES][64];                       // per compacted list: address base
+    __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];   // bitmap of list starts
     const int j = n - 1 - int(blockIdx.x);
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);  // visible targets: [0, T)
@@ -457,8 +571,9 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     uint32_t written = 0;
     unsigned long long trav = 0;
-    uint32_t* const wx = sx[wave];
-    uint32_t* const wo = so[wave];
+    uint32_t abl = 0;
+    uint32_t* const wb_ = s_wb[wave];
+    unsigned long long* const bm_ = s_bm[wave];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     for (uint32_t rbase = 0; rbase < T; rbase += range) {
@@ -477,6 +592,7 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
                 const int64_t t = b + wave * 64 + lane;
                 if (t < e) index_lookup(rows, cap, shift, mins[t], o_nx, c_nx, q_nx);
             }
+            if (V == 5) continue;  // ablation: no probes, no traversal
             for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
                 uint32_t o = o_nx, len = c_nx;
                 const uint32_t qi = q_nx;
@@ -496,47 +612,18 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
                         if (eshift < 30) len = (qi >> eshift) & 1023u;
                     } else {
                         const uint32_t* pl = post + o;
-                        const uint32_t i0 = rbase ? list_lower_bound(pl, len, rbase) : 0u;
+                        // (start rounded down to a 16-byte unit; entries < rbase are rejected below)
+                        const uint32_t i0 = rbase ? (list_lower_bound(pl, len, rbase) & ~3u) : 0u;
                         const uint32_t i1 = list_lower_bound(pl, len, hi);
                         len = i1 - i0;
                         o += i0;
                     }
                 }
-                const unsigned long long nz = __ballot(len != 0);
-                const uint32_t nl = uint32_t(__popcll(nz));
-                if (nl == 0) continue;
-                const uint32_t incl = wave_incl_scan(len);
-                const uint32_t total = __shfl(incl, 63);
-                if (len) {
-                    const uint32_t r = uint32_t(__popcll(nz & lt_mask));
-                    wx[r] = incl - len;
-                    wo[r] = o;
+                if (V == 4) {  // ablation: probes only
+                    abl += len + o;
+                } else {
+                    flat_traverse<V>(post, o, len, wb_, bm_, h, rbase, hi, trav, abl);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t p0 = lane; p0 < total; p0 += 64 * IOC_FLAT_UNROLL) {
-                    uint32_t r[IOC_FLAT_UNROLL], tg[IOC_FLAT_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < IOC_FLAT_UNROLL; ++u) r[u] = 0;
-#pragma unroll
-                    for (uint32_t hh = 32; hh > 0; hh >>= 1) {
-#pragma unroll
-                        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
-                            const uint32_t r2 = r[u] + hh;
-                            if (r2 < nl && wx[r2] <= p0 + 64u * u) r[u] = r2;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
-                        const uint32_t p = p0 + 64u * u;
-                        tg[u] = (p < total) ? post[wo[r[u]] + (p - wx[r[u]])] : IOC_EMPTY;
-                    }
-#pragma unroll
-                    for (int u = 0; u < IOC_FLAT_UNROLL; ++u)
-                        if (tg[u] < hi) atomicAdd(&h[tg[u] - rbase], 1u);  // ascending list: entries >= hi are not visible
-                }
-                trav += total;
-                __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
@@ -589,7 +676,159 @@ k_score(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* _
         __syncthreads();
     }
     if (threadIdx.x == 0 && !audit_valid) cand_count[j] = written;
+    if (V != 0 && abl == 0x12345678u) cand_count[j] = abl;  // keeps the ablated loads alive
     if (traversed && lane == 0) atomicAdd(traversed, trav);
+}
+
+// =====================================================================================================
+// XCD-partitioned scoring (single-pass case).  The index (rows + postings) is several times larger
+// than one XCD's 4 MiB L2, and a query's probes are random, so the plain kernel misses L2 on >80 % of
+// its requests.  Here the value space is cut into 8 partitions by the top 3 bits of the hash slot —
+// rows and postings of a partition are contiguous — and workgroup (query j, partition x) has
+// blockIdx = 8*j' + x.  Workgroups are dealt round-robin over the 8 XCDs, so partition x is only
+// ever touched from one XCD and its slice of the index stays L2-resident (placement is a speed
+// assumption only: any mapping gives the same result).  Each workgroup keeps a private LDS histogram
+// of its partition's hits and stores it; k_score_compact adds the 8 partial histograms of a query
+// and writes the candidate list.
+// =====================================================================================================
+#define IOC_PARTS 8
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+             const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
+             const uint32_t* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1, uint32_t e2, uint32_t e3,
+             unsigned long long* __restrict__ traversed)
+{
+    extern __shared__ uint32_t hist[];  // 2 * (L + j)
+    __shared__ uint32_t s_wb[IOC_WAVES][64];
+    __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];
+    __shared__ uint32_t wq[IOC_WAVES][128];  // per-wave ring of minimizer values of this partition
+    const int j = n - 1 - int(blockIdx.x / IOC_PARTS);
+    const uint32_t x = blockIdx.x % IOC_PARTS;
+    if (j < 0) return;
+    const uint32_t T = L + uint32_t(j);
+    if (T == 0) return;
+    const uint32_t eshift = T <= e1 ? 0u : T <= e2 ? 10u : T <= e3 ? 20u : 30u;
+    const int lane = lane_id(), wave = wave_id();
+    const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
+    const uint32_t pshift = (32u - shift) - 3u;  // slot bits - 3
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t* const wb_ = s_wb[wave];
+    unsigned long long* const bm_ = s_bm[wave];
+    uint32_t* const q = wq[wave];
+    unsigned long long trav = 0;
+    uint32_t abl = 0;
+    for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) hist[i] = 0;
+    __syncthreads();
+    for (int s = 0; s < 2; ++s) {
+        const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
+        const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
+        uint32_t* h = hist + uint32_t(s) * T;
+        uint32_t qhead = 0, qn = 0;  // wave-uniform ring state
+        for (int64_t c0 = b + wave * 64;; c0 += IOC_WAVES * 64) {
+            const bool more = c0 < e;  // wave-uniform
+            if (more) {
+                const int64_t t = c0 + lane;
+                uint32_t v = 0;
+                bool mine = false;
+                if (t < e) {
+                    v = mins[t];
+                    const uint32_t pv = (v == IOC_EMPTY) ? 0u : (hash_slot(v, shift) >> pshift);
+                    mine = pv == x;
+                }
+                const unsigned long long bm = __ballot(mine);
+                if (mine) q[(qhead + qn + uint32_t(__popcll(bm & lt_mask))) & 127u] = v;
+                qn += uint32_t(__popcll(bm));
+            }
+            // drain: full chunks while reading, everything at the end
+            while (qn >= 64 || (!more && qn > 0)) {
+                const uint32_t take = qn < 64 ? qn : 64;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t o = 0, len = 0, qi = 0;
+                if (uint32_t(lane) < take) index_lookup(rows, cap, shift, q[(qhead + lane) & 127u], o, len, qi);
+                qhead = (qhead + take) & 127u;
+                qn -= take;
+                if (len) {
+                    if (!(qi & 0x80000000u)) {
+                        if (eshift < 30) len = (qi >> eshift) & 1023u;
+                    } else {
+                        len = list_lower_bound(post + o, len, T);
+                    }
+                }
+                flat_traverse<0>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
+            }
+            if (!more) break;
+        }
+    }
+    __syncthreads();
+    uint32_t* out = part + IOC_PARTS * cbase + size_t(x) * 2 * T;
+    for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) out[i] = hist[i];
+    if (traversed && lane == 0) atomicAdd(traversed, trav);
+}
+
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t keep,
+                uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_size,
+                uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ audit_valid,
+                unsigned long long* __restrict__ audit_sum)
+{
+    extern __shared__ uint32_t hist[];  // 2 * (L + j)
+    __shared__ uint32_t wcount[IOC_WAVES];
+    const int j = n - 1 - int(blockIdx.x);
+    if (j < 0) return;
+    const uint32_t T = L + uint32_t(j);
+    const int lane = lane_id(), wave = wave_id();
+    const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
+    const uint32_t tot = 2 * T;
+    const uint32_t* src = part + IOC_PARTS * cbase;
+    for (uint32_t i = threadIdx.x; i < tot; i += IOC_BLOCK) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int x = 0; x < IOC_PARTS; ++x) v += src[size_t(x) * tot + i];
+        hist[i] = v;
+    }
+    __syncthreads();
+    if (audit_valid) {
+        unsigned long long sum = 0;
+        for (uint32_t i = threadIdx.x; i < tot; i += IOC_BLOCK) {
+            const uint32_t tg = i >= T ? i - T : i;
+            if (tg < L || audit_valid[tg - L]) sum += hist[i];
+        }
+        for (int o2 = 32; o2 > 0; o2 >>= 1) sum += __shfl_down(sum, o2);
+        if (lane == 0 && sum) atomicAdd(audit_sum, sum);
+        return;
+    }
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t per = (tot + IOC_WAVES - 1) / IOC_WAVES;
+    const uint32_t w0 = wave * per;
+    const uint32_t w1 = (w0 + per < tot) ? (w0 + per) : tot;
+    uint32_t my = 0;
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool f = (i < w1) && (hist[i] >= keep);
+        my += __popcll(__ballot(f));
+    }
+    if (lane == 0) wcount[wave] = my;
+    __syncthreads();
+    uint32_t wbase = 0, all = 0;
+    for (int w = 0; w < IOC_WAVES; ++w) {
+        if (w < wave) wbase += wcount[w];
+        all += wcount[w];
+    }
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = (i < w1) ? hist[i] : 0;
+        const bool f = (i < w1) && (v >= keep);
+        const unsigned long long bm = __ballot(f);
+        if (f) {
+            const uint32_t pos = wbase + __popcll(bm & lt_mask);
+            const uint32_t strandbit = (i >= T) ? 1u : 0u;
+            const uint32_t tg = strandbit ? i - T : i;
+            cand_key[cbase + pos] = (tg << 1) | strandbit;
+            cand_size[cbase + pos] = v;
+        }
+        wbase += __popcll(bm);
+    }
+    if (threadIdx.x == 0) cand_count[j] = all;
 }
 
 // =====================================================================================================
@@ -1002,7 +1241,11 @@ k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int6
         if (e_ != hipSuccess) return e_; \
     } while (0)
 
+static int g_score_variant = 0;
+
 extern "C" {
+
+void iock_set_score_variant(int v) { g_score_variant = v; }
 
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
                          uint32_t* dvals, uint32_t* dcount, uint32_t pmax)
@@ -1035,13 +1278,14 @@ hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* 
 }
 
 // exclusive scan of in[0..n) into out[0..n], out[n] = total. scratch: ceil(n/1024)+1 words.
-hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch)
+hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch,
+                               uint32_t round_mask)
 {
     if (n <= 0) return hipSuccess;
     int64_t nb = (n + IOC_SCAN_ELEMS - 1) / IOC_SCAN_ELEMS;
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(IOC_BLOCK), 0, st, in, n, scratch);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(IOC_BLOCK), 0, st, in, n, scratch, round_mask);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(IOC_BLOCK), 0, st, scratch, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(IOC_BLOCK), 0, st, in, n, scratch, out);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(IOC_BLOCK), 0, st, in, n, scratch, out, round_mask);
     return hipGetLastError();
 }
 
@@ -1095,18 +1339,46 @@ hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys,
 hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                       const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
-                      unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum)
+                      unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
+                      uint32_t* part)
 {
     if (n <= 0) return hipSuccess;
     uint32_t tmax = L + uint32_t(n - 1);
     uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
     size_t lds = size_t(2) * r * 4;
-    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_score, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    if (part && tmax <= range && cap >= 1024) {
+        uint32_t e1, e2, e3;
+        epoch_bounds(L, uint32_t(n), e1, e2, e3);
+        if (lds > 40 * 1024) {
+            CK(hipFuncSetAttribute((const void*)k_score_part, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            CK(hipFuncSetAttribute((const void*)k_score_compact, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        }
+        hipLaunchKernelGGL(k_score_part, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev,
+                           mins, (const uint4*)rows, cap, shift, post, part, e1, e2, e3, traversed);
+        hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
+                           cand_count, audit_valid, audit_sum);
+        return hipGetLastError();
+    }
     uint32_t e1, e2, e3;
     epoch_bounds(L, uint32_t(n), e1, e2, e3);
-    hipLaunchKernelGGL(k_score, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins, (const uint4*)rows,
-                       cap, shift, post, range, keep, cand_key, cand_size, cand_count, traversed, e1, e2, e3,
-                       audit_valid, audit_sum);
+#define LAUNCH_SCORE(V)                                                                                              \
+    do {                                                                                                             \
+        if (lds > 48 * 1024)                                                                                         \
+            CK(hipFuncSetAttribute((const void*)k_score_t<V>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); \
+        hipLaunchKernelGGL(k_score_t<V>, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,            \
+                           (const uint4*)rows, cap, shift, post, range, keep, cand_key, cand_size, cand_count,       \
+                           traversed, e1, e2, e3, audit_valid, audit_sum);                                           \
+    } while (0)
+    switch (g_score_variant) {  // ablation builds for profiling only (IOC_SCORE_VARIANT); 0 = production
+        case 1: LAUNCH_SCORE(1); break;
+        case 2: LAUNCH_SCORE(2); break;
+        case 3: LAUNCH_SCORE(3); break;
+        case 4: LAUNCH_SCORE(4); break;
+        case 5: LAUNCH_SCORE(5); break;
+        case 6: LAUNCH_SCORE(6); break;
+        case 7: LAUNCH_SCORE(7); break;
+        default: LAUNCH_SCORE(0); break;
+    }
     return hipGetLastError();
 }
 
