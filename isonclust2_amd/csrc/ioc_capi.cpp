@@ -102,7 +102,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -555,27 +555,36 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.n_evals = d_evals;
     a.min_shared = c->params.min_shared;
     a.min_fraction = c->params.min_fraction;
-    // misc layout (uint32 words): [8] first_changed, [9] q_count, [10] incomplete
+    // misc layout (uint32 words): [8] first_changed, [9] q_count (phase 1), [10] incomplete, [11] q_count (phase 2)
     const uint32_t q_cap = env_u32("IOC_QUEUE_CAP", 1u << 20);
     RESERVE(c, c->b_queue, size_t(q_cap) * 8);
-    RESERVE(c, c->b_cut, size_t(n) * 4);
+    RESERVE(c, c->b_cut, size_t(n) * 9 + 64);
     a.cut = P<int32_t>(c->b_cut);
+    a.top = P<uint32_t>(c->b_cut) + n;
+    a.done = reinterpret_cast<uint8_t*>(P<uint32_t>(c->b_cut) + 2 * size_t(n));
     a.q_items = P<uint32_t>(c->b_queue);
     a.q_count = P<uint32_t>(c->b_misc) + 9;
     a.q_cap = q_cap;
     a.incomplete = P<uint32_t>(c->b_misc) + 10;
     const int eval_blocks = int(env_u32("IOC_EVAL_BLOCKS", 256 * 4));
+    const bool diag = getenv("IOC_EVAL_DIAG") != nullptr;
+    a.diag = nullptr;
+    if (diag) {
+        RESERVE(c, c->b_diag, 64);
+        HIPCHK(c, hipMemsetAsync(c->b_diag.p, 0, 64, s));
+        a.diag = P<unsigned long long>(c->b_diag);
+    }
     int first = 0, iters = 0, sweeps = 0;
     while (first < n) {
         uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
         uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
-        const uint32_t init[3] = {0xFFFFFFFFu, 0u, 0u};
-        HIPCHK(c, hipMemcpyAsync(d_first_changed, init, 12, hipMemcpyHostToDevice, s));
+        const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+        HIPCHK(c, hipMemcpyAsync(d_first_changed, init, 16, hipMemcpyHostToDevice, s));
         HIPCHK(c, iock_copy_prefix_valid(s, first, vin, vout));
         a.first = first;
         a.valid_in = vin;
         a.valid_out = vout;
-        HIPCHK(c, iock_decide_sweep(s, &a, n - first, eval_blocks));
+        HIPCHK(c, iock_decide_sweep(s, &a, n - first, eval_blocks, P<uint32_t>(c->b_misc) + 11));
         uint32_t res[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(res, d_first_changed, 12, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -595,6 +604,13 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     HIPCHK(c, hipMemcpyAsync(&ev, d_evals, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     c->tm.n_mapped_evals = int64_t(ev);
+    if (diag) {
+        unsigned long long d[8];
+        HIPCHK(c, hipMemcpy(d, c->b_diag.p, 64, hipMemcpyDeviceToHost));
+fprintf(stderr, "[ioc eval diag] evals %llu: total %.0f cyc/eval = clear %.0f + insert %.0f + probe %.0f + gaps %.0f\n", d[2],
+                d[2] ? double(d[1]) / d[2] : 0.0, d[2] ? double(d[5]) / d[2] : 0.0, d[2] ? double(d[6]) / d[2] : 0.0,
+                d[2] ? double(d[7]) / d[2] : 0.0, d[2] ? double(d[0]) / d[2] : 0.0);
+    }
     c->tm.resolve_iters = iters;
     if (n_iter) *n_iter = iters;
     c->resolved = true;

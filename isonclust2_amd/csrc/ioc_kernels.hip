@@ -843,9 +843,9 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
 //                  in descending-Size order); >= 2 passing at that Size -> order-dependent tie flag.
 // =====================================================================================================
 #define IOC_CUT_NEG INT32_MAX
-#define IOC_BITWORDS 1024   // 65536 minimizers per strand per pass
-#define IOC_SET_LDS 8192    // target value sets up to this size are staged in LDS (32 KiB)
-#define IOC_EVAL_ILP 4
+#define IOC_BITWORDS 256    // 16384 minimizers per strand per pass (slow path)
+#define IOC_HSET_SLOTS 8192  // LDS hash-set slots (32 KiB); sets up to 60 % of it
+#define IOC_EVAL_ILP 8
 
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_decide_scan(DecideArgs a)
@@ -858,80 +858,148 @@ k_decide_scan(DecideArgs a)
     const uint32_t L = a.L;
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     const uint32_t C = a.cand_count[j];
-    if (a.forced_t[j] != INT32_MIN) {
-        if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
-        return;
+    int cut;
+    uint32_t top;
+    if (a.phase == 1) {
+        if (a.forced_t[j] != INT32_MIN) {
+            if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
+            return;
+        }
+        top = 0;
+        for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
+            uint32_t tg = a.cand_key[cbase + c] >> 1;
+            bool ok = (tg < L) || a.valid_in[tg - L];
+            uint32_t sz = a.cand_size[cbase + c];
+            if (ok && sz > top) top = sz;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            uint32_t t = __shfl_down(top, o);
+            top = t > top ? t : top;
+        }
+        if (lane == 0) red[wave] = top;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) t = red[w] > t ? red[w] : t;
+            s_top = t;
+        }
+        __syncthreads();
+        top = s_top;
+        if (top < uint32_t(a.min_shared)) {
+            if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
+            return;
+        }
+        cut = int(double(top) * a.min_fraction);
+        if (threadIdx.x == 0) {
+            a.cut[j] = cut;
+            a.top[j] = top;
+        }
+    } else {
+        if (a.done[j]) return;
+        cut = a.cut[j];
+        top = a.top[j];
+        if (cut == IOC_CUT_NEG) return;
     }
-    uint32_t top = 0;
-    for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
-        uint32_t tg = a.cand_key[cbase + c] >> 1;
-        bool ok = (tg < L) || a.valid_in[tg - L];
-        uint32_t sz = a.cand_size[cbase + c];
-        if (ok && sz > top) top = sz;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = __shfl_down(top, o);
-        top = t > top ? t : top;
-    }
-    if (lane == 0) red[wave] = top;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < IOC_WAVES; ++w) t = red[w] > t ? red[w] : t;
-        s_top = t;
-    }
-    __syncthreads();
-    top = s_top;
-    if (top < uint32_t(a.min_shared)) {
-        if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
-        return;
-    }
-    const int cut = int(double(top) * a.min_fraction);
-    if (threadIdx.x == 0) a.cut[j] = cut;
+    // phase 1 queues only the candidates of maximal Size (the first ones the reference walks): most
+    // queries are decided by them; phase 2 queues the rest of the walk for the undecided queries.
+    // A query's items occupy one contiguous range of the queue (k_eval reuses the query's minimizers
+    // across consecutive items): count, reserve with one atomicAdd, write in candidate order.
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t wtot[IOC_WAVES];
+    uint32_t mine = 0;
     for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
         const uint32_t c = c0 + threadIdx.x;
         bool f = false;
         if (c < C) {
             uint32_t tg = a.cand_key[cbase + c] >> 1;
             bool ok = (tg < L) || a.valid_in[tg - L];
-            f = ok && (int(a.cand_size[cbase + c]) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
+            const uint32_t sz = a.cand_size[cbase + c];
+            f = ok && (a.phase == 1 ? sz == top : int(sz) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
+        }
+        mine += uint32_t(__popcll(__ballot(f)));
+    }
+    // every lane of a wave holds the wave's count; per slice the waves interleave, so positions are
+    // computed per slice below from running per-slice prefix sums
+    if (lane == 0) wtot[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t all = 0;
+        for (int w = 0; w < IOC_WAVES; ++w) all += wtot[w];
+        s_base = all ? atomicAdd(a.q_count, all) : 0u;
+    }
+    __syncthreads();
+    uint32_t run = s_base;
+    __shared__ uint32_t slice[IOC_WAVES];
+    for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
+        const uint32_t c = c0 + threadIdx.x;
+        bool f = false;
+        if (c < C) {
+            uint32_t tg = a.cand_key[cbase + c] >> 1;
+            bool ok = (tg < L) || a.valid_in[tg - L];
+            const uint32_t sz = a.cand_size[cbase + c];
+            f = ok && (a.phase == 1 ? sz == top : int(sz) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
         }
         const unsigned long long bm = __ballot(f);
-        if (bm) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.q_count, uint32_t(__popcll(bm)));
-            base = __shfl(base, 0);
-            if (f) {
-                uint32_t slot = base + uint32_t(__popcll(bm & ((1ull << lane) - 1ull)));
-                if (slot < a.q_cap) {
-                    a.q_items[2 * size_t(slot)] = uint32_t(j);
-                    a.q_items[2 * size_t(slot) + 1] = c;
-                }
+        if (lane == 0) slice[wave] = uint32_t(__popcll(bm));
+        __syncthreads();
+        uint32_t wb = run, all = 0;
+        for (int w = 0; w < IOC_WAVES; ++w) {
+            if (w < wave) wb += slice[w];
+            all += slice[w];
+        }
+        if (f) {
+            const uint32_t slot = wb + uint32_t(__popcll(bm & ((1ull << lane) - 1ull)));
+            if (slot < a.q_cap) {
+                a.q_items[2 * size_t(slot)] = uint32_t(j);
+                a.q_items[2 * size_t(slot) + 1] = c;
             }
         }
+        run += all;
+        __syncthreads();
     }
 }
 
 // totalMapped of one (query, target, strand): src/cluster.cpp:324-353 with the pow() predicate
 // replaced by the integer gap limit (a gap of n missing minimizers passes iff n < limEx).
-// LDS copy of a sorted set is stored skewed (one pad word per 32) so that the power-of-two strides of
-// the binary search do not land on one bank.
-#define IOC_SKEW(i) ((i) + ((i) >> 5))
-template <bool SET_IN_LDS>
-__device__ __forceinline__ uint32_t set_at(const uint32_t* set, uint32_t i)
+// Membership structure of one evaluation: the target's distinct values as an open-addressed hash set in
+// LDS (<= 60 % full, linear probing; the value 0xFFFFFFFF is kept as a flag), built by the workgroup
+// with ds atomics.  ~1.5 LDS reads per lookup instead of a 12-step binary search whose power-of-two
+// strides collide on one bank.  Sets too large for the table use a binary search in global memory.
+__device__ __forceinline__ uint32_t hset_hash(uint32_t v, uint32_t mask) { return ((v * 0x9E3779B1u) >> 7) & mask; }
+
+template <bool HASH_SET>
+__device__ __forceinline__ bool set_contains(const uint32_t* set, uint32_t setN, uint32_t mask, bool has_ff,
+                                             uint32_t hp2, uint32_t v)
 {
-    return SET_IN_LDS ? set[IOC_SKEW(i)] : set[i];
+    if (HASH_SET) {
+        if (v == IOC_EMPTY) return has_ff;
+        uint32_t h = hset_hash(v, mask);
+        for (;;) {
+            const uint32_t x = set[h];
+            if (x == v) return true;
+            if (x == IOC_EMPTY) return false;
+            h = (h + 1) & mask;
+        }
+    } else {
+        uint32_t pos = 0;
+        for (uint32_t h = hp2; h > 0; h >>= 1) {
+            const uint32_t q = pos + h;
+            if (q <= setN && set[q - 1] < v) pos = q;
+        }
+        return pos < setN && set[pos] == v;
+    }
 }
 
-template <bool SET_IN_LDS>
+template <bool HASH_SET>
 __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict__ qmin,
                                                       const uint32_t* __restrict__ qpos, uint32_t M,
-                                                      const uint32_t* set, uint32_t setN, uint32_t limEx,
-                                                      uint32_t hpcLen, unsigned long long* bits, uint32_t* red,
-                                                      uint32_t* carry)
+                                                      const uint32_t* set, uint32_t setN, uint32_t mask, bool has_ff,
+                                                      uint32_t limEx, uint32_t hpcLen, unsigned long long* bits,
+                                                      uint32_t* red, uint32_t* carry, unsigned long long* diag)
 {
     const int lane = lane_id(), wave = wave_id();
     uint32_t total = 0;
+    long long ta = 0, tb = 0, tc = 0;
     if (threadIdx.x == 0) {
         carry[0] = 0;  // any hit so far
         carry[1] = 0;  // index of the last hit so far
@@ -943,32 +1011,27 @@ __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict
     for (uint32_t pbase = 0; pbase < M; pbase += IOC_BITWORDS * 64) {
         const uint32_t Mp = (M - pbase < IOC_BITWORDS * 64) ? (M - pbase) : IOC_BITWORDS * 64;
         const uint32_t nwords = (Mp + 63) >> 6;
-        // phase A: hit bitmap; IOC_EVAL_ILP independent branchless searches per lane
+        if (diag) ta = clock64();
+        // phase A: hit bitmap, one 64-bit word per wave step; the loads of IOC_EVAL_ILP words are
+        // issued together (coalesced reads of qmin)
         for (uint32_t wd0 = wave * IOC_EVAL_ILP; wd0 < nwords; wd0 += IOC_WAVES * IOC_EVAL_ILP) {
-            uint32_t v[IOC_EVAL_ILP], pos[IOC_EVAL_ILP];
+            uint32_t v[IOC_EVAL_ILP];
             bool in[IOC_EVAL_ILP];
 #pragma unroll
             for (int u = 0; u < IOC_EVAL_ILP; ++u) {
                 const uint32_t i = pbase + (wd0 + u) * 64 + lane;
                 in[u] = (wd0 + u < nwords) && (i < M);
                 v[u] = in[u] ? qmin[i] : 0u;
-                pos[u] = 0;
-            }
-            for (uint32_t h = hp2; h > 0; h >>= 1) {
-#pragma unroll
-                for (int u = 0; u < IOC_EVAL_ILP; ++u) {
-                    const uint32_t q = pos[u] + h;
-                    if (q <= setN && set_at<SET_IN_LDS>(set, q - 1) < v[u]) pos[u] = q;
-                }
             }
 #pragma unroll
             for (int u = 0; u < IOC_EVAL_ILP; ++u) {
-                const bool hit = in[u] && pos[u] < setN && set_at<SET_IN_LDS>(set, pos[u]) == v[u];
+                const bool hit = in[u] && set_contains<HASH_SET>(set, setN, mask, has_ff, hp2, v[u]);
                 const unsigned long long m = __ballot(hit);
                 if (lane == 0 && wd0 + u < nwords) bits[wd0 + u] = m;
             }
         }
         __syncthreads();
+        if (diag) tb = clock64();
         // phase B: one thread per minimizer index (coalesced reads of qpos); the previous hit is
         // the highest set bit below i: same word, else an earlier word, else the carry of the
         // previous pass.
@@ -1008,6 +1071,11 @@ __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict
         for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
         if (lane == 0) red[wave] = local;
         __syncthreads();
+        if (diag && threadIdx.x == 0) {
+            tc = clock64();
+            atomicAdd(&diag[5], (unsigned long long)(tb - ta));
+            atomicAdd(&diag[6], (unsigned long long)(tc - tb));
+        }
         if (threadIdx.x == 0) {
             uint32_t sum = 0;
             for (int w = 0; w < IOC_WAVES; ++w) sum += red[w];
@@ -1032,17 +1100,257 @@ __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict
     return total;
 }
 
+// Fast path of one evaluation (target set <= 4096 values, the common case).
+//   * every global load is issued up front and coalesced (16 set values per thread; 16 query values per
+//     thread and pass, kept in registers across consecutive items of the same (query, strand));
+//   * membership = a 64 Kbit filter in LDS (one ds_or per set value, one ds_read per query value, all
+//     batched, no probe chains) followed by an exact binary search in an LDS copy of the sorted set for
+//     the few positives, which are first compacted across the wave so that the search runs on full
+//     waves;
+//   * hit bitmap -> previous-hit table -> gap scan; the hits are spread over the threads when sparse.
+#define IOC_EV_PER 16                              // indices per thread per pass
+#define IOC_EV_PASS (IOC_EV_PER * IOC_BLOCK)       // 4096 query minimizers per pass
+#define IOC_EV_FILTER_WORDS 2048                   // 65536-bit membership filter
+struct EvQuery {
+    uint32_t qv[IOC_EV_PER];
+    uint32_t pend0;  // valid-index mask of the cached pass
+};
+struct EvLds {
+    uint32_t sset[IOC_EV_PASS];             // sorted copy of the target set
+    uint32_t filt[IOC_EV_FILTER_WORDS];
+    unsigned long long bits[64];            // hit bitmap of the pass
+    uint32_t prevlast[65];
+    uint32_t wq[IOC_WAVES][256];            // per-wave ring of (value, index): filter positives awaiting the exact test
+    uint32_t red[IOC_WAVES + 1];
+    uint32_t carry[4];
+    uint32_t nhits;
+};
+
+__device__ __forceinline__ uint32_t ev_filter_hash(uint32_t v) { return (v * 0x9E3779B1u) >> 16; }
+
+__device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin, const uint32_t* __restrict__ qpos,
+                                              uint32_t M, const uint32_t* __restrict__ set, uint32_t setN,
+                                              uint32_t limEx, uint32_t hpcLen, EvLds& S, EvQuery& Q, bool reuse,
+                                              unsigned long long* diag)
+{
+    long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    if (diag) s0 = clock64();
+    const int lane = lane_id(), wave = wave_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t sv[IOC_EV_PER];
+#pragma unroll
+    for (int u = 0; u < IOC_EV_PER; ++u) {
+        const uint32_t i = uint32_t(u) * IOC_BLOCK + threadIdx.x;
+        sv[u] = i < setN ? set[i] : IOC_EMPTY;
+    }
+    const bool single = M <= IOC_EV_PASS;
+    if (!(reuse && single)) {
+        Q.pend0 = 0;
+#pragma unroll
+        for (int u = 0; u < IOC_EV_PER; ++u) {
+            const uint32_t li = (uint32_t(u) * IOC_WAVES + wave) * 64 + lane;
+            const bool in = li < M;
+            Q.qv[u] = in ? qmin[li] : 0u;
+            if (in) Q.pend0 |= 1u << u;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < IOC_EV_FILTER_WORDS; i += IOC_BLOCK) S.filt[i] = 0;
+    if (threadIdx.x == 0) {
+        S.carry[0] = 0;  // any hit so far
+        S.carry[1] = 0;  // index of the last hit so far
+    }
+    __syncthreads();
+    if (diag) s1 = clock64();
+#pragma unroll
+    for (int u = 0; u < IOC_EV_PER; ++u) {
+        const uint32_t i = uint32_t(u) * IOC_BLOCK + threadIdx.x;
+        S.sset[i] = sv[u];  // entries >= setN hold 0xFFFFFFFF (never searched beyond setN)
+        if (i < setN) {
+            const uint32_t h = ev_filter_hash(sv[u]);
+            atomicOr(&S.filt[h >> 5], 1u << (h & 31u));
+        }
+    }
+    __syncthreads();
+    if (diag) s2 = clock64();
+    uint32_t hp2 = 1;
+    while ((hp2 << 1) <= setN) hp2 <<= 1;
+    if (setN == 0) hp2 = 0;
+    uint32_t* const q = S.wq[wave];
+    uint32_t total = 0;
+    for (uint32_t pbase = 0; pbase < M; pbase += IOC_EV_PASS) {
+        const uint32_t Mp = (M - pbase < IOC_EV_PASS) ? (M - pbase) : IOC_EV_PASS;
+        // thread owns local indices (u * IOC_WAVES + wave) * 64 + lane: word u*IOC_WAVES+wave of the pass
+        uint32_t qv[IOC_EV_PER], fw[IOC_EV_PER];
+        uint32_t pend = 0;
+        if (pbase == 0) {
+            pend = Q.pend0;
+#pragma unroll
+            for (int u = 0; u < IOC_EV_PER; ++u) qv[u] = Q.qv[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < IOC_EV_PER; ++u) {
+                const uint32_t li = (uint32_t(u) * IOC_WAVES + wave) * 64 + lane;
+                const bool in = li < Mp;
+                qv[u] = in ? qmin[pbase + li] : 0u;
+                if (in) pend |= 1u << u;
+            }
+        }
+        if (threadIdx.x < 64) S.bits[threadIdx.x] = 0ull;
+        // filter: 16 independent LDS reads
+#pragma unroll
+        for (int u = 0; u < IOC_EV_PER; ++u) fw[u] = S.filt[ev_filter_hash(qv[u]) >> 5];
+        uint32_t pos_mask = 0;
+#pragma unroll
+        for (int u = 0; u < IOC_EV_PER; ++u) {
+            const uint32_t h = ev_filter_hash(qv[u]);
+            pos_mask |= (((fw[u] >> (h & 31u)) & (pend >> u)) & 1u) << u;
+        }
+        __syncthreads();  // bits cleared
+        // exact test of the positives, compacted through a per-wave ring so that each search step runs
+        // on a full wave: ring entry = local index (the value is re-read from the register file copy
+        // kept in LDS-free form: we push value and index as two words)
+        uint32_t qhead = 0, qn = 0;
+        for (int u = 0; u <= IOC_EV_PER; ++u) {
+            if (u < IOC_EV_PER) {
+                const bool f = (pos_mask >> u) & 1u;
+                const unsigned long long bm = __ballot(f);
+                if (f) {
+                    const uint32_t slot = (qhead + qn + uint32_t(__popcll(bm & lt_mask))) & 127u;
+                    q[slot] = qv[u];
+                    q[128 + slot] = (uint32_t(u) * IOC_WAVES + wave) * 64 + lane;
+                }
+                qn += uint32_t(__popcll(bm));
+            }
+            // ring of 128 (value, index) pairs: full waves while filling, the remainder at the end
+            while (qn >= 64 || (u == IOC_EV_PER && qn > 0)) {
+                const uint32_t take = qn < 64 ? qn : 64;
+                __builtin_amdgcn_wave_barrier();
+                const bool act = uint32_t(lane) < take;
+                const uint32_t v = act ? q[(qhead + lane) & 127u] : 0u;
+                const uint32_t li = act ? q[128 + ((qhead + lane) & 127u)] : 0u;
+                uint32_t pos = 0;
+                for (uint32_t h = hp2; h > 0; h >>= 1) {
+                    const uint32_t t = pos + h;
+                    if (t <= setN && S.sset[t - 1] < v) pos = t;
+                }
+                const bool member = act && pos < setN && S.sset[pos] == v;
+                if (member) atomicOr(&S.bits[li >> 6], 1ull << (li & 63u));
+                qhead = (qhead + take) & 127u;
+                qn -= take;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (diag) s3 = clock64();
+        // prevlast[w] = 1 + local index of the last hit in words < w (0 = none); hit count
+        if (wave == 0) {
+            const unsigned long long m = S.bits[lane];
+            uint32_t v = m ? uint32_t(lane) * 64 + uint32_t(63 - __builtin_clzll(m)) + 1u : 0u;
+            uint32_t cnt = uint32_t(__popcll(m));
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(v, o);
+                const uint32_t c2 = __shfl_up(cnt, o);
+                if (lane >= o) {
+                    v = t > v ? t : v;
+                    cnt += c2;
+                }
+            }
+            S.prevlast[lane + 1] = v;
+            if (lane == 0) S.prevlast[0] = 0;
+            if (lane == 63) S.nhits = cnt;
+        }
+        __syncthreads();
+        // ---- gap scan over the hit bitmap: one thread per 16-bit quarter word ----
+        uint32_t local = 0;
+        const uint32_t had_any = S.carry[0], had_last = S.carry[1];
+        {
+            const uint32_t wd = threadIdx.x >> 2;        // 64 words
+            const uint32_t qtr = threadIdx.x & 3u;       // 16 bits each
+            const unsigned long long m = S.bits[wd];
+            uint32_t part = uint32_t(m >> (16 * qtr)) & 0xFFFFu;
+            // previous hit before this quarter
+            bool pany = false;
+            uint32_t pidx = 0;
+            const unsigned long long below = qtr ? (m & ((1ull << (16 * qtr)) - 1ull)) : 0ull;
+            if (below) {
+                pany = true;
+                pidx = pbase + wd * 64 + uint32_t(63 - __builtin_clzll(below));
+            } else {
+                const uint32_t pl = S.prevlast[wd];
+                if (pl) {
+                    pany = true;
+                    pidx = pbase + pl - 1u;
+                } else if (had_any) {
+                    pany = true;
+                    pidx = had_last;
+                }
+            }
+            uint32_t ppos = (part && pany) ? qpos[pidx] : 0u;
+            while (part) {
+                const uint32_t bit = uint32_t(__builtin_ctz(part));
+                part &= part - 1;
+                const uint32_t i = pbase + wd * 64 + 16 * qtr + bit;
+                const uint32_t ipos = qpos[i];
+                if (!pany) {
+                    if (i < limEx) local += ipos;  // pow(pError, hits[0].Index) >= p0
+                } else if (i - pidx - 1 < limEx) {
+                    local += ipos - ppos;
+                }
+                pany = true;
+                pidx = i;
+                ppos = ipos;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+        if (lane == 0) S.red[wave] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) sum += S.red[w];
+            S.red[IOC_WAVES] = sum;
+            const uint32_t pl = S.prevlast[64];
+            if (pl) {
+                S.carry[0] = 1;
+                S.carry[1] = pbase + pl - 1u;
+            }
+        }
+        __syncthreads();
+        total += S.red[IOC_WAVES];
+        __syncthreads();
+    }
+    // tail: pow(pError, nMins - (lastIdx + 1)) >= p0
+    if (S.carry[0] && (M - S.carry[1] - 1 < limEx)) total += hpcLen - qpos[S.carry[1]];
+    __syncthreads();
+    if (diag && threadIdx.x == 0) {
+        s4 = clock64();
+        atomicAdd(&diag[5], (unsigned long long)(s1 - s0));  // issue loads + clear filter
+        atomicAdd(&diag[6], (unsigned long long)(s2 - s1));  // set copy + filter build (waits for the loads)
+        atomicAdd(&diag[7], (unsigned long long)(s3 - s2));  // filter + exact tests
+        atomicAdd(&diag[0], (unsigned long long)(s4 - s3));  // gap scan + reduce
+    }
+    return total;
+}
+
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_eval(DecideArgs a)
 {
-    __shared__ unsigned long long bits[IOC_BITWORDS];
-    __shared__ uint32_t sset[IOC_SET_LDS + IOC_SET_LDS / 32 + 1];
+    __shared__ unsigned long long bits[IOC_BITWORDS];  // slow path only
     __shared__ uint32_t red[IOC_WAVES + 1];
-    __shared__ uint32_t carry[2];
+    __shared__ uint32_t carry[4];
+    __shared__ EvLds S;
     uint32_t count = *a.q_count;
     if (count > a.q_cap) count = a.q_cap;
     const uint32_t L = a.L;
-    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+    // each workgroup takes one contiguous chunk of the queue: consecutive items share the query
+    const uint32_t per = (count + gridDim.x - 1) / gridDim.x;
+    const uint32_t w_begin = blockIdx.x * per;
+    const uint32_t w_end = (w_begin + per < count) ? (w_begin + per) : count;
+    EvQuery Q;
+    Q.pend0 = 0;
+    uint32_t prev_j = 0xFFFFFFFFu;
+    int prev_strand = -1;
+    for (uint32_t w = w_begin; w < w_end; ++w) {
         const uint32_t j = a.q_items[2 * size_t(w)];
         const uint32_t c = a.q_items[2 * size_t(w) + 1];
         const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
@@ -1066,12 +1374,25 @@ k_eval(DecideArgs a)
         const int64_t qb = strandbit ? a.off_rev[j] : a.off_fwd[j];
         const uint32_t M = uint32_t((strandbit ? a.off_rev[j + 1] : a.off_fwd[j + 1]) - qb);
         uint32_t tm;
-        if (setN <= IOC_SET_LDS) {
-            for (uint32_t i = threadIdx.x; i < setN; i += IOC_BLOCK) sset[IOC_SKEW(i)] = set[i];
-            __syncthreads();
-            tm = eval_total_mapped<true>(a.mins + qb, a.pos + qb, M, sset, setN, limEx, a.hpc_len[j], bits, red, carry);
+        long long t0 = 0, t1 = 0, t2 = 0;
+        if (a.diag) t0 = clock64();
+        if (setN <= IOC_EV_PASS) {
+            const bool reuse = (j == prev_j) && (strandbit == prev_strand);
+            if (a.diag) t1 = clock64();
+            tm = eval_fast(a.mins + qb, a.pos + qb, M, set, setN, limEx, a.hpc_len[j], S, Q, reuse, a.diag);
+            prev_j = j;
+            prev_strand = strandbit;
         } else {
-            tm = eval_total_mapped<false>(a.mins + qb, a.pos + qb, M, set, setN, limEx, a.hpc_len[j], bits, red, carry);
+            tm = eval_total_mapped<false>(a.mins + qb, a.pos + qb, M, set, setN, 0u, false, limEx, a.hpc_len[j], bits,
+                                          red, carry, a.diag);
+            prev_j = 0xFFFFFFFFu;
+        }
+        if (a.diag && threadIdx.x == 0) {
+            t2 = clock64();
+            atomicAdd(&a.diag[1], (unsigned long long)(t2 - t1));  // phases A + B
+            atomicAdd(&a.diag[2], 1ull);
+            atomicAdd(&a.diag[3], (unsigned long long)M);
+            atomicAdd(&a.diag[4], (unsigned long long)setN);
         }
         if (threadIdx.x == 0) {
             a.cand_mapped[cbase + c] = tm;
@@ -1084,11 +1405,12 @@ k_eval(DecideArgs a)
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_decide_pick(DecideArgs a)
 {
-    __shared__ uint32_t rs[IOC_WAVES], re[IOC_WAVES], rc[IOC_WAVES];
+    __shared__ uint32_t rs[IOC_WAVES], re[IOC_WAVES], rc[IOC_WAVES], rm[IOC_WAVES];
     const int j = a.first + int(blockIdx.x);
     if (j >= a.n) return;
     const int lane = lane_id(), wave = wave_id();
     const uint32_t L = a.L;
+    if (a.phase == 2 && a.done[j]) return;
     const int32_t ft = a.forced_t[j];
     if (ft != INT32_MIN) {
         if (threadIdx.x == 0) {
@@ -1097,6 +1419,7 @@ k_decide_pick(DecideArgs a)
             a.dec_strand[j] = (ft < 0) ? 0 : a.forced_s[j];
             a.flags[j] = 0;
             a.valid_out[j] = nv;
+            a.done[j] = 1;
             if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
         }
         return;
@@ -1105,20 +1428,21 @@ k_decide_pick(DecideArgs a)
     int32_t out_t = -1;
     int8_t out_s = 0;
     uint8_t out_f = 0;
+    bool decided = true;
     if (cut != IOC_CUT_NEG) {
         const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
         const uint32_t C = a.cand_count[j];
         const uint32_t need = a.min_total[j];
-        uint32_t bs = 0, be = 0xFFFFFFFFu, bc = 0;
-        bool missing = false;
+        const uint32_t top = a.top[j];
+        uint32_t bs = 0, be = 0xFFFFFFFFu, bc = 0, miss = 0;
         for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
             const uint32_t tg = a.cand_key[cbase + c] >> 1;
             const bool ok = (tg < L) || a.valid_in[tg - L];
             const uint32_t sz = a.cand_size[cbase + c];
-            if (!ok || int(sz) < cut) continue;
+            if (!ok || (a.phase == 1 ? sz != top : int(sz) < cut)) continue;
             const uint32_t tm = a.cand_mapped[cbase + c];
             if (tm == 0xFFFFFFFFu) {
-                missing = true;
+                miss = 1;
                 continue;
             }
             if (tm >= need) {
@@ -1132,9 +1456,9 @@ k_decide_pick(DecideArgs a)
                 }
             }
         }
-        if (__ballot(missing) && lane == 0) atomicAdd(a.incomplete, 1u);
         for (int o = 32; o > 0; o >>= 1) {
             const uint32_t os = __shfl_down(bs, o), oe = __shfl_down(be, o), oc = __shfl_down(bc, o);
+            miss |= __shfl_down(miss, o);
             if (os > bs) {
                 bs = os;
                 be = oe;
@@ -1148,13 +1472,16 @@ k_decide_pick(DecideArgs a)
             rs[wave] = bs;
             re[wave] = be;
             rc[wave] = bc;
+            rm[wave] = miss;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             bs = 0;
             be = 0xFFFFFFFFu;
             bc = 0;
+            miss = 0;
             for (int w = 0; w < IOC_WAVES; ++w) {
+                miss |= rm[w];
                 if (rs[w] > bs) {
                     bs = rs[w];
                     be = re[w];
@@ -1164,6 +1491,7 @@ k_decide_pick(DecideArgs a)
                     be = re[w] < be ? re[w] : be;
                 }
             }
+            if (miss) atomicAdd(a.incomplete, 1u);
             if (bs > 0 && be != 0xFFFFFFFFu) {
                 const uint32_t key = a.cand_key[cbase + be];
                 out_t = int32_t(key >> 1);
@@ -1171,16 +1499,22 @@ k_decide_pick(DecideArgs a)
                 if (bc > 1) out_f |= 1;
             } else {
                 out_f |= 2;  // no mapping hit although top >= MinShared (cluster.cpp:553-566)
+                // phase 1 only looked at the maximal-Size candidates: the walk goes on in phase 2
+                if (a.phase == 1) decided = false;
             }
+            if (miss) decided = false;
         }
     }
     if (threadIdx.x == 0) {
-        const uint8_t nv = (out_t < 0) ? 1 : 0;
-        a.dec_target[j] = out_t;
-        a.dec_strand[j] = out_s;
-        a.flags[j] = out_f;
-        a.valid_out[j] = nv;
-        if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
+        a.done[j] = decided ? 1 : 0;
+        if (decided) {
+            const uint8_t nv = (out_t < 0) ? 1 : 0;
+            a.dec_target[j] = out_t;
+            a.dec_strand[j] = out_s;
+            a.flags[j] = out_f;
+            a.valid_out[j] = nv;
+            if (nv != a.valid_in[j]) atomicMin(a.first_changed, uint32_t(j));
+        }
     }
 }
 
@@ -1382,10 +1716,16 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     return hipGetLastError();
 }
 
-hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int eval_blocks)
+hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int eval_blocks, uint32_t* q_count2)
 {
     if (nblocks <= 0) return hipSuccess;
     DecideArgs a = *reinterpret_cast<const DecideArgs*>(args_);
+    a.phase = 1;
+    hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    a.phase = 2;
+    a.q_count = q_count2;
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
