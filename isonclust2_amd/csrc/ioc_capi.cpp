@@ -102,7 +102,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -443,6 +443,7 @@ int ioc_score(ioc_ctx* c)
     RESERVE(c, c->b_cand_size, size_t(capacity) * 4);
     RESERVE(c, c->b_cand_mapped, size_t(capacity) * 4);
     RESERVE(c, c->b_cand_count, size_t(n) * 4);
+    RESERVE(c, c->b_top_all, size_t(n) * 4);
     RESERVE(c, c->b_misc, 256);
     c->cand_capacity = int64_t(capacity);
     hipStream_t s = c->stream;
@@ -465,7 +466,8 @@ int ioc_score(ioc_ctx* c)
     HIPCHK(c, iock_score(s, n, uint32_t(L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part));
+                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all)));
+    c->have_guess = d_part != nullptr;
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
         unsigned long long t = 0;
@@ -519,8 +521,16 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         c->forced_dirty = false;
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
-    // initial guess: every query opens a cluster (any guess converges to the same fixed point)
-    if (n > 0) HIPCHK(c, hipMemsetAsync(c->b_valid0.p, 1, size_t(n), s));
+    // initial guess (any guess converges to the same fixed point): "every query opens a cluster".
+    // A guess from the all-pairs top Size (IOC_RESOLVE_GUESS=1) was measured SLOWER on config 2
+    // (4 sweeps / 3.5 ms vs 3 sweeps / 2.0 ms): many entries with a large top still fail the mapped-ratio
+    // test and do open clusters, and that side of the error cascades.
+    if (n > 0) {
+        if (c->have_guess && env_u32("IOC_RESOLVE_GUESS", 0) == 1)
+            HIPCHK(c, iock_guess_valid(s, n, c->d_off_fwd, c->d_off_rev, P<uint32_t>(c->b_top_all), P<uint8_t>(c->b_valid0)));
+        else
+            HIPCHK(c, hipMemsetAsync(c->b_valid0.p, 1, size_t(n), s));
+    }
     c->cur_valid = 0;
     uint32_t* d_first_changed = P<uint32_t>(c->b_misc) + 8;
     unsigned long long* d_evals = reinterpret_cast<unsigned long long*>(P<uint8_t>(c->b_misc) + 128);
@@ -566,7 +576,7 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.q_count = P<uint32_t>(c->b_misc) + 9;
     a.q_cap = q_cap;
     a.incomplete = P<uint32_t>(c->b_misc) + 10;
-    const int eval_blocks = int(env_u32("IOC_EVAL_BLOCKS", 256 * 4));
+    const int eval_blocks = int(env_u32("IOC_EVAL_BLOCKS", 256 * 5));
     const bool diag = getenv("IOC_EVAL_DIAG") != nullptr;
     a.diag = nullptr;
     if (diag) {
@@ -778,7 +788,7 @@ int ioc_count_reference_postings(ioc_ctx* c, int64_t* n_postings)
     HIPCHK(c, iock_score(s, c->n, uint32_t(c->L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         nullptr, valid, d_sum, P<uint32_t>(c->b_part)));
+                         nullptr, valid, d_sum, P<uint32_t>(c->b_part), nullptr));
     unsigned long long h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

@@ -60,7 +60,8 @@ struct ioc_ctx {
 
     // ---- scoring ----
     bool scored = false;
-    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo, b_part, b_diag;
+    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo, b_part, b_diag, b_top_all;
+    bool have_guess = false;
     int64_t cand_capacity = 0;
 
     // ---- resolve ----

@@ -769,10 +769,11 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t keep,
                 uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_size,
                 uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ audit_valid,
-                unsigned long long* __restrict__ audit_sum)
+                unsigned long long* __restrict__ audit_sum, uint32_t* __restrict__ top_all)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
+    __shared__ uint32_t wtop[IOC_WAVES];
     const int j = n - 1 - int(blockIdx.x);
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);
@@ -780,13 +781,25 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     const uint32_t tot = 2 * T;
     const uint32_t* src = part + IOC_PARTS * cbase;
+    uint32_t tmax = 0;
     for (uint32_t i = threadIdx.x; i < tot; i += IOC_BLOCK) {
         uint32_t v = 0;
 #pragma unroll
         for (int x = 0; x < IOC_PARTS; ++x) v += src[size_t(x) * tot + i];
         hist[i] = v;
+        tmax = v > tmax ? v : tmax;
     }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        const uint32_t t = __shfl_down(tmax, o2);
+        tmax = t > tmax ? t : tmax;
+    }
+    if (lane == 0) wtop[wave] = tmax;
     __syncthreads();
+    if (threadIdx.x == 0 && top_all && !audit_valid) {
+        uint32_t t = 0;
+        for (int w = 0; w < IOC_WAVES; ++w) t = wtop[w] > t ? wtop[w] : t;
+        top_all[j] = t;  // largest Size against ANY earlier entry: seeds the resolve's first guess
+    }
     if (audit_valid) {
         unsigned long long sum = 0;
         for (uint32_t i = threadIdx.x; i < tot; i += IOC_BLOCK) {
@@ -1518,6 +1531,21 @@ k_decide_pick(DecideArgs a)
     }
 }
 
+// First guess of "entry j opens a cluster" for the fixed-point resolve: j probably joins an earlier
+// cluster when some earlier entry shares more than ~5 % of its minimizers (background between unrelated
+// reads is ~1.6 % at k = 11).  Any guess converges to the same result; a good one saves sweeps and
+// evaluations.
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_guess_valid(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+              const uint32_t* __restrict__ top_all, uint8_t* __restrict__ valid)
+{
+    const int j = blockIdx.x * IOC_BLOCK + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t nf = uint32_t(off_fwd[j + 1] - off_fwd[j]), nr = uint32_t(off_rev[j + 1] - off_rev[j]);
+    const uint32_t m = nf < nr ? nf : nr;
+    valid[j] = (uint64_t(top_all[j]) * 20ull < uint64_t(m)) ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_copy_prefix_valid(int first, const uint8_t* __restrict__ vin, uint8_t* __restrict__ vout)
 {
@@ -1674,7 +1702,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
                       const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
                       unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
-                      uint32_t* part)
+                      uint32_t* part, uint32_t* top_all)
 {
     if (n <= 0) return hipSuccess;
     uint32_t tmax = L + uint32_t(n - 1);
@@ -1690,7 +1718,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
         hipLaunchKernelGGL(k_score_part, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev,
                            mins, (const uint4*)rows, cap, shift, post, part, e1, e2, e3, traversed);
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
-                           cand_count, audit_valid, audit_sum);
+                           cand_count, audit_valid, audit_sum, top_all);
         return hipGetLastError();
     }
     uint32_t e1, e2, e3;
@@ -1729,6 +1757,15 @@ hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev,
+                            const uint32_t* top_all, uint8_t* valid)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_guess_valid, dim3((n + IOC_BLOCK - 1) / IOC_BLOCK), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev,
+                       top_all, valid);
     return hipGetLastError();
 }
 
