@@ -181,6 +181,19 @@ uint8_t ioc_host_err_cell(double err_rate);
 /* smallest T with float(double(T)/double(hpc_len)) >= mapped_threshold (src/cluster.cpp:390-400) */
 uint32_t ioc_host_min_total(uint32_t hpc_len, double mapped_threshold);
 
+/* ---- host alignment fallback (sahlin / furious; stays on the host, src/cluster.cpp:408-515) ------ */
+/* Semi-global affine alignment replacing parasail_sg_trace_scan_16/32 + parasail_result_get_traceback
+ * (src/cluster.cpp:413-419, 500-502): all four ends free, gap of length n costs open + (n-1)*extend;
+ * comp receives the comparison string of the whole alignment (0x7C = identical bases, ' ' otherwise).
+ * Returns its length (comp_cap >= qlen + rlen + 1).  Parity with parasail's tie-breaking is pinned only
+ * by the reference's AlnRatioTest vector. */
+int ioc_host_align(const char* query, int32_t qlen, const char* ref, int32_t rlen, int32_t match,
+                   int32_t mismatch, int32_t gap_open, int32_t gap_extend, char* comp, int32_t comp_cap,
+                   int32_t* score_out);
+int32_t ioc_host_gap_open(double e1_plus_e2);                     /* setGapOpen,  src/cluster.cpp:425-440 */
+double ioc_host_aln_ratio(const char* comp, int32_t comp_len, double e, uint32_t slen, uint32_t k);
+                                                                  /* getAlnRatio, src/cluster.cpp:442-459 */
+
 /* ---- host driver: ClusterSortedReads on flat arrays (src/cluster.cpp:67-322, consensus off) ------ */
 typedef struct {
     /* right batch, one record per entry in loop order */
@@ -199,6 +212,9 @@ typedef struct {
     double min_qual;           /* CmdArgs::MinQual     */
     /* merge only (right batch already clustered: one record per right cluster, the arrays above
      * describe its representative, cluster.cpp:537): */
+    /* sahlin / furious only: raw sequences for the host alignment fallback (cluster.cpp:461-515) */
+    const char* raw_seq;       /* RawSeq->Str() of all entries, concatenated; NULL in fast mode */
+    const int64_t* raw_off;    /* [n+1] */
     const int32_t* n_members;  /* reads[i]->size() - 1; NULL = fresh reads */
     int32_t depth;             /* right Batch::Depth; the MinClsSize filter applies when > 0 (:119-123) */
     int32_t min_cls_size;      /* left SortArgs.MinClsSize after the -A override (main.cpp:329-331) */
@@ -213,6 +229,10 @@ typedef struct {
     const uint32_t* keys;
     const int64_t* offs;       /* [n_keys+1] */
     const uint32_t* postings;
+    /* sahlin / furious only: the representatives' raw sequences and raw error rates */
+    const char* rep_seq;
+    const int64_t* rep_off;    /* [n_clusters+1] */
+    const double* cls_raw_err; /* RawSeq->ErrorRate() of each representative */
 } ioc_left_view;
 
 typedef struct {

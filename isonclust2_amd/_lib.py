@@ -31,13 +31,15 @@ class BatchView(C.Structure):
                 ("hpc_len", C.POINTER(C.c_uint32)), ("score", C.POINTER(C.c_double)),
                 ("raw_err", C.POINTER(C.c_double)), ("hpc_err", C.POINTER(C.c_double)),
                 ("state", C.POINTER(C.c_uint8)), ("min_qual", C.c_double),
+                ("raw_seq", C.c_char_p), ("raw_off", C.POINTER(C.c_int64)),
                 ("n_members", C.POINTER(C.c_int32)), ("depth", C.c_int32), ("min_cls_size", C.c_int32)]
 
 
 class LeftView(C.Structure):
     _fields_ = [("n_clusters", C.c_int32), ("cls_hpc_err", C.POINTER(C.c_double)), ("n_keys", C.c_int64),
                 ("keys", C.POINTER(C.c_uint32)), ("offs", C.POINTER(C.c_int64)),
-                ("postings", C.POINTER(C.c_uint32))]
+                ("postings", C.POINTER(C.c_uint32)), ("rep_seq", C.c_char_p),
+                ("rep_off", C.POINTER(C.c_int64)), ("cls_raw_err", C.POINTER(C.c_double))]
 
 
 class ClusterStats(C.Structure):
@@ -67,7 +69,8 @@ SYMBOLS = [
     "ioc_clear_forced", "ioc_query_candidates", "ioc_index_export", "ioc_qual_scores",
     "ioc_extract_minimizers", "ioc_extracted_download", "ioc_queries_from_extracted",
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
-    "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident",
+    "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
+    "ioc_host_aln_ratio",
 ]
 
 _lib = None
@@ -119,6 +122,10 @@ def load():
                                     C.POINTER(ClusterStats)]
     L.ioc_cluster_merge.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(LeftView), C.POINTER(BatchView),
                                     pi32, pi8, C.POINTER(ClusterStats)]
+    L.ioc_host_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, C.c_char_p, i32, pi32]
+    L.ioc_host_gap_open.argtypes = [C.c_double]
+    L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]
+    L.ioc_host_aln_ratio.restype = C.c_double
     L.ioc_cluster_resident.argtypes = [vp, pi32, pi8, C.POINTER(ClusterStats)]
     _lib = L
     return L

@@ -216,12 +216,17 @@ class Context:
         nm = None
         if batch.get("n_members") is not None:
             nm = np.ascontiguousarray(batch["n_members"], np.int32)
+        rseq = roff = None
+        if batch.get("raw_seq") is not None:   # sahlin / furious: sequences for the host aligner
+            rseq = batch["raw_seq"] if isinstance(batch["raw_seq"], bytes) else np.asarray(batch["raw_seq"], np.uint8).tobytes()
+            roff = np.ascontiguousarray(batch["raw_off"], np.int64)
         v = BatchView(n=n, off_fwd=_p(arrs["off_fwd"], C.c_int64), off_rev=_p(arrs["off_rev"], C.c_int64),
                       min_val=_p(arrs["min_val"], C.c_uint32), min_pos=_p(arrs["min_pos"], C.c_uint32),
                       total=len(arrs["min_val"]), raw_len=_p(arrs["raw_len"], C.c_uint32),
                       hpc_len=_p(arrs["hpc_len"], C.c_uint32), score=_p(arrs["score"], C.c_double),
                       raw_err=_p(arrs["raw_err"], C.c_double), hpc_err=_p(arrs["hpc_err"], C.c_double),
                       state=_p(arrs["state"], C.c_uint8), min_qual=float(batch.get("min_qual", 7.0)),
+                      raw_seq=rseq, raw_off=_p(roff, C.c_int64) if roff is not None else None,
                       n_members=_p(nm, C.c_int32) if nm is not None else None,
                       depth=int(batch.get("depth", -1)), min_cls_size=int(batch.get("min_cls_size", 3)))
         lv = None
@@ -230,8 +235,15 @@ class Context:
             lk = np.ascontiguousarray(left["keys"], np.uint32)
             lo = np.ascontiguousarray(left["offs"], np.int64)
             lp = np.ascontiguousarray(left["postings"], np.uint32)
+            lseq = loff = lerr = None
+            if left.get("rep_seq") is not None:
+                lseq = left["rep_seq"] if isinstance(left["rep_seq"], bytes) else np.asarray(left["rep_seq"], np.uint8).tobytes()
+                loff = np.ascontiguousarray(left["rep_off"], np.int64)
+                lerr = np.ascontiguousarray(left["cls_raw_err"], np.float64)
             lv = LeftView(n_clusters=len(le), cls_hpc_err=_p(le, C.c_double), n_keys=len(lk),
-                          keys=_p(lk, C.c_uint32), offs=_p(lo, C.c_int64), postings=_p(lp, C.c_uint32))
+                          keys=_p(lk, C.c_uint32), offs=_p(lo, C.c_int64), postings=_p(lp, C.c_uint32),
+                          rep_seq=lseq, rep_off=_p(loff, C.c_int64) if loff is not None else None,
+                          cls_raw_err=_p(lerr, C.c_double) if lerr is not None else None)
         cls, strand = np.zeros(n, np.int32), np.zeros(n, np.int8)
         st = ClusterStats()
         self._chk(self.L.ioc_cluster_merge(self.h, C.byref(params), table.encode(),

@@ -144,12 +144,19 @@ uint32_t ioc_host_min_total(uint32_t hpc_len, double thr)
     return lo;
 }
 
-// ---- tie replay ---------------------------------------------------------------------------------------
-// Rebuilds the reference's `order` for one query from the device-computed hit table and returns
-// the first passing candidate in that order (cluster.cpp:381-403).
-static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint32_t need, int32_t& out_target,
-                        int8_t& out_strand)
+// ---- candidate order replay ---------------------------------------------------------------------------
+// Rebuilds the reference's `hitOrder` (SortMinimizerHits over the GetMinimizerHits map) for one query
+// from the device-computed hit table: same container types, same insertion order, same std::sort.
+struct Ordered {
+    int32_t cls;      // final cluster id
+    int32_t target;   // device target id
+    int8_t strand;
+    uint32_t size, mapped;
+};
+
+static int build_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::vector<Ordered>& out)
 {
+    out.clear();
     const int T = c->L + q;
     std::vector<int32_t> tg(size_t(2) * T + 1);
     std::vector<int8_t> st(size_t(2) * T + 1);
@@ -172,11 +179,16 @@ static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint
     });
     const size_t nm = size_t(c->h_off_fwd[size_t(q) + 1] - c->h_off_fwd[size_t(q)]) +
                       size_t(c->h_off_rev[size_t(q) + 1] - c->h_off_rev[size_t(q)]);
-    std::unordered_map<StrandedCluster, HitInfo, StrandedClsHash> res(20 * nm, StrandedClsHash());
+    struct Info {
+        unsigned Size = 0, Mapped = 0;
+        int32_t Target = -1;
+    };
+    std::unordered_map<StrandedCluster, Info, StrandedClsHash> res(20 * nm, StrandedClsHash());
     for (auto& x : cs) {
-        HitInfo& h = res[std::make_pair(int(x.cls), int(x.strand))];
+        Info& h = res[std::make_pair(int(x.cls), int(x.strand))];
         h.Size = x.size;
         h.Mapped = x.mapped;
+        h.Target = x.target;
     }
     std::vector<std::unique_ptr<SortedHit>> order;
     order.reserve(res.size());
@@ -188,19 +200,91 @@ static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint
         order.push_back(std::unique_ptr<SortedHit>(p));
     }
     std::sort(order.begin(), order.end(), by_size_desc);
+    out.reserve(order.size());
+    for (auto& o : order) {
+        const Info& h = res.at(std::make_pair(int(o->Cls), o->Strand));
+        out.push_back(Ordered{int32_t(o->Cls), h.Target, int8_t(o->Strand), o->Size, h.Mapped});
+    }
+    return IOC_OK;
+}
+
+// first passing candidate in the reference's order (cluster.cpp:381-403) — used for the queries whose
+// winner is order-dependent
+static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint32_t need, int32_t& out_cls,
+                        int8_t& out_strand)
+{
+    std::vector<Ordered> order;
+    int r = build_order(c, q, cid, order);
+    if (r != IOC_OK) return r;
+    out_cls = -1;
+    out_strand = 0;
+    if (order.empty()) return IOC_OK;
+    const unsigned top = order[0].size;
+    if (top < unsigned(c->params.min_shared)) return IOC_OK;
+    for (auto& o : order) {
+        if (int(o.size) < int(double(top) * c->params.min_fraction)) break;
+        if (o.mapped == 0xFFFFFFFFu)
+            return ioc_fail(c, IOC_ERR_STATE, "tie replay met a candidate the device did not evaluate");
+        if (o.mapped >= need) {
+            out_cls = o.cls;
+            out_strand = o.strand;
+            return IOC_OK;
+        }
+    }
+    return IOC_OK;
+}
+
+// sequences the alignment fallback needs (raw read / representative sequences, raw error rates)
+struct SeqAccess {
+    const char* r_seq = nullptr;      // right entries, concatenated
+    const int64_t* r_off = nullptr;
+    const double* r_err = nullptr;    // RawSeq->ErrorRate()
+    const char* l_seq = nullptr;      // left cluster representatives
+    const int64_t* l_off = nullptr;
+    const double* l_err = nullptr;
+};
+
+static void revcomp_inplace(std::string& s)
+{
+    std::reverse(s.begin(), s.end());
+    for (auto& ch : s) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+}
+
+// getBestClusterAln (cluster.cpp:461-515) for query q: candidates tied at the top Size, in hitOrder
+static int align_query(ioc_ctx* c, int q, const std::vector<int32_t>& cid, const SeqAccess& sa, int32_t& out_target,
+                       int8_t& out_strand)
+{
+    std::vector<Ordered> order;
+    int r = build_order(c, q, cid, order);
+    if (r != IOC_OK) return r;
     out_target = -1;
     out_strand = 0;
     if (order.empty()) return IOC_OK;
-    const unsigned top = order[0]->Size;
-    if (top < unsigned(c->params.min_shared)) return IOC_OK;
+    const unsigned top = order[0].size;
+    const std::string read(sa.r_seq + sa.r_off[q], size_t(sa.r_off[q + 1] - sa.r_off[q]));
+    std::vector<char> comp;
     for (auto& o : order) {
-        if (int(o->Size) < int(double(top) * c->params.min_fraction)) break;
-        const HitInfo& h = res.at(std::make_pair(int(o->Cls), o->Strand));
-        if (h.Mapped == 0xFFFFFFFFu)
-            return ioc_fail(c, IOC_ERR_STATE, "tie replay met a candidate the device did not evaluate");
-        if (h.Mapped >= need) {
-            out_target = int32_t(o->Cls);  // a final cluster id
-            out_strand = int8_t(o->Strand);
+        if (o.size < top) break;
+        std::string rep;
+        double e2;
+        if (o.target < c->L) {
+            rep.assign(sa.l_seq + sa.l_off[o.target], size_t(sa.l_off[o.target + 1] - sa.l_off[o.target]));
+            e2 = sa.l_err[o.target];
+        } else {
+            const int t = o.target - c->L;
+            rep.assign(sa.r_seq + sa.r_off[t], size_t(sa.r_off[t + 1] - sa.r_off[t]));
+            e2 = sa.r_err[t];
+        }
+        if (o.strand == -1) revcomp_inplace(rep);
+        const double e = sa.r_err[q] + e2;
+        comp.resize(read.size() + rep.size() + 2);
+        int len = ioc_host_align(read.data(), int32_t(read.size()), rep.data(), int32_t(rep.size()), 2, -2,
+                                 ioc_host_gap_open(e), 1, comp.data(), int32_t(comp.size()), nullptr);
+        if (len < 0) return ioc_fail(c, len, "host alignment failed (sequence too long for the traceback matrix)");
+        const double ratio = ioc_host_aln_ratio(comp.data(), len, e, uint32_t(read.size()), uint32_t(c->params.k));
+        if (ratio >= c->params.aligned_threshold) {
+            out_target = o.target;
+            out_strand = o.strand;
             return IOC_OK;
         }
     }
@@ -208,7 +292,7 @@ static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint
 }
 
 static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std::vector<uint32_t>& need,
-                        int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+                        int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats, const SeqAccess* sa)
 {
     const int n = c->n;
     int r;
@@ -218,18 +302,52 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     // gated entries never become clusters: force them out of the target set
     for (int i = 0; i < n; ++i)
         if (gated[size_t(i)] && (r = ioc_force_decision(c, i, -2, 0)) != IOC_OK) return r;
-    int32_t iters = 0;
-    if ((r = ioc_resolve(c, &iters)) != IOC_OK) return r;
-    if (c->params.mode != IOC_MODE_FAST && c->params.mode != IOC_MODE_NONE) {
-        return ioc_fail(c, IOC_ERR_STATE,
-                        "sahlin/furious need the host alignment fallback (cluster.cpp:461-515): not wired yet");
-    }
+    const bool aln_mode = c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS;
+    if (aln_mode && (!sa || !sa->r_seq || !sa->r_off || !sa->r_err || (c->L > 0 && (!sa->l_seq || !sa->l_off || !sa->l_err))))
+        return ioc_fail(c, IOC_ERR_ARG, "sahlin/furious need the raw sequences for the alignment fallback (cluster.cpp:461-515)");
+    int32_t iters = 0, total_iters = 0;
     std::vector<int32_t> tgt(size_t(n) + 1);
     std::vector<int8_t> str(size_t(n) + 1);
-    std::vector<uint8_t> flg(size_t(n) + 1);
-    if ((r = ioc_get_decisions(c, tgt.data(), str.data(), flg.data())) != IOC_OK) return r;
-    // final cluster ids in creation order (newId = cls.size(), cluster.cpp:178)
+    std::vector<uint8_t> flg(size_t(n) + 1), aligned(size_t(n) + 1, 0);
     std::vector<int32_t> cid(size_t(n) + 1, -1);
+    int64_t aln_invoked = 0;
+    int scan_from = 0;
+    for (;;) {
+        if ((r = ioc_resolve(c, &iters)) != IOC_OK) return r;
+        total_iters += iters;
+        if ((r = ioc_get_decisions(c, tgt.data(), str.data(), flg.data())) != IOC_OK) return r;
+        if (!aln_mode) break;
+        // Alignment fallback (cluster.cpp:553-566): queries whose mapping found nothing although
+        // top >= MinShared, in loop order.  Everything before the first such query is final, so its
+        // candidate set is the reference's; a verdict "new cluster" equals the provisional decision and
+        // changes nothing downstream, a verdict "join" changes which entries are clusters: resolve again.
+        bool changed = false;
+        int32_t next_id = c->L;
+        for (int i = 0; i < scan_from; ++i)
+            if (!gated[size_t(i)] && tgt[size_t(i)] < 0) cid[size_t(i)] = next_id++;
+            else cid[size_t(i)] = -1;
+        int i = scan_from;
+        for (; i < n; ++i) {
+            cid[size_t(i)] = (!gated[size_t(i)] && tgt[size_t(i)] < 0) ? next_id : -1;
+            if (!gated[size_t(i)] && (flg[size_t(i)] & 2) && !aligned[size_t(i)]) {
+                int32_t at = -1;
+                int8_t as = 0;
+                aln_invoked++;
+                if ((r = align_query(c, i, cid, *sa, at, as)) != IOC_OK) return r;
+                aligned[size_t(i)] = 1;
+                if ((r = ioc_force_decision(c, i, at, at < 0 ? 0 : as)) != IOC_OK) return r;
+                if (at >= 0) {
+                    changed = true;
+                    scan_from = i + 1;
+                    break;
+                }
+            }
+            if (cid[size_t(i)] >= 0) next_id++;
+        }
+        if (!changed) break;
+    }
+    // final cluster ids in creation order (newId = cls.size(), cluster.cpp:178)
+    std::fill(cid.begin(), cid.end(), -1);
     int32_t next = c->L;
     for (int i = 0; i < n; ++i)
         if (!gated[size_t(i)] && tgt[size_t(i)] < 0) cid[size_t(i)] = next++;
@@ -268,8 +386,8 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         stats->n_joined = joined;
         stats->n_gated = ngated;
         stats->n_tie_replays = ties;
-        stats->n_aln_invoked = 0;
-        stats->resolve_iters = iters;
+        stats->n_aln_invoked = aln_invoked;
+        stats->resolve_iters = total_iters;
     }
     return IOC_OK;
 }
@@ -382,7 +500,24 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
         r = ioc_left_load(c, 0, nullptr, 0, nullptr, nullptr, nullptr);
     }
     if (r != IOC_OK) return r;
-    return run_pipeline(c, gated, need, out_cls, out_strand, stats);
+    SeqAccess sa;
+    sa.r_seq = rb->raw_seq;
+    sa.r_off = rb->raw_off;
+    sa.r_err = rb->raw_err;
+    if (left) {
+        sa.l_seq = left->rep_seq;
+        sa.l_off = left->rep_off;
+        sa.l_err = left->cls_raw_err;
+    }
+    // furious mode skips the mapping test altogether (cluster.cpp:545-551): no candidate can pass
+    if (p->mode == IOC_MODE_FURIOUS) {
+        std::vector<uint32_t> never(size_t(n) + 1, 0xFFFFFFFEu);
+        if (n > 0) {
+            hipError_t e = hipMemcpy(const_cast<uint32_t*>(c->d_min_total), never.data(), size_t(n) * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
+        }
+    }
+    return run_pipeline(c, gated, need, out_cls, out_strand, stats, &sa);
 }
 
 int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
@@ -397,7 +532,9 @@ int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_c
         hipError_t e = hipMemcpy(need.data(), c->d_min_total, size_t(n) * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
     }
-    return run_pipeline(c, gated, need, out_cls, out_strand, stats);
+    if (c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS)
+        return ioc_fail(c, IOC_ERR_STATE, "ioc_cluster_resident has no sequences: use ioc_cluster_batch for sahlin/furious");
+    return run_pipeline(c, gated, need, out_cls, out_strand, stats, nullptr);
 }
 
 }  // extern "C"

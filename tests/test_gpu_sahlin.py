@@ -1,0 +1,66 @@
+"""GPU parity of sahlin / furious mode (minimizer mapping on the device + host alignment fallback,
+src/cluster.cpp:545-566) against the oracle.  parasail is absent from the reference tree, so both sides
+use the product's host aligner (the oracle through its aligner hook): what is checked is the control
+flow — which reads reach the fallback, which candidates are aligned in which order, and how the verdicts
+feed back into the greedy loop."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import _lib, api, synth
+from oracle import pyoracle as po
+from tests.helpers import oracle_entry_assignments, oracle_sorted_batch
+
+pytestmark = pytest.mark.gpu
+
+_CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+
+
+@pytest.fixture(scope="module")
+def hooked_oracle():
+    L = _lib.load()
+
+    def cb(read, nread, rep, nrep, go, ge, out, cap):
+        return L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None)
+
+    fn = _CB(cb)
+    po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
+    yield fn
+    po.lib().orc_set_aligner(None)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _with_sequences(rs, view):
+    seqs = [rs.read(int(i))[0] for i in view["orig"]]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    v = dict(view)
+    v.update(raw_seq=b"".join(seqs), raw_off=off)
+    return v
+
+
+@pytest.mark.parametrize("mode", ["sahlin", "furious"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_alignment_fallback_modes(ctx, hooked_oracle, mode, seed):
+    rs = synth.generate(220, 25, 500, 9, 20, seed=seed)
+    B, view = oracle_sorted_batch(rs)
+    ocl, ost, ostat = oracle_entry_assignments(B, view, mode=mode)
+    cls, strand, st = ctx.cluster_batch(api.default_params(11, 15, mode), _with_sequences(rs, view))
+    bad = np.nonzero((cls != ocl) | (strand != ost))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
+    assert st["n_aln_invoked"] == ostat["aln_invoked"] > 0
+    assert st["n_clusters"] == B.n_clusters()
+
+
+def test_sahlin_needs_sequences(ctx):
+    rs = synth.generate_config("tiny")
+    B, view = oracle_sorted_batch(rs)
+    with pytest.raises(api.IocError):
+        ctx.cluster_batch(api.default_params(11, 15, "sahlin"), view)
