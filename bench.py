@@ -46,7 +46,33 @@ def prepare_resident_batch(ctx, api, synth, config, seed, k, w):
                      for h, kp in zip(ex["hpc_len"], keep)], np.uint32)
     ctx.queries_from_extracted(keep, cell, need)
     ctx.left_load(0, None, None, None, None)
+    ex.update(score=score[order], raw_err=err[order])
+    ctx._last_extract = ex
     return rs, order, int(ex["off_rev"][-1])
+
+
+def resident_to_clustered(ctx, api, pipeline, rs, order, cls, strand, rank):
+    """ClusteredBatch (representative records + membership + MinDB) of the batch just clustered."""
+    import numpy as np
+    n_min = ctx.timings()["n_minimizers"]
+    mn, ps = ctx.extracted_download(int(n_min))
+    ex = ctx._last_extract
+    view = dict(off_fwd=ex["off_fwd"], off_rev=ex["off_rev"], min_val=mn, min_pos=ps,
+                raw_len=np.diff(rs.offs)[order].astype(np.uint32), hpc_len=ex["hpc_len"],
+                score=ex["score"], raw_err=ex["raw_err"], hpc_err=ex["hpc_err"],
+                state=np.zeros(rs.n, np.uint8), min_qual=7.0)
+    keys, offs, post = ctx.index_export()
+    ok = cls >= 0
+    ncl = int(cls.max()) + 1 if ok.any() else 0
+    rep_entry = np.full(ncl, -1, np.int64)
+    for i in np.nonzero(ok)[0][::-1]:
+        rep_entry[cls[i]] = i            # first entry of each cluster = its creator
+    base = rank * 10_000_000
+    return pipeline.ClusteredBatch(rep_view=pipeline.gather_records(view, rep_entry),
+                                   member_cls=cls[ok].astype(np.int32),
+                                   member_read=(base + order[ok]).astype(np.int64),
+                                   member_strand=strand[ok].astype(np.int32), mindb=(keys, offs, post),
+                                   depth=0, batch_start=base, batch_end=base + rs.n - 1)
 
 
 def cpu_baseline_and_parity(rs, order, cls, strand, k, w):
@@ -72,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--merge", action="store_true",
+                    help="after the timed region: all-gather the clustered batches and left-fold merge them on rank 0")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,17 +112,20 @@ def main():
     from isonclust2_amd import api, synth
 
     dist = None
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev          # one process per GPU; (gloo smoke runs may share a device)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if a.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=a.backend)
+    dev = torch.device("cuda", dev_index) if (dist is None or a.backend == "nccl") else torch.device("cpu")
 
-    ctx = api.Context(local_rank)
+    ctx = api.Context(dev_index)
     rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w)
 
     def barrier():
@@ -176,6 +208,21 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out), flush=True)
+    if a.merge:
+        # config 4: RCCL all-gather of every rank's clustered batch, then the reference's left fold
+        # ((b0 + b1) + b2) ... with ioc_cluster_merge on rank 0 (untimed extra, reported on stderr)
+        from isonclust2_amd import dist as idist
+        from isonclust2_amd import pipeline
+        cb = resident_to_clustered(ctx, api, pipeline, rs, order, cls, strand, rank)
+        t1 = time.perf_counter()
+        allb = idist.allgather_clustered(cb, dist)
+        t2 = time.perf_counter()
+        if rank == 0:
+            merged = idist.fold_merge(ctx, api.default_params(k, w, "fast"), allb)
+            t3 = time.perf_counter()
+            print(json.dumps({"merge": {"batches": len(allb), "clusters_in": [b.n_clusters for b in allb],
+                                        "clusters_out": merged.n_clusters, "allgather_ms": (t2 - t1) * 1e3,
+                                        "fold_ms": (t3 - t2) * 1e3}}), file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
