@@ -49,3 +49,51 @@ def test_k13_w20(ctx):
 
 def test_mixed_lengths(ctx):
     _check(ctx, synth.generate(400, 40, 900, 9, 22, seed=9, len_jitter=0.6))
+
+
+def test_long_reads_multi_pass_evaluation(ctx):
+    """40 kb reads: > 4096 minimizers per strand and > 4096 distinct values per representative, i.e. the
+    multi-pass evaluator and the large-set (global binary search) membership path."""
+    _check(ctx, synth.generate(60, 6, 40000, 11, 20, seed=13))
+
+
+def test_range_passes_and_unpartitioned_kernel(ctx, monkeypatch):
+    """More visible targets than the LDS histogram window: k_score_t with range passes (forced small)."""
+    monkeypatch.setenv("IOC_SCORE_RANGE", "96")
+    _check(ctx, synth.generate_config("config1", seed=5))
+    monkeypatch.setenv("IOC_SCORE_RANGE", "8192")
+    monkeypatch.setenv("IOC_SCORE_PARTS", "0")
+    _check(ctx, synth.generate_config("short_dup", seed=4))
+
+
+def test_tiny_work_queue_forces_repeated_sweeps(ctx, monkeypatch):
+    """A work queue smaller than the number of pending evaluations: sweeps repeat until complete."""
+    monkeypatch.setenv("IOC_QUEUE_CAP", "64")
+    _check(ctx, synth.generate_config("config1", seed=6))
+
+
+def test_empty_and_degenerate_batches(ctx):
+    p = api.default_params(11, 15, "fast")
+    empty = dict(off_fwd=np.zeros(1, np.int64), off_rev=np.zeros(1, np.int64), min_val=np.zeros(0, np.uint32),
+                 min_pos=np.zeros(0, np.uint32), raw_len=np.zeros(0, np.uint32), hpc_len=np.zeros(0, np.uint32),
+                 score=np.zeros(0), raw_err=np.zeros(0), hpc_err=np.zeros(0), state=np.zeros(0, np.uint8))
+    cls, strand, st = ctx.cluster_batch(p, empty)
+    assert len(cls) == 0 and st["n_clusters"] == 0
+    # one read; and a batch in which every read is gated (quality below MinQual)
+    rs = synth.generate(1, 1, 800, 15, 15, seed=1)
+    _check(ctx, rs)
+    rs = synth.generate(20, 2, 600, 3, 5, seed=2)
+    B, view = oracle_sorted_batch(rs)
+    cls, strand, st = ctx.cluster_batch(p, view)
+    ocl, ost, _ = oracle_entry_assignments(B, view)
+    assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
+    assert st["n_gated"] == int((ocl < 0).sum())
+
+
+def test_mode_none_opens_one_cluster_per_read(ctx):
+    """`cluster` without -x: Mode = None, no branch of getBestCluster fires (cluster.cpp:545-567)."""
+    rs = synth.generate_config("tiny")
+    B, view = oracle_sorted_batch(rs)
+    ocl, ost, _ = oracle_entry_assignments(B, view, mode="none")
+    cls, strand, st = ctx.cluster_batch(api.default_params(11, 15, "none"), view)
+    assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
