@@ -334,6 +334,10 @@ int ioc_index_build(ioc_ctx* c)
     if (pmax > 32768) return ioc_fail(c, IOC_ERR_CAPACITY, "a query has more than 32768 forward minimizers");
     hipStream_t s = c->stream;
     HIPCHK(c, hipEventRecord(c->ev[0], s));
+    // 16-bit postings when every target id fits (the padding value 0xFFFF must stay above every id)
+    c->post16 = (uint64_t(c->L) + uint64_t(n) <= 65535ull && env_u32("IOC_POST16", 1) == 1) ? 1 : 0;
+    const uint32_t psize = c->post16 ? 2u : 4u;
+    const uint32_t pmask = 16u / psize - 1u;  // lists are padded to whole 16-byte units
 
     RESERVE(c, c->b_dvals, size_t(nfwd_total) * 4);
     RESERVE(c, c->b_dslot, size_t(nfwd_total) * 4);
@@ -380,7 +384,7 @@ int ioc_index_build(ioc_ctx* c)
                                            P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_fill),
                                            d_err));
         // posting lists start 16-byte aligned and are padded to a multiple of 4 entries (0xFFFFFFFF)
-        HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan), 3u));
+        HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan), pmask));
         uint32_t h_err = 0, h_total = 0;
         HIPCHK(c, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&h_total, P<uint32_t>(c->b_off) + nslots, 4, hipMemcpyDeviceToHost, s));
@@ -393,15 +397,15 @@ int ioc_index_build(ioc_ctx* c)
         c->cap = cap;
         c->n_post = h_total;
         if (uint64_t(h_total) >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 padded index postings");
-        RESERVE(c, c->b_post, size_t(h_total) * 4 + 256);
-        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, size_t(h_total) * 4 + 256, s));
+        RESERVE(c, c->b_post, size_t(h_total) * psize + 256);
+        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, size_t(h_total) * psize + 256, s));
         HIPCHK(c, iock_fill_left(s, c->n_left_keys, P<int64_t>(c->b_loffs), P<uint32_t>(c->b_lpost),
-                                 P<uint32_t>(c->b_lslot), P<uint32_t>(c->b_off), P<uint32_t>(c->b_post)));
+                                 P<uint32_t>(c->b_lslot), P<uint32_t>(c->b_off), c->b_post.p, c->post16));
         HIPCHK(c, iock_fill_queries(s, n, uint32_t(c->L), P<int64_t>(c->b_doff), P<uint32_t>(c->b_dcount),
                                     P<uint32_t>(c->b_dslot), P<uint32_t>(c->b_fill), P<uint32_t>(c->b_off),
-                                    P<uint32_t>(c->b_post)));
-        HIPCHK(c, iock_sort_lists(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_post),
-                                  uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048, P<uint32_t>(c->b_qinfo)));
+                                    c->b_post.p, c->post16));
+        HIPCHK(c, iock_sort_lists(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p,
+                                  uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048, P<uint32_t>(c->b_qinfo), c->post16));
         HIPCHK(c, iock_pack_rows(s, nslots, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt),
                                  P<uint32_t>(c->b_qinfo), c->b_rows.p));
         break;
@@ -464,9 +468,9 @@ int ioc_score(ioc_ctx* c)
     }
     HIPCHK(c, hipEventRecord(c->ev[2], s));
     HIPCHK(c, iock_score(s, n, uint32_t(L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
-                         hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
+                         hash_shift(c->cap), c->b_post.p, range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all)));
+                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all), c->post16));
     c->have_guess = d_part != nullptr;
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
@@ -584,7 +588,12 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         HIPCHK(c, hipMemsetAsync(c->b_diag.p, 0, 64, s));
         a.diag = P<unsigned long long>(c->b_diag);
     }
+    // Two stages.  Lazy sweeps walk only each query's maximal-Size candidates and let a query whose top
+    // candidates fail open a cluster provisionally; once those sweeps are stable, exact sweeps (the whole
+    // walk) restart from query 0 on an almost final `valid`, so the long tails of the walk are evaluated
+    // against actual clusters only.  The result is the fixed point of the exact sweeps either way.
     int first = 0, iters = 0, sweeps = 0;
+    a.lazy = env_u32("IOC_RESOLVE_LAZY", 1) == 1 ? 1 : 0;
     while (first < n) {
         uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
         uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
@@ -604,7 +613,14 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         iters++;
         c->cur_valid ^= 1;
         const uint32_t fc = res[0];
-        if (fc == 0xFFFFFFFFu) break;  // fixed point: valid_out == valid_in
+        if (fc == 0xFFFFFFFFu) {
+            if (a.lazy) {  // lazy fixed point reached: switch to the exact sweeps
+                a.lazy = 0;
+                first = 0;
+                continue;
+            }
+            break;  // fixed point: valid_out == valid_in
+        }
         // queries <= fc are final: fc was computed from a correct prefix, everything before it
         // did not change ("fixed point of the greedy loop")
         first = int(fc) + 1;
@@ -672,7 +688,7 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
     if (e == hipSuccess) e = hipMemsetAsync(first.p, 0xFF, size_t(2) * T * 4, s);
     if (e == hipSuccess)
         e = iock_query_table(s, q, L, c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap, hash_shift(c->cap),
-                             P<uint32_t>(c->b_post), valid, P<uint32_t>(hist), P<uint32_t>(first));
+                             c->b_post.p, valid, P<uint32_t>(hist), P<uint32_t>(first), c->post16);
     if (e == hipSuccess) e = hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), first.p, hf.size() * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&cc, P<uint32_t>(c->b_cand_count) + q, 4, hipMemcpyDeviceToHost, s);
@@ -726,15 +742,21 @@ int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t*
     if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
     hipStream_t s = c->stream;
     const uint32_t nslots = c->cap + 1;
+    const uint32_t psize = c->post16 ? 2u : 4u;
     std::vector<uint32_t> hk(nslots), ho(size_t(nslots) + 1), hc(nslots), hp(size_t(c->n_post) + 1);
+    std::vector<uint16_t> hp16(c->post16 ? size_t(c->n_post) + 1 : 1);
     std::vector<uint8_t> valid(size_t(c->n) + 1);
     HIPCHK(c, hipMemcpyAsync(hk.data(), c->b_keys.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(ho.data(), c->b_off.p, size_t(nslots + 1) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(hc.data(), c->b_cnt.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
-    if (c->n_post) HIPCHK(c, hipMemcpyAsync(hp.data(), c->b_post.p, size_t(c->n_post) * 4, hipMemcpyDeviceToHost, s));
+    if (c->n_post)
+        HIPCHK(c, hipMemcpyAsync(c->post16 ? (void*)hp16.data() : (void*)hp.data(), c->b_post.p,
+                                 size_t(c->n_post) * psize, hipMemcpyDeviceToHost, s));
     const void* v = c->cur_valid == 0 ? c->b_valid0.p : c->b_valid1.p;
     if (c->n) HIPCHK(c, hipMemcpyAsync(valid.data(), v, size_t(c->n), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (c->post16)
+        for (size_t i = 0; i < size_t(c->n_post); ++i) hp[i] = hp16[i];
     // final cluster id of query i that opened a cluster = L + rank among such queries (cluster.cpp:178)
     std::vector<int32_t> cid(size_t(c->n) + 1, -1);
     int32_t next = c->L;
@@ -786,9 +808,9 @@ int ioc_count_reference_postings(ioc_ctx* c, int64_t* n_postings)
     const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
     const uint32_t range = env_u32("IOC_SCORE_RANGE", 8192);
     HIPCHK(c, iock_score(s, c->n, uint32_t(c->L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
-                         hash_shift(c->cap), P<uint32_t>(c->b_post), range, uint32_t(c->keep),
+                         hash_shift(c->cap), c->b_post.p, range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         nullptr, valid, d_sum, P<uint32_t>(c->b_part), nullptr));
+                         nullptr, valid, d_sum, P<uint32_t>(c->b_part), nullptr, c->post16));
     unsigned long long h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

@@ -57,6 +57,7 @@ struct ioc_ctx {
     uint32_t cap = 0;  // power of two; slot `cap` is reserved for the key 0xFFFFFFFF
     DevBuf b_keys, b_cnt, b_off, b_fill, b_rows, b_post, b_dvals, b_dcount, b_dslot, b_scan;
     int64_t n_post = 0;
+    int post16 = 0;  // postings stored as uint16_t (L + N <= 65535)
 
     // ---- scoring ----
     bool scored = false;

@@ -51,6 +51,7 @@ struct DecideArgs {
     uint32_t* top;          // per query: top Size over the targets that are clusters
     uint8_t* done;          // per query: decided in phase 1
     unsigned long long* diag;  // diagnostic cycle sums (IOC_EVAL_DIAG), normally nullptr
+    int lazy;               // lazy sweep: only the maximal-Size candidates are walked (see ioc_resolve)
 };
 
 extern "C" {
@@ -65,25 +66,25 @@ hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* 
 hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch,
                                uint32_t round_mask);
 hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
-                          const uint32_t* lslot, const uint32_t* off, uint32_t* post);
+                          const uint32_t* lslot, const uint32_t* off, void* post, int post16);
 hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
-                             const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, uint32_t* post);
-hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
-                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo);
+                             const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, void* post, int post16);
+hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, void* post,
+                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16);
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
                           const uint32_t* cnt, const uint32_t* qinfo, void* rows);
 hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
-                      const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
+                      const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
                       unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
-                      uint32_t* part, uint32_t* top_all);
+                      uint32_t* part, uint32_t* top_all, int post16);
 hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* top_all, uint8_t* valid);
 hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks, uint32_t* q_count2);
 hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout);
 hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
-                            const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
-                            const uint8_t* valid, uint32_t* hist, uint32_t* first);
+                            const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post,
+                            const uint8_t* valid, uint32_t* hist, uint32_t* first, int post16);
 size_t iock_decide_args_size();
 void iock_set_score_variant(int v);
 

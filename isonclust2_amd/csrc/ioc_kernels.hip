@@ -289,9 +289,12 @@ k_scan_apply(const uint32_t* __restrict__ in, int64_t n, const uint32_t* __restr
 }
 
 // ---- fill ------------------------------------------------------------------------------------------
+// Postings are stored as PT = uint16_t when every target id fits (L + N <= 65535: 8 postings per 16-byte
+// unit, half the bytes), else uint32_t.
+template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_fill_left(int64_t nkeys, const int64_t* __restrict__ loffs, const uint32_t* __restrict__ lpost,
-            const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ off, uint32_t* __restrict__ post)
+            const uint32_t* __restrict__ lslot, const uint32_t* __restrict__ off, PT* __restrict__ post)
 {
     // one wave per key
     int64_t key = (int64_t(blockIdx.x) * IOC_BLOCK + threadIdx.x) >> 6;
@@ -300,20 +303,21 @@ k_fill_left(int64_t nkeys, const int64_t* __restrict__ loffs, const uint32_t* __
     int64_t b = loffs[key];
     uint32_t m = uint32_t(loffs[key + 1] - b);
     uint32_t o = off[slot];
-    for (uint32_t t = lane_id(); t < m; t += 64) post[o + t] = lpost[b + t];
+    for (uint32_t t = lane_id(); t < m; t += 64) post[o + t] = PT(lpost[b + t]);
 }
 
+template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32_t* __restrict__ dcount,
                const uint32_t* __restrict__ dslot, const uint32_t* __restrict__ dpos,
-               const uint32_t* __restrict__ off, uint32_t* __restrict__ post)
+               const uint32_t* __restrict__ off, PT* __restrict__ post)
 {
     int j = blockIdx.x;
     if (j >= n) return;
     int64_t b = doff[j];
     uint32_t m = dcount[j];
     for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) {
-        post[off[dslot[b + d]] + dpos[b + d]] = L + uint32_t(j);
+        post[off[dslot[b + d]] + dpos[b + d]] = PT(L + uint32_t(j));
     }
 }
 
@@ -321,9 +325,10 @@ k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32
 // src/minimizer.cpp:38-40); the atomic fill leaves the query part of each list unordered.
 // One wave per slot: rank-by-counting for lists <= 64; longer lists go through a per-wave LDS bitmap
 // (the query part holds distinct integers in [L, L+n)).
+template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-             uint32_t* __restrict__ post, uint32_t L, uint32_t words_per_wave, uint32_t e1, uint32_t e2,
+             PT* __restrict__ post, uint32_t L, uint32_t words_per_wave, uint32_t e1, uint32_t e2,
              uint32_t e3, uint32_t* __restrict__ qinfo)
 {
     extern __shared__ uint32_t sbits[];  // IOC_WAVES * words_per_wave
@@ -365,7 +370,7 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
         }
         const uint32_t m = c - a;
         if (m < 2) continue;
-        uint32_t* p = post + o + a;
+        PT* p = post + o + a;
         if (m <= 64) {
             uint32_t x = (uint32_t(lane) < m) ? p[lane] : IOC_EMPTY;
             uint32_t rank = 0;
@@ -373,7 +378,7 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
                 uint32_t y = __shfl(x, int(t));
                 rank += (y < x);
             }
-            if (uint32_t(lane) < m) p[rank] = x;
+            if (uint32_t(lane) < m) p[rank] = PT(x);
         } else {
             for (uint32_t wd = lane; wd < words_per_wave; wd += 64) bits[wd] = 0;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -392,7 +397,7 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
                 while (bw) {
                     uint32_t bit = __ffs(bw) - 1;
                     bw &= bw - 1;
-                    p[ex++] = L + wd * 32 + bit;
+                    p[ex++] = PT(L + wd * 32 + bit);
                 }
                 base += __shfl(incl, 63);
             }
@@ -423,7 +428,8 @@ k_pack_rows(uint32_t nslots, const uint32_t* __restrict__ keys, const uint32_t* 
 // Output: compacted candidate list (target<<1|strandbit, Size) for Size >= keep, ordered by
 // (strand, target) — deterministic.
 // =====================================================================================================
-__device__ __forceinline__ uint32_t list_lower_bound(const uint32_t* __restrict__ p, uint32_t n, uint32_t v)
+template <typename PT>
+__device__ __forceinline__ uint32_t list_lower_bound(const PT* __restrict__ p, uint32_t n, uint32_t v)
 {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
@@ -445,8 +451,8 @@ __device__ __forceinline__ uint32_t list_lower_bound(const uint32_t* __restrict_
 // a 6-step search per posting.  The kernel is VALU-issue bound, so instructions per posting are what
 // counts: the list bookkeeping is amortised over 4 postings.
 #define IOC_BM_WORDS 128  // + IOC_FLAT_UNROLL words of slack are allocated
-template <int V>
-__device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post, uint32_t o, uint32_t len,
+template <int V, typename PT>
+__device__ __forceinline__ void flat_traverse(const PT* __restrict__ post, uint32_t o, uint32_t len,
                                               uint32_t* __restrict__ wb, unsigned long long* __restrict__ bm,
                                               uint32_t* __restrict__ h, uint32_t rbase, uint32_t hi,
                                               unsigned long long& trav, uint32_t& abl)
@@ -454,7 +460,9 @@ __device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post,
     const int lane = lane_id();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const unsigned long long le_mask = lt_mask | (1ull << lane);
-    const uint32_t lenU = (len + 3u) >> 2;  // units of 4 postings
+    constexpr uint32_t PER = 16u / uint32_t(sizeof(PT));  // postings per 16-byte unit: 4 or 8
+    constexpr uint32_t PSH = PER == 8 ? 3u : 2u;
+    const uint32_t lenU = (len + PER - 1u) >> PSH;
     const unsigned long long nz = __ballot(lenU != 0);
     const uint32_t nl = uint32_t(__popcll(nz));
     if (nl == 0) return;
@@ -463,14 +471,14 @@ __device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post,
     const uint32_t excl = incl - lenU;
     const uint32_t nwords = (total + 63) >> 6;
     const uint4* __restrict__ post4 = reinterpret_cast<const uint4*>(post);
-    trav += 4ull * total;
+    trav += (unsigned long long)PER * total;
     if (nwords <= IOC_BM_WORDS) {
         // (zero IOC_FLAT_UNROLL words past the end so that the unrolled loop reads unconditionally)
         for (uint32_t w = lane; w < nwords + IOC_FLAT_UNROLL; w += 64) bm[w] = 0ull;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lenU) {
-            wb[__popcll(nz & lt_mask)] = (o >> 2) - excl;  // unit address = wb[list] + p
+            wb[__popcll(nz & lt_mask)] = (o >> PSH) - excl;  // unit address = wb[list] + p
             atomicOr(&bm[excl >> 6], 1ull << (excl & 63u));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -506,9 +514,22 @@ __device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post,
             }
 #pragma unroll
             for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
-                const uint32_t t4[4] = {tg[u].x, tg[u].y, tg[u].z, tg[u].w};
+                uint32_t t4[PER];
+                if (PER == 4) {
+                    t4[0] = tg[u].x;
+                    t4[1] = tg[u].y;
+                    t4[2] = tg[u].z;
+                    t4[3] = tg[u].w;
+                } else {
+                    const uint32_t w4[4] = {tg[u].x, tg[u].y, tg[u].z, tg[u].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 4; ++e) {
+                        t4[2 * e] = w4[e] & 0xFFFFu;
+                        t4[2 * e + 1] = w4[e] >> 16;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < int(PER); ++e) {
                     if (V == 1 || V == 6) {  // ablation: no LDS atomics
                         if (t4[e] < hi) abl += t4[e];
                     } else if (V == 7) {  // ablation: plain LDS stores instead of atomics
@@ -528,7 +549,7 @@ __device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post,
         if (lenU) {
             const uint32_t r = uint32_t(__popcll(nz & lt_mask));
             wx[r] = excl;
-            wb[r] = o >> 2;
+            wb[r] = o >> PSH;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -540,20 +561,27 @@ __device__ __forceinline__ void flat_traverse(const uint32_t* __restrict__ post,
                 if (r2 < nl && wx[r2] <= p) r = r2;
             }
             const uint4 t = post4[wb[r] + (p - wx[r])];
-            if (t.x - rbase < hi - rbase) atomicAdd(&h[t.x - rbase], 1u);
-            if (t.y - rbase < hi - rbase) atomicAdd(&h[t.y - rbase], 1u);
-            if (t.z - rbase < hi - rbase) atomicAdd(&h[t.z - rbase], 1u);
-            if (t.w - rbase < hi - rbase) atomicAdd(&h[t.w - rbase], 1u);
+            const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (PER == 4) {
+                    if (w4[e] - rbase < hi - rbase) atomicAdd(&h[w4[e] - rbase], 1u);
+                } else {
+                    const uint32_t a0 = w4[e] & 0xFFFFu, a1 = w4[e] >> 16;
+                    if (a0 - rbase < hi - rbase) atomicAdd(&h[a0 - rbase], 1u);
+                    if (a1 - rbase < hi - rbase) atomicAdd(&h[a1 - rbase], 1u);
+                }
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int V>
+template <int V, typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
         const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
-        const uint32_t* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
+        const PT* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
         unsigned long long* __restrict__ traversed, uint32_t e1, uint32_t e2, uint32_t e3,
         const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum)
@@ -611,9 +639,9 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
                     if (rbase == 0 && hi == T && !(qi & 0x80000000u)) {
                         if (eshift < 30) len = (qi >> eshift) & 1023u;
                     } else {
-                        const uint32_t* pl = post + o;
+                        const PT* pl = post + o;
                         // (start rounded down to a 16-byte unit; entries < rbase are rejected below)
-                        const uint32_t i0 = rbase ? (list_lower_bound(pl, len, rbase) & ~3u) : 0u;
+                        const uint32_t i0 = rbase ? (list_lower_bound(pl, len, rbase) & ~(16u / uint32_t(sizeof(PT)) - 1u)) : 0u;
                         const uint32_t i1 = list_lower_bound(pl, len, hi);
                         len = i1 - i0;
                         o += i0;
@@ -622,7 +650,7 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
                 if (V == 4) {  // ablation: probes only
                     abl += len + o;
                 } else {
-                    flat_traverse<V>(post, o, len, wb_, bm_, h, rbase, hi, trav, abl);
+                    flat_traverse<V, PT>(post, o, len, wb_, bm_, h, rbase, hi, trav, abl);
                 }
             }
         }
@@ -692,10 +720,11 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
 // and writes the candidate list.
 // =====================================================================================================
 #define IOC_PARTS 8
+template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
-             const uint32_t* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1, uint32_t e2, uint32_t e3,
+             const PT* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1, uint32_t e2, uint32_t e3,
              unsigned long long* __restrict__ traversed)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
@@ -754,7 +783,7 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
                         len = list_lower_bound(post + o, len, T);
                     }
                 }
-                flat_traverse<0>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
+                flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
             }
             if (!more) break;
         }
@@ -1512,8 +1541,10 @@ k_decide_pick(DecideArgs a)
                 if (bc > 1) out_f |= 1;
             } else {
                 out_f |= 2;  // no mapping hit although top >= MinShared (cluster.cpp:553-566)
-                // phase 1 only looked at the maximal-Size candidates: the walk goes on in phase 2
-                if (a.phase == 1) decided = false;
+                // phase 1 only looked at the maximal-Size candidates: the walk goes on in phase 2 —
+                // unless this is a lazy sweep, which provisionally lets the query open a cluster (what
+                // almost always happens) and leaves the rest of the walk to the final exact sweeps
+                if (a.phase == 1 && !a.lazy) decided = false;
             }
             if (miss) decided = false;
         }
@@ -1558,10 +1589,11 @@ k_copy_prefix_valid(int first, const uint8_t* __restrict__ vin, uint8_t* __restr
 // the host): Size and the Index of the first hitting read minimizer per (target, strand).
 // hist/first live in global scratch (2 * T words each), zeroed / set to 0xFFFFFFFF by the host.
 // =====================================================================================================
+template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
               const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
-              const uint32_t* __restrict__ post, const uint8_t* __restrict__ valid, uint32_t* __restrict__ hist,
+              const PT* __restrict__ post, const uint8_t* __restrict__ valid, uint32_t* __restrict__ hist,
               uint32_t* __restrict__ first)
 {
     const uint32_t T = L + uint32_t(j);
@@ -1652,20 +1684,30 @@ hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, ui
 }
 
 hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,
-                          const uint32_t* lslot, const uint32_t* off, uint32_t* post)
+                          const uint32_t* lslot, const uint32_t* off, void* post, int post16)
 {
     if (nkeys <= 0) return hipSuccess;
     int64_t threads = nkeys * 64;
-    hipLaunchKernelGGL(k_fill_left, dim3((unsigned)((threads + IOC_BLOCK - 1) / IOC_BLOCK)), dim3(IOC_BLOCK), 0, st,
-                       nkeys, loffs, lpost, lslot, off, post);
+    const dim3 grid((unsigned)((threads + IOC_BLOCK - 1) / IOC_BLOCK));
+    if (post16)
+        hipLaunchKernelGGL(k_fill_left<uint16_t>, grid, dim3(IOC_BLOCK), 0, st, nkeys, loffs, lpost, lslot, off,
+                           (uint16_t*)post);
+    else
+        hipLaunchKernelGGL(k_fill_left<uint32_t>, grid, dim3(IOC_BLOCK), 0, st, nkeys, loffs, lpost, lslot, off,
+                           (uint32_t*)post);
     return hipGetLastError();
 }
 
 hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
-                             const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, uint32_t* post)
+                             const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, void* post, int post16)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_queries, dim3(n), dim3(IOC_BLOCK), 0, st, n, L, doff, dcount, dslot, dpos, off, post);
+    if (post16)
+        hipLaunchKernelGGL(k_fill_queries<uint16_t>, dim3(n), dim3(IOC_BLOCK), 0, st, n, L, doff, dcount, dslot, dpos,
+                           off, (uint16_t*)post);
+    else
+        hipLaunchKernelGGL(k_fill_queries<uint32_t>, dim3(n), dim3(IOC_BLOCK), 0, st, n, L, doff, dcount, dslot, dpos,
+                           off, (uint32_t*)post);
     return hipGetLastError();
 }
 
@@ -1676,17 +1718,25 @@ static void epoch_bounds(uint32_t L, uint32_t n, uint32_t& e1, uint32_t& e2, uin
     e3 = L + uint32_t((3ull * n + 3) / 4);
 }
 
-hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, uint32_t* post,
-                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo)
+hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, void* post,
+                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16)
 {
     uint32_t e1, e2, e3;
     epoch_bounds(L, n, e1, e2, e3);
     uint32_t words = (n + 31) / 32;
     if (words == 0) words = 1;
     size_t lds = size_t(IOC_WAVES) * words * 4;
-    if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_sort_lists, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(k_sort_lists, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt, post, L, words, e1, e2,
-                       e3, qinfo);
+    if (post16) {
+        if (lds > 48 * 1024)
+            CK(hipFuncSetAttribute((const void*)k_sort_lists<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(k_sort_lists<uint16_t>, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt,
+                           (uint16_t*)post, L, words, e1, e2, e3, qinfo);
+    } else {
+        if (lds > 48 * 1024)
+            CK(hipFuncSetAttribute((const void*)k_sort_lists<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        hipLaunchKernelGGL(k_sort_lists<uint32_t>, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt,
+                           (uint32_t*)post, L, words, e1, e2, e3, qinfo);
+    }
     return hipGetLastError();
 }
 
@@ -1699,11 +1749,13 @@ hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys,
 }
 
 hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
-                      const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
+                      const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post_,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
                       unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
-                      uint32_t* part, uint32_t* top_all)
+                      uint32_t* part, uint32_t* top_all, int post16)
 {
+    const uint32_t* post = (const uint32_t*)post_;
+    const uint16_t* post_h = (const uint16_t*)post_;
     if (n <= 0) return hipSuccess;
     uint32_t tmax = L + uint32_t(n - 1);
     uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
@@ -1712,34 +1764,43 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
         uint32_t e1, e2, e3;
         epoch_bounds(L, uint32_t(n), e1, e2, e3);
         if (lds > 40 * 1024) {
-            CK(hipFuncSetAttribute((const void*)k_score_part, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            CK(hipFuncSetAttribute((const void*)k_score_part<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
             CK(hipFuncSetAttribute((const void*)k_score_compact, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         }
-        hipLaunchKernelGGL(k_score_part, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev,
-                           mins, (const uint4*)rows, cap, shift, post, part, e1, e2, e3, traversed);
+        if (post16)
+            hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
+                               off_fwd, off_rev, mins, (const uint4*)rows, cap, shift, post_h, part, e1, e2, e3, traversed);
+        else
+            hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
+                               off_fwd, off_rev, mins, (const uint4*)rows, cap, shift, post, part, e1, e2, e3, traversed);
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
                            cand_count, audit_valid, audit_sum, top_all);
         return hipGetLastError();
     }
     uint32_t e1, e2, e3;
     epoch_bounds(L, uint32_t(n), e1, e2, e3);
-#define LAUNCH_SCORE(V)                                                                                              \
+#define LAUNCH_SCORE(V, PT, PP)                                                                                      \
     do {                                                                                                             \
         if (lds > 48 * 1024)                                                                                         \
-            CK(hipFuncSetAttribute((const void*)k_score_t<V>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); \
-        hipLaunchKernelGGL(k_score_t<V>, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,            \
-                           (const uint4*)rows, cap, shift, post, range, keep, cand_key, cand_size, cand_count,       \
+            CK(hipFuncSetAttribute((const void*)k_score_t<V, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); \
+        hipLaunchKernelGGL((k_score_t<V, PT>), dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,      \
+                           (const uint4*)rows, cap, shift, PP, range, keep, cand_key, cand_size, cand_count,         \
                            traversed, e1, e2, e3, audit_valid, audit_sum);                                           \
     } while (0)
+    if (post16) {
+        LAUNCH_SCORE(0, uint16_t, post_h);
+        return hipGetLastError();
+    }
     switch (g_score_variant) {  // ablation builds for profiling only (IOC_SCORE_VARIANT); 0 = production
-        case 1: LAUNCH_SCORE(1); break;
-        case 2: LAUNCH_SCORE(2); break;
-        case 3: LAUNCH_SCORE(3); break;
-        case 4: LAUNCH_SCORE(4); break;
-        case 5: LAUNCH_SCORE(5); break;
-        case 6: LAUNCH_SCORE(6); break;
-        case 7: LAUNCH_SCORE(7); break;
-        default: LAUNCH_SCORE(0); break;
+        case 1: LAUNCH_SCORE(1, uint32_t, post); break;
+        case 2: LAUNCH_SCORE(2, uint32_t, post); break;
+        case 3: LAUNCH_SCORE(3, uint32_t, post); break;
+        case 4: LAUNCH_SCORE(4, uint32_t, post); break;
+        case 5: LAUNCH_SCORE(5, uint32_t, post); break;
+        case 6: LAUNCH_SCORE(6, uint32_t, post); break;
+        case 7: LAUNCH_SCORE(7, uint32_t, post); break;
+        default: LAUNCH_SCORE(0, uint32_t, post); break;
     }
     return hipGetLastError();
 }
@@ -1752,6 +1813,7 @@ hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    if (a.lazy) return hipGetLastError();
     a.phase = 2;
     a.q_count = q_count2;
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
@@ -1778,11 +1840,15 @@ hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin,
 }
 
 hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
-                            const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const uint32_t* post,
-                            const uint8_t* valid, uint32_t* hist, uint32_t* first)
+                            const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post,
+                            const uint8_t* valid, uint32_t* hist, uint32_t* first, int post16)
 {
-    hipLaunchKernelGGL(k_query_table, dim3(64), dim3(IOC_BLOCK), 0, st, j, L, off_fwd, off_rev, mins,
-                       (const uint4*)rows, cap, shift, post, valid, hist, first);
+    if (post16)
+        hipLaunchKernelGGL(k_query_table<uint16_t>, dim3(64), dim3(IOC_BLOCK), 0, st, j, L, off_fwd, off_rev, mins,
+                           (const uint4*)rows, cap, shift, (const uint16_t*)post, valid, hist, first);
+    else
+        hipLaunchKernelGGL(k_query_table<uint32_t>, dim3(64), dim3(IOC_BLOCK), 0, st, j, L, off_fwd, off_rev, mins,
+                           (const uint4*)rows, cap, shift, (const uint32_t*)post, valid, hist, first);
     return hipGetLastError();
 }
 
