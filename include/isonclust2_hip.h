@@ -144,6 +144,9 @@ int ioc_qual_scores(ioc_ctx* ctx, int32_t n, const int64_t* offs, const uint8_t*
 int ioc_extract_minimizers(ioc_ctx* ctx, int32_t n, const int64_t* offs, const uint8_t* seq,
                            const uint8_t* qual, int32_t k, int32_t w, uint32_t* hpc_len,
                            double* hpc_err, int64_t* off_fwd, int64_t* off_rev, int32_t* status);
+/* Device->host copy of the HPC sequences / qualities of the last ioc_extract_minimizers (ASCII; read
+ * i occupies [offs[i], offs[i] + hpc_len[i]) of the buffers, which have the size of the raw input). */
+int ioc_extracted_hpc_download(ioc_ctx* ctx, char* hpc_seq, char* hpc_qual, int64_t cap);
 /* Device->host copy of the minimizers produced by the last ioc_extract_minimizers. */
 int ioc_extracted_download(ioc_ctx* ctx, uint32_t* min_val, uint32_t* min_pos, int64_t cap);
 /* Make the extracted minimizers the current queries (no host round trip of the 8 B/minimizer SoA).

@@ -67,7 +67,7 @@ SYMBOLS = [
     "ioc_set_params", "ioc_queries_upload", "ioc_queries_bind_device", "ioc_left_load",
     "ioc_index_build", "ioc_score", "ioc_resolve", "ioc_get_decisions", "ioc_force_decision",
     "ioc_clear_forced", "ioc_query_candidates", "ioc_index_export", "ioc_qual_scores",
-    "ioc_extract_minimizers", "ioc_extracted_download", "ioc_queries_from_extracted",
+    "ioc_extract_minimizers", "ioc_extracted_download", "ioc_extracted_hpc_download", "ioc_queries_from_extracted",
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
     "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
     "ioc_host_aln_ratio",
@@ -110,6 +110,7 @@ def load():
     L.ioc_qual_scores.argtypes = [vp, i32, pi64, pu8, i32, pd, pd]
     L.ioc_extract_minimizers.argtypes = [vp, i32, pi64, pu8, pu8, i32, i32, pu32, pd, pi64, pi64, pi32]
     L.ioc_extracted_download.argtypes = [vp, pu32, pu32, i64]
+    L.ioc_extracted_hpc_download.argtypes = [vp, C.c_char_p, C.c_char_p, i64]
     L.ioc_queries_from_extracted.argtypes = [vp, pu8, pu8, pu32]
     L.ioc_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.ioc_count_reference_postings.argtypes = [vp, pi64]

@@ -1,0 +1,318 @@
+// cer.cpp — binary (.cer) reader / writer for the batch record (see cer.hpp for the layout rules).
+#include "cer.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <unordered_map>
+
+namespace cer {
+namespace {
+
+struct Writer {
+    FILE* f;
+    bool ok = true;
+    uint32_t next_ptr = 1;
+    std::vector<char> buf;
+    explicit Writer(FILE* f_) : f(f_) { buf.reserve(1 << 22); }
+    void raw(const void* p, size_t n)
+    {
+        const char* c = static_cast<const char*>(p);
+        buf.insert(buf.end(), c, c + n);
+        if (buf.size() >= (1u << 22)) flush();
+    }
+    void flush()
+    {
+        if (!buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) ok = false;
+        buf.clear();
+    }
+    template <class T>
+    void pod(T v) { raw(&v, sizeof(T)); }
+    void str(const std::string& s)
+    {
+        pod<uint64_t>(s.size());
+        raw(s.data(), s.size());
+    }
+    uint32_t new_shared() { return (next_ptr++) | 0x80000000u; }
+};
+
+struct Reader {
+    const uint8_t* p;
+    const uint8_t* e;
+    bool ok = true;
+    void raw(void* d, size_t n)
+    {
+        if (size_t(e - p) < n) {
+            ok = false;
+            memset(d, 0, n);
+            return;
+        }
+        memcpy(d, p, n);
+        p += n;
+    }
+    template <class T>
+    T pod()
+    {
+        T v;
+        raw(&v, sizeof(T));
+        return v;
+    }
+    std::string str()
+    {
+        uint64_t n = pod<uint64_t>();
+        if (!ok || uint64_t(e - p) < n) {
+            ok = false;
+            return std::string();
+        }
+        std::string s(reinterpret_cast<const char*>(p), size_t(n));
+        p += n;
+        return s;
+    }
+};
+
+void put_seq(Writer& w, const Seq& s)
+{
+    w.str(s.name);
+    w.str(s.seq);
+    w.str(s.qual);
+    w.pod<double>(s.score);
+    w.pod<double>(s.errorRate);
+}
+void get_seq(Reader& r, Seq& s)
+{
+    s.name = r.str();
+    s.seq = r.str();
+    s.qual = r.str();
+    s.score = r.pod<double>();
+    s.errorRate = r.pod<double>();
+}
+void put_useq(Writer& w, const std::unique_ptr<Seq>& s)
+{
+    w.pod<uint8_t>(s ? 1 : 0);
+    if (s) put_seq(w, *s);
+}
+void get_useq(Reader& r, std::unique_ptr<Seq>& s)
+{
+    if (r.pod<uint8_t>()) {
+        s.reset(new Seq);
+        get_seq(r, *s);
+    } else {
+        s.reset();
+    }
+}
+void put_mins(Writer& w, const std::vector<Minimizer>& m)
+{
+    w.pod<uint64_t>(m.size());
+    if (!m.empty()) w.raw(m.data(), m.size() * sizeof(Minimizer));
+}
+void get_mins(Reader& r, std::vector<Minimizer>& m)
+{
+    uint64_t n = r.pod<uint64_t>();
+    if (!r.ok || uint64_t(r.e - r.p) < n * sizeof(Minimizer)) {
+        r.ok = false;
+        return;
+    }
+    m.resize(size_t(n));
+    if (n) r.raw(m.data(), size_t(n) * sizeof(Minimizer));
+}
+void put_args(Writer& w, const CmdArgs& a)
+{
+    w.pod<uint8_t>(a.Verbose);
+    w.pod<uint8_t>(a.Debug);
+    w.str(a.InFastq);
+    for (int32_t v : {a.KmerSize, a.BatchSize, a.BatchMaxSeq, a.WindowSize, a.MinShared, a.ConsMinSize, a.ConsMaxSize,
+                      a.ConsPeriod, a.MinClsSize})
+        w.pod<int32_t>(v);
+    for (double v : {a.MinQual, a.MappedThreshold, a.AlignedThreshold, a.MinFraction, a.MinProbNoHits}) w.pod<double>(v);
+    w.str(a.BatchOutFolder);
+    w.pod<int32_t>(a.Mode);
+}
+void get_args(Reader& r, CmdArgs& a)
+{
+    a.Verbose = r.pod<uint8_t>() != 0;
+    a.Debug = r.pod<uint8_t>() != 0;
+    a.InFastq = r.str();
+    for (int32_t* v : {&a.KmerSize, &a.BatchSize, &a.BatchMaxSeq, &a.WindowSize, &a.MinShared, &a.ConsMinSize,
+                       &a.ConsMaxSize, &a.ConsPeriod, &a.MinClsSize})
+        *v = r.pod<int32_t>();
+    for (double* v : {&a.MinQual, &a.MappedThreshold, &a.AlignedThreshold, &a.MinFraction, &a.MinProbNoHits})
+        *v = r.pod<double>();
+    a.BatchOutFolder = r.str();
+    a.Mode = r.pod<int32_t>();
+}
+
+}  // namespace
+
+bool save_batch(const Batch& b, const std::string& path, std::string& err)
+{
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) {
+        err = "Failed to open " + path + "!";
+        return false;
+    }
+    Writer w(f);
+    w.pod<int32_t>(b.BatchNr);
+    w.pod<uint64_t>(b.BatchStart);
+    w.pod<uint64_t>(b.BatchEnd);
+    w.pod<uint64_t>(b.BatchBases);
+    w.pod<int32_t>(b.TotalReads);
+    w.pod<int32_t>(b.NrCls);
+    put_args(w, b.SortArgs);
+    w.str(b.LeftLeaf);
+    w.str(b.RightLeaf);
+    w.pod<int32_t>(b.Depth);
+    w.pod<uint64_t>(b.Db.size());
+    for (auto& kv : b.Db) {
+        w.pod<uint32_t>(kv.first);
+        w.pod<uint64_t>(kv.second.size());
+        if (!kv.second.empty()) w.raw(kv.second.data(), kv.second.size() * 4);
+    }
+    w.pod<uint64_t>(b.Cls.size());
+    for (auto& c : b.Cls) {
+        if (!c) {
+            w.pod<uint32_t>(0);
+            continue;
+        }
+        w.pod<uint32_t>(w.new_shared());
+        w.pod<uint64_t>(c->size());
+        for (auto& ps : *c) {
+            if (!ps) {
+                w.pod<uint32_t>(0);
+                continue;
+            }
+            w.pod<uint32_t>(w.new_shared());
+            put_useq(w, ps->RawSeq);
+            put_useq(w, ps->HpcSeq);
+            put_mins(w, ps->Mins);
+            put_mins(w, ps->RevMins);
+            w.pod<int32_t>(ps->MatchStrand);
+            w.str(ps->Id);
+        }
+    }
+    w.pod<uint64_t>(b.NrConsGs);
+    for (uint64_t i = 0; i < b.NrConsGs; ++i) w.pod<uint8_t>(0);  // null unique_ptr<spoa::Graph>
+    w.flush();
+    bool ok = w.ok && fclose(f) == 0;
+    if (!ok) err = "Failed to write " + path + "!";
+    return ok;
+}
+
+bool load_batch(Batch& b, const std::string& path, std::string& err)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        err = "Failed to load batch " + path + ": cannot open";
+        return false;
+    }
+    std::vector<uint8_t> data;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    data.resize(size_t(sz > 0 ? sz : 0));
+    if (sz > 0 && fread(data.data(), 1, size_t(sz), f) != size_t(sz)) {
+        fclose(f);
+        err = "Failed to load batch " + path + ": short read";
+        return false;
+    }
+    fclose(f);
+    Reader r{data.data(), data.data() + data.size()};
+    b = Batch();
+    b.BatchNr = r.pod<int32_t>();
+    b.BatchStart = r.pod<uint64_t>();
+    b.BatchEnd = r.pod<uint64_t>();
+    b.BatchBases = r.pod<uint64_t>();
+    b.TotalReads = r.pod<int32_t>();
+    b.NrCls = r.pod<int32_t>();
+    get_args(r, b.SortArgs);
+    b.LeftLeaf = r.str();
+    b.RightLeaf = r.str();
+    b.Depth = r.pod<int32_t>();
+    uint64_t nk = r.pod<uint64_t>();
+    for (uint64_t i = 0; r.ok && i < nk; ++i) {
+        uint32_t key = r.pod<uint32_t>();
+        uint64_t m = r.pod<uint64_t>();
+        if (uint64_t(r.e - r.p) < m * 4) {
+            r.ok = false;
+            break;
+        }
+        std::vector<uint32_t> v(static_cast<size_t>(m));
+        if (m) r.raw(v.data(), size_t(m) * 4);
+        b.Db.emplace_back(key, std::move(v));
+    }
+    std::sort(b.Db.begin(), b.Db.end(), [](const std::pair<uint32_t, std::vector<uint32_t>>& x,
+                                           const std::pair<uint32_t, std::vector<uint32_t>>& y) { return x.first < y.first; });
+    std::unordered_map<uint32_t, std::shared_ptr<Cluster>> seenC;
+    std::unordered_map<uint32_t, std::shared_ptr<ProcSeq>> seenP;
+    uint64_t nc = r.pod<uint64_t>();
+    for (uint64_t i = 0; r.ok && i < nc; ++i) {
+        uint32_t id = r.pod<uint32_t>();
+        if (id == 0) {
+            b.Cls.push_back(nullptr);
+            continue;
+        }
+        if (!(id & 0x80000000u)) {
+            b.Cls.push_back(seenC[id]);
+            continue;
+        }
+        auto c = std::make_shared<Cluster>();
+        seenC[id & 0x7FFFFFFFu] = c;
+        uint64_t m = r.pod<uint64_t>();
+        for (uint64_t j = 0; r.ok && j < m; ++j) {
+            uint32_t pid = r.pod<uint32_t>();
+            if (pid == 0) {
+                c->push_back(nullptr);
+                continue;
+            }
+            if (!(pid & 0x80000000u)) {
+                c->push_back(seenP[pid]);
+                continue;
+            }
+            auto ps = std::make_shared<ProcSeq>();
+            seenP[pid & 0x7FFFFFFFu] = ps;
+            get_useq(r, ps->RawSeq);
+            get_useq(r, ps->HpcSeq);
+            get_mins(r, ps->Mins);
+            get_mins(r, ps->RevMins);
+            ps->MatchStrand = r.pod<int32_t>();
+            ps->Id = r.str();
+            c->push_back(ps);
+        }
+        b.Cls.push_back(c);
+    }
+    b.NrConsGs = r.pod<uint64_t>();
+    for (uint64_t i = 0; r.ok && i < b.NrConsGs; ++i)
+        if (r.pod<uint8_t>() != 0) {
+            err = "Failed to load batch " + path + ": consensus graphs are not supported by this build";
+            return false;
+        }
+    if (!r.ok) {
+        err = "Failed to load batch " + path + ": truncated or corrupt archive";
+        return false;
+    }
+    return true;
+}
+
+bool save_sorted_idx(const std::string& fastq_path, const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    uint64_t n = fastq_path.size();
+    bool ok = fwrite(&n, 8, 1, f) == 1 && fwrite(fastq_path.data(), 1, n, f) == n;
+    return fclose(f) == 0 && ok;
+}
+
+bool load_sorted_idx(std::string& fastq_path, const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t n = 0;
+    bool ok = fread(&n, 8, 1, f) == 1 && n < (1u << 20);
+    if (ok) {
+        fastq_path.resize(size_t(n));
+        ok = fread(&fastq_path[0], 1, size_t(n), f) == n;
+    }
+    fclose(f);
+    return ok;
+}
+
+}  // namespace cer

@@ -1,0 +1,804 @@
+// isONclust2-hip — the `isONclust2 sort | cluster | dump | info` command line on top of the MI355X path.
+//
+// Mirrors the sub-commands and flags of the reference (src/main.cpp:29-73, src/args.cpp) so that the
+// external batch-and-merge pipeline (README.md:105-117) can call it unchanged; every hot-path
+// computation goes through the C ABI of libisonclust2_hip.so (no CPU fallback: without a GPU the
+// tool exits with an error).  Host code here is I/O and bookkeeping only: FASTQ parsing, the batching
+// policy of `sort` (main.cpp:149-199), the member moves of `cluster` (cluster.cpp:177-261), the TSV /
+// FASTQ writers of `dump` (output.cpp:151-275).
+#include <getopt.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cer.hpp"
+#include "isonclust2_hip.h"
+
+using namespace cer;
+using std::cerr;
+using std::endl;
+using std::string;
+
+static const char* VERSION = "2.4-hip-r1";
+static bool VERBOSE = false;
+
+[[noreturn]] static void die(const string& m)
+{
+    cerr << m << endl;
+    exit(1);
+}
+
+static string table_path()
+{
+    if (const char* e = getenv("ISONCLUST2_TABLE")) return e;
+    char buf[4096];
+    ssize_t n = readlink("/proc/self/exe", buf, sizeof(buf) - 1);
+    string exe = n > 0 ? string(buf, size_t(n)) : string(".");
+    size_t p = exe.rfind('/');
+    string dir = p == string::npos ? "." : exe.substr(0, p);
+    return dir + "/../data/pmin_shared.bin";
+}
+
+static ioc_ctx* make_ctx()
+{
+    ioc_ctx* c = nullptr;
+    int dev = 0;
+    if (const char* e = getenv("ISONCLUST2_DEVICE")) dev = atoi(e);
+    int rc = ioc_ctx_create(dev, &c);
+    if (rc != IOC_OK) die("No usable MI355X device (ioc_ctx_create failed with " + std::to_string(rc) + "); there is no CPU fallback.");
+    return c;
+}
+
+static void check(ioc_ctx* c, int rc, const char* what)
+{
+    if (rc < 0) die(string(what) + ": " + ioc_last_error(c));
+}
+
+static int dir_exists(const string& p)
+{
+    struct stat info;
+    return stat(p.c_str(), &info) == 0 && (info.st_mode & S_IFDIR);
+}
+static void create_outdir(const string& d)
+{
+    if (dir_exists(d)) {
+        cerr << "Warning: reusing existing output directory: " << d << endl;
+        return;
+    }
+    if (mkdir(d.c_str(), 0755) != 0) die("Failed to create output directory!");
+}
+static void create_file(const string& p, std::ofstream& f)
+{
+    f.open(p);
+    if (!f.is_open()) die("Failed to open " + p + "!");
+}
+
+static void print_batch_info(const Batch& b)
+{
+    int ncls = 0, nnt = 0;
+    for (auto& c : b.Cls)
+        if (c && !c->empty() && c->at(0) && c->at(0)->RawSeq && c->at(0)->RawSeq->score > -1) {
+            ncls++;
+            if (c->size() > 2) nnt++;
+        }
+    cerr << "\tBatch number: " << b.BatchNr << endl;
+    cerr << "\tBatch range: [" << b.BatchStart << "," << b.BatchEnd << "]" << endl;
+    cerr << "\tDepth: " << b.Depth << endl;
+    cerr << "\tNr sequences: " << b.BatchEnd - b.BatchStart + 1 << endl;
+    cerr << "\tNr bases: " << b.BatchBases << endl;
+    cerr << "\tNr clusters: " << ncls << endl;
+    cerr << "\tNr nontrivial clusters: " << nnt << endl;
+    cerr << "\tMinimizers in database: " << b.Db.size() << endl;
+}
+
+static int parse_mode(const string& m)
+{
+    if (m == "sahlin") return Sahlin;
+    if (m == "fast") return Fast;
+    if (m == "furious") return Furious;
+    die("Illegal clustering mode: " + m);
+}
+
+// ===================================================================================================
+// sort  (src/main.cpp:75-202)
+// ===================================================================================================
+static int main_sort(int argc, char** argv)
+{
+    static const struct option lo[] = {
+        {"version", no_argument, 0, 'V'}, {"verbose", no_argument, 0, 'v'}, {"debug", no_argument, 0, 'd'},
+        {"mode", required_argument, 0, 'x'}, {"help", no_argument, 0, 'h'}, {"kmer-size", required_argument, 0, 'k'},
+        {"window-size", required_argument, 0, 'w'}, {"min-shared", required_argument, 0, 'm'},
+        {"mapped-threshold", required_argument, 0, 'r'}, {"aligned-threshold", required_argument, 0, 'a'},
+        {"min-fraction", required_argument, 0, 'f'}, {"min-prob-no-hits", required_argument, 0, 'p'},
+        {"min-qual", required_argument, 0, 'q'}, {"min-cls-size", required_argument, 0, 'F'},
+        {"low-cons-size", required_argument, 0, 'g'}, {"max-cons-size", required_argument, 0, 'c'},
+        {"cons-period", required_argument, 0, 'P'}, {"outfolder", required_argument, 0, 'o'},
+        {"batch-size", required_argument, 0, 'B'}, {"batch-max-seq", required_argument, 0, 'M'}, {0, 0, 0, 0}};
+    CmdArgs a;
+    int o;
+    while ((o = getopt_long(argc, argv, "k:w:dhvo:m:r:a:f:p:q:B:x:g:c:M:P:F:", lo, nullptr)) != -1) {
+        switch (o) {
+            case 'k': a.KmerSize = atoi(optarg); break;
+            case 'w': a.WindowSize = atoi(optarg); break;
+            case 'm': a.MinShared = atoi(optarg); break;
+            case 'r': a.MappedThreshold = atof(optarg); break;
+            case 'a': a.AlignedThreshold = atof(optarg); break;
+            case 'f': a.MinFraction = atof(optarg); break;
+            case 'p': a.MinProbNoHits = atof(optarg); break;
+            case 'q': a.MinQual = atof(optarg); break;
+            case 'B': a.BatchSize = atoi(optarg); break;
+            case 'M': a.BatchMaxSeq = atoi(optarg); break;
+            case 'P': a.ConsPeriod = atoi(optarg); break;
+            case 'g': a.ConsMinSize = atoi(optarg); break;
+            case 'c': a.ConsMaxSize = atoi(optarg); break;
+            case 'F': a.MinClsSize = atoi(optarg); break;
+            case 'o': a.BatchOutFolder = optarg; break;
+            case 'v': a.Verbose = true; break;
+            case 'd': a.Debug = true; break;
+            case 'x': a.Mode = parse_mode(optarg); break;
+            case 'h': cerr << "isONclust2-hip sort [options] reads.fastq  (flags as `isONclust2 sort`)" << endl; exit(0);
+            default: break;
+        }
+    }
+    // src/args.cpp:135-148
+    if (a.KmerSize < 10 || a.KmerSize > 31) die("Invalid kmer size (must be in [10,31])!");
+    if (a.KmerSize > a.WindowSize) die("The window size must be larger than or equal to the kmer size!");
+    if (a.ConsMaxSize > 0) die("Consensus (-c > 0) is not supported by this build (spoa is out of scope)");
+    if (optind >= argc) die("No input fastq specified!");
+    a.InFastq = argv[optind];
+    VERBOSE = a.Verbose;
+
+    // ---- FASTQ (whole file in RAM, like bioparser Parse(-1), main.cpp:109-112) ----
+    std::ifstream in(a.InFastq);
+    if (!in.is_open()) die("Failed to open " + a.InFastq + "!");
+    std::vector<Seq> reads;
+    string h, s, p, q;
+    while (std::getline(in, h)) {
+        if (h.empty()) continue;
+        if (!std::getline(in, s) || !std::getline(in, p) || !std::getline(in, q)) die("Truncated fastq record: " + h);
+        if (h[0] != '@' || s.size() != q.size()) die("Malformed fastq record: " + h);
+        Seq r;
+        size_t sp = h.find_first_of(" \t");
+        r.name = h.substr(1, sp == string::npos ? string::npos : sp - 1);
+        r.seq.swap(s);
+        r.qual.swap(q);
+        reads.push_back(std::move(r));
+    }
+    const int n = int(reads.size());
+    if (VERBOSE) cerr << "Parsed " << n << " sequences." << endl;
+
+    ioc_ctx* c = make_ctx();
+    // ---- FillQualScores on the device, SortByQualScores on the host ----
+    std::vector<int64_t> offs(static_cast<size_t>(n) + 1, 0);
+    for (int i = 0; i < n; ++i) offs[size_t(i) + 1] = offs[size_t(i)] + int64_t(reads[size_t(i)].qual.size());
+    {
+        std::vector<uint8_t> qual(static_cast<size_t>(offs[size_t(n)]));
+        for (int i = 0; i < n; ++i) memcpy(qual.data() + offs[size_t(i)], reads[size_t(i)].qual.data(), reads[size_t(i)].qual.size());
+        std::vector<double> score(static_cast<size_t>(n)), err(static_cast<size_t>(n));
+        check(c, ioc_qual_scores(c, n, offs.data(), qual.data(), a.KmerSize, score.data(), err.data()), "quality scores");
+        for (int i = 0; i < n; ++i) {
+            reads[size_t(i)].score = score[size_t(i)];
+            reads[size_t(i)].errorRate = err[size_t(i)];
+        }
+    }
+    std::stable_sort(reads.begin(), reads.end(), [](const Seq& x, const Seq& y) { return x.score > y.score; });
+
+    const string batch_dir = a.BatchOutFolder + "/batches";
+    create_outdir(a.BatchOutFolder);
+    create_outdir(batch_dir);
+    {
+        std::ofstream fq, tsv, sc;
+        const string sorted = a.BatchOutFolder + "/sorted_reads.fastq";
+        create_file(sorted, fq);
+        create_file(a.BatchOutFolder + "/sorted_reads_idx.tsv", tsv);
+        tsv << "Id\tPos" << endl;
+        unsigned long long seek = 0;
+        for (auto& r : reads) {
+            if (r.score < 0) continue;
+            tsv << r.name << "\t" << seek << endl;
+            fq << "@" << r.name << "\n" << r.seq << "\n+\n" << r.qual << "\n";
+            seek += r.name.size() + r.seq.size() + r.qual.size() + 6;
+        }
+        save_sorted_idx(sorted, a.BatchOutFolder + "/sorted_reads_idx.cer");
+        create_file(a.BatchOutFolder + "/scores.tsv", sc);
+        for (auto& r : reads) sc << r.name << "\t" << r.score << endl;
+    }
+
+    // ---- batches (main.cpp:149-199) ----
+    auto write_batch = [&](int start, int end, unsigned long bases, int nr) {
+        const int m = end - start + 1;
+        std::vector<int64_t> bo(static_cast<size_t>(m) + 1, 0);
+        for (int i = 0; i < m; ++i) bo[size_t(i) + 1] = bo[size_t(i)] + int64_t(reads[size_t(start + i)].seq.size());
+        std::vector<uint8_t> seq(static_cast<size_t>(bo[size_t(m)])), qual(static_cast<size_t>(bo[size_t(m)]));
+        for (int i = 0; i < m; ++i) {
+            memcpy(seq.data() + bo[size_t(i)], reads[size_t(start + i)].seq.data(), reads[size_t(start + i)].seq.size());
+            memcpy(qual.data() + bo[size_t(i)], reads[size_t(start + i)].qual.data(), reads[size_t(start + i)].qual.size());
+        }
+        std::vector<uint32_t> hlen(static_cast<size_t>(m));
+        std::vector<double> herr(static_cast<size_t>(m));
+        std::vector<int64_t> of(static_cast<size_t>(m) + 1), orv(static_cast<size_t>(m) + 1);
+        std::vector<int32_t> status(static_cast<size_t>(m));
+        check(c, ioc_extract_minimizers(c, m, bo.data(), seq.data(), qual.data(), a.KmerSize, a.WindowSize, hlen.data(),
+                                        herr.data(), of.data(), orv.data(), status.data()), "minimizer extraction");
+        const int64_t tot = orv[size_t(m)];
+        std::vector<uint32_t> mv(static_cast<size_t>(tot) + 1), mp(static_cast<size_t>(tot) + 1);
+        check(c, ioc_extracted_download(c, mv.data(), mp.data(), tot + 1), "minimizer download");
+        std::vector<char> hs(static_cast<size_t>(bo[size_t(m)]) + 1), hq(static_cast<size_t>(bo[size_t(m)]) + 1);
+        check(c, ioc_extracted_hpc_download(c, hs.data(), hq.data(), int64_t(hs.size())), "hpc download");
+        Batch b;
+        b.Cls.resize(size_t(m));
+        for (int i = 0; i < m; ++i) {
+            Seq& r = reads[size_t(start + i)];
+            auto cl = std::make_shared<Cluster>();
+            auto ps = std::make_shared<ProcSeq>();
+            ps->Id = r.name;
+            const bool lowq = (-10 * log10(r.errorRate)) <= a.MinQual;            // qualscore.cpp:56
+            const bool lenok = r.seq.size() > size_t(2 * a.KmerSize) || r.seq.size() >= size_t(a.WindowSize);
+            if (status[size_t(i)] == 2) die("Invalid base encountered in read " + r.name);   // RevComp throws
+            if (lowq) {
+                // placeholder {nullptr, nullptr, {}, {}, 0, name}
+            } else if (!lenok || status[size_t(i)] == 1) {
+                r.score = -1.0;  // qualscore.cpp:67, :91 (the reference's raw-only branch is unreachable without a crash)
+            } else {
+                ps->RawSeq.reset(new Seq(r));
+                ps->HpcSeq.reset(new Seq);
+                ps->HpcSeq->name = r.name;
+                ps->HpcSeq->seq.assign(hs.data() + bo[size_t(i)], hlen[size_t(i)]);
+                ps->HpcSeq->qual.assign(hq.data() + bo[size_t(i)], hlen[size_t(i)]);
+                ps->HpcSeq->score = r.score;
+                ps->HpcSeq->errorRate = herr[size_t(i)];
+                auto fill = [&](std::vector<Minimizer>& dst, int64_t b0, int64_t e0) {
+                    dst.resize(size_t(e0 - b0));
+                    for (int64_t t = b0; t < e0; ++t) dst[size_t(t - b0)] = Minimizer{mv[size_t(t)], mp[size_t(t)], uint32_t(t - b0)};
+                };
+                fill(ps->Mins, of[size_t(i)], of[size_t(i) + 1]);
+                fill(ps->RevMins, orv[size_t(i)], orv[size_t(i) + 1]);
+                ps->MatchStrand = 1;
+            }
+            cl->push_back(ps);
+            b.Cls[size_t(i)] = cl;
+        }
+        b.NrCls = m;
+        b.BatchStart = uint64_t(start);
+        b.BatchEnd = uint64_t(end);
+        b.Depth = -1;
+        b.BatchNr = nr;
+        b.BatchBases = bases;
+        b.SortArgs = a;
+        string err;
+        if (!save_batch(b, batch_dir + "/isONbatch_" + std::to_string(nr) + ".cer", err)) die(err);
+        if (VERBOSE)
+            cerr << "\tWritten batch " << nr << " with " << m << " sequences and " << int(double(bases) / 1000.0) << " kilobases." << endl;
+    };
+    unsigned long batch_bases = 0;
+    int batch_seqs = 0, nr_batches = 0, batch_start = 0;
+    for (int i = 0; i < n; ++i) {
+        batch_bases += reads[size_t(i)].seq.size();
+        batch_seqs++;
+        if (a.BatchSize > 0 && (batch_bases > (unsigned long)(a.BatchSize) * 1000ul || (a.BatchMaxSeq > 0 && batch_seqs >= a.BatchMaxSeq))) {
+            write_batch(batch_start, i, batch_bases, nr_batches);
+            batch_bases = 0;
+            batch_seqs = 0;
+            batch_start = i + 1;
+            nr_batches++;
+        }
+    }
+    if (batch_start < n) write_batch(batch_start, n - 1, batch_bases, nr_batches);
+    ioc_ctx_destroy(c);
+    return 0;
+}
+
+// ===================================================================================================
+// cluster  (src/main.cpp:238-382 + the bookkeeping of src/cluster.cpp:67-322)
+// ===================================================================================================
+static int main_cluster(int argc, char** argv)
+{
+    static const struct option lo[] = {
+        {"quiet", no_argument, 0, 'Q'}, {"version", no_argument, 0, 'V'}, {"verbose", no_argument, 0, 'v'},
+        {"min-purge", no_argument, 0, 'z'}, {"min-cls-size", required_argument, 0, 'F'}, {"keep-seq", no_argument, 0, 'j'},
+        {"debug", no_argument, 0, 'd'}, {"spoa-algo", required_argument, 0, 'A'}, {"mode", required_argument, 0, 'x'},
+        {"help", no_argument, 0, 'h'}, {"outfile", required_argument, 0, 'o'}, {"left-batch", required_argument, 0, 'l'},
+        {"right-batch", required_argument, 0, 'r'}, {0, 0, 0, 0}};
+    string left_path, right_path, out_path;
+    int mode = None, min_cls = -1;
+    bool min_purge = false, keep_seq = false;
+    int o;
+    while ((o = getopt_long(argc, argv, "Vdhvo:l:r:Qx:A:zjF:", lo, nullptr)) != -1) {
+        switch (o) {
+            case 'o': out_path = optarg; break;
+            case 'l': left_path = optarg; break;
+            case 'r': right_path = optarg; break;
+            case 'v': VERBOSE = true; break;
+            case 'z': min_purge = true; break;
+            case 'j': keep_seq = true; break;
+            case 'F': min_cls = atoi(optarg); break;
+            case 'x': mode = parse_mode(optarg); break;
+            case 'h': cerr << "isONclust2-hip cluster -l left.cer [-r right.cer] -o out.cer [-x fast|sahlin|furious] [-F n] [-z] [-j] [-v]" << endl; exit(0);
+            default: break;
+        }
+    }
+    if (left_path.empty()) die("Specifying left input batch is mandatory!");
+    if (out_path.empty()) die("Specifying output batch file is mandatory!");
+    auto t_begin = std::chrono::steady_clock::now();
+    Batch left, right;
+    string err;
+    if (!load_batch(left, left_path, err)) die(err);
+    if (VERBOSE) {
+        cerr << "Loaded input batch from " << left_path << ":" << endl;
+        print_batch_info(left);
+    }
+    const bool single = right_path.empty();
+    if (!single) {
+        if (!load_batch(right, right_path, err)) die(err);
+        cerr << "Loaded input batch from " << right_path << ":" << endl;
+        right.Db.clear();
+        print_batch_info(right);
+    } else {  // CreatePseudoBatch, serialize.cpp:29-43
+        right.BatchNr = -left.BatchNr;
+        right.BatchStart = left.BatchStart;
+        right.BatchEnd = left.BatchEnd;
+        right.BatchBases = 0;
+        right.SortArgs = left.SortArgs;
+        right.Depth = -1;
+        right.Cls = left.Cls;
+        right.NrCls = int32_t(right.Cls.size());
+        left.Cls.clear();
+        if (left.Depth > 0) left.Depth = -left.Depth;
+        left.NrCls = 0;
+        left.Db.clear();
+    }
+    left.SortArgs.Mode = mode;
+    right.SortArgs.Mode = mode;
+    if (min_cls > 0) left.SortArgs.MinClsSize = min_cls;
+    if (VERBOSE && mode == None) die("Invalid clustering mode: 3");
+    // ---- batch compatibility checks, cluster.cpp:70-90 ----
+    {
+        const CmdArgs &x = left.SortArgs, &y = right.SortArgs;
+        if (!(x.KmerSize == y.KmerSize && x.WindowSize == y.WindowSize && x.MinShared == y.MinShared && x.MinQual == y.MinQual &&
+              x.MappedThreshold == y.MappedThreshold && x.AlignedThreshold == y.AlignedThreshold &&
+              x.MinFraction == y.MinFraction && x.MinProbNoHits == y.MinProbNoHits && x.Mode == y.Mode))
+            die("The left and right batches have been sorted with different parameters! \nRefusing to carry on with clustering as results would not make sense! ");
+        if (right.Depth > 0 && right.BatchStart != left.BatchEnd + 1) die("Trying to merge non-consecutive batches! Giving up!");
+        if (left.Depth > 0 && right.Depth > left.Depth) die("The left input batch must have higher depth!");
+        if (x.ConsMaxSize > 0) die("Consensus (ConsMaxSize > 0) is not supported by this build");
+    }
+    const CmdArgs& a = left.SortArgs;
+    const bool need_seq = (mode == Sahlin || mode == Furious);
+
+    // ---- right batch -> ioc_batch_view ----
+    const int n = int(right.Cls.size());
+    std::vector<int64_t> of(static_cast<size_t>(n) + 1, 0), orv(static_cast<size_t>(n) + 1, 0), roff(static_cast<size_t>(n) + 1, 0);
+    std::vector<uint32_t> raw_len(static_cast<size_t>(n) + 1, 0), hpc_len(static_cast<size_t>(n) + 1, 0);
+    std::vector<double> score(static_cast<size_t>(n) + 1, -1.0), raw_err(static_cast<size_t>(n) + 1, 1.0), hpc_err(static_cast<size_t>(n) + 1, 1.0);
+    std::vector<uint8_t> state(static_cast<size_t>(n) + 1, 1);
+    std::vector<int32_t> nmem(static_cast<size_t>(n) + 1, 0);
+    int64_t tot = 0, rtot = 0;
+    auto rep_of = [&](int i) -> ProcSeq* {
+        auto& e = right.Cls[size_t(i)];
+        if (!e || e->empty() || !e->at(0) || !e->at(0)->RawSeq) return nullptr;
+        return e->at(0).get();
+    };
+    for (int i = 0; i < n; ++i) {
+        of[size_t(i)] = tot;
+        if (ProcSeq* r = rep_of(i)) tot += int64_t(r->Mins.size());
+    }
+    of[size_t(n)] = tot;
+    for (int i = 0; i < n; ++i) {
+        orv[size_t(i)] = tot;
+        if (ProcSeq* r = rep_of(i)) tot += int64_t(r->RevMins.size());
+    }
+    orv[size_t(n)] = tot;
+    std::vector<uint32_t> mv(static_cast<size_t>(tot) + 1), mp(static_cast<size_t>(tot) + 1);
+    string rseq;
+    for (int i = 0; i < n; ++i) {
+        roff[size_t(i)] = rtot;
+        ProcSeq* r = rep_of(i);
+        if (!r) continue;
+        if (!r->HpcSeq) die("Entry without HpcSeq in the right batch");
+        state[size_t(i)] = 0;
+        nmem[size_t(i)] = int32_t(right.Cls[size_t(i)]->size()) - 1;
+        raw_len[size_t(i)] = uint32_t(r->RawSeq->seq.size());
+        hpc_len[size_t(i)] = uint32_t(r->HpcSeq->seq.size());
+        score[size_t(i)] = r->RawSeq->score;
+        raw_err[size_t(i)] = r->RawSeq->errorRate;
+        hpc_err[size_t(i)] = r->HpcSeq->errorRate;
+        for (size_t t = 0; t < r->Mins.size(); ++t) {
+            if (r->Mins[t].Index != t) die("Minimizer Index is not the ordinal");
+            mv[size_t(of[size_t(i)]) + t] = r->Mins[t].Min;
+            mp[size_t(of[size_t(i)]) + t] = r->Mins[t].Pos;
+        }
+        for (size_t t = 0; t < r->RevMins.size(); ++t) {
+            if (r->RevMins[t].Index != t) die("Minimizer Index is not the ordinal");
+            mv[size_t(orv[size_t(i)]) + t] = r->RevMins[t].Min;
+            mp[size_t(orv[size_t(i)]) + t] = r->RevMins[t].Pos;
+        }
+        if (need_seq) {
+            rseq += r->RawSeq->seq;
+            rtot += int64_t(r->RawSeq->seq.size());
+        }
+    }
+    roff[size_t(n)] = rtot;
+    ioc_batch_view rv{};
+    rv.n = n;
+    rv.off_fwd = of.data();
+    rv.off_rev = orv.data();
+    rv.min_val = mv.data();
+    rv.min_pos = mp.data();
+    rv.total = tot;
+    rv.raw_len = raw_len.data();
+    rv.hpc_len = hpc_len.data();
+    rv.score = score.data();
+    rv.raw_err = raw_err.data();
+    rv.hpc_err = hpc_err.data();
+    rv.state = state.data();
+    rv.min_qual = a.MinQual;
+    rv.raw_seq = need_seq ? rseq.data() : nullptr;
+    rv.raw_off = need_seq ? roff.data() : nullptr;
+    rv.n_members = nmem.data();
+    rv.depth = right.Depth;
+    rv.min_cls_size = a.MinClsSize;
+
+    // ---- left batch -> ioc_left_view ----
+    const int L = int(left.Cls.size());
+    std::vector<double> l_hpc_err(static_cast<size_t>(L) + 1, 0.0), l_raw_err(static_cast<size_t>(L) + 1, 0.0);
+    std::vector<int64_t> l_off(static_cast<size_t>(L) + 1, 0), k_offs;
+    std::vector<uint32_t> keys, post;
+    string lseq;
+    for (int i = 0; i < L; ++i) {
+        auto& cl = left.Cls[size_t(i)];
+        if (!cl || cl->empty() || !cl->at(0) || !cl->at(0)->HpcSeq || !cl->at(0)->RawSeq) die("Left cluster without representative");
+        l_hpc_err[size_t(i)] = cl->at(0)->HpcSeq->errorRate;
+        l_raw_err[size_t(i)] = cl->at(0)->RawSeq->errorRate;
+        l_off[size_t(i)] = int64_t(lseq.size());
+        if (need_seq) lseq += cl->at(0)->RawSeq->seq;
+    }
+    l_off[size_t(L)] = int64_t(lseq.size());
+    k_offs.push_back(0);
+    for (auto& kv : left.Db) {
+        if (kv.second.empty()) continue;
+        keys.push_back(kv.first);
+        post.insert(post.end(), kv.second.begin(), kv.second.end());
+        k_offs.push_back(int64_t(post.size()));
+    }
+    ioc_left_view lv{};
+    lv.n_clusters = L;
+    lv.cls_hpc_err = l_hpc_err.data();
+    lv.n_keys = int64_t(keys.size());
+    lv.keys = keys.data();
+    lv.offs = k_offs.data();
+    lv.postings = post.data();
+    lv.rep_seq = need_seq ? lseq.data() : nullptr;
+    lv.rep_off = need_seq ? l_off.data() : nullptr;
+    lv.cls_raw_err = l_raw_err.data();
+
+    ioc_params p{a.KmerSize, a.WindowSize, a.MinShared, mode, a.MinFraction, a.MappedThreshold, a.MinProbNoHits, a.AlignedThreshold};
+    ioc_ctx* c = make_ctx();
+    std::vector<int32_t> out_cls(static_cast<size_t>(n) + 1);
+    std::vector<int8_t> out_strand(static_cast<size_t>(n) + 1);
+    ioc_cluster_stats st{};
+    auto t_core = std::chrono::steady_clock::now();
+    check(c, ioc_cluster_merge(c, &p, table_path().c_str(), L > 0 ? &lv : nullptr, &rv, out_cls.data(), out_strand.data(), &st),
+          "clustering");
+    double core_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count();
+
+    // ---- bookkeeping of the loop, cluster.cpp:115-310 ----
+    for (int i = 0; i < n; ++i) {
+        auto& entry = right.Cls[size_t(i)];
+        ProcSeq* r = rep_of(i);
+        if (out_cls[size_t(i)] < 0) {
+            if (r && r->RawSeq->score >= 0) {
+                // gates that mark the read as unusable (cluster.cpp:148-160)
+                if (r->RawSeq->seq.size() < size_t(2 * a.KmerSize) || r->HpcSeq->seq.size() < size_t(2 * a.KmerSize) ||
+                    (-10 * log10(r->RawSeq->errorRate)) <= a.MinQual)
+                    r->RawSeq->score = -1.0;
+            }
+            continue;
+        }
+        const int best = out_cls[size_t(i)];
+        if (best == int(left.Cls.size())) {  // opens a new cluster (cluster.cpp:177-222)
+            if (entry->size() == 1) {
+                auto rep = std::make_shared<ProcSeq>();
+                rep->RawSeq.reset(new Seq(*r->RawSeq));
+                rep->HpcSeq.reset(new Seq(*r->HpcSeq));
+                rep->Mins = r->Mins;
+                rep->RevMins = r->RevMins;
+                rep->MatchStrand = r->MatchStrand;
+                rep->Id = r->Id;
+                const string nm = "rep_" + std::to_string(left.BatchNr) + "_" + std::to_string(best);
+                rep->RawSeq->name = nm;
+                rep->HpcSeq->name = nm;
+                entry->insert(entry->begin(), rep);
+            }
+            left.Cls.push_back(entry);
+            left.NrCls++;
+        } else {  // joins (cluster.cpp:223-261)
+            if (best > int(left.Cls.size())) die("Inconsistent cluster id from the device path");
+            for (auto& s : *entry) {
+                if (!s) die("Null pointer in read array");
+                if (out_strand[size_t(i)] == -1) {
+                    if (s->MatchStrand == 1) s->MatchStrand = -1;
+                    else if (s->MatchStrand == -1) s->MatchStrand = 1;
+                    else die("Invalid match strand!");
+                }
+                s->Mins.clear();
+                s->RevMins.clear();
+                if (!keep_seq) {
+                    s->RawSeq.reset();
+                    s->HpcSeq.reset();
+                }
+            }
+            auto& dst = *left.Cls[size_t(best)];
+            size_t from = entry->size() > 1 ? 1 : 0;
+            for (size_t t = from; t < entry->size(); ++t) dst.push_back((*entry)[t]);
+        }
+    }
+    left.Depth++;
+    left.BatchEnd = right.BatchEnd;
+    left.BatchBases += right.BatchBases;
+    // MinDB after AddMinimizers of every new representative
+    {
+        int64_t nk = 0, np = 0;
+        check(c, ioc_index_export(c, &nk, &np, nullptr, nullptr, nullptr), "index export");
+        std::vector<uint32_t> ek(static_cast<size_t>(nk) + 1), ep(static_cast<size_t>(np) + 1);
+        std::vector<int64_t> eo(static_cast<size_t>(nk) + 2);
+        check(c, ioc_index_export(c, &nk, &np, ek.data(), eo.data(), ep.data()), "index export");
+        left.Db.clear();
+        left.Db.reserve(size_t(nk));
+        for (int64_t i = 0; i < nk; ++i)
+            left.Db.emplace_back(ek[size_t(i)], std::vector<uint32_t>(ep.begin() + eo[size_t(i)], ep.begin() + eo[size_t(i) + 1]));
+    }
+    ioc_ctx_destroy(c);
+    if (VERBOSE) {
+        cerr << "Finished clustering!" << endl;
+        cerr << "Alignment invocation count: " << st.n_aln_invoked << " (" << (n ? double(st.n_aln_invoked) / n * 100 : 0.0) << "%)" << endl;
+        cerr << "Consensus invocation count: 0 (0%)" << endl;
+        unsigned cnt = 0;
+        for (auto& cl : left.Cls) cnt += cl->size() > 1;
+        cerr << "Number of clusters larger than 1: " << cnt << endl;
+        cerr << "Output batch statistics:" << endl;
+        print_batch_info(left);
+    }
+    left.LeftLeaf = left_path;
+    left.RightLeaf = right_path;
+    if (min_purge) {
+        cerr << "Purging minimizer database in output batch!" << endl;
+        left.Db.clear();
+    }
+    left.NrConsGs = left.Cls.size();
+    if (!save_batch(left, out_path, err)) die(err);
+    double cli_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (VERBOSE) cerr << "Output batch written to: " << out_path << endl;
+    if (getenv("ISONCLUST2_STATS_JSON"))
+        fprintf(stderr, "{\"entries\": %d, \"clusters\": %lld, \"core_ms\": %.3f, \"cli_ms\": %.3f, \"resolve_sweeps\": %d}\n", n,
+                (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters);
+    return 0;
+}
+
+// ===================================================================================================
+// dump  (src/main.cpp:204-236, 430-453; src/output.cpp:151-275)   and   info (src/main.cpp:384-399)
+// ===================================================================================================
+static int main_dump(int argc, char** argv)
+{
+    static const struct option lo[] = {{"verbose", no_argument, 0, 'v'}, {"debug", no_argument, 0, 'd'}, {"help", no_argument, 0, 'h'},
+                                       {"outdir", required_argument, 0, 'o'}, {"index", required_argument, 0, 'i'}, {0, 0, 0, 0}};
+    string outdir, index;
+    int o;
+    while ((o = getopt_long(argc, argv, "dhvo:i:", lo, nullptr)) != -1) {
+        switch (o) {
+            case 'o': outdir = optarg; break;
+            case 'i': index = optarg; break;
+            case 'v': VERBOSE = true; break;
+            case 'h': cerr << "isONclust2-hip dump -i sorted_reads_idx.cer -o outdir final.cer" << endl; exit(0);
+            default: break;
+        }
+    }
+    if (optind >= argc) die("No input batch specified!");
+    if (outdir.empty()) die("Specifying output directory is mandatory!");
+    if (index.empty()) die("Specifying the sorted read index is mandatory!");
+    Batch b;
+    string err, fastq;
+    if (!load_batch(b, argv[optind], err)) die(err);
+    if (!load_sorted_idx(fastq, index)) die("Failed to load index " + index);
+    create_outdir(outdir);
+    b.Db.clear();
+    // SortClustersBySize, cluster.cpp:570-580 (std::sort, same comparator)
+    std::sort(b.Cls.begin(), b.Cls.end(), [](const std::shared_ptr<Cluster> x, const std::shared_ptr<Cluster> y) {
+        if (x->size() == y->size()) return x->at(0)->RawSeq->score > y->at(0)->RawSeq->score;
+        return x->size() > y->size();
+    });
+    {
+        std::ofstream bi;
+        create_file(outdir + "/batch_info.tsv", bi);
+        int ncls = 0, nnt = 0;
+        for (auto& c : b.Cls)
+            if (c->at(0)->RawSeq && c->at(0)->RawSeq->score > -1) {
+                ncls++;
+                nnt += c->size() > 2;
+            }
+        bi << "Name\tValue\nBatchNumber\t" << b.BatchNr << "\nBatchStart\t" << b.BatchStart << "\nBatchEnd\t" << b.BatchEnd << "\nDepth\t"
+           << b.Depth << "\nNrBases\t" << b.BatchBases << "\nNrClusters\t" << ncls << "\nNrNontrivialCls\t" << nnt << "\nMinDBsize\t0\n";
+    }
+    struct IdInfo {
+        unsigned cls;
+        int strand;
+    };
+    std::unordered_map<string, IdInfo> id2cls;
+    {
+        std::ofstream info;
+        create_file(outdir + "/clusters_info.tsv", info);
+        create_outdir(outdir + "/cluster_fastq");
+        info << "ClusterId\tSize" << endl;
+        unsigned i = 0;
+        for (auto& cl : b.Cls) {
+            info << i << "\t" << cl->size() - 1 << endl;
+            for (auto& m : *cl) id2cls[m->Id] = IdInfo{i, m->MatchStrand};
+            i++;
+        }
+    }
+    auto revcomp = [](string s) {
+        std::reverse(s.begin(), s.end());
+        for (auto& ch : s) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
+        return s;
+    };
+    {
+        std::ofstream cons;
+        create_file(outdir + "/cluster_cons.fq", cons);
+        for (size_t i = 0; i < b.Cls.size(); ++i) {
+            auto& rep = b.Cls[i]->at(0);
+            if (!rep->RawSeq) die("Null pointer instead of cluster rep sequence at index: " + std::to_string(i));
+            if (rep->RawSeq->score < 0) continue;
+            string seq = rep->RawSeq->seq;
+            if (rep->MatchStrand == -1) seq = revcomp(seq);
+            cons << "@cluster_" << i << " origin=" << rep->RawSeq->name << ":" << rep->MatchStrand << " length=" << seq.size()
+                 << " size=" << b.Cls[i]->size() - 1 << "\n" << seq << "\n+\n" << rep->RawSeq->qual << "\n";
+        }
+    }
+    std::ifstream fq(fastq);
+    if (!fq.is_open()) die("Failed to open " + fastq + "!");
+    std::ofstream tsv;
+    create_file(outdir + "/clusters.tsv", tsv);
+    tsv << "ClusterId\tStrand\tRead" << endl;
+    std::unordered_map<unsigned, string> per_cluster;
+    string h, s, p, q;
+    while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q)) {
+        const string id = h.substr(1);
+        auto it = id2cls.find(id);
+        if (it == id2cls.end()) continue;
+        if (it->second.strand == -1) {
+            s = revcomp(s);
+            std::reverse(q.begin(), q.end());
+        }
+        tsv << it->second.cls << "\t" << it->second.strand << "\t" << id << endl;
+        per_cluster[it->second.cls] += h + "\n" + s + "\n" + p + "\n" + q + "\n";
+    }
+    for (auto& kv : per_cluster) {
+        std::ofstream f;
+        create_file(outdir + "/cluster_fastq/" + std::to_string(kv.first) + ".fq", f);
+        f << kv.second;
+    }
+    if (VERBOSE) cerr << "Dump complete." << endl;
+    return 0;
+}
+
+static int main_info(int argc, char** argv)
+{
+    if (argc < 2 || string(argv[1]) == "-h") {
+        cerr << "isONclust2-hip info batch.cer" << endl;
+        exit(0);
+    }
+    Batch b;
+    string err;
+    if (!load_batch(b, argv[1], err)) die(err);
+    cerr << "Loaded batch from " << argv[1] << ":" << endl;
+    print_batch_info(b);
+    return 0;
+}
+
+// .cer round trip on a synthetic batch (host only; used by the CPU test-suite)
+static int main_selftest(int argc, char** argv)
+{
+    const string path = argc > 1 ? argv[1] : "/tmp/isonclust2_selftest.cer";
+    Batch b;
+    b.BatchNr = 3;
+    b.BatchStart = 10;
+    b.BatchEnd = 12;
+    b.BatchBases = 12345;
+    b.NrCls = 3;
+    b.Depth = 1;
+    b.SortArgs.KmerSize = 13;
+    b.SortArgs.WindowSize = 20;
+    b.SortArgs.Mode = Fast;
+    b.SortArgs.InFastq = "reads.fq";
+    b.LeftLeaf = "a.cer";
+    b.RightLeaf = "";
+    b.Db = {{7u, {0u, 2u}}, {0xFFFFFFFFu, {1u}}, {99u, {}}};
+    for (int c = 0; c < 3; ++c) {
+        auto cl = std::make_shared<Cluster>();
+        for (int m = 0; m <= c; ++m) {
+            auto ps = std::make_shared<ProcSeq>();
+            ps->Id = "r" + std::to_string(c) + "_" + std::to_string(m);
+            ps->MatchStrand = m % 2 ? -1 : 1;
+            if (m == 0) {
+                ps->RawSeq.reset(new Seq{ps->Id, "ACGTACGT", "IIIIIIII", 7.5, 0.01});
+                ps->HpcSeq.reset(new Seq{ps->Id, "ACGT", "IIII", 7.5, 0.02});
+                ps->Mins = {{1, 0, 0}, {5, 3, 1}};
+                ps->RevMins = {{3, 6, 0}};
+            }
+            cl->push_back(ps);
+        }
+        b.Cls.push_back(cl);
+    }
+    b.Cls.push_back(nullptr);
+    b.NrConsGs = 3;
+    string err;
+    if (!save_batch(b, path, err)) die(err);
+    Batch r;
+    if (!load_batch(r, path, err)) die(err);
+    bool ok = r.BatchNr == 3 && r.BatchStart == 10 && r.BatchEnd == 12 && r.BatchBases == 12345 && r.NrCls == 3 && r.Depth == 1 &&
+              r.SortArgs.KmerSize == 13 && r.SortArgs.WindowSize == 20 && r.SortArgs.Mode == Fast && r.SortArgs.InFastq == "reads.fq" &&
+              r.SortArgs.MinFraction == 0.8 && r.LeftLeaf == "a.cer" && r.Db.size() == 3 && r.Db[0].first == 7u &&
+              r.Db[0].second == std::vector<uint32_t>({0u, 2u}) && r.Db[2].first == 0xFFFFFFFFu && r.Cls.size() == 4 && !r.Cls[3] &&
+              r.NrConsGs == 3;
+    for (int c = 0; ok && c < 3; ++c) {
+        ok = r.Cls[size_t(c)] && int(r.Cls[size_t(c)]->size()) == c + 1;
+        for (int m = 0; ok && m <= c; ++m) {
+            auto& x = (*r.Cls[size_t(c)])[size_t(m)];
+            auto& y = (*b.Cls[size_t(c)])[size_t(m)];
+            ok = x->Id == y->Id && x->MatchStrand == y->MatchStrand && bool(x->RawSeq) == bool(y->RawSeq) &&
+                 x->Mins.size() == y->Mins.size();
+            if (ok && x->RawSeq)
+                ok = x->RawSeq->seq == "ACGTACGT" && x->HpcSeq->errorRate == 0.02 && x->Mins[1].Pos == 3 && x->RevMins[0].Min == 3;
+        }
+    }
+    // a truncated file must be rejected, not crash
+    {
+        std::ifstream in(path, std::ios::binary);
+        string all((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        std::ofstream out(path + ".trunc", std::ios::binary);
+        out.write(all.data(), std::streamsize(all.size() / 2));
+        out.close();
+        Batch t;
+        ok = ok && !load_batch(t, path + ".trunc", err);
+        remove((path + ".trunc").c_str());
+    }
+    remove(path.c_str());
+    cerr << (ok ? "selftest ok" : "selftest FAILED") << endl;
+    return ok ? 0 : 1;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) {
+        cerr << "isONclust2-hip <sort|cluster|dump|info|version|help> ..." << endl;
+        return 0;
+    }
+    const string cmd = argv[1];
+    if (cmd == "sort") return main_sort(argc - 1, argv + 1);
+    if (cmd == "cluster") return main_cluster(argc - 1, argv + 1);
+    if (cmd == "dump") return main_dump(argc - 1, argv + 1);
+    if (cmd == "info") return main_info(argc - 1, argv + 1);
+    if (cmd == "selftest") return main_selftest(argc - 1, argv + 1);
+    if (cmd == "version") {
+        cerr << "isONclust2 version: " << VERSION << endl;
+        return 0;
+    }
+    if (cmd == "help") {
+        cerr << "isONclust2-hip: sort, cluster, dump, info, version, help — flags as in isONclust2 v2.4" << endl;
+        return 0;
+    }
+    cerr << "Invalid command: " << cmd << endl;
+    return 0;
+}

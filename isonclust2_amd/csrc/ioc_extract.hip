@@ -399,6 +399,15 @@ struct Tmp {
     }
 };
 
+struct Borrow {
+    void* p;
+    template <class T>
+    T* as()
+    {
+        return static_cast<T*>(p);
+    }
+};
+
 // InitQualTab / InitQualTabNomin, src/qualscore.cpp:156-180 (host libm pow, uploaded)
 void qual_tables(double* capped, double* nomin)
 {
@@ -478,12 +487,18 @@ int ioc_extract_minimizers(ioc_ctx* c, int32_t n, const int64_t* offs, const uin
     if (n == 0) return IOC_OK;
     const int64_t total = offs[n];
     hipStream_t s = c->stream;
-    Tmp d_offs, d_seq, d_qual, d_hseq, d_hqual, d_status, d_err, d_cnt, d_tab;
+    Tmp d_offs, d_seq, d_qual, d_status, d_err, d_cnt, d_tab;
+    Borrow d_hseq{nullptr}, d_hqual{nullptr};  // the HPC strings stay in the context (ioc_extracted_hpc_download)
     XCHK(c, d_offs.alloc(size_t(n + 1) * 8));
     XCHK(c, d_seq.alloc(size_t(total)));
     XCHK(c, d_qual.alloc(size_t(total)));
-    XCHK(c, d_hseq.alloc(size_t(total)));
-    XCHK(c, d_hqual.alloc(size_t(total)));
+    {
+        int rc0;
+        if ((rc0 = reserve_x(c, c->x_hseq, size_t(total))) != IOC_OK) return rc0;
+        if ((rc0 = reserve_x(c, c->x_hqual, size_t(total))) != IOC_OK) return rc0;
+        d_hseq.p = c->x_hseq.p;
+        d_hqual.p = c->x_hqual.p;
+    }
     XCHK(c, d_status.alloc(size_t(n) * 4));
     XCHK(c, d_err.alloc(size_t(n) * 8));
     XCHK(c, d_cnt.alloc(size_t(n) * 8));
@@ -551,6 +566,26 @@ int ioc_extract_minimizers(ioc_ctx* c, int32_t n, const int64_t* offs, const uin
     c->xh_off_rev.assign(off_rev, off_rev + n + 1);
     c->xh_hpc_len.assign(hpc_len, hpc_len + n);
     c->xh_status.assign(status, status + n);
+    c->xh_offs.assign(offs, offs + n + 1);
+    return IOC_OK;
+}
+
+int ioc_extracted_hpc_download(ioc_ctx* c, char* hpc_seq, char* hpc_qual, int64_t cap)
+{
+    if (!c || !hpc_seq || !hpc_qual) return IOC_ERR_ARG;
+    XCHK(c, hipSetDevice(c->device));
+    const int n = c->x_n;
+    if (n <= 0) return ioc_fail(c, IOC_ERR_STATE, "ioc_extract_minimizers first");
+    const int64_t total = c->xh_offs[size_t(n)];
+    if (cap < total) return ioc_fail(c, IOC_ERR_CAPACITY, "buffer smaller than the raw sequence bytes");
+    // layout: read i's HPC string occupies [offs[i], offs[i] + hpc_len[i]) (capacity = raw length)
+    XCHK(c, hipMemcpyAsync(hpc_seq, c->x_hseq.p, size_t(total), hipMemcpyDeviceToHost, c->stream));
+    XCHK(c, hipMemcpyAsync(hpc_qual, c->x_hqual.p, size_t(total), hipMemcpyDeviceToHost, c->stream));
+    XCHK(c, hipStreamSynchronize(c->stream));
+    static const char L[5] = {'A', 'C', 'G', 'T', 'N'};
+    for (int i = 0; i < n; ++i)
+        for (int64_t t = c->xh_offs[size_t(i)]; t < c->xh_offs[size_t(i)] + c->xh_hpc_len[size_t(i)]; ++t)
+            hpc_seq[t] = L[uint8_t(hpc_seq[t]) > 3 ? 4 : uint8_t(hpc_seq[t])];
     return IOC_OK;
 }
 

@@ -75,7 +75,8 @@ struct ioc_ctx {
     bool forced_dirty = false;
 
     // ---- extraction (K1) outputs ----
-    DevBuf x_min, x_pos, x_off_fwd, x_off_rev, x_hpc_len;
+    DevBuf x_min, x_pos, x_off_fwd, x_off_rev, x_hpc_len, x_hseq, x_hqual;
+    std::vector<int64_t> xh_offs;
     int32_t x_n = 0;
     int64_t x_total = 0;
     std::vector<int64_t> xh_off_fwd, xh_off_rev;

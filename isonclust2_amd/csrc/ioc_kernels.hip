@@ -183,6 +183,7 @@ __device__ __forceinline__ uint32_t hash_insert(uint32_t* __restrict__ keys, uin
     return cap + 1;  // table full (host sizes the table so that this cannot happen)
 }
 
+#define IOC_INS_ILP 4
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_hash_insert_queries(int n, const int64_t* __restrict__ doff, const uint32_t* __restrict__ dvals,
                       const uint32_t* __restrict__ dcount, uint32_t* __restrict__ keys, uint32_t cap,
@@ -193,17 +194,45 @@ k_hash_insert_queries(int n, const int64_t* __restrict__ doff, const uint32_t* _
     if (j >= n) return;
     int64_t b = doff[j];
     uint32_t m = dcount[j];
-    for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) {
-        uint32_t slot = hash_insert(keys, cap, shift, dvals[b + d]);
-        uint32_t pos = 0;
-        if (slot > cap) {
-            atomicAdd(err, 1u);
-            slot = cap;
-        } else {
-            pos = atomicAdd(&cnt[slot], 1u);  // position inside the posting list (after the left part)
+    // IOC_INS_ILP values per thread in flight: the first probe of each (almost always a hit once a few
+    // queries have been inserted) and the returning atomicAdd are issued back to back
+    for (uint32_t d0 = threadIdx.x; d0 < m; d0 += IOC_BLOCK * IOC_INS_ILP) {
+        uint32_t v[IOC_INS_ILP], h[IOC_INS_ILP], k0[IOC_INS_ILP], slot[IOC_INS_ILP], pos[IOC_INS_ILP];
+        bool in[IOC_INS_ILP];
+#pragma unroll
+        for (int u = 0; u < IOC_INS_ILP; ++u) {
+            const uint32_t d = d0 + uint32_t(u) * IOC_BLOCK;
+            in[u] = d < m;
+            v[u] = in[u] ? dvals[b + d] : 0u;
+            h[u] = hash_slot(v[u], shift);
         }
-        dslot[b + d] = slot;
-        dpos[b + d] = pos;
+#pragma unroll
+        for (int u = 0; u < IOC_INS_ILP; ++u) k0[u] = (in[u] && v[u] != IOC_EMPTY) ? keys[h[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < IOC_INS_ILP; ++u) {
+            slot[u] = cap + 1;
+            if (in[u]) slot[u] = (v[u] != IOC_EMPTY && k0[u] == v[u]) ? h[u] : hash_insert(keys, cap, shift, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < IOC_INS_ILP; ++u) {
+            pos[u] = 0;
+            if (in[u]) {
+                if (slot[u] > cap) {
+                    atomicAdd(err, 1u);
+                    slot[u] = cap;
+                } else {
+                    pos[u] = atomicAdd(&cnt[slot[u]], 1u);  // position inside the posting list (after the left part)
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < IOC_INS_ILP; ++u) {
+            const uint32_t d = d0 + uint32_t(u) * IOC_BLOCK;
+            if (in[u]) {
+                dslot[b + d] = slot[u];
+                dpos[b + d] = pos[u];
+            }
+        }
     }
 }
 

@@ -1,0 +1,100 @@
+"""The isONclust2-hip command line (isonclust2_amd/bin): CPU part — the .cer round trip of its own
+writer/reader, error paths that need no GPU — and, under -m gpu, the whole sort -> cluster -> merge ->
+dump pipeline on a synthetic FASTQ compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
+
+
+def run(*args, **kw):
+    return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_cer_roundtrip_selftest(tmp_path):
+    r = run("selftest", str(tmp_path / "t.cer"))
+    assert r.returncode == 0 and "selftest ok" in r.stderr
+
+
+def test_error_paths_exit_1(tmp_path):
+    r = run("info", str(tmp_path / "missing.cer"))
+    assert r.returncode == 1 and "Failed to load batch" in r.stderr
+    r = run("cluster", "-o", str(tmp_path / "o.cer"))
+    assert r.returncode == 1 and "left input batch is mandatory" in r.stderr
+    r = run("sort", "-k", "9", str(tmp_path / "x.fq"))
+    assert r.returncode == 1 and "kmer size" in r.stderr.lower()
+    assert run("version").returncode == 0
+
+
+def _write_fastq(rs, path):
+    with open(path, "wb") as f:
+        for i in range(rs.n):
+            s, q = rs.read(i)
+            f.write(b"@r%d extra words\n" % i + s + b"\n+\n" + q + b"\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fast", "sahlin"])
+def test_sort_cluster_merge_dump_matches_oracle(tmp_path, mode):
+    from oracle import pyoracle as po
+    rs = synth.generate(360, 30, 700, 9, 21, seed=21) if mode == "fast" else synth.generate(160, 16, 450, 9, 20, seed=22)
+    half = rs.n // 2
+    fq = tmp_path / "reads.fq"
+    _write_fastq(rs, fq)
+    out = tmp_path / "sorted"
+    r = run("sort", "-v", "-B", "1000000", "-M", str(half), "-o", str(out), str(fq))
+    assert r.returncode == 0, r.stderr
+    b0, b1 = out / "batches" / "isONbatch_0.cer", out / "batches" / "isONbatch_1.cer"
+    assert b0.exists() and b1.exists()
+    for b, o in ((b0, "c0.cer"), (b1, "c1.cer")):
+        r = run("cluster", "-l", str(b), "-o", str(tmp_path / o), "-x", mode)
+        assert r.returncode == 0, r.stderr
+    r = run("cluster", "-v", "-l", str(tmp_path / "c0.cer"), "-r", str(tmp_path / "c1.cer"), "-o", str(tmp_path / "m.cer"),
+            "-x", mode, env=dict(os.environ, ISONCLUST2_STATS_JSON="1"))
+    assert r.returncode == 0, r.stderr
+    assert "core_ms" in r.stderr
+    r = run("dump", "-i", str(out / "sorted_reads_idx.cer"), "-o", str(tmp_path / "dump"), str(tmp_path / "m.cer"))
+    assert r.returncode == 0, r.stderr
+
+    # ---- oracle: same global sort, same two batches, same fold ----
+    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+    R.score_sort(11, 15)
+    order, score, _ = R.order()
+    p = po.default_params(11, 15)
+    A, B = po.Batch(R, 0, half - 1, p, 0), po.Batch(R, half, rs.n - 1, p, 1)
+    if mode == "sahlin":
+        import ctypes as C
+        from isonclust2_amd import _lib
+        L = _lib.load()
+        CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+        fn = CB(lambda a, na, b, nb, go, ge, o, cap: L.ioc_host_align(a, na, b, nb, 2, -2, go, ge, C.cast(o, C.c_char_p), cap, None))
+        po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
+    A.cluster(mode=mode)
+    B.cluster(mode=mode)
+    A.cluster(right=B, mode=mode)
+    if mode == "sahlin":
+        po.lib().orc_set_aligner(None)
+    ocl, ost = A.assignments(rs.n)
+    # the dump sorts clusters by size (unstable std::sort, cluster.cpp:570-580): compare partitions + strands
+    got = {}
+    for line in open(tmp_path / "dump" / "clusters.tsv").read().splitlines()[1:]:
+        c, st, name = line.split("\t")
+        got[int(name[1:])] = (int(c), int(st))
+    assigned = np.nonzero(ocl >= 0)[0]
+    assert sorted(got) == assigned.tolist()
+    m = {}
+    for i in assigned:
+        assert got[int(i)][1] == ost[i]
+        assert m.setdefault(int(ocl[i]), got[int(i)][0]) == got[int(i)][0]
+    assert len(set(m.values())) == len(m)
+    # sorted_reads.fastq holds the score >= 0 reads in score order; scores.tsv every read
+    names = [l[1:] for l in open(out / "sorted_reads.fastq").read().splitlines()[0::4]]
+    assert names == [f"r{i}" for i, s in zip(order, score) if s >= 0]
+    info = open(tmp_path / "dump" / "clusters_info.tsv").read().splitlines()
+    assert len(info) - 1 == A.n_clusters()
