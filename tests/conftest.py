@@ -9,6 +9,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    """The native pieces are git-ignored build products: build them in-tree when a fresh checkout lacks
+    them (hipcc cross-compiles gfx950 without a GPU).  Building is not a fallback: the tests still fail
+    if the HIP library cannot be built or loaded."""
+    lib = os.path.join(ROOT, "isonclust2_amd", "libisonclust2_hip.so")
+    cli = os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
+    orc = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(cli) and os.path.exists(orc)):
+        import __graft_entry__ as g
+        g.build()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
