@@ -91,21 +91,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     return base + incl - v;
 }
 
-// lower_bound style membership test in a sorted array
-__device__ __forceinline__ bool sorted_contains(const uint32_t* __restrict__ a, uint32_t n, uint32_t v)
-{
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        uint32_t x = a[mid];
-        if (x < v)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo < n && a[lo] == v;
-}
-
 }  // namespace
 
 // =====================================================================================================
@@ -915,7 +900,6 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
 // =====================================================================================================
 #define IOC_CUT_NEG INT32_MAX
 #define IOC_BITWORDS 256    // 16384 minimizers per strand per pass (slow path)
-#define IOC_HSET_SLOTS 8192  // LDS hash-set slots (32 KiB); sets up to 60 % of it
 #define IOC_EVAL_ILP 8
 
 __global__ void __launch_bounds__(IOC_BLOCK)
@@ -1032,40 +1016,22 @@ k_decide_scan(DecideArgs a)
 
 // totalMapped of one (query, target, strand): src/cluster.cpp:324-353 with the pow() predicate
 // replaced by the integer gap limit (a gap of n missing minimizers passes iff n < limEx).
-// Membership structure of one evaluation: the target's distinct values as an open-addressed hash set in
-// LDS (<= 60 % full, linear probing; the value 0xFFFFFFFF is kept as a flag), built by the workgroup
-// with ds atomics.  ~1.5 LDS reads per lookup instead of a 12-step binary search whose power-of-two
-// strides collide on one bank.  Sets too large for the table use a binary search in global memory.
-__device__ __forceinline__ uint32_t hset_hash(uint32_t v, uint32_t mask) { return ((v * 0x9E3779B1u) >> 7) & mask; }
-
-template <bool HASH_SET>
-__device__ __forceinline__ bool set_contains(const uint32_t* set, uint32_t setN, uint32_t mask, bool has_ff,
-                                             uint32_t hp2, uint32_t v)
+// Slow path of one evaluation (target sets above 4096 values, i.e. reads beyond ~13 kb HPC as
+// representatives): membership by a branchless binary search in the sorted set in global memory.
+__device__ __forceinline__ bool set_contains_global(const uint32_t* __restrict__ set, uint32_t setN, uint32_t hp2,
+                                                    uint32_t v)
 {
-    if (HASH_SET) {
-        if (v == IOC_EMPTY) return has_ff;
-        uint32_t h = hset_hash(v, mask);
-        for (;;) {
-            const uint32_t x = set[h];
-            if (x == v) return true;
-            if (x == IOC_EMPTY) return false;
-            h = (h + 1) & mask;
-        }
-    } else {
-        uint32_t pos = 0;
-        for (uint32_t h = hp2; h > 0; h >>= 1) {
-            const uint32_t q = pos + h;
-            if (q <= setN && set[q - 1] < v) pos = q;
-        }
-        return pos < setN && set[pos] == v;
+    uint32_t pos = 0;
+    for (uint32_t h = hp2; h > 0; h >>= 1) {
+        const uint32_t q = pos + h;
+        if (q <= setN && set[q - 1] < v) pos = q;
     }
+    return pos < setN && set[pos] == v;
 }
 
-template <bool HASH_SET>
 __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict__ qmin,
                                                       const uint32_t* __restrict__ qpos, uint32_t M,
-                                                      const uint32_t* set, uint32_t setN, uint32_t mask, bool has_ff,
-                                                      uint32_t limEx, uint32_t hpcLen, unsigned long long* bits,
+                                                      const uint32_t* set, uint32_t setN, uint32_t limEx, uint32_t hpcLen, unsigned long long* bits,
                                                       uint32_t* red, uint32_t* carry, unsigned long long* diag)
 {
     const int lane = lane_id(), wave = wave_id();
@@ -1096,7 +1062,7 @@ __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict
             }
 #pragma unroll
             for (int u = 0; u < IOC_EVAL_ILP; ++u) {
-                const bool hit = in[u] && set_contains<HASH_SET>(set, setN, mask, has_ff, hp2, v[u]);
+                const bool hit = in[u] && set_contains_global(set, setN, hp2, v[u]);
                 const unsigned long long m = __ballot(hit);
                 if (lane == 0 && wd0 + u < nwords) bits[wd0 + u] = m;
             }
@@ -1445,8 +1411,7 @@ k_eval(DecideArgs a)
         const int64_t qb = strandbit ? a.off_rev[j] : a.off_fwd[j];
         const uint32_t M = uint32_t((strandbit ? a.off_rev[j + 1] : a.off_fwd[j + 1]) - qb);
         uint32_t tm;
-        long long t0 = 0, t1 = 0, t2 = 0;
-        if (a.diag) t0 = clock64();
+        long long t1 = 0, t2 = 0;
         if (setN <= IOC_EV_PASS) {
             const bool reuse = (j == prev_j) && (strandbit == prev_strand);
             if (a.diag) t1 = clock64();
@@ -1454,8 +1419,7 @@ k_eval(DecideArgs a)
             prev_j = j;
             prev_strand = strandbit;
         } else {
-            tm = eval_total_mapped<false>(a.mins + qb, a.pos + qb, M, set, setN, 0u, false, limEx, a.hpc_len[j], bits,
-                                          red, carry, a.diag);
+            tm = eval_total_mapped(a.mins + qb, a.pos + qb, M, set, setN, limEx, a.hpc_len[j], bits, red, carry, a.diag);
             prev_j = 0xFFFFFFFFu;
         }
         if (a.diag && threadIdx.x == 0) {

@@ -17,7 +17,10 @@ def first(pattern):
 
 
 def short(name):
-    return name.split("(")[0]
+    n = name.split("(")[0]
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
 
 
 summary = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline", "kernels": {}}
