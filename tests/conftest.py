@@ -19,6 +19,14 @@ def pytest_sessionstart(session):
     if not (os.path.exists(lib) and os.path.exists(cli) and os.path.exists(orc)):
         import __graft_entry__ as g
         g.build()
+    # torch ships its own HIP runtime; in a process that uses both, torch has to initialise first
+    # (bench.py does the same), so do it once here on a GPU box
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
 
 
 def pytest_configure(config):
