@@ -84,6 +84,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise IocError(-100, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # torch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot both own the
+    # GPU.  Importing torch first makes the dynamic loader resolve our DT_NEEDED libamdhip64 to the copy
+    # torch already mapped, so both sides share one runtime whatever the initialisation order.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     pi64, pu32, pu8 = C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
