@@ -102,7 +102,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -461,6 +461,8 @@ int ioc_score(ioc_ctx* c)
     iock_set_score_variant(int(env_u32("IOC_SCORE_VARIANT", 0)));
     if (env_u32("IOC_SCORE_PARTS", 1) == 1 && L + uint64_t(n) <= range && capacity * 8 * 4 + (1ull << 28) < have - need) {
         RESERVE(c, c->b_part, size_t(capacity) * 8 * 4);
+        RESERVE(c, c->b_pmins, size_t(c->total) * 4);
+        RESERVE(c, c->b_pbnd, size_t(n) * 2 * 9 * 4);
         d_part = P<uint32_t>(c->b_part);
     } else if (c->b_part.p) {
         HIPCHK(c, hipStreamSynchronize(s));
@@ -470,7 +472,8 @@ int ioc_score(ioc_ctx* c)
     HIPCHK(c, iock_score(s, n, uint32_t(L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), c->b_post.p, range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all), c->post16));
+                         count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all), c->post16,
+                         P<uint32_t>(c->b_pmins), P<uint32_t>(c->b_pbnd)));
     c->have_guess = d_part != nullptr;
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
@@ -810,7 +813,8 @@ int ioc_count_reference_postings(ioc_ctx* c, int64_t* n_postings)
     HIPCHK(c, iock_score(s, c->n, uint32_t(c->L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), c->b_post.p, range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
-                         nullptr, valid, d_sum, P<uint32_t>(c->b_part), nullptr, c->post16));
+                         nullptr, valid, d_sum, P<uint32_t>(c->b_part), nullptr, c->post16, P<uint32_t>(c->b_pmins),
+                         P<uint32_t>(c->b_pbnd)));
     unsigned long long h = 0;
     HIPCHK(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

@@ -61,7 +61,7 @@ struct ioc_ctx {
 
     // ---- scoring ----
     bool scored = false;
-    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo, b_part, b_diag, b_top_all;
+    DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo, b_part, b_diag, b_top_all, b_pmins, b_pbnd;
     bool have_guess = false;
     int64_t cand_capacity = 0;
 

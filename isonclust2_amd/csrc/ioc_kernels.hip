@@ -734,17 +734,57 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
 // and writes the candidate list.
 // =====================================================================================================
 #define IOC_PARTS 8
+// Minimizer values of every query, bucketed by index partition (order inside a bucket is irrelevant to a
+// histogram): pmins holds a permutation of mins per (query, strand), pbnd the 9 bucket boundaries.
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_partition_mins(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+                 const uint32_t* __restrict__ mins, uint32_t shift, uint32_t* __restrict__ pmins,
+                 uint32_t* __restrict__ pbnd)
+{
+    __shared__ uint32_t cnt[IOC_PARTS], cur[IOC_PARTS];
+    const int j = blockIdx.x;
+    if (j >= n) return;
+    const uint32_t pshift = (32u - shift) - 3u;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
+        const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
+        if (threadIdx.x < IOC_PARTS) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int64_t t = b + threadIdx.x; t < e; t += IOC_BLOCK) {
+            const uint32_t v = mins[t];
+            atomicAdd(&cnt[(v == IOC_EMPTY) ? 0u : (hash_slot(v, shift) >> pshift)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            uint32_t* out = pbnd + (size_t(j) * 2 + s) * (IOC_PARTS + 1);
+            for (int x = 0; x < IOC_PARTS; ++x) {
+                out[x] = acc;
+                cur[x] = acc;
+                acc += cnt[x];
+            }
+            out[IOC_PARTS] = acc;
+        }
+        __syncthreads();
+        for (int64_t t = b + threadIdx.x; t < e; t += IOC_BLOCK) {
+            const uint32_t v = mins[t];
+            const uint32_t pos = atomicAdd(&cur[(v == IOC_EMPTY) ? 0u : (hash_slot(v, shift) >> pshift)], 1u);
+            pmins[b + pos] = v;
+        }
+        __syncthreads();
+    }
+}
+
 template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
-             const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
-             const PT* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1, uint32_t e2, uint32_t e3,
-             unsigned long long* __restrict__ traversed)
+             const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
+             uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1,
+             uint32_t e2, uint32_t e3, unsigned long long* __restrict__ traversed)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t s_wb[IOC_WAVES][64];
     __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];
-    __shared__ uint32_t wq[IOC_WAVES][128];  // per-wave ring of minimizer values of this partition
     const int j = n - 1 - int(blockIdx.x / IOC_PARTS);
     const uint32_t x = blockIdx.x % IOC_PARTS;
     if (j < 0) return;
@@ -753,53 +793,29 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
     const uint32_t eshift = T <= e1 ? 0u : T <= e2 ? 10u : T <= e3 ? 20u : 30u;
     const int lane = lane_id(), wave = wave_id();
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
-    const uint32_t pshift = (32u - shift) - 3u;  // slot bits - 3
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t* const wb_ = s_wb[wave];
     unsigned long long* const bm_ = s_bm[wave];
-    uint32_t* const q = wq[wave];
     unsigned long long trav = 0;
     uint32_t abl = 0;
     for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) hist[i] = 0;
     __syncthreads();
     for (int s = 0; s < 2; ++s) {
-        const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
-        const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
+        const int64_t b0 = s == 0 ? off_fwd[j] : off_rev[j];
+        const uint32_t* bnd = pbnd + (size_t(j) * 2 + s) * (IOC_PARTS + 1);
+        const int64_t b = b0 + bnd[x], e = b0 + bnd[x + 1];  // this partition's bucket
         uint32_t* h = hist + uint32_t(s) * T;
-        uint32_t qhead = 0, qn = 0;  // wave-uniform ring state
-        for (int64_t c0 = b + wave * 64;; c0 += IOC_WAVES * 64) {
-            const bool more = c0 < e;  // wave-uniform
-            if (more) {
-                const int64_t t = c0 + lane;
-                uint32_t v = 0;
-                bool mine = false;
-                if (t < e) {
-                    v = mins[t];
-                    const uint32_t pv = (v == IOC_EMPTY) ? 0u : (hash_slot(v, shift) >> pshift);
-                    mine = pv == x;
+        for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
+            const int64_t t = c0 + lane;
+            uint32_t o = 0, len = 0, qi = 0;
+            if (t < e) index_lookup(rows, cap, shift, pmins[t], o, len, qi);
+            if (len) {
+                if (!(qi & 0x80000000u)) {
+                    if (eshift < 30) len = (qi >> eshift) & 1023u;
+                } else {
+                    len = list_lower_bound(post + o, len, T);
                 }
-                const unsigned long long bm = __ballot(mine);
-                if (mine) q[(qhead + qn + uint32_t(__popcll(bm & lt_mask))) & 127u] = v;
-                qn += uint32_t(__popcll(bm));
             }
-            // drain: full chunks while reading, everything at the end
-            while (qn >= 64 || (!more && qn > 0)) {
-                const uint32_t take = qn < 64 ? qn : 64;
-                __builtin_amdgcn_wave_barrier();
-                uint32_t o = 0, len = 0, qi = 0;
-                if (uint32_t(lane) < take) index_lookup(rows, cap, shift, q[(qhead + lane) & 127u], o, len, qi);
-                qhead = (qhead + take) & 127u;
-                qn -= take;
-                if (len) {
-                    if (!(qi & 0x80000000u)) {
-                        if (eshift < 30) len = (qi >> eshift) & 1023u;
-                    } else {
-                        len = list_lower_bound(post + o, len, T);
-                    }
-                }
-                flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
-            }
-            if (!more) break;
+            flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
         }
     }
     __syncthreads();
@@ -1745,7 +1761,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
                       const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post_,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
                       unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
-                      uint32_t* part, uint32_t* top_all, int post16)
+                      uint32_t* part, uint32_t* top_all, int post16, uint32_t* pmins, uint32_t* pbnd)
 {
     const uint32_t* post = (const uint32_t*)post_;
     const uint16_t* post_h = (const uint16_t*)post_;
@@ -1753,7 +1769,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     uint32_t tmax = L + uint32_t(n - 1);
     uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
     size_t lds = size_t(2) * r * 4;
-    if (part && tmax <= range && cap >= 1024) {
+    if (part && pmins && pbnd && tmax <= range && cap >= 1024) {
         uint32_t e1, e2, e3;
         epoch_bounds(L, uint32_t(n), e1, e2, e3);
         if (lds > 40 * 1024) {
@@ -1761,12 +1777,15 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
             CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
             CK(hipFuncSetAttribute((const void*)k_score_compact, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         }
+        hipLaunchKernelGGL(k_partition_mins, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd);
         if (post16)
             hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
-                               off_fwd, off_rev, mins, (const uint4*)rows, cap, shift, post_h, part, e1, e2, e3, traversed);
+                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, e1, e2, e3,
+                               traversed);
         else
             hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
-                               off_fwd, off_rev, mins, (const uint4*)rows, cap, shift, post, part, e1, e2, e3, traversed);
+                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, e1, e2, e3,
+                               traversed);
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
                            cand_count, audit_valid, audit_sum, top_all);
         return hipGetLastError();
