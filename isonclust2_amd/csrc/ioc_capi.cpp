@@ -459,10 +459,11 @@ int ioc_score(ioc_ctx* c)
     // XCD-partitioned scoring keeps 8 partial histograms per query (single-pass case only)
     uint32_t* d_part = nullptr;
     iock_set_score_variant(int(env_u32("IOC_SCORE_VARIANT", 0)));
+    iock_set_part32(int(env_u32("IOC_PART32", 0)));
     if (env_u32("IOC_SCORE_PARTS", 1) == 1 && L + uint64_t(n) <= range && capacity * 8 * 4 + (1ull << 28) < have - need) {
         RESERVE(c, c->b_part, size_t(capacity) * 8 * 4);
         RESERVE(c, c->b_pmins, size_t(c->total) * 4);
-        RESERVE(c, c->b_pbnd, size_t(n) * 2 * 9 * 4);
+        RESERVE(c, c->b_pbnd, (size_t(n) * 2 * 9 + 1) * 4);
         d_part = P<uint32_t>(c->b_part);
     } else if (c->b_part.p) {
         HIPCHK(c, hipStreamSynchronize(s));

@@ -87,6 +87,7 @@ hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* of
                             const uint8_t* valid, uint32_t* hist, uint32_t* first, int post16);
 size_t iock_decide_args_size();
 void iock_set_score_variant(int v);
+void iock_set_part32(int v);
 
 // ---- sort-stage kernels (ioc_extract.hip) ----
 hipError_t iock_qual_scores(hipStream_t st, int n, const int64_t* offs, const uint8_t* qual, int k,

@@ -739,7 +739,7 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_partition_mins(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
                  const uint32_t* __restrict__ mins, uint32_t shift, uint32_t* __restrict__ pmins,
-                 uint32_t* __restrict__ pbnd)
+                 uint32_t* __restrict__ pbnd, uint32_t* __restrict__ max_len)
 {
     __shared__ uint32_t cnt[IOC_PARTS], cur[IOC_PARTS];
     const int j = blockIdx.x;
@@ -749,6 +749,8 @@ k_partition_mins(int n, const int64_t* __restrict__ off_fwd, const int64_t* __re
         const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
         const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
         if (threadIdx.x < IOC_PARTS) cnt[threadIdx.x] = 0;
+        // a Size can never exceed the strand's minimizer count: below 65536 the partial histograms are u16
+        if (threadIdx.x == 0 && uint32_t(e - b) > 65535u) atomicMax(max_len, uint32_t(e - b));
         __syncthreads();
         for (int64_t t = b + threadIdx.x; t < e; t += IOC_BLOCK) {
             const uint32_t v = mins[t];
@@ -780,7 +782,7 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
              uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1,
-             uint32_t e2, uint32_t e3, unsigned long long* __restrict__ traversed)
+             uint32_t e2, uint32_t e3, unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t s_wb[IOC_WAVES][64];
@@ -819,8 +821,13 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
         }
     }
     __syncthreads();
-    uint32_t* out = part + IOC_PARTS * cbase + size_t(x) * 2 * T;
-    for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) out[i] = hist[i];
+    if (*max_len < 65536u) {  // two u16 counts per word (cbase and 2T are even)
+        uint32_t* out = part + (IOC_PARTS * cbase) / 2 + size_t(x) * T;
+        for (uint32_t i = threadIdx.x; i < T; i += IOC_BLOCK) out[i] = hist[2 * i] | (hist[2 * i + 1] << 16);
+    } else {
+        uint32_t* out = part + IOC_PARTS * cbase + size_t(x) * 2 * T;
+        for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) out[i] = hist[i];
+    }
     if (traversed && lane == 0) atomicAdd(traversed, trav);
 }
 
@@ -828,7 +835,8 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t keep,
                 uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_size,
                 uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ audit_valid,
-                unsigned long long* __restrict__ audit_sum, uint32_t* __restrict__ top_all)
+                unsigned long long* __restrict__ audit_sum, uint32_t* __restrict__ top_all,
+                const uint32_t* __restrict__ max_len)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
@@ -839,14 +847,31 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
     const int lane = lane_id(), wave = wave_id();
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     const uint32_t tot = 2 * T;
-    const uint32_t* src = part + IOC_PARTS * cbase;
     uint32_t tmax = 0;
-    for (uint32_t i = threadIdx.x; i < tot; i += IOC_BLOCK) {
-        uint32_t v = 0;
+    if (*max_len < 65536u) {
+        const uint32_t* src = part + (IOC_PARTS * cbase) / 2;
+        for (uint32_t i = threadIdx.x; i < T; i += IOC_BLOCK) {
+            uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int x = 0; x < IOC_PARTS; ++x) v += src[size_t(x) * tot + i];
-        hist[i] = v;
-        tmax = v > tmax ? v : tmax;
+            for (int x = 0; x < IOC_PARTS; ++x) {
+                const uint32_t w = src[size_t(x) * T + i];
+                lo += w & 0xFFFFu;
+                hi += w >> 16;
+            }
+            hist[2 * i] = lo;
+            hist[2 * i + 1] = hi;
+            tmax = lo > tmax ? lo : tmax;
+            tmax = hi > tmax ? hi : tmax;
+        }
+    } else {
+        const uint32_t* src = part + IOC_PARTS * cbase;
+        for (uint32_t i = threadIdx.x; i < tot; i += IOC_BLOCK) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int x = 0; x < IOC_PARTS; ++x) v += src[size_t(x) * tot + i];
+            hist[i] = v;
+            tmax = v > tmax ? v : tmax;
+        }
     }
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
         const uint32_t t = __shfl_down(tmax, o2);
@@ -1645,10 +1670,12 @@ k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int6
     } while (0)
 
 static int g_score_variant = 0;
+static int g_part32 = 0;
 
 extern "C" {
 
 void iock_set_score_variant(int v) { g_score_variant = v; }
+void iock_set_part32(int v) { g_part32 = v; }
 
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
                          uint32_t* dvals, uint32_t* dcount, uint32_t pmax)
@@ -1777,17 +1804,20 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
             CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
             CK(hipFuncSetAttribute((const void*)k_score_compact, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         }
-        hipLaunchKernelGGL(k_partition_mins, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd);
+        uint32_t* max_len = pbnd + size_t(n) * 2 * (IOC_PARTS + 1);  // one extra word behind the boundaries
+        CK(hipMemsetAsync(max_len, g_part32 ? 0xFF : 0, 4, st));  // IOC_PART32=1 forces u32 partials (tests)
+        hipLaunchKernelGGL(k_partition_mins, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd,
+                           max_len);
         if (post16)
             hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
                                off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, e1, e2, e3,
-                               traversed);
+                               traversed, max_len);
         else
             hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
                                off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, e1, e2, e3,
-                               traversed);
+                               traversed, max_len);
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
-                           cand_count, audit_valid, audit_sum, top_all);
+                           cand_count, audit_valid, audit_sum, top_all, max_len);
         return hipGetLastError();
     }
     uint32_t e1, e2, e3;

@@ -66,6 +66,12 @@ def test_range_passes_and_unpartitioned_kernel(ctx, monkeypatch):
     _check(ctx, synth.generate_config("short_dup", seed=4))
 
 
+def test_u32_partial_histograms(ctx, monkeypatch):
+    """Strands of >= 65536 minimizers switch the partial histograms from packed u16 to u32 (forced here)."""
+    monkeypatch.setenv("IOC_PART32", "1")
+    _check(ctx, synth.generate_config("config1", seed=8))
+
+
 def test_tiny_work_queue_forces_repeated_sweeps(ctx, monkeypatch):
     """A work queue smaller than the number of pending evaluations: sweeps repeat until complete."""
     monkeypatch.setenv("IOC_QUEUE_CAP", "64")
