@@ -197,6 +197,27 @@ int32_t ioc_host_gap_open(double e1_plus_e2);                     /* setGapOpen,
 double ioc_host_aln_ratio(const char* comp, int32_t comp_len, double e, uint32_t slen, uint32_t k);
                                                                   /* getAlnRatio, src/cluster.cpp:442-459 */
 
+/* ---- the same alignment on the GPU, batched (getBestClusterAln's ParasailAlign + getAlnRatio,
+ * src/cluster.cpp:408-423, 442-459, 498-507) ------------------------------------------------------- */
+/* One pair = read `query` against representative `ref` (indices into the sequence pool), the reference
+ * optionally reverse-complemented (RevComp, src/util.cpp:13-38; cluster.cpp:491-495); e = sum of the two
+ * raw error rates (cluster.cpp:497), which selects the gap-open penalty (setGapOpen) and the per-window
+ * match limit floor((1-e)k).  Results are bit-identical to ioc_host_align + ioc_host_aln_ratio. */
+typedef struct {
+    int32_t query;
+    int32_t ref;
+    int32_t ref_revcomp;
+    int32_t reserved;
+    double e;
+} ioc_aln_pair;
+/* Upload the sequence pool (concatenated raw sequences, offs[n_seqs + 1], offs[0] == 0). */
+int ioc_align_set_pool(ioc_ctx* ctx, int32_t n_seqs, const char* seqs, const int64_t* offs);
+/* Align n_pairs pairs; any of the outputs may be NULL.  out_windows = number of qualifying k-windows
+ * (`aligned` of getAlnRatio), out_ratio = out_windows / query length (its return value). */
+int ioc_align_pairs(ioc_ctx* ctx, int32_t n_pairs, const ioc_aln_pair* pairs, int32_t k, int32_t match,
+                    int32_t mismatch, int32_t gap_extend, int32_t* out_score, int64_t* out_windows,
+                    double* out_ratio);
+
 /* ---- host driver: ClusterSortedReads on flat arrays (src/cluster.cpp:67-322, consensus off) ------ */
 typedef struct {
     /* right batch, one record per entry in loop order */

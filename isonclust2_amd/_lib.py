@@ -51,6 +51,11 @@ class ClusterStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class AlnPair(C.Structure):  # ioc_aln_pair
+    _fields_ = [("query", C.c_int32), ("ref", C.c_int32), ("ref_revcomp", C.c_int32), ("reserved", C.c_int32),
+                ("e", C.c_double)]
+
+
 class Timings(C.Structure):
     _fields_ = [("ms_build", C.c_float), ("ms_score", C.c_float), ("ms_resolve", C.c_float),
                 ("resolve_iters", C.c_int32), ("n_queries", C.c_int32), ("n_minimizers", C.c_int64),
@@ -70,7 +75,7 @@ SYMBOLS = [
     "ioc_extract_minimizers", "ioc_extracted_download", "ioc_extracted_hpc_download", "ioc_queries_from_extracted",
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
     "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
-    "ioc_host_aln_ratio",
+    "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs",
 ]
 
 _lib = None
@@ -135,5 +140,8 @@ def load():
     L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]
     L.ioc_host_aln_ratio.restype = C.c_double
     L.ioc_cluster_resident.argtypes = [vp, pi32, pi8, C.POINTER(ClusterStats)]
+    L.ioc_align_set_pool.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_int64)]
+    L.ioc_align_pairs.argtypes = [vp, i32, C.POINTER(AlnPair), i32, i32, i32, i32, pi32, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_double)]
     _lib = L
     return L

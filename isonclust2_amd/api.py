@@ -136,6 +136,26 @@ class Context:
                                           _p(offs, C.c_int64), _p(post, C.c_uint32)))
         return keys[:nk.value], offs, post[:npost.value]
 
+    # ---- alignment fallback on the GPU ---------------------------------------------------------
+    def align_set_pool(self, seqs):
+        """Upload the raw sequences (list of bytes) the pairs of align_pairs index into."""
+        offs = np.zeros(len(seqs) + 1, np.int64)
+        np.cumsum([len(x) for x in seqs], out=offs[1:])
+        blob = b"".join(seqs)
+        self._chk(self.L.ioc_align_set_pool(self.h, len(seqs), blob, _p(offs, C.c_int64)))
+
+    def align_pairs(self, pairs, k, match=2, mismatch=-2, gap_extend=1):
+        """ParasailAlign + getAlnRatio (src/cluster.cpp:408-459) for (query, ref, ref_revcomp, e) tuples:
+        returns (score, qualifying windows, ratio) arrays."""
+        n = len(pairs)
+        arr = (_lib.AlnPair * max(n, 1))()
+        for i, (qi, ri, rc, e) in enumerate(pairs):
+            arr[i].query, arr[i].ref, arr[i].ref_revcomp, arr[i].e = int(qi), int(ri), int(bool(rc)), float(e)
+        score, win, ratio = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.float64)
+        self._chk(self.L.ioc_align_pairs(self.h, n, arr, k, match, mismatch, gap_extend, _p(score, C.c_int32),
+                                         _p(win, C.c_int64), _p(ratio, C.c_double)))
+        return score, win, ratio
+
     # ---- sort-stage feeders --------------------------------------------------------------------
     def qual_scores(self, offs, qual, k):
         """CalcQualScore / CalcErrorRate per read (src/qualscore.cpp:14-37, 107-154)."""

@@ -84,6 +84,10 @@ struct ioc_ctx {
     std::vector<int32_t> xh_status;
     std::vector<uint8_t> x_keep;
 
+    // ---- GPU alignment fallback (ioc_align_gpu.hip) ----
+    DevBuf a_pool, a_pairs, a_order, a_out, a_bnd, a_lrow;
+    std::vector<int64_t> aln_offs;
+
     // ---- instrumentation ----
     hipEvent_t ev[6]{};
     ioc_timings tm{};

@@ -1,0 +1,113 @@
+"""GPU batched aligner (ioc_align_pairs) against the host aligner (ioc_host_align + ioc_host_aln_ratio):
+score and getAlnRatio must be identical — same recurrence, tie-breaks and end-cell choice, with the
+window statistics carried forward instead of a traceback (src/cluster.cpp:408-459)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import _lib, api
+
+pytestmark = pytest.mark.gpu
+
+_COMP = {65: 84, 67: 71, 71: 67, 84: 65}
+
+
+def _host(L, q, r, rc, e, k):
+    if rc:
+        r = bytes(_COMP.get(ch, ch) for ch in reversed(r))
+    cap = len(q) + len(r) + 2
+    comp = C.create_string_buffer(cap)
+    sc = C.c_int32()
+    n = L.ioc_host_align(q, len(q), r, len(r), 2, -2, L.ioc_host_gap_open(e), 1, comp, cap, C.byref(sc))
+    assert n >= 0
+    return sc.value, L.ioc_host_aln_ratio(comp, n, e, len(q), k)
+
+
+def _mutate(rng, s, rate):
+    out = bytearray()
+    for ch in s:
+        x = rng.random()
+        if x < rate / 3:
+            out.append(rng.choice(b"ACGT"))
+        elif x < 2 * rate / 3:
+            continue
+        elif x < rate:
+            out.append(ch)
+            out.append(rng.choice(b"ACGT"))
+        else:
+            out.append(ch)
+    return bytes(out)
+
+
+def _check(ctx, seqs, pairs, k):
+    L = _lib.load()
+    ctx.align_set_pool(seqs)
+    score, win, ratio = ctx.align_pairs(pairs, k)
+    for i, (qi, ri, rc, e) in enumerate(pairs):
+        hs, hr = _host(L, seqs[qi], seqs[ri], rc, e, k)
+        assert score[i] == hs, (i, len(seqs[qi]), len(seqs[ri]), rc, e, k)
+        assert ratio[i] == hr, (i, len(seqs[qi]), len(seqs[ri]), rc, e, k, win[i])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return api.Context(0)
+
+
+def test_reference_aln_ratio_vector(ctx, kat):
+    """AlnRatioTest (test/isONclust2_test.cpp:137-181): the reference's only alignment known answer."""
+    from oracle import pyoracle as po
+    ref, read = kat["min_match"]["ref"].encode(), kat["min_match"]["read"].encode()
+    e = po.error_rate(b"I" * len(ref), nomin=False) + po.error_rate(b"I" * len(read), nomin=False)
+    ctx.align_set_pool([ref, read])
+    _, win, _ = ctx.align_pairs([(0, 1, 0, e)], kat["aln_ratio"]["k"])   # the test aligns (ref, read)
+    assert abs(win[0] / len(read) - kat["aln_ratio"]["expected_double_eq"]) < 1e-15
+
+
+@pytest.mark.parametrize("waves", ["1", "2", "8"])
+def test_small_random_pairs(ctx, monkeypatch, waves):
+    """Lengths 0..200 incl. empty / one base, every gap-open class, limits <= 0 and > k, k = 1..32."""
+    monkeypatch.setenv("IOC_ALIGN_WAVES", waves)
+    rng = random.Random(11 + int(waves))
+    seqs, pairs = [], []
+    for t in range(120):
+        n, m = rng.randint(0, 200), rng.randint(0, 200)
+        base = bytes(rng.choice(b"ACGT") for _ in range(max(n, m) + 20))
+        q = _mutate(rng, base, 0.15)[:n]
+        r = _mutate(rng, base[rng.randint(0, 12):], 0.15)[:m]
+        if t % 9 == 0:
+            q = bytes(rng.choice(b"AC") for _ in range(n))
+        if t % 11 == 0:
+            r = q
+        seqs += [q, r]
+        pairs.append((2 * t, 2 * t + 1, t % 2, rng.choice([0.0, 0.02, 0.05, 0.12, 0.3, 0.95, 1.3])))
+    for k in (1, 5, 11, 13, 32):
+        _check(ctx, seqs, pairs, k)
+
+
+@pytest.mark.parametrize("waves", ["1", "8"])
+def test_multi_strip_pairs(ctx, monkeypatch, waves):
+    """References wider than one strip of the workgroup (512 columns per wave): the edge column goes
+    through the global scratch; unequal lengths, contained and overlapping pairs."""
+    monkeypatch.setenv("IOC_ALIGN_WAVES", waves)
+    rng = random.Random(5)
+    base = bytes(rng.choice(b"ACGT") for _ in range(12000))
+    seqs = [
+        _mutate(rng, base[:9000], 0.08), _mutate(rng, base[:9100], 0.10),        # same transcript
+        _mutate(rng, base[2000:3000], 0.05), _mutate(rng, base, 0.12),           # short read inside a long one
+        _mutate(rng, base[6000:], 0.1), _mutate(rng, base[:7000], 0.1),          # suffix / prefix overlap
+        bytes(rng.choice(b"ACGT") for _ in range(4100)), _mutate(rng, base[:4097], 0.02),  # unrelated
+    ]
+    pairs = [(0, 1, 0, 0.18), (1, 0, 0, 0.18), (2, 3, 0, 0.17), (3, 2, 0, 0.17), (4, 5, 0, 0.2), (6, 7, 0, 0.05),
+             (0, 1, 1, 0.18), (7, 0, 0, 0.1)]
+    _check(ctx, seqs, pairs, 11)
+
+
+def test_automatic_width_and_many_pairs(ctx):
+    rng = random.Random(3)
+    base = [bytes(rng.choice(b"ACGT") for _ in range(1500)) for _ in range(6)]
+    seqs = [_mutate(rng, base[i % 6], 0.1) for i in range(60)]
+    pairs = [(i, (i + 6) % 60, i % 2, 0.2) for i in range(60)] + [(i, (i + 1) % 60, 0, 0.2) for i in range(60)]
+    _check(ctx, seqs, pairs, 11)
