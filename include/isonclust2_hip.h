@@ -118,6 +118,16 @@ int ioc_get_decisions(ioc_ctx* ctx, int32_t* target, int8_t* strand, uint8_t* fl
  * next ioc_resolve. target -1 = new cluster. */
 int ioc_force_decision(ioc_ctx* ctx, int32_t query, int32_t target, int32_t strand);
 int ioc_clear_forced(ioc_ctx* ctx);
+/* Verdicts of the alignment fallback (getBestClusterAln, src/cluster.cpp:461-515), one per query:
+ * target[q] = INT32_MIN (none yet), -1 (no candidate aligned: opens a cluster) or the joined target with
+ * strand[q] = +1/-1.  Unlike a forced decision a verdict is used by ioc_resolve only when the query's
+ * mapping walk finds nothing although top >= MinShared (flags bit1 stays set), so verdicts may be
+ * supplied speculatively for many queries at once.  target == NULL switches verdicts off. */
+int ioc_set_aln_verdicts(ioc_ctx* ctx, const int32_t* target, const int8_t* strand);
+/* With verdicts set, ioc_resolve also reports per query the candidates tied at the top Size among the
+ * current clusters — the ones getBestClusterAln tries (cluster.cpp:481-489): count[n] and up to 4 keys
+ * per query (keys[4 * q + i] = target << 1 | (strand == -1), unordered); more than 4: ioc_query_candidates. */
+int ioc_get_ties(ioc_ctx* ctx, uint32_t* count, uint32_t* keys);
 
 /* Full candidate table of one query against the targets that are clusters under the current
  * decisions, in the fields the reference's hit map holds (src/minimizer.cpp:44-76): target id,
@@ -264,8 +274,11 @@ typedef struct {
     int64_t n_joined;
     int64_t n_gated;
     int64_t n_tie_replays;
-    int64_t n_aln_invoked;
+    int64_t n_aln_invoked;   /* reads that reached the alignment fallback (ALN_INVOKED, cluster.cpp:21,559) */
     int32_t resolve_iters;
+    int32_t aln_rounds;      /* verdict rounds of the alignment fallback driver */
+    int64_t n_aln_pairs;     /* (read, candidate, strand) pairs actually aligned */
+    int64_t n_aln_order_dep; /* verdicts that depended on the reference's candidate order */
 } ioc_cluster_stats;
 
 /* Initial clustering of one sorted batch (`cluster -l batch.cer`, src/main.cpp:262-275):

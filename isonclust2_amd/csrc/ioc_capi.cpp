@@ -102,7 +102,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -177,6 +177,7 @@ static int queries_common(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const i
     c->h_forced_t.assign(size_t(n), INT32_MIN);
     c->h_forced_s.assign(size_t(n), 0);
     c->forced_dirty = true;
+    c->aln_verdicts = false;
     RESERVE(c, c->b_doff, size_t(n + 1) * 8);
     HIPCHK(c, hipMemcpyAsync(c->b_doff.p, c->h_doff.data(), size_t(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     return IOC_OK;
@@ -508,6 +509,44 @@ int ioc_clear_forced(ioc_ctx* c)
     return IOC_OK;
 }
 
+// Verdicts of the alignment fallback (getBestClusterAln, cluster.cpp:461-515), one per query: used by
+// ioc_resolve only for a query whose mapping walk finds nothing although top >= MinShared.
+int ioc_set_aln_verdicts(ioc_ctx* c, const int32_t* target, const int8_t* strand)
+{
+    if (!c) return IOC_ERR_ARG;
+    if (!target) {
+        c->aln_verdicts = false;
+        return IOC_OK;
+    }
+    if (!strand) return IOC_ERR_ARG;
+    const size_t n = size_t(c->n);
+    for (size_t i = 0; i < n; ++i) {
+        if (target[i] != INT32_MIN && target[i] >= c->L + int32_t(i))
+            return ioc_fail(c, IOC_ERR_ARG, "alignment verdict is not an earlier target");
+        if (target[i] >= 0 && strand[i] != 1 && strand[i] != -1) return ioc_fail(c, IOC_ERR_ARG, "strand must be +1/-1");
+    }
+    c->h_aln_t.assign(target, target + n);
+    c->h_aln_s.assign(strand, strand + n);
+    c->aln_verdicts = true;
+    c->aln_dirty = true;
+    return IOC_OK;
+}
+
+// Candidates tied at the top Size among the current clusters, per query, as of the last ioc_resolve
+// (only collected while verdicts are set): count[n], keys[n * 4] = target << 1 | (strand == -1).
+int ioc_get_ties(ioc_ctx* c, uint32_t* count, uint32_t* keys)
+{
+    if (!c || !count || !keys) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved || !c->aln_verdicts) return ioc_fail(c, IOC_ERR_STATE, "ioc_set_aln_verdicts + ioc_resolve first");
+    const size_t n = size_t(c->n);
+    if (n == 0) return IOC_OK;
+    HIPCHK(c, hipMemcpyAsync(count, c->b_tie_count.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(keys, c->b_tie_keys.p, n * IOC_TIE_SLOTS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IOC_OK;
+}
+
 int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
 {
     if (!c) return IOC_ERR_ARG;
@@ -527,6 +566,17 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         HIPCHK(c, hipMemcpyAsync(c->b_forced_t.p, c->h_forced_t.data(), size_t(n) * 4, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->b_forced_s.p, c->h_forced_s.data(), size_t(n), hipMemcpyHostToDevice, s));
         c->forced_dirty = false;
+    }
+    if (c->aln_verdicts) {
+        RESERVE(c, c->b_aln_t, size_t(n) * 4);
+        RESERVE(c, c->b_aln_s, size_t(n));
+        RESERVE(c, c->b_tie_count, size_t(n) * 4);
+        RESERVE(c, c->b_tie_keys, size_t(n) * IOC_TIE_SLOTS * 4);
+        if (c->aln_dirty && n > 0) {
+            HIPCHK(c, hipMemcpyAsync(c->b_aln_t.p, c->h_aln_t.data(), size_t(n) * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(c->b_aln_s.p, c->h_aln_s.data(), size_t(n), hipMemcpyHostToDevice, s));
+            c->aln_dirty = false;
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
     // initial guess (any guess converges to the same fixed point): "every query opens a cluster".
@@ -573,6 +623,12 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.n_evals = d_evals;
     a.min_shared = c->params.min_shared;
     a.min_fraction = c->params.min_fraction;
+    if (c->aln_verdicts) {
+        a.aln_t = P<int32_t>(c->b_aln_t);
+        a.aln_s = P<int8_t>(c->b_aln_s);
+        a.tie_count = P<uint32_t>(c->b_tie_count);
+        a.tie_keys = P<uint32_t>(c->b_tie_keys);
+    }
     // misc layout (uint32 words): [8] first_changed, [9] q_count (phase 1), [10] incomplete, [11] q_count (phase 2)
     const uint32_t q_cap = env_u32("IOC_QUEUE_CAP", 1u << 20);
     RESERVE(c, c->b_queue, size_t(q_cap) * 8);

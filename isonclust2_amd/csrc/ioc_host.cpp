@@ -250,44 +250,112 @@ static void revcomp_inplace(std::string& s)
     for (auto& ch : s) ch = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
 }
 
-// getBestClusterAln (cluster.cpp:461-515) for query q: candidates tied at the top Size, in hitOrder
-static int align_query(ioc_ctx* c, int q, const std::vector<int32_t>& cid, const SeqAccess& sa, int32_t& out_target,
-                       int8_t& out_strand)
-{
-    std::vector<Ordered> order;
-    int r = build_order(c, q, cid, order);
-    if (r != IOC_OK) return r;
-    out_target = -1;
-    out_strand = 0;
-    if (order.empty()) return IOC_OK;
-    const unsigned top = order[0].size;
-    const std::string read(sa.r_seq + sa.r_off[q], size_t(sa.r_off[q + 1] - sa.r_off[q]));
-    std::vector<char> comp;
-    for (auto& o : order) {
-        if (o.size < top) break;
+// ---- alignment fallback (getBestClusterAln, cluster.cpp:461-515) --------------------------------------
+// The alignment of (query, candidate, strand) is a pure function of the two sequences, so results are
+// cached and the pairs of many queries are aligned in one GPU batch (ioc_align_pairs).  IOC_ALIGN_HOST=1
+// (or k > 32) routes the same pairs through the host aligner instead.
+struct AlnDriver {
+    ioc_ctx* c = nullptr;
+    const SeqAccess* sa = nullptr;
+    int n = 0;
+    bool host_only = false;
+    std::unordered_map<uint64_t, double> cache;  // (query, tie key) -> getAlnRatio
+
+    static uint64_t key(int q, uint32_t tie) { return (uint64_t(uint32_t(q)) << 32) | tie; }
+
+    int init()
+    {
+        host_only = getenv("IOC_ALIGN_HOST") != nullptr || c->params.k > 32;
+        if (host_only) return IOC_OK;
+        // pool: right entries 0..n-1, then the left representatives
+        const int L = c->L;
+        std::vector<int64_t> off(size_t(n) + size_t(L) + 1, 0);
+        for (int i = 0; i < n; ++i) off[size_t(i) + 1] = off[size_t(i)] + (sa->r_off[i + 1] - sa->r_off[i]);
+        for (int t = 0; t < L; ++t) off[size_t(n + t) + 1] = off[size_t(n + t)] + (sa->l_off[t + 1] - sa->l_off[t]);
+        std::vector<char> pool(size_t(off.back()) + 1);
+        if (n > 0) memcpy(pool.data(), sa->r_seq + sa->r_off[0], size_t(off[size_t(n)]));
+        if (L > 0) memcpy(pool.data() + off[size_t(n)], sa->l_seq + sa->l_off[0], size_t(off.back() - off[size_t(n)]));
+        return ioc_align_set_pool(c, n + L, pool.data(), off.data());
+    }
+
+    double err_of(int32_t target) const { return target < c->L ? sa->l_err[target] : sa->r_err[target - c->L]; }
+
+    int host_pair(int q, uint32_t tie, double& ratio)
+    {
+        const int32_t target = int32_t(tie >> 1);
+        const std::string read(sa->r_seq + sa->r_off[q], size_t(sa->r_off[q + 1] - sa->r_off[q]));
         std::string rep;
-        double e2;
-        if (o.target < c->L) {
-            rep.assign(sa.l_seq + sa.l_off[o.target], size_t(sa.l_off[o.target + 1] - sa.l_off[o.target]));
-            e2 = sa.l_err[o.target];
-        } else {
-            const int t = o.target - c->L;
-            rep.assign(sa.r_seq + sa.r_off[t], size_t(sa.r_off[t + 1] - sa.r_off[t]));
-            e2 = sa.r_err[t];
-        }
-        if (o.strand == -1) revcomp_inplace(rep);
-        const double e = sa.r_err[q] + e2;
-        comp.resize(read.size() + rep.size() + 2);
-        int len = ioc_host_align(read.data(), int32_t(read.size()), rep.data(), int32_t(rep.size()), 2, -2,
-                                 ioc_host_gap_open(e), 1, comp.data(), int32_t(comp.size()), nullptr);
+        if (target < c->L)
+            rep.assign(sa->l_seq + sa->l_off[target], size_t(sa->l_off[target + 1] - sa->l_off[target]));
+        else
+            rep.assign(sa->r_seq + sa->r_off[target - c->L], size_t(sa->r_off[target - c->L + 1] - sa->r_off[target - c->L]));
+        if (tie & 1u) revcomp_inplace(rep);
+        const double e = sa->r_err[q] + err_of(target);
+        std::vector<char> comp(read.size() + rep.size() + 2);
+        const int len = ioc_host_align(read.data(), int32_t(read.size()), rep.data(), int32_t(rep.size()), 2, -2,
+                                       ioc_host_gap_open(e), 1, comp.data(), int32_t(comp.size()), nullptr);
         if (len < 0) return ioc_fail(c, len, "host alignment failed (sequence too long for the traceback matrix)");
-        const double ratio = ioc_host_aln_ratio(comp.data(), len, e, uint32_t(read.size()), uint32_t(c->params.k));
-        if (ratio >= c->params.aligned_threshold) {
-            out_target = o.target;
-            out_strand = o.strand;
+        ratio = ioc_host_aln_ratio(comp.data(), len, e, uint32_t(read.size()), uint32_t(c->params.k));
+        return IOC_OK;
+    }
+
+    // make sure every (query, tie key) of `want` is in the cache
+    int ensure(std::vector<std::pair<int, uint32_t>>& want)
+    {
+        std::sort(want.begin(), want.end());
+        want.erase(std::unique(want.begin(), want.end()), want.end());
+        std::vector<std::pair<int, uint32_t>> todo;
+        for (auto& w : want)
+            if (!cache.count(key(w.first, w.second))) todo.push_back(w);
+        if (todo.empty()) return IOC_OK;
+        if (host_only) {
+            for (auto& w : todo) {
+                double ratio = 0;
+                int r = host_pair(w.first, w.second, ratio);
+                if (r != IOC_OK) return r;
+                cache[key(w.first, w.second)] = ratio;
+            }
             return IOC_OK;
         }
+        std::vector<ioc_aln_pair> pairs(todo.size());
+        for (size_t i = 0; i < todo.size(); ++i) {
+            const int32_t target = int32_t(todo[i].second >> 1);
+            pairs[i].query = todo[i].first;
+            pairs[i].ref = target < c->L ? n + target : target - c->L;
+            pairs[i].ref_revcomp = int32_t(todo[i].second & 1u);
+            pairs[i].reserved = 0;
+            pairs[i].e = sa->r_err[todo[i].first] + err_of(target);
+        }
+        std::vector<double> ratio(todo.size());
+        int r = ioc_align_pairs(c, int32_t(pairs.size()), pairs.data(), c->params.k, 2, -2, 1, nullptr, nullptr, ratio.data());
+        if (r != IOC_OK) return r;
+        for (size_t i = 0; i < todo.size(); ++i) cache[key(todo[i].first, todo[i].second)] = ratio[i];
+        return IOC_OK;
     }
+};
+
+// candidates of query q tied at the top Size among the current clusters (used when the device's 4
+// slots overflowed)
+static int fetch_ties(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::vector<uint32_t>& ties)
+{
+    const int T = c->L + q;
+    std::vector<int32_t> tg(size_t(2) * T + 1);
+    std::vector<int8_t> st(size_t(2) * T + 1);
+    std::vector<uint32_t> sz(size_t(2) * T + 1), fi(size_t(2) * T + 1), tm(size_t(2) * T + 1);
+    const int nc = ioc_query_candidates(c, q, 2 * T, tg.data(), st.data(), sz.data(), fi.data(), tm.data());
+    if (nc < 0) return nc;
+    uint32_t top = 0;
+    ties.clear();
+    for (int i = 0; i < nc; ++i) {
+        const int32_t id = tg[size_t(i)] < c->L ? tg[size_t(i)] : cid[size_t(tg[size_t(i)] - c->L)];
+        if (id < 0) continue;
+        if (sz[size_t(i)] > top) {
+            top = sz[size_t(i)];
+            ties.clear();
+        }
+        if (sz[size_t(i)] == top) ties.push_back((uint32_t(tg[size_t(i)]) << 1) | (st[size_t(i)] < 0 ? 1u : 0u));
+    }
+    std::sort(ties.begin(), ties.end());
     return IOC_OK;
 }
 
@@ -308,44 +376,108 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     int32_t iters = 0, total_iters = 0;
     std::vector<int32_t> tgt(size_t(n) + 1);
     std::vector<int8_t> str(size_t(n) + 1);
-    std::vector<uint8_t> flg(size_t(n) + 1), aligned(size_t(n) + 1, 0);
+    std::vector<uint8_t> flg(size_t(n) + 1);
     std::vector<int32_t> cid(size_t(n) + 1, -1);
     int64_t aln_invoked = 0;
-    int scan_from = 0;
-    for (;;) {
+    int32_t aln_rounds = 0;
+    // Alignment fallback (cluster.cpp:553-566) for the queries whose mapping finds nothing although
+    // top >= MinShared.  The verdict of query i is a function of the candidates tied at its top Size
+    // among the clusters that exist when the loop reaches i (and, if two of them align, of the cluster
+    // numbering).  Verdicts are computed for ALL such queries at once under the current decisions, handed
+    // to the device as conditional decisions, and the resolve is repeated until every verdict was derived
+    // from the very tie set (and order) it is applied to.  The first query whose verdict is stale sees a
+    // final prefix, so its new verdict is final: the loop ends after at most (#flagged + 1) rounds, in
+    // practice a handful.
+    AlnDriver ad;
+    std::vector<int32_t> v_t;
+    std::vector<int8_t> v_s;
+    std::vector<std::vector<uint32_t>> v_ties;
+    std::vector<uint8_t> order_dep;
+    std::vector<uint32_t> tcount, tkeys;
+    if (aln_mode) {
+        ad.c = c;
+        ad.sa = sa;
+        ad.n = n;
+        if ((r = ad.init()) != IOC_OK) return r;
+        v_t.assign(size_t(n) + 1, INT32_MIN);
+        v_s.assign(size_t(n) + 1, 0);
+        v_ties.assign(size_t(n) + 1, std::vector<uint32_t>());
+        order_dep.assign(size_t(n) + 1, 0);
+        tcount.assign(size_t(n) + 1, 0);
+        tkeys.assign(size_t(n) * 4 + 4, 0);
+        if ((r = ioc_set_aln_verdicts(c, v_t.data(), v_s.data())) != IOC_OK) return r;
+    }
+    for (int round = 0;; ++round) {
         if ((r = ioc_resolve(c, &iters)) != IOC_OK) return r;
         total_iters += iters;
         if ((r = ioc_get_decisions(c, tgt.data(), str.data(), flg.data())) != IOC_OK) return r;
         if (!aln_mode) break;
-        // Alignment fallback (cluster.cpp:553-566): queries whose mapping found nothing although
-        // top >= MinShared, in loop order.  Everything before the first such query is final, so its
-        // candidate set is the reference's; a verdict "new cluster" equals the provisional decision and
-        // changes nothing downstream, a verdict "join" changes which entries are clusters: resolve again.
-        bool changed = false;
+        if (round > 2 * n + 8) return ioc_fail(c, IOC_ERR_STATE, "alignment fallback did not converge");
+        if ((r = ioc_get_ties(c, tcount.data(), tkeys.data())) != IOC_OK) return r;
         int32_t next_id = c->L;
-        for (int i = 0; i < scan_from; ++i)
-            if (!gated[size_t(i)] && tgt[size_t(i)] < 0) cid[size_t(i)] = next_id++;
-            else cid[size_t(i)] = -1;
-        int i = scan_from;
-        for (; i < n; ++i) {
-            cid[size_t(i)] = (!gated[size_t(i)] && tgt[size_t(i)] < 0) ? next_id : -1;
-            if (!gated[size_t(i)] && (flg[size_t(i)] & 2) && !aligned[size_t(i)]) {
-                int32_t at = -1;
-                int8_t as = 0;
-                aln_invoked++;
-                if ((r = align_query(c, i, cid, *sa, at, as)) != IOC_OK) return r;
-                aligned[size_t(i)] = 1;
-                if ((r = ioc_force_decision(c, i, at, at < 0 ? 0 : as)) != IOC_OK) return r;
-                if (at >= 0) {
-                    changed = true;
-                    scan_from = i + 1;
-                    break;
-                }
+        for (int i = 0; i < n; ++i) cid[size_t(i)] = (!gated[size_t(i)] && tgt[size_t(i)] < 0) ? next_id++ : -1;
+        // queries that reach the alignment and whose verdict is missing, stale or order-dependent
+        std::vector<int> bad;
+        std::vector<std::vector<uint32_t>> cur;
+        std::vector<std::pair<int, uint32_t>> want;
+        aln_invoked = 0;
+        for (int i = 0; i < n; ++i) {
+            if (gated[size_t(i)] || !(flg[size_t(i)] & 2)) continue;
+            aln_invoked++;
+            std::vector<uint32_t> ties;
+            if (tcount[size_t(i)] <= 4) {
+                ties.assign(tkeys.begin() + size_t(i) * 4, tkeys.begin() + size_t(i) * 4 + tcount[size_t(i)]);
+                std::sort(ties.begin(), ties.end());
+            } else if ((r = fetch_ties(c, i, cid, ties)) != IOC_OK) {
+                return r;
             }
-            if (cid[size_t(i)] >= 0) next_id++;
+            if (v_t[size_t(i)] != INT32_MIN && ties == v_ties[size_t(i)] && !order_dep[size_t(i)]) continue;
+            bad.push_back(i);
+            for (uint32_t t : ties) want.emplace_back(i, t);
+            cur.push_back(std::move(ties));
+            if (ad.host_only && v_t[size_t(i)] == INT32_MIN) break;  // host aligner: no speculation beyond the first
+        }
+        if (bad.empty()) break;
+        aln_rounds++;
+        if ((r = ad.ensure(want)) != IOC_OK) return r;
+        bool changed = false;
+        for (size_t b = 0; b < bad.size(); ++b) {
+            const int i = bad[b];
+            const std::vector<uint32_t>& ties = cur[b];
+            std::vector<uint32_t> pass;
+            for (uint32_t t : ties)
+                if (ad.cache[AlnDriver::key(i, t)] >= c->params.aligned_threshold) pass.push_back(t);
+            int32_t vt = -1;
+            int8_t vs = 0;
+            order_dep[size_t(i)] = pass.size() > 1;
+            if (pass.size() == 1) {
+                vt = int32_t(pass[0] >> 1);
+                vs = (pass[0] & 1u) ? -1 : 1;
+            } else if (pass.size() > 1) {
+                // several candidates align: the first one in the reference's hitOrder wins (cluster.cpp:481-511)
+                std::vector<Ordered> order;
+                if ((r = build_order(c, i, cid, order)) != IOC_OK) return r;
+                const unsigned top = order.empty() ? 0 : order[0].size;
+                for (auto& o : order) {
+                    if (o.size < top) break;
+                    const uint32_t k = (uint32_t(o.target) << 1) | (o.strand < 0 ? 1u : 0u);
+                    if (std::find(pass.begin(), pass.end(), k) != pass.end()) {
+                        vt = o.target;
+                        vs = o.strand;
+                        break;
+                    }
+                }
+                if (vt < 0) return ioc_fail(c, IOC_ERR_STATE, "aligned candidate missing from the candidate order");
+            }
+            if (vt != v_t[size_t(i)] || vs != v_s[size_t(i)] || ties != v_ties[size_t(i)]) changed = true;
+            v_t[size_t(i)] = vt;
+            v_s[size_t(i)] = vs;
+            v_ties[size_t(i)] = ties;
         }
         if (!changed) break;
+        if ((r = ioc_set_aln_verdicts(c, v_t.data(), v_s.data())) != IOC_OK) return r;
     }
+    if (aln_mode && (r = ioc_set_aln_verdicts(c, nullptr, nullptr)) != IOC_OK) return r;
     // final cluster ids in creation order (newId = cls.size(), cluster.cpp:178)
     std::fill(cid.begin(), cid.end(), -1);
     int32_t next = c->L;
@@ -388,6 +520,10 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         stats->n_tie_replays = ties;
         stats->n_aln_invoked = aln_invoked;
         stats->resolve_iters = total_iters;
+        stats->aln_rounds = aln_rounds;
+        stats->n_aln_pairs = int64_t(ad.cache.size());
+        stats->n_aln_order_dep = 0;
+        for (uint8_t x : order_dep) stats->n_aln_order_dep += x;
     }
     return IOC_OK;
 }

@@ -87,6 +87,10 @@ struct ioc_ctx {
     // ---- GPU alignment fallback (ioc_align_gpu.hip) ----
     DevBuf a_pool, a_pairs, a_order, a_out, a_bnd, a_lrow;
     std::vector<int64_t> aln_offs;
+    DevBuf b_aln_t, b_aln_s, b_tie_count, b_tie_keys;
+    std::vector<int32_t> h_aln_t;
+    std::vector<int8_t> h_aln_s;
+    bool aln_verdicts = false, aln_dirty = false;
 
     // ---- instrumentation ----
     hipEvent_t ev[6]{};

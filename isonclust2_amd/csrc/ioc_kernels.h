@@ -52,7 +52,15 @@ struct DecideArgs {
     uint8_t* done;          // per query: decided in phase 1
     unsigned long long* diag;  // diagnostic cycle sums (IOC_EVAL_DIAG), normally nullptr
     int lazy;               // lazy sweep: only the maximal-Size candidates are walked (see ioc_resolve)
+    // alignment fallback (sahlin / furious): verdict of the alignment for a query, used only if its
+    // mapping walk finds nothing although top >= MinShared (INT32_MIN = none yet, -1 = no hit either);
+    // the candidates tied at the top Size (the ones getBestClusterAln tries) are reported per query
+    const int32_t* aln_t;
+    const int8_t* aln_s;
+    uint32_t* tie_count;    // per query: number of top-Size candidates that are clusters
+    uint32_t* tie_keys;     // per query: up to IOC_TIE_SLOTS of their keys (target << 1 | strand bit), any order
 };
+#define IOC_TIE_SLOTS 4
 
 extern "C" {
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,

@@ -1505,6 +1505,11 @@ k_decide_pick(DecideArgs a)
     int8_t out_s = 0;
     uint8_t out_f = 0;
     bool decided = true;
+    __shared__ uint32_t s_tn, s_tk[IOC_TIE_SLOTS];
+    if (a.tie_count) {
+        if (threadIdx.x == 0) s_tn = 0;
+        __syncthreads();
+    }
     if (cut != IOC_CUT_NEG) {
         const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
         const uint32_t C = a.cand_count[j];
@@ -1512,9 +1517,14 @@ k_decide_pick(DecideArgs a)
         const uint32_t top = a.top[j];
         uint32_t bs = 0, be = 0xFFFFFFFFu, bc = 0, miss = 0;
         for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
-            const uint32_t tg = a.cand_key[cbase + c] >> 1;
+            const uint32_t key = a.cand_key[cbase + c];
+            const uint32_t tg = key >> 1;
             const bool ok = (tg < L) || a.valid_in[tg - L];
             const uint32_t sz = a.cand_size[cbase + c];
+            if (a.tie_count && ok && sz == top) {  // what getBestClusterAln would try (cluster.cpp:481-489)
+                const uint32_t pos = atomicAdd(&s_tn, 1u);
+                if (pos < IOC_TIE_SLOTS) s_tk[pos] = key;
+            }
             if (!ok || (a.phase == 1 ? sz != top : int(sz) < cut)) continue;
             const uint32_t tm = a.cand_mapped[cbase + c];
             if (tm == 0xFFFFFFFFu) {
@@ -1575,6 +1585,11 @@ k_decide_pick(DecideArgs a)
                 if (bc > 1) out_f |= 1;
             } else {
                 out_f |= 2;  // no mapping hit although top >= MinShared (cluster.cpp:553-566)
+                if (a.aln_t && a.aln_t[j] != INT32_MIN) {  // the alignment fallback's verdict for this query
+                    out_t = a.aln_t[j];
+                    out_s = out_t < 0 ? int8_t(0) : a.aln_s[j];
+                    if (out_t < 0) out_t = -1;
+                }
                 // phase 1 only looked at the maximal-Size candidates: the walk goes on in phase 2 —
                 // unless this is a lazy sweep, which provisionally lets the query open a cluster (what
                 // almost always happens) and leaves the rest of the walk to the final exact sweeps
@@ -1584,6 +1599,10 @@ k_decide_pick(DecideArgs a)
         }
     }
     if (threadIdx.x == 0) {
+        if (a.tie_count) {
+            a.tie_count[j] = (cut != IOC_CUT_NEG) ? s_tn : 0u;
+            for (int t = 0; t < IOC_TIE_SLOTS; ++t) a.tie_keys[size_t(j) * IOC_TIE_SLOTS + t] = s_tk[t];
+        }
         a.done[j] = decided ? 1 : 0;
         if (decided) {
             const uint8_t nv = (out_t < 0) ? 1 : 0;

@@ -1,8 +1,9 @@
-"""GPU parity of sahlin / furious mode (minimizer mapping on the device + host alignment fallback,
-src/cluster.cpp:545-566) against the oracle.  parasail is absent from the reference tree, so both sides
-use the product's host aligner (the oracle through its aligner hook): what is checked is the control
-flow — which reads reach the fallback, which candidates are aligned in which order, and how the verdicts
-feed back into the greedy loop."""
+"""GPU parity of sahlin / furious mode (minimizer mapping + alignment fallback, src/cluster.cpp:545-566)
+against the oracle.  parasail is absent from the reference tree, so the oracle aligns through its aligner
+hook with the product's host aligner, while the product aligns on the GPU (ioc_align_pairs, bit-identical
+to that host aligner: tests/test_gpu_align.py).  What is checked is the control flow — which reads reach
+the fallback, which candidates are aligned in which order, and how the batched, speculative verdicts feed
+back into the greedy loop."""
 import ctypes as C
 
 import numpy as np
@@ -57,6 +58,30 @@ def test_alignment_fallback_modes(ctx, hooked_oracle, mode, seed):
     assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
     assert st["n_aln_invoked"] == ostat["aln_invoked"] > 0
     assert st["n_clusters"] == B.n_clusters()
+
+
+def test_host_aligner_route(ctx, hooked_oracle, monkeypatch):
+    """IOC_ALIGN_HOST=1: same driver, pairs aligned by the host aligner one verdict at a time."""
+    monkeypatch.setenv("IOC_ALIGN_HOST", "1")
+    rs = synth.generate(120, 15, 400, 9, 20, seed=3)
+    B, view = oracle_sorted_batch(rs)
+    ocl, ost, ostat = oracle_entry_assignments(B, view, mode="sahlin")
+    cls, strand, st = ctx.cluster_batch(api.default_params(11, 15, "sahlin"), _with_sequences(rs, view))
+    assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
+    assert st["n_aln_invoked"] == ostat["aln_invoked"] > 0
+
+
+@pytest.mark.parametrize("mode", ["sahlin", "furious"])
+def test_duplicated_transcripts_order_dependent_verdicts(ctx, hooked_oracle, mode):
+    """Paralog-like duplicates: several candidates tie at the top Size and more than one aligns, so the
+    verdict depends on the reference's candidate order (cluster.cpp:481-511) and on the cluster numbering."""
+    rs = synth.generate(400, 40, 300, 9, 20, seed=7, dup_every=2)
+    B, view = oracle_sorted_batch(rs)
+    ocl, ost, ostat = oracle_entry_assignments(B, view, mode=mode)
+    cls, strand, st = ctx.cluster_batch(api.default_params(11, 15, mode), _with_sequences(rs, view))
+    bad = np.nonzero((cls != ocl) | (strand != ost))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
+    assert st["n_aln_invoked"] == ostat["aln_invoked"] > 0
 
 
 def test_sahlin_needs_sequences(ctx):
