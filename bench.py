@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def prepare_resident_batch(ctx, api, synth, config, seed, k, w):
+def prepare_resident_batch(ctx, api, synth, config, seed, k, w, mode="fast"):
     """raw reads -> GPU quality scores -> stable sort -> GPU HPC/minimizers -> resident queries."""
     rs = synth.generate_config(config, seed=seed)
     score, err = ctx.qual_scores(rs.offs, rs.qual, k)                       # FillQualScores
@@ -37,7 +37,7 @@ def prepare_resident_batch(ctx, api, synth, config, seed, k, w):
     starts = rs.offs[:-1][order]
     idx = np.repeat(starts - so[:-1], lens) + np.arange(so[-1])
     ex = ctx.extract_minimizers(so, rs.seq[idx], rs.qual[idx], k, w)        # PrepareSortedBatch
-    p = api.default_params(k, w, "fast")
+    p = api.default_params(k, w, mode)
     ctx.set_params(p)
     # gates of the clustering loop (src/cluster.cpp:116-160); MinQual default 7.0
     keep = (ex["status"] == 0) & (score[order] >= 0) & (-10 * np.log10(err[order]) > 7.0)
@@ -46,6 +46,8 @@ def prepare_resident_batch(ctx, api, synth, config, seed, k, w):
                      for h, kp in zip(ex["hpc_len"], keep)], np.uint32)
     ctx.queries_from_extracted(keep, cell, need)
     ctx.left_load(0, None, None, None, None)
+    if mode == "sahlin":   # BASELINE.json configs[2]: the alignment fallback needs the raw sequences
+        ctx.resident_set_sequences(rs.seq[idx], so, err[order])
     ex.update(score=score[order], raw_err=err[order])
     ctx._last_extract = ex
     return rs, order, int(ex["off_rev"][-1])
@@ -75,6 +77,44 @@ def resident_to_clustered(ctx, api, pipeline, rs, order, cls, strand, rank):
                                    depth=0, batch_start=base, batch_end=base + rs.n - 1)
 
 
+def cpu_baseline_sahlin_sample(rs, order, cls, strand, k, w, sample):
+    """Sahlin mode on one host core is dominated by 16.7 kb x 16.7 kb alignments (~1 s each): the oracle
+    runs on the first `sample` reads of the sorted batch only (its aligner hook calls the product's host
+    aligner, parasail being absent); the GPU result on the same sub-batch is the parity check."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    from isonclust2_amd import _lib, api
+    from tests.helpers import oracle_sorted_batch
+    sub = rs.subset(order[:sample]) if hasattr(rs, "subset") else None
+    if sub is None:
+        return None
+    B, view = oracle_sorted_batch(sub, k, w)
+    L = _lib.load()
+    CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+    fn = CB(lambda read, nread, rep, nrep, go, ge, out, cap:
+            L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None))
+    po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
+    try:
+        t0 = time.perf_counter()
+        st = B.cluster(mode="sahlin", stats=True)
+        dt = time.perf_counter() - t0
+    finally:
+        po.lib().orc_set_aligner(None)
+    acl, ast = B.assignments(sub.n)
+    ocl, ost = acl[view["orig"]], ast[view["orig"]]
+    # the same sub-batch through the product (own context: the benchmark's resident batch stays untouched)
+    seqs = [sub.read(int(i))[0] for i in view["orig"]]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    v = dict(view)
+    v.update(raw_seq=b"".join(seqs), raw_off=off)
+    c2 = api.Context(0)
+    gcl, gst, _ = c2.cluster_batch(api.default_params(k, w, "sahlin"), v)
+    c2.close()
+    mism = int(np.count_nonzero((ocl != gcl) | (ost != gst)))
+    return dt, st, mism, sub.n
+
+
 def cpu_baseline_and_parity(rs, order, cls, strand, k, w):
     """Oracle (CPU restatement, 1 core) on the SAME batch: timing of the ClusterSortedReads region,
     exact M/H/C_s counts for the roofline, and a full-size parity check of the GPU result."""
@@ -97,6 +137,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="config2")
+    ap.add_argument("--mode", default="fast", choices=["fast", "sahlin"],
+                    help="fast = BASELINE.json configs[1] (default); sahlin = configs[2] (GPU alignment fallback)")
+    ap.add_argument("--cpu-sample", type=int, default=40, help="sahlin: reads in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--merge", action="store_true",
@@ -126,7 +169,7 @@ def main():
     dev = torch.device("cuda", dev_index) if (dist is None or a.backend == "nccl") else torch.device("cpu")
 
     ctx = api.Context(dev_index)
-    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w)
+    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w, a.mode)
 
     def barrier():
         if dist is not None:
@@ -170,7 +213,15 @@ def main():
         H = ctx.count_reference_postings()
         Cs = tm["n_mapped_evals"]
         h_source = "device count (ioc_count_reference_postings)"
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.mode == "sahlin":
+            res = cpu_baseline_sahlin_sample(rs, order, cls, strand, k, w, a.cpu_sample)
+            if res is not None:
+                dt, ost, mism, ns = res
+                cpu = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                       "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 -msse3 with the "
+                                 "product's host aligner behind its aligner hook (parasail absent), 1 run"}
+                parity = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
+        elif world == 1 and not a.no_cpu_baseline:
             dt, ost, mism = cpu_baseline_and_parity(rs, order, cls, strand, k, w)
             cpu = {"value": rs.n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
                    "sample": f"the full {a.config} batch ({rs.n} reads), ClusterSortedReads region, oracle -O3 -msse3, 1 run"}
@@ -196,17 +247,20 @@ def main():
                 except Exception:
                     pass
         out = {
-            "metric": "reads/s clustered (fast mode, k=11 w=15, 3000-read / 50 Mb batch per GPU)",
+            "metric": f"reads/s clustered ({a.mode} mode, k=11 w=15, 3000-read / 50 Mb batch per GPU)",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{a.config}: {rs.tag}; one sorted batch per GPU, minimizer SoA resident in HBM",
-                       "mode": "fast", "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
+                       "mode": a.mode, "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
                        "parallelism": f"batch-shard x{world}, no data-path collective"},
             "phase_ms": {"index_build": ms_build, "score": ms_score, "resolve": ms_resolve,
                          "resolve_sweeps": tm["resolve_iters"]},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
+        if a.mode == "sahlin":
+            out["alignment"] = {"reads_aligned": st["n_aln_invoked"], "pairs": st["n_aln_pairs"],
+                                "rounds": st["aln_rounds"], "order_dependent": st["n_aln_order_dep"]}
         print(json.dumps(out), flush=True)
     if a.merge:
         # config 4: RCCL all-gather of every rank's clustered batch, then the reference's left fold

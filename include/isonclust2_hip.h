@@ -296,8 +296,11 @@ int ioc_cluster_merge(ioc_ctx* ctx, const ioc_params* p, const char* table_path,
                       const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
                       ioc_cluster_stats* stats);
 /* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries
- * must all be clusterable. */
+ * must all be clusterable.  Fast mode, or sahlin mode after ioc_resident_set_sequences. */
 int ioc_cluster_resident(ioc_ctx* ctx, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);
+/* Raw sequences (RawSeq->Str(), concatenated; raw_off[n + 1]) and raw error rates of the resident
+ * queries, for the alignment fallback of sahlin mode (cluster.cpp:491-497). */
+int ioc_resident_set_sequences(ioc_ctx* ctx, const char* raw_seq, const int64_t* raw_off, const double* raw_err);
 
 #ifdef __cplusplus
 }

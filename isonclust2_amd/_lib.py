@@ -76,7 +76,7 @@ SYMBOLS = [
     "ioc_extract_minimizers", "ioc_extracted_download", "ioc_extracted_hpc_download", "ioc_queries_from_extracted",
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
     "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
-    "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties",
+    "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
 ]
 
 _lib = None
@@ -141,6 +141,7 @@ def load():
     L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]
     L.ioc_host_aln_ratio.restype = C.c_double
     L.ioc_cluster_resident.argtypes = [vp, pi32, pi8, C.POINTER(ClusterStats)]
+    L.ioc_resident_set_sequences.argtypes = [vp, C.c_char_p, pi64, pd]
     L.ioc_set_aln_verdicts.argtypes = [vp, pi32, pi8]
     L.ioc_get_ties.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ioc_align_set_pool.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_int64)]

@@ -136,6 +136,13 @@ class Context:
                                           _p(offs, C.c_int64), _p(post, C.c_uint32)))
         return keys[:nk.value], offs, post[:npost.value]
 
+    def resident_set_sequences(self, raw_seq, raw_off, raw_err):
+        """Raw sequences of the resident queries: lets cluster_resident run sahlin mode."""
+        raw_seq = raw_seq if isinstance(raw_seq, bytes) else np.asarray(raw_seq, np.uint8).tobytes()
+        raw_off = np.ascontiguousarray(raw_off, np.int64)
+        raw_err = np.ascontiguousarray(raw_err, np.float64)
+        self._chk(self.L.ioc_resident_set_sequences(self.h, raw_seq, _p(raw_off, C.c_int64), _p(raw_err, C.c_double)))
+
     # ---- alignment fallback on the GPU ---------------------------------------------------------
     def align_set_pool(self, seqs):
         """Upload the raw sequences (list of bytes) the pairs of align_pairs index into."""

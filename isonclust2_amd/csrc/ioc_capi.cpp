@@ -178,6 +178,7 @@ static int queries_common(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const i
     c->h_forced_s.assign(size_t(n), 0);
     c->forced_dirty = true;
     c->aln_verdicts = false;
+    c->have_res_seq = false;
     RESERVE(c, c->b_doff, size_t(n + 1) * 8);
     HIPCHK(c, hipMemcpyAsync(c->b_doff.p, c->h_doff.data(), size_t(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     return IOC_OK;

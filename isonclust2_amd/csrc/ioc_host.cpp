@@ -656,6 +656,20 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
     return run_pipeline(c, gated, need, out_cls, out_strand, stats, &sa);
 }
 
+int ioc_resident_set_sequences(ioc_ctx* c, const char* raw_seq, const int64_t* raw_off, const double* raw_err)
+{
+    if (!c || !raw_seq || !raw_off || !raw_err) return IOC_ERR_ARG;
+    const int n = c->n;
+    if (raw_off[0] != 0) return ioc_fail(c, IOC_ERR_ARG, "raw_off must start at 0");
+    for (int i = 0; i < n; ++i)
+        if (raw_off[i + 1] < raw_off[i]) return ioc_fail(c, IOC_ERR_ARG, "raw_off must be ascending");
+    c->res_seq.assign(raw_seq, size_t(raw_off[n]));
+    c->res_off.assign(raw_off, raw_off + n + 1);
+    c->res_err.assign(raw_err, raw_err + n);
+    c->have_res_seq = true;
+    return IOC_OK;
+}
+
 int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
 {
     if (!c || !out_cls || !out_strand) return IOC_ERR_ARG;
@@ -668,8 +682,17 @@ int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_c
         hipError_t e = hipMemcpy(need.data(), c->d_min_total, size_t(n) * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
     }
-    if (c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS)
-        return ioc_fail(c, IOC_ERR_STATE, "ioc_cluster_resident has no sequences: use ioc_cluster_batch for sahlin/furious");
+    if (c->params.mode == IOC_MODE_FURIOUS || c->params.mode == IOC_MODE_NONE)
+        return ioc_fail(c, IOC_ERR_STATE, "ioc_cluster_resident runs fast and sahlin mode: use ioc_cluster_batch for furious / none");
+    if (c->params.mode == IOC_MODE_SAHLIN) {
+        if (!c->have_res_seq || c->L > 0)
+            return ioc_fail(c, IOC_ERR_STATE, "sahlin on resident queries needs ioc_resident_set_sequences (and no left clusters)");
+        SeqAccess sa;
+        sa.r_seq = c->res_seq.data();
+        sa.r_off = c->res_off.data();
+        sa.r_err = c->res_err.data();
+        return run_pipeline(c, gated, need, out_cls, out_strand, stats, &sa);
+    }
     return run_pipeline(c, gated, need, out_cls, out_strand, stats, nullptr);
 }
 

@@ -91,6 +91,11 @@ struct ioc_ctx {
     std::vector<int32_t> h_aln_t;
     std::vector<int8_t> h_aln_s;
     bool aln_verdicts = false, aln_dirty = false;
+    // raw sequences of the resident queries (ioc_resident_set_sequences): sahlin on ioc_cluster_resident
+    std::string res_seq;
+    std::vector<int64_t> res_off;
+    std::vector<double> res_err;
+    bool have_res_seq = false;
 
     // ---- instrumentation ----
     hipEvent_t ev[6]{};

@@ -28,6 +28,16 @@ class ReadSet:
     def n(self):
         return len(self.offs) - 1
 
+    def subset(self, idx):
+        """The reads idx (in that order) as a new ReadSet."""
+        idx = np.asarray(idx, np.int64)
+        lens = np.diff(self.offs)[idx]
+        offs = np.zeros(len(idx) + 1, np.int64)
+        offs[1:] = np.cumsum(lens)
+        gather = np.repeat(self.offs[:-1][idx] - offs[:-1], lens) + np.arange(offs[-1])
+        return ReadSet(seq=self.seq[gather], qual=self.qual[gather], offs=offs, transcript=self.transcript[idx],
+                       strand=self.strand[idx], tag=f"{self.tag}[{len(idx)} reads]")
+
     def read(self, i):
         a, b = int(self.offs[i]), int(self.offs[i + 1])
         return self.seq[a:b].tobytes(), self.qual[a:b].tobytes()
