@@ -62,18 +62,26 @@ __device__ __forceinline__ uint32_t spaces_c(uint32_t g, uint32_t k, int il)
 }
 
 // append one comparison character (bit = mbit for '|', 0 for ' ') to a path's statistics.
+// hb = 64 - ilimit (ilimit clamped to 0..33): popc(window) + hb has bit 6 set iff popc >= ilimit, so the
+// "window qualifies" test is two plain ALU ops and never touches VCC.
 // GEN: paths shorter than k may exist (top-left k x k corner of the matrix only).
 template <bool GEN>
-__device__ __forceinline__ void append(uint32_t& b, uint32_t& c, uint32_t bit, int il, uint32_t k)
+__device__ __forceinline__ void append(uint32_t& b, uint32_t& c, uint32_t bit, uint32_t hb, uint32_t k)
 {
-    const bool hit = int(__popc(b)) >= il;
+    const uint32_t hit = (uint32_t(__popc(b)) + hb) >> 6;  // 0 or 1
     if (GEN) {
         const bool full = (c >> ALN_LEN_SHIFT) >= k;
-        c += full ? (hit ? 1u : 0u) : (1u << ALN_LEN_SHIFT);
+        c += full ? hit : (1u << ALN_LEN_SHIFT);
     } else {
-        c += hit ? 1u : 0u;
+        c += hit;
     }
     b = (b << 1) | bit;
+}
+
+// value of the left neighbour lane (lane 0 keeps its own): one DPP move instead of an LDS permute
+__device__ __forceinline__ uint32_t from_left(uint32_t v)
+{
+    return uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
 __device__ __forceinline__ uint8_t comp_base(uint8_t ch)
@@ -82,9 +90,8 @@ __device__ __forceinline__ uint8_t comp_base(uint8_t ch)
 }
 
 template <bool GEN>
-__device__ __forceinline__ void row_cells(St (&Hp)[ALN_C], St (&F)[ALN_C], const uint32_t (&rch)[ALN_C], St& hl,
-                                          St& el, St dg, uint32_t qc, int go, int il, const AlnParams& P, int lastc,
-                                          St& bc, uint32_t& bc_i, uint32_t row1)
+__device__ __forceinline__ void row_cells(St (&Hp)[ALN_C], St (&F)[ALN_C], const uint32_t (&rpk)[ALN_C / 4], St& hl,
+                                          St& el, St dg, uint32_t qc, int go, uint32_t hb, const AlnParams& P)
 {
 #pragma unroll
     for (int c = 0; c < ALN_C; ++c) {
@@ -96,7 +103,7 @@ __device__ __forceinline__ void row_cells(St (&Hp)[ALN_C], St (&F)[ALN_C], const
             E.s = ex ? ee : eo;
             E.b = ex ? el.b : hl.b;
             E.c = ex ? el.c : hl.c;
-            append<GEN>(E.b, E.c, 0u, il, P.k);
+            append<GEN>(E.b, E.c, 0u, hb, P.k);
         }
         // F: gap in the reference (vertical move) from the cell above
         St Fn;
@@ -106,15 +113,15 @@ __device__ __forceinline__ void row_cells(St (&Hp)[ALN_C], St (&F)[ALN_C], const
             Fn.s = fx ? fe : fo;
             Fn.b = fx ? F[c].b : Hp[c].b;
             Fn.c = fx ? F[c].c : Hp[c].c;
-            append<GEN>(Fn.b, Fn.c, 0u, il, P.k);
+            append<GEN>(Fn.b, Fn.c, 0u, hb, P.k);
         }
         St h;
         {
-            const bool mt = qc == rch[c];
+            const bool mt = qc == ((rpk[c >> 2] >> (8 * (c & 3))) & 0xFFu);
             h.s = dg.s + (mt ? P.match : P.mismatch);
             h.b = dg.b;
             h.c = dg.c;
-            append<GEN>(h.b, h.c, mt ? P.mbit : 0u, il, P.k);
+            append<GEN>(h.b, h.c, mt ? P.mbit : 0u, hb, P.k);
         }
         if (E.s > h.s) h = E;
         if (Fn.s > h.s) h = Fn;
@@ -123,24 +130,22 @@ __device__ __forceinline__ void row_cells(St (&Hp)[ALN_C], St (&F)[ALN_C], const
         F[c] = Fn;
         hl = h;
         el = E;
-        if (c == lastc && h.s > bc.s) {  // best of the last column, first row wins ties
-            bc = h;
-            bc_i = row1;
-        }
     }
 }
 
-__global__ void __launch_bounds__(64 * ALN_MAXW)
+__global__ void __launch_bounds__(64 * ALN_MAXW, 3)
 k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
         AlnParams P, uint32_t* __restrict__ bnd, uint64_t bnd_stride, uint32_t* __restrict__ lrow,
         uint64_t lrow_stride, int32_t* __restrict__ out_score, uint32_t* __restrict__ out_count)
 {
     __shared__ uint32_t xb[2][ALN_MAXW][8];
+    __shared__ uint32_t s_look[7][64];
     __shared__ uint32_t s_lc[4];
     const uint32_t pid = order[blockIdx.x];
     const AlnPairDev pr = pairs[pid];
     const uint32_t n = pr.n, m = pr.m;
     const int go = pr.gap_open, il = pr.ilimit;
+    const uint32_t hb = uint32_t(64 - (il < 0 ? 0 : il > 33 ? 33 : il));
     const uint8_t* __restrict__ q = pool + pr.q_off;
     const uint8_t* __restrict__ r = pool + pr.r_off;
     const uint32_t NT = blockDim.x;
@@ -157,13 +162,18 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
 
     for (uint32_t p = 0; p < nstrips; ++p) {
         const uint32_t jb = p * strip_cols + g * ALN_C;  // columns to the left of this thread's block
-        uint32_t rch[ALN_C];
+        uint32_t rpk[ALN_C / 4];  // this thread's reference bytes, 4 per register; 0 (never a base) beyond the end
 #pragma unroll
-        for (int c = 0; c < ALN_C; ++c) {
-            const uint32_t j = jb + c;
-            uint32_t ch = 0xFFFFu;  // never equals a query byte
-            if (j < m) ch = pr.rc ? comp_base(r[m - 1 - j]) : r[j];
-            rch[c] = ch;
+        for (int c4 = 0; c4 < ALN_C / 4; ++c4) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t j = jb + c4 * 4 + e;
+                uint32_t ch = 0;
+                if (j < m) ch = pr.rc ? comp_base(r[m - 1 - j]) : r[j];
+                w |= ch << (8 * e);
+            }
+            rpk[c4] = w;
         }
         St Hp[ALN_C], F[ALN_C];
 #pragma unroll
@@ -184,27 +194,27 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
         uint32_t* bout = mybnd + uint64_t(p & 1u) * 6u * n;
         const bool write_edge = (g == NT - 1) && (p + 1 < nstrips);
 
-        // wave 0 looks ahead in blocks of 64 rows: the query bytes and (strips > 0) the left-edge records
-        uint32_t qblk = 0, qnext = 0;
-        uint32_t eb[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
+        // wave 0 looks ahead in blocks of 64 rows — the query bytes and (strips > 0) the left-edge records:
+        // loaded one block early into registers, published to LDS when the block becomes current; lane 0
+        // (the only consumer) picks one row per step
+        uint32_t qn = 0, en[6] = {0, 0, 0, 0, 0, 0};
         St out_h{0, 0u, 0u}, out_e{ALN_NEG, 0u, 0u};
         uint32_t out_q = 0;
         for (uint32_t s = 0; s < nsteps; ++s) {
             if (wave == 0 && (s & 63u) == 0) {
-                // rotate the look-ahead blocks; block s / 64 becomes current (lane 0 of wave 0 is at row s)
                 if (s == 0) {
                     const uint32_t row = lane;
-                    qnext = row < n ? q[row] : 0u;
+                    qn = row < n ? q[row] : 0u;
                     if (p > 0) {
 #pragma unroll
                         for (int w = 0; w < 6; ++w) en[w] = row < n ? bin[uint64_t(w) * n + row] : 0u;
                     }
                 }
-                qblk = qnext;
+                s_look[6][lane] = qn;
 #pragma unroll
-                for (int w = 0; w < 6; ++w) eb[w] = en[w];
+                for (int w = 0; w < 6; ++w) s_look[w][lane] = en[w];
                 const uint32_t row = s + 64u + lane;
-                qnext = row < n ? q[row] : 0u;
+                qn = row < n ? q[row] : 0u;
                 if (p > 0) {
 #pragma unroll
                     for (int w = 0; w < 6; ++w) en[w] = row < n ? bin[uint64_t(w) * n + row] : 0u;
@@ -213,16 +223,14 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
             // inputs of this step: what the left neighbour produced in the previous step
             St hl, el;
             uint32_t qc;
-            hl.s = __shfl_up(out_h.s, 1);
-            hl.b = __shfl_up(out_h.b, 1);
-            hl.c = __shfl_up(out_h.c, 1);
-            el.s = __shfl_up(out_e.s, 1);
-            el.b = __shfl_up(out_e.b, 1);
-            el.c = __shfl_up(out_e.c, 1);
-            qc = __shfl_up(out_q, 1);
-            const uint32_t q0 = __shfl(qblk, int(s & 63u));  // query byte of row s (meaningful in wave 0)
+            hl.s = int(from_left(uint32_t(out_h.s)));
+            hl.b = from_left(out_h.b);
+            hl.c = from_left(out_h.c);
+            el.s = int(from_left(uint32_t(out_e.s)));
+            el.b = from_left(out_e.b);
+            el.c = from_left(out_e.c);
+            qc = from_left(out_q);
             if (lane == 0) {
-                qc = q0;
                 if (wave > 0) {
                     const uint32_t* x = xb[(s + 1) & 1u][wave - 1];
                     hl.s = int(x[0]);
@@ -232,27 +240,24 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
                     el.b = x[4];
                     el.c = x[5];
                     qc = x[6];
-                } else if (p == 0) {
-                    hl.s = 0;  // column 0: free leading gap of s + 1 blank columns
-                    hl.b = 0;
-                    hl.c = spaces_c(s + 1, P.k, il);
-                    el.s = ALN_NEG;
-                    el.b = 0;
-                    el.c = 0;
-                }
-            }
-            if (wave == 0 && p > 0) {
-                // (all lanes take part in the broadcast; only lane 0 uses it)
-                const int sl = int(s & 63u);
-                const uint32_t e0 = __shfl(eb[0], sl), e1 = __shfl(eb[1], sl), e2 = __shfl(eb[2], sl);
-                const uint32_t e3 = __shfl(eb[3], sl), e4 = __shfl(eb[4], sl), e5 = __shfl(eb[5], sl);
-                if (lane == 0) {
-                    hl.s = int(e0);
-                    hl.b = e1;
-                    hl.c = e2;
-                    el.s = int(e3);
-                    el.b = e4;
-                    el.c = e5;
+                } else {
+                    const uint32_t sl = s & 63u;
+                    qc = s_look[6][sl];
+                    if (p == 0) {
+                        hl.s = 0;  // column 0: free leading gap of s + 1 blank columns
+                        hl.b = 0;
+                        hl.c = spaces_c(s + 1, P.k, il);
+                        el.s = ALN_NEG;
+                        el.b = 0;
+                        el.c = 0;
+                    } else {
+                        hl.s = int(s_look[0][sl]);
+                        hl.b = s_look[1][sl];
+                        hl.c = s_look[2][sl];
+                        el.s = int(s_look[3][sl]);
+                        el.b = s_look[4][sl];
+                        el.c = s_look[5][sl];
+                    }
                 }
             }
             const int i = int(s) - int(g);
@@ -260,10 +265,20 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
             if (active) {
                 const St hl_in = hl;
                 if (corner_cols && uint32_t(i) < P.k)
-                    row_cells<true>(Hp, F, rch, hl, el, dg, qc, go, il, P, lastc, bc, bc_i, uint32_t(i) + 1u);
+                    row_cells<true>(Hp, F, rpk, hl, el, dg, qc, go, hb, P);
                 else
-                    row_cells<false>(Hp, F, rch, hl, el, dg, qc, go, il, P, lastc, bc, bc_i, uint32_t(i) + 1u);
+                    row_cells<false>(Hp, F, rpk, hl, el, dg, qc, go, hb, P);
                 dg = hl_in;
+                if (lastc >= 0) {  // one thread of the last strip: best of the last column, first row wins ties
+                    St hm = Hp[0];
+#pragma unroll
+                    for (int c = 1; c < ALN_C; ++c)
+                        if (c == lastc) hm = Hp[c];
+                    if (hm.s > bc.s) {
+                        bc = hm;
+                        bc_i = uint32_t(i) + 1u;
+                    }
+                }
                 if (write_edge) {
                     bout[0ull * n + uint32_t(i)] = uint32_t(hl.s);
                     bout[1ull * n + uint32_t(i)] = hl.b;
@@ -303,7 +318,7 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
                 x[5] = el.c;
                 x[6] = qc;
             }
-            __syncthreads();
+            if (nwaves > 1) __syncthreads();
         }
         if (lastc >= 0) {
             s_lc[0] = uint32_t(bc.s);
@@ -352,7 +367,7 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
             // trailing end gaps: (m - bj) + (n - bi) blanks
             const uint32_t gtrail = (m - bjj) + (n - bi);
             const uint32_t t = gtrail < P.k ? gtrail : P.k;
-            for (uint32_t x = 0; x < t; ++x) append<true>(fin.b, fin.c, 0u, il, P.k);
+            for (uint32_t x = 0; x < t; ++x) append<true>(fin.b, fin.c, 0u, hb, P.k);
             uint32_t cnt = fin.c & ((1u << ALN_LEN_SHIFT) - 1u);
             if (il <= 0) cnt += gtrail - t;
             out_score[pid] = fin.s;
