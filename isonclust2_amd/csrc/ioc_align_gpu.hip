@@ -2,19 +2,23 @@
 // (getBestClusterAln, src/cluster.cpp:461-515: ParasailAlign :408-423 + getAlnRatio :442-459).
 //
 // The reference needs the alignment only for ONE number: how many k-windows of the comparison string
-// hold at least floor((1-e)k) matches (getAlnRatio).  That number is a function of the optimal path, so
-// the traceback matrix is not needed: every DP state (H, E, F of a cell) carries the statistics of ITS
-// best path — the last k comparison characters as a bit window and the count of qualifying windows so
-// far — and the move that wins the max also hands over its statistics.  The recurrence, the strict-`>`
-// tie-breaks and the end-cell choice are those of the host aligner (ioc_align.cpp), whose traceback
-// would walk exactly the moves recorded here, so (score, window count) are bit-identical to it.
-// No traceback storage: 280 M cells of a 16.7 kb x 16.7 kb pair stay in registers.
+// hold at least floor((1-e)k) matches (getAlnRatio).  Two device formulations, both bit-identical to the
+// host aligner (ioc_align.cpp: same recurrence, strict-`>` tie-breaks, end-cell choice):
 //
-// Mapping: one workgroup per pair, NT = 64 * waves threads.  Thread g owns ALN_C consecutive columns of
-// a strip of NT * ALN_C columns and walks down the rows skewed by g (systolic wavefront): at step s it
-// computes row s - g.  Its right-edge (H, E) record and the query base move to thread g + 1 by a wave
-// shuffle (through LDS between waves, one barrier per step); the strip's right edge goes through a
-// global scratch column to the next strip.
+//  * "trace" (default) — what parasail_sg_trace does, without its O(n*m) traceback matrix:
+//      pass 1  k_align_fwd    score-only Gotoh DP (~10 VALU per cell), which also drops CHECKPOINTS: (H, F)
+//                             of every 256th row and (H, E) of every 256th column, and finds the end cell;
+//      pass 2  k_align_trace  walks back from the end cell one 256 x 256 tile at a time: the tile's
+//                             direction nibbles are recomputed in LDS from its top-row / left-column
+//                             checkpoints, the walk feeds the comparison bits (in reverse order) into the
+//                             sliding window counter.  Only ~(n + m) / 256 * 2 tiles are ever recomputed.
+//  * "carry" (IOC_ALIGN_VARIANT=carry) — single pass, every DP state carries the window statistics of its
+//      best path (~39 VALU per cell); kept as an independent cross-check of the trace variant.
+//
+// Mapping of the forward passes: one workgroup per pair, NT = 64 * waves threads.  Thread g owns C
+// consecutive columns of a strip of NT * C columns and walks down the rows skewed by g (systolic wavefront):
+// at step s it computes row s - g.  Its right-edge (H, E) and the query base move to thread g + 1 by one DPP
+// wave shift (through LDS between waves, one barrier per step).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -134,7 +138,7 @@ __device__ __forceinline__ void row_cells(St (&Hp)[ALN_C], St (&F)[ALN_C], const
 }
 
 __global__ void __launch_bounds__(64 * ALN_MAXW, 3)
-k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
+k_align_carry(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
         AlnParams P, uint32_t* __restrict__ bnd, uint64_t bnd_stride, uint32_t* __restrict__ lrow,
         uint64_t lrow_stride, int32_t* __restrict__ out_score, uint32_t* __restrict__ out_count)
 {
@@ -376,6 +380,393 @@ k_align(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order
     }
 }
 
+// ---- "trace" variant ------------------------------------------------------------------------------
+constexpr int FW_C = 16;      // columns per thread in the forward pass
+constexpr int TILE = 256;     // checkpoint pitch = traceback tile edge
+constexpr int TR_C = TILE / 64;  // columns per lane in the traceback tile (one wave per pair)
+
+struct AlnCk {  // where a pair's checkpoints live in the arena, in int2 units
+    uint64_t row_off;  // [(n - 1) / TILE][m]  (H, F) of rows TILE, 2 TILE, ...   (DP row index, 1-based)
+    uint64_t col_off;  // [(m - 1) / TILE][n]  (H, E) of columns TILE, 2 TILE, ...
+};
+
+__device__ __forceinline__ uint32_t ref_byte(const uint8_t* __restrict__ r, uint32_t m, uint32_t rc, uint32_t j)
+{
+    if (j >= m) return 0u;  // never equals a base
+    return rc ? comp_base(r[m - 1 - j]) : r[j];
+}
+
+template <int C>
+__device__ __forceinline__ void fwd_cells(int (&Hp)[C], int (&F)[C], const uint32_t (&rpk)[C / 4], int& hl, int& el,
+                                          int dg, uint32_t qc, int go, const AlnParams& P)
+{
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int E = max(hl - go, el - P.gap_extend);
+        const int Fn = max(Hp[c] - go, F[c] - P.gap_extend);
+        const bool mt = qc == ((rpk[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+        const int h = max(max(dg + (mt ? P.match : P.mismatch), E), Fn);
+        dg = Hp[c];
+        Hp[c] = h;
+        F[c] = Fn;
+        hl = h;
+        el = E;
+    }
+}
+
+// Pass 1: scores only.  Strips are NT * FW_C columns wide, a multiple of TILE, so the right edge of a
+// strip IS a column checkpoint and the next strip reads its left edge from there.
+__global__ void __launch_bounds__(64 * ALN_MAXW)
+k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
+            AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow, uint64_t lrow_stride, int4* __restrict__ ends)
+{
+    __shared__ uint32_t xb[2][ALN_MAXW][4];
+    __shared__ uint32_t s_look[3][64];
+    __shared__ int s_lc[2];
+    const uint32_t pid = order[blockIdx.x];
+    const AlnPairDev pr = pairs[pid];
+    const uint32_t n = pr.n, m = pr.m;
+    const int go = pr.gap_open;
+    const uint8_t* __restrict__ q = pool + pr.q_off;
+    const uint8_t* __restrict__ r = pool + pr.r_off;
+    const uint32_t NT = blockDim.x;
+    const uint32_t g = threadIdx.x, lane = g & 63u, wave = g >> 6, nwaves = NT >> 6;
+    int2* rowck = ck + cko[pid].row_off;
+    int2* colck = ck + cko[pid].col_off;
+    int2* mylrow = lrow + uint64_t(blockIdx.x) * lrow_stride;
+    const uint32_t strip_cols = NT * FW_C;
+    const uint32_t nstrips = (m + strip_cols - 1) / strip_cols;
+    const uint32_t nsteps = n + NT - 1;
+    if (g == 0) {
+        s_lc[0] = ALN_NEG;
+        s_lc[1] = 0;
+    }
+
+    for (uint32_t p = 0; p < nstrips; ++p) {
+        const uint32_t jb = p * strip_cols + g * FW_C;  // columns to the left of this thread's block
+        uint32_t rpk[FW_C / 4];
+#pragma unroll
+        for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w |= ref_byte(r, m, pr.rc, jb + c4 * 4 + e) << (8 * e);
+            rpk[c4] = w;
+        }
+        int Hp[FW_C], F[FW_C];
+#pragma unroll
+        for (int c = 0; c < FW_C; ++c) {
+            Hp[c] = 0;  // row 0: free leading gap
+            F[c] = ALN_NEG;
+        }
+        int dg = 0;  // H(0, jb)
+        const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
+        int bc = ALN_NEG;
+        uint32_t bc_i = 0;
+        // this thread's right edge is a column checkpoint (and, for the last thread, the next strip's input)
+        const uint32_t jr = jb + FW_C;
+        const bool wr_col = (jr % TILE) == 0 && jr < m;
+        int2* colout = wr_col ? colck + uint64_t(jr / TILE - 1) * n : colck;
+        const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * n : colck;
+
+        // wave 0 looks ahead in blocks of 64 rows — the query bytes and (strips > 0) the left-edge records
+        uint32_t qn = 0;
+        int2 en{0, 0};
+        int out_h = 0, out_e = ALN_NEG;
+        uint32_t out_q = 0;
+        for (uint32_t s = 0; s < nsteps; ++s) {
+            if (wave == 0 && (s & 63u) == 0) {
+                if (s == 0) {
+                    const uint32_t row = lane;
+                    qn = row < n ? q[row] : 0u;
+                    if (p > 0 && row < n) en = colin[row];
+                }
+                s_look[2][lane] = qn;
+                s_look[0][lane] = uint32_t(en.x);
+                s_look[1][lane] = uint32_t(en.y);
+                const uint32_t row = s + 64u + lane;
+                qn = row < n ? q[row] : 0u;
+                if (p > 0 && row < n) en = colin[row];
+            }
+            int hl = int(from_left(uint32_t(out_h)));
+            int el = int(from_left(uint32_t(out_e)));
+            uint32_t qc = from_left(out_q);
+            if (lane == 0) {
+                if (wave > 0) {
+                    const uint32_t* x = xb[(s + 1) & 1u][wave - 1];
+                    hl = int(x[0]);
+                    el = int(x[1]);
+                    qc = x[2];
+                } else {
+                    const uint32_t sl = s & 63u;
+                    qc = s_look[2][sl];
+                    if (p == 0) {
+                        hl = 0;  // column 0: free leading gap
+                        el = ALN_NEG;
+                    } else {
+                        hl = int(s_look[0][sl]);
+                        el = int(s_look[1][sl]);
+                    }
+                }
+            }
+            const int i = int(s) - int(g);
+            if (i >= 0 && uint32_t(i) < n) {
+                const int hl_in = hl;
+                fwd_cells<FW_C>(Hp, F, rpk, hl, el, dg, qc, go, P);
+                dg = hl_in;
+                if (lastc >= 0) {  // best of the last column, first row wins ties
+                    int hm = Hp[0];
+#pragma unroll
+                    for (int c = 1; c < FW_C; ++c)
+                        if (c == lastc) hm = Hp[c];
+                    if (hm > bc) {
+                        bc = hm;
+                        bc_i = uint32_t(i) + 1u;
+                    }
+                }
+                if (wr_col) colout[uint32_t(i)] = int2{hl, el};
+                const uint32_t i1 = uint32_t(i) + 1u;  // DP row index
+                if ((i1 % TILE) == 0 && i1 < n) {
+                    int2* ro = rowck + uint64_t(i1 / TILE - 1) * m + jb;
+#pragma unroll
+                    for (int c = 0; c < FW_C; ++c)
+                        if (jb + c < m) ro[c] = int2{Hp[c], F[c]};
+                }
+                if (i1 == n) {  // last row: this thread's best cell, first column wins ties
+                    int br = ALN_NEG;
+                    uint32_t bj = 0;
+#pragma unroll
+                    for (int c = 0; c < FW_C; ++c) {
+                        if (jb + c < m && Hp[c] > br) {
+                            br = Hp[c];
+                            bj = jb + c + 1;
+                        }
+                    }
+                    mylrow[p * NT + g] = int2{br, int(bj)};
+                }
+            }
+            out_h = hl;
+            out_e = el;
+            out_q = qc;
+            if (lane == 63 && wave + 1 < nwaves) {
+                uint32_t* x = xb[s & 1u][wave];
+                x[0] = uint32_t(hl);
+                x[1] = uint32_t(el);
+                x[2] = qc;
+            }
+            if (nwaves > 1) __syncthreads();
+        }
+        if (lastc >= 0) {
+            s_lc[0] = bc;
+            s_lc[1] = int(bc_i);
+        }
+        __syncthreads();  // also orders this strip's column checkpoints before the next strip reads them
+    }
+
+    // end cell: best of the last column (rows ascending), replaced only by a strictly larger cell of the
+    // last row (columns ascending from 0) — the host aligner's scan order (ioc_align.cpp)
+    if (wave == 0) {
+        int br = 0;  // H(n, 0)
+        uint32_t bj = 0;
+        const uint32_t entries = nstrips * NT;
+        for (uint32_t e = lane; e < entries; e += 64) {
+            const int2 x = mylrow[e];
+            if (x.x > br || (x.x == br && uint32_t(x.y) < bj)) {
+                br = x.x;
+                bj = uint32_t(x.y);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int s = __shfl_xor(br, o);
+            const uint32_t j = __shfl_xor(bj, o);
+            if (s > br || (s == br && j < bj)) {
+                br = s;
+                bj = j;
+            }
+        }
+        if (lane == 0) {
+            int fin = s_lc[0];
+            uint32_t bi = uint32_t(s_lc[1]), bjj = m;
+            if (br > fin) {
+                fin = br;
+                bi = n;
+                bjj = bj;
+            }
+            ends[pid] = int4{fin, int(bi), int(bjj), 0};
+        }
+    }
+}
+
+// sliding k-window counter over the comparison string, fed in REVERSE order: getAlnRatio counts the
+// windows [i, i + k) for i = 0 .. len - k - 1, i.e. every window but the last one — in reverse order,
+// every window but the first one to complete.
+struct WinStat {
+    uint32_t wb = 0, pushed = 0, cnt = 0;
+    __device__ __forceinline__ void push(uint32_t bit, uint32_t kmask, uint32_t k, int il)
+    {
+        wb = ((wb << 1) | bit) & kmask;
+        ++pushed;
+        if (pushed > k && int(__popc(wb)) >= il) ++cnt;
+    }
+    __device__ void blanks(uint32_t g, uint32_t kmask, uint32_t k, int il)
+    {
+        const uint32_t t = g < k ? g : k;
+        for (uint32_t x = 0; x < t; ++x) push(0u, kmask, k, il);
+        if (g > t) {  // the window is all blanks from here on
+            const uint32_t rest = g - t;
+            const uint32_t first_counted = pushed >= k ? 0u : k - pushed;  // pushes until pushed > k holds
+            pushed += rest;
+            if (il <= 0 && rest > first_counted) cnt += rest - first_counted;
+        }
+    }
+};
+
+// Pass 2: one wave per pair.  Direction nibble of a cell: bits 0-1 = where H came from (0 diagonal with
+// identical bases, 3 diagonal with different bases, 1 E, 2 F), bit 2 = E extended, bit 3 = F extended.
+__global__ void __launch_bounds__(64)
+k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
+              AlnParams P, const int2* __restrict__ ck, const AlnCk* __restrict__ cko, const int4* __restrict__ ends,
+              int32_t* __restrict__ out_score, uint32_t* __restrict__ out_count)
+{
+    __shared__ uint16_t dirs[TILE][64];
+    __shared__ int2 s_left[TILE];
+    __shared__ uint32_t s_q[TILE];
+    const uint32_t pid = order[blockIdx.x];
+    const AlnPairDev pr = pairs[pid];
+    const uint32_t n = pr.n, m = pr.m;
+    const int go = pr.gap_open, il = pr.ilimit;
+    const uint8_t* __restrict__ q = pool + pr.q_off;
+    const uint8_t* __restrict__ r = pool + pr.r_off;
+    const int2* __restrict__ rowck = ck + cko[pid].row_off;
+    const int2* __restrict__ colck = ck + cko[pid].col_off;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = P.k, kmask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const int4 en = ends[pid];
+    uint32_t i = uint32_t(en.y), j = uint32_t(en.z);
+    int state = 0;  // 0 = H, 1 = E, 2 = F
+    WinStat ws;
+    ws.blanks((m - j) + (n - i), kmask, k, il);  // trailing end gaps are the tail of the string
+
+    while (i > 0 && j > 0) {
+        const uint32_t r0 = ((i - 1) / TILE) * TILE, c0 = ((j - 1) / TILE) * TILE;
+        const uint32_t rows = i - r0, cols = j - c0;
+        for (uint32_t x = lane; x < rows; x += 64) {
+            s_q[x] = q[r0 + x];
+            s_left[x] = c0 ? colck[uint64_t(c0 / TILE - 1) * n + r0 + x] : int2{0, ALN_NEG};
+        }
+        const uint32_t jb = c0 + lane * TR_C;  // columns to the left of this lane's block
+        uint32_t rpk[1];
+        {
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < TR_C; ++e) w |= ref_byte(r, m, pr.rc, jb + e) << (8 * e);
+            rpk[0] = w;
+        }
+        int Hp[TR_C], F[TR_C];
+        int dg = 0;
+        if (r0 == 0) {
+#pragma unroll
+            for (int c = 0; c < TR_C; ++c) {
+                Hp[c] = 0;
+                F[c] = ALN_NEG;
+            }
+        } else {
+            const int2* ro = rowck + uint64_t(r0 / TILE - 1) * m;
+#pragma unroll
+            for (int c = 0; c < TR_C; ++c) {
+                const int2 v = (jb + c < m) ? ro[jb + c] : int2{0, ALN_NEG};
+                Hp[c] = v.x;
+                F[c] = v.y;
+            }
+            if (jb > 0 && jb <= m) dg = ro[jb - 1].x;  // H(r0, jb); column 0 holds 0
+        }
+        __syncthreads();
+        const uint32_t nact = (cols + TR_C - 1) / TR_C;
+        const uint32_t nsteps = rows + nact - 1;
+        int out_h = 0, out_e = ALN_NEG;
+        uint32_t out_q = 0;
+        for (uint32_t s = 0; s < nsteps; ++s) {
+            int hl = int(from_left(uint32_t(out_h)));
+            int el = int(from_left(uint32_t(out_e)));
+            uint32_t qc = from_left(out_q);
+            if (lane == 0 && s < rows) {
+                const int2 le = s_left[s];
+                hl = le.x;
+                el = le.y;
+                qc = s_q[s];
+            }
+            const int ri = int(s) - int(lane);
+            if (ri >= 0 && uint32_t(ri) < rows && lane < nact) {
+                const int hl_in = hl;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int c = 0; c < TR_C; ++c) {
+                    // the host aligner's cell, verbatim (ioc_align.cpp)
+                    const int eo = hl - go, ee = el - P.gap_extend;
+                    const bool ex = ee > eo;
+                    const int E = ex ? ee : eo;
+                    const int fo = Hp[c] - go, fe = F[c] - P.gap_extend;
+                    const bool fx = fe > fo;
+                    const int Fn = fx ? fe : fo;
+                    const bool mt = qc == ((rpk[0] >> (8 * c)) & 0xFFu);
+                    int h = dg + (mt ? P.match : P.mismatch);
+                    uint32_t from = mt ? 0u : 3u;
+                    if (E > h) {
+                        h = E;
+                        from = 1u;
+                    }
+                    if (Fn > h) {
+                        h = Fn;
+                        from = 2u;
+                    }
+                    bits |= (from | (ex ? 4u : 0u) | (fx ? 8u : 0u)) << (4 * c);
+                    dg = Hp[c];
+                    Hp[c] = h;
+                    F[c] = Fn;
+                    hl = h;
+                    el = E;
+                }
+                dg = hl_in;
+                dirs[ri][lane] = uint16_t(bits);
+            }
+            out_h = hl;
+            out_e = el;
+            out_q = qc;
+        }
+        __syncthreads();
+        // the host aligner's traceback loop inside this tile (identical in every lane)
+        while (i > r0 && j > c0) {
+            const uint32_t cj = j - c0 - 1;
+            const uint32_t t = (uint32_t(dirs[i - r0 - 1][cj / TR_C]) >> (4 * (cj % TR_C))) & 0xFu;
+            if (state == 0) {
+                const uint32_t from = t & 3u;
+                if (from == 1u) {
+                    state = 1;
+                } else if (from == 2u) {
+                    state = 2;
+                } else {
+                    ws.push(from == 0u ? 1u : 0u, kmask, k, il);
+                    --i;
+                    --j;
+                }
+            } else if (state == 1) {
+                ws.push(0u, kmask, k, il);
+                if (!(t & 4u)) state = 0;
+                --j;
+            } else {
+                ws.push(0u, kmask, k, il);
+                if (!(t & 8u)) state = 0;
+                --i;
+            }
+        }
+        __syncthreads();
+    }
+    ws.blanks(i + j, kmask, k, il);  // leading end gaps
+    if (lane == 0) {
+        out_score[pid] = en.x;
+        out_count[pid] = ws.cnt;
+    }
+}
+
 struct DevTmp {
     void* p = nullptr;
     ~DevTmp()
@@ -485,6 +876,9 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return uint64_t(dp[x].n) * dp[x].m > uint64_t(dp[y].n) * dp[y].m;
     });
+    const char* ev = getenv("IOC_ALIGN_VARIANT");
+    const bool carry = ev && strcmp(ev, "carry") == 0;
+    const uint32_t colsper = carry ? ALN_C : FW_C;
     // waves per pair: few pairs -> wide workgroups (latency), many pairs -> narrow ones (no fill/drain waste)
     uint32_t waves = ALN_MAXW;
     if (const char* e = getenv("IOC_ALIGN_WAVES")) {
@@ -492,35 +886,84 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         if (v >= 1 && v <= ALN_MAXW) waves = uint32_t(v);
     } else {
         while (waves > 1 && uint64_t(np) * waves > 4096) waves >>= 1;
-        while (waves > 1 && uint64_t(waves / 2) * 64 * ALN_C >= max_m) waves >>= 1;
+        while (waves > 1 && uint64_t(waves / 2) * 64 * colsper >= max_m) waves >>= 1;
     }
     const uint32_t NT = waves * 64;
-    const uint64_t bnd_stride = 2ull * 6ull * max_n;
-    const uint64_t lrow_entries = uint64_t((max_m + NT * ALN_C - 1) / (NT * ALN_C)) * NT;
-    const uint64_t lrow_stride = lrow_entries * 4ull;
-    // scratch is per workgroup; run in slices when the whole batch would not fit the budget
-    uint64_t budget = 8ull << 30;
-    const uint64_t per_pair = (bnd_stride + lrow_stride) * 4ull;
-    uint32_t slice = uint32_t(std::min<uint64_t>(np, std::max<uint64_t>(1, budget / per_pair)));
     int r;
     if ((r = reserve(c, c->a_pairs, size_t(np) * sizeof(AlnPairDev))) != IOC_OK) return r;
     if ((r = reserve(c, c->a_order, size_t(np) * 4)) != IOC_OK) return r;
     if ((r = reserve(c, c->a_out, size_t(np) * 8)) != IOC_OK) return r;
-    if ((r = reserve(c, c->a_bnd, size_t(slice) * bnd_stride * 4)) != IOC_OK) return r;
-    if ((r = reserve(c, c->a_lrow, size_t(slice) * lrow_stride * 4)) != IOC_OK) return r;
     hipStream_t s = c->stream;
     ACHK(c, hipMemcpyAsync(c->a_pairs.p, dp.data(), size_t(np) * sizeof(AlnPairDev), hipMemcpyHostToDevice, s));
     ACHK(c, hipMemcpyAsync(c->a_order.p, order.data(), size_t(np) * 4, hipMemcpyHostToDevice, s));
     AlnParams P{match, mismatch, gap_extend, uint32_t(k), 1u << (32 - k)};
     int32_t* d_score = static_cast<int32_t*>(c->a_out.p);
     uint32_t* d_count = reinterpret_cast<uint32_t*>(d_score + np);
-    for (uint32_t first = 0; first < np; first += slice) {
-        const uint32_t cnt = std::min(slice, np - first);
-        hipLaunchKernelGGL(k_align, dim3(cnt), dim3(NT), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p),
-                           static_cast<const uint32_t*>(c->a_order.p) + first, static_cast<const uint8_t*>(c->a_pool.p), P,
-                           static_cast<uint32_t*>(c->a_bnd.p), bnd_stride, static_cast<uint32_t*>(c->a_lrow.p),
-                           lrow_stride, d_score, d_count);
-        ACHK(c, hipGetLastError());
+    if (carry) {
+        const uint64_t bnd_stride = 2ull * 6ull * max_n;
+        const uint64_t lrow_entries = uint64_t((max_m + NT * ALN_C - 1) / (NT * ALN_C)) * NT;
+        const uint64_t lrow_stride = lrow_entries * 4ull;
+        // scratch is per workgroup; run in slices when the whole batch would not fit the budget
+        const uint64_t budget = 8ull << 30;
+        const uint64_t per_pair = (bnd_stride + lrow_stride) * 4ull;
+        const uint32_t slice = uint32_t(std::min<uint64_t>(np, std::max<uint64_t>(1, budget / per_pair)));
+        if ((r = reserve(c, c->a_bnd, size_t(slice) * bnd_stride * 4)) != IOC_OK) return r;
+        if ((r = reserve(c, c->a_lrow, size_t(slice) * lrow_stride * 4)) != IOC_OK) return r;
+        for (uint32_t first = 0; first < np; first += slice) {
+            const uint32_t cnt = std::min(slice, np - first);
+            hipLaunchKernelGGL(k_align_carry, dim3(cnt), dim3(NT), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p),
+                               static_cast<const uint32_t*>(c->a_order.p) + first, static_cast<const uint8_t*>(c->a_pool.p), P,
+                               static_cast<uint32_t*>(c->a_bnd.p), bnd_stride, static_cast<uint32_t*>(c->a_lrow.p),
+                               lrow_stride, d_score, d_count);
+            ACHK(c, hipGetLastError());
+        }
+    } else {
+        // checkpoint arena: slices of pairs (in `order`) whose checkpoints fit the budget together
+        size_t free_b = 0, total_b = 0;
+        ACHK(c, hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = uint64_t(free_b + c->a_ck.cap) / 2;
+        if (const char* e = getenv("IOC_ALIGN_CK_BUDGET_MB")) budget = uint64_t(atoll(e)) << 20;
+        auto ck_units = [&](const AlnPairDev& d) {
+            return uint64_t((d.n - 1) / TILE) * d.m + uint64_t((d.m - 1) / TILE) * d.n;
+        };
+        const uint64_t lrow_stride = uint64_t((max_m + NT * FW_C - 1) / (NT * FW_C)) * NT;  // int2 per pair
+        std::vector<AlnCk> cko(np);
+        std::vector<std::pair<uint32_t, uint32_t>> slices;  // [first, count) in `order`
+        uint64_t arena = 0;
+        for (uint32_t first = 0; first < np;) {
+            uint64_t used = 0;
+            uint32_t cnt = 0;
+            while (first + cnt < np) {
+                const AlnPairDev& d = dp[order[first + cnt]];
+                const uint64_t u = ck_units(d);
+                if (cnt > 0 && (used + u) * 8ull > budget) break;
+                cko[order[first + cnt]] = AlnCk{used, used + uint64_t((d.n - 1) / TILE) * d.m};
+                used += u;
+                ++cnt;
+            }
+            arena = std::max(arena, used);
+            slices.emplace_back(first, cnt);
+            first += cnt;
+        }
+        uint32_t max_cnt = 0;
+        for (auto& sl : slices) max_cnt = std::max(max_cnt, sl.second);
+        if ((r = reserve(c, c->a_ck, size_t(arena) * 8)) != IOC_OK) return r;
+        if ((r = reserve(c, c->a_cko, size_t(np) * sizeof(AlnCk))) != IOC_OK) return r;
+        if ((r = reserve(c, c->a_ends, size_t(np) * sizeof(int4))) != IOC_OK) return r;
+        if ((r = reserve(c, c->a_lrow, size_t(max_cnt) * lrow_stride * 8)) != IOC_OK) return r;
+        ACHK(c, hipMemcpyAsync(c->a_cko.p, cko.data(), size_t(np) * sizeof(AlnCk), hipMemcpyHostToDevice, s));
+        for (auto& sl : slices) {
+            const uint32_t* ord = static_cast<const uint32_t*>(c->a_order.p) + sl.first;
+            hipLaunchKernelGGL(k_align_fwd, dim3(sl.second), dim3(NT), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
+                               static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
+                               static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
+                               static_cast<int4*>(c->a_ends.p));
+            ACHK(c, hipGetLastError());
+            hipLaunchKernelGGL(k_align_trace, dim3(sl.second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
+                               static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const int2*>(c->a_ck.p),
+                               static_cast<const AlnCk*>(c->a_cko.p), static_cast<const int4*>(c->a_ends.p), d_score, d_count);
+            ACHK(c, hipGetLastError());
+        }
     }
     std::vector<int32_t> hs(np);
     std::vector<uint32_t> hc(np);
