@@ -415,13 +415,19 @@ __device__ __forceinline__ void fwd_cells(int (&Hp)[C], int (&F)[C], const uint3
 }
 
 // Pass 1: scores only.  Strips are NT * FW_C columns wide, a multiple of TILE, so the right edge of a
-// strip IS a column checkpoint and the next strip reads its left edge from there.
+// strip IS a column checkpoint and the next strip reads its left edge from there.  A thread takes FW_R
+// rows per step (a FW_R x FW_C block of cells between two exchanges with its neighbours), so the DPP
+// shifts, the LDS hand-over between waves and the loop control are paid once per 64 cells.
+constexpr int FW_R = 4;
+
 __global__ void __launch_bounds__(64 * ALN_MAXW)
 k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
             AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow, uint64_t lrow_stride, int4* __restrict__ ends)
 {
-    __shared__ uint32_t xb[2][ALN_MAXW][4];
-    __shared__ uint32_t s_look[3][64];
+    // right edge of a wave for the next one, double-buffered, one barrier per step.  (An LDS ring with
+    // step counters instead of the barrier — waves free to drift up to 30 steps apart — measured 40 % SLOWER.)
+    __shared__ __attribute__((aligned(16))) uint32_t xb[2][ALN_MAXW][3][FW_R];
+    __shared__ __attribute__((aligned(16))) uint32_t s_look[3][64];
     __shared__ int s_lc[2];
     const uint32_t pid = order[blockIdx.x];
     const AlnPairDev pr = pairs[pid];
@@ -436,7 +442,8 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     int2* mylrow = lrow + uint64_t(blockIdx.x) * lrow_stride;
     const uint32_t strip_cols = NT * FW_C;
     const uint32_t nstrips = (m + strip_cols - 1) / strip_cols;
-    const uint32_t nsteps = n + NT - 1;
+    const uint32_t nblocks = (n + FW_R - 1) / FW_R;   // row blocks
+    const uint32_t nsteps = nblocks + NT - 1;
     if (g == 0) {
         s_lc[0] = ALN_NEG;
         s_lc[1] = 0;
@@ -459,6 +466,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             F[c] = ALN_NEG;
         }
         int dg = 0;  // H(0, jb)
+        const bool has_cols = jb < m;   // threads right of the matrix only take part in the barriers
         const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
         int bc = ALN_NEG;
         uint32_t bc_i = 0;
@@ -471,10 +479,16 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
         // wave 0 looks ahead in blocks of 64 rows — the query bytes and (strips > 0) the left-edge records
         uint32_t qn = 0;
         int2 en{0, 0};
-        int out_h = 0, out_e = ALN_NEG;
-        uint32_t out_q = 0;
+        int out_h[FW_R], out_e[FW_R];
+        uint32_t out_q[FW_R];
+#pragma unroll
+        for (int rr = 0; rr < FW_R; ++rr) {
+            out_h[rr] = 0;
+            out_e[rr] = ALN_NEG;
+            out_q[rr] = 0;
+        }
         for (uint32_t s = 0; s < nsteps; ++s) {
-            if (wave == 0 && (s & 63u) == 0) {
+            if (wave == 0 && (s & (64 / FW_R - 1)) == 0 && s < nblocks) {
                 if (s == 0) {
                     const uint32_t row = lane;
                     qn = row < n ? q[row] : 0u;
@@ -483,75 +497,108 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 s_look[2][lane] = qn;
                 s_look[0][lane] = uint32_t(en.x);
                 s_look[1][lane] = uint32_t(en.y);
-                const uint32_t row = s + 64u + lane;
+                const uint32_t row = s * FW_R + 64u + lane;
                 qn = row < n ? q[row] : 0u;
                 if (p > 0 && row < n) en = colin[row];
             }
-            int hl = int(from_left(uint32_t(out_h)));
-            int el = int(from_left(uint32_t(out_e)));
-            uint32_t qc = from_left(out_q);
+            int hl[FW_R], el[FW_R];
+            uint32_t qc[FW_R];
+#pragma unroll
+            for (int rr = 0; rr < FW_R; ++rr) {
+                hl[rr] = int(from_left(uint32_t(out_h[rr])));
+                el[rr] = int(from_left(uint32_t(out_e[rr])));
+                qc[rr] = from_left(out_q[rr]);
+            }
             if (lane == 0) {
                 if (wave > 0) {
-                    const uint32_t* x = xb[(s + 1) & 1u][wave - 1];
-                    hl = int(x[0]);
-                    el = int(x[1]);
-                    qc = x[2];
+                    const uint32_t(*x)[FW_R] = xb[(s + 1) & 1u][wave - 1];
+#pragma unroll
+                    for (int rr = 0; rr < FW_R; ++rr) {
+                        hl[rr] = int(x[0][rr]);
+                        el[rr] = int(x[1][rr]);
+                        qc[rr] = x[2][rr];
+                    }
                 } else {
-                    const uint32_t sl = s & 63u;
-                    qc = s_look[2][sl];
-                    if (p == 0) {
-                        hl = 0;  // column 0: free leading gap
-                        el = ALN_NEG;
-                    } else {
-                        hl = int(s_look[0][sl]);
-                        el = int(s_look[1][sl]);
+                    const uint32_t sl = (s * FW_R) & 63u;
+#pragma unroll
+                    for (int rr = 0; rr < FW_R; ++rr) {
+                        qc[rr] = s_look[2][sl + rr];
+                        hl[rr] = p == 0 ? 0 : int(s_look[0][sl + rr]);        // column 0: free leading gap
+                        el[rr] = p == 0 ? ALN_NEG : int(s_look[1][sl + rr]);
                     }
                 }
             }
-            const int i = int(s) - int(g);
-            if (i >= 0 && uint32_t(i) < n) {
-                const int hl_in = hl;
-                fwd_cells<FW_C>(Hp, F, rpk, hl, el, dg, qc, go, P);
-                dg = hl_in;
-                if (lastc >= 0) {  // best of the last column, first row wins ties
-                    int hm = Hp[0];
+            const int bi = int(s) - int(g);  // row block of this thread in this step
+            if (bi >= 0 && uint32_t(bi) < nblocks && has_cols) {
+                const uint32_t i0 = uint32_t(bi) * FW_R;
+                if (uint32_t(bi) + 1u < nblocks && lastc < 0) {
+                    // interior block: no per-row bookkeeping
 #pragma unroll
-                    for (int c = 1; c < FW_C; ++c)
-                        if (c == lastc) hm = Hp[c];
-                    if (hm > bc) {
-                        bc = hm;
-                        bc_i = uint32_t(i) + 1u;
+                    for (int rr = 0; rr < FW_R; ++rr) {
+                        const int hl_in = hl[rr];
+                        fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], go, P);
+                        dg = hl_in;
+                    }
+                    if (wr_col) {
+#pragma unroll
+                        for (int rr = 0; rr < FW_R; ++rr) colout[i0 + rr] = int2{hl[rr], el[rr]};
+                    }
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < FW_R; ++rr) {
+                        const uint32_t i = i0 + rr;  // 0-based row
+                        if (i < n) {
+                            const int hl_in = hl[rr];
+                            fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], go, P);
+                            dg = hl_in;
+                            if (lastc >= 0) {  // best of the last column, first row wins ties
+                                int hm = Hp[0];
+#pragma unroll
+                                for (int c = 1; c < FW_C; ++c)
+                                    if (c == lastc) hm = Hp[c];
+                                if (hm > bc) {
+                                    bc = hm;
+                                    bc_i = i + 1u;
+                                }
+                            }
+                            if (wr_col) colout[i] = int2{hl[rr], el[rr]};
+                            if (i + 1u == n) {  // last row: this thread's best cell, first column wins ties
+                                int br = ALN_NEG;
+                                uint32_t bj = 0;
+#pragma unroll
+                                for (int c = 0; c < FW_C; ++c) {
+                                    if (jb + c < m && Hp[c] > br) {
+                                        br = Hp[c];
+                                        bj = jb + c + 1;
+                                    }
+                                }
+                                mylrow[p * NT + g] = int2{br, int(bj)};
+                            }
+                        }
                     }
                 }
-                if (wr_col) colout[uint32_t(i)] = int2{hl, el};
-                const uint32_t i1 = uint32_t(i) + 1u;  // DP row index
+                const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
                 if ((i1 % TILE) == 0 && i1 < n) {
                     int2* ro = rowck + uint64_t(i1 / TILE - 1) * m + jb;
 #pragma unroll
                     for (int c = 0; c < FW_C; ++c)
                         if (jb + c < m) ro[c] = int2{Hp[c], F[c]};
                 }
-                if (i1 == n) {  // last row: this thread's best cell, first column wins ties
-                    int br = ALN_NEG;
-                    uint32_t bj = 0;
-#pragma unroll
-                    for (int c = 0; c < FW_C; ++c) {
-                        if (jb + c < m && Hp[c] > br) {
-                            br = Hp[c];
-                            bj = jb + c + 1;
-                        }
-                    }
-                    mylrow[p * NT + g] = int2{br, int(bj)};
-                }
             }
-            out_h = hl;
-            out_e = el;
-            out_q = qc;
+#pragma unroll
+            for (int rr = 0; rr < FW_R; ++rr) {
+                out_h[rr] = hl[rr];
+                out_e[rr] = el[rr];
+                out_q[rr] = qc[rr];
+            }
             if (lane == 63 && wave + 1 < nwaves) {
-                uint32_t* x = xb[s & 1u][wave];
-                x[0] = uint32_t(hl);
-                x[1] = uint32_t(el);
-                x[2] = qc;
+                uint32_t(*x)[FW_R] = xb[s & 1u][wave];
+#pragma unroll
+                for (int rr = 0; rr < FW_R; ++rr) {
+                    x[0][rr] = uint32_t(hl[rr]);
+                    x[1][rr] = uint32_t(el[rr]);
+                    x[2][rr] = qc[rr];
+                }
             }
             if (nwaves > 1) __syncthreads();
         }
@@ -567,8 +614,8 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     if (wave == 0) {
         int br = 0;  // H(n, 0)
         uint32_t bj = 0;
-        const uint32_t entries = nstrips * NT;
-        for (uint32_t e = lane; e < entries; e += 64) {
+        for (uint32_t e = lane; e < nstrips * NT; e += 64) {
+            if (uint64_t(e / NT) * strip_cols + uint64_t(e % NT) * FW_C >= m) continue;  // thread right of the matrix
             const int2 x = mylrow[e];
             if (x.x > br || (x.x == br && uint32_t(x.y) < bj)) {
                 br = x.x;
@@ -952,9 +999,20 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         if ((r = reserve(c, c->a_ends, size_t(np) * sizeof(int4))) != IOC_OK) return r;
         if ((r = reserve(c, c->a_lrow, size_t(max_cnt) * lrow_stride * 8)) != IOC_OK) return r;
         ACHK(c, hipMemcpyAsync(c->a_cko.p, cko.data(), size_t(np) * sizeof(AlnCk), hipMemcpyHostToDevice, s));
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+        if (n_cu < 1) n_cu = 256;
         for (auto& sl : slices) {
             const uint32_t* ord = static_cast<const uint32_t*>(c->a_order.p) + sl.first;
-            hipLaunchKernelGGL(k_align_fwd, dim3(sl.second), dim3(NT), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
+            // Every workgroup lives for the whole launch (equal-sized pairs), so the launch ends with the
+            // fullest CU: cap the residency at ceil(workgroups / CUs) per CU with an LDS reservation, or the
+            // dispatcher may stack 8 workgroups on some CUs and leave others with 3.
+            size_t lds_pad = 0;
+            const uint32_t per_cu = (sl.second + uint32_t(n_cu) - 1) / uint32_t(n_cu);
+            if (!getenv("IOC_ALIGN_NO_CAP") && per_cu >= 3 && per_cu * waves < 32)
+                // per-workgroup LDS halfway between 160 KB / (per_cu + 1) and 160 KB / per_cu (2 KB of it static)
+                lds_pad = (size_t(160u * 1024u) * (2 * per_cu + 1) / (2 * per_cu * (per_cu + 1)) - 2048u) & ~size_t(255);
+            hipLaunchKernelGGL(k_align_fwd, dim3(sl.second), dim3(NT), lds_pad, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
                                static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
                                static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
                                static_cast<int4*>(c->a_ends.p));

@@ -11,6 +11,7 @@
 // All arithmetic of the hot path itself (hits, Sizes, mapped totals, candidate walk) runs on the
 // GPU; there is no CPU fallback: without a device every entry point fails.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -70,6 +71,19 @@ bool by_size_desc(const std::unique_ptr<SortedHit>& a, const std::unique_ptr<Sor
 {
     return a->Size > b->Size;
 }
+
+// IOC_TRACE=1: wall-clock of the driver's phases on stderr (developer aid)
+struct PhaseTrace {
+    bool on = getenv("IOC_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ioc] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 struct Cand {
     int32_t cls;  // final cluster id
@@ -364,9 +378,12 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
 {
     const int n = c->n;
     int r;
+    PhaseTrace tr;
     if ((r = ioc_index_build(c)) != IOC_OK) return r;
     if ((r = ioc_score(c)) != IOC_OK) return r;
     if ((r = ioc_clear_forced(c)) != IOC_OK) return r;
+    if (tr.on) (void)ioc_synchronize(c);
+    tr.mark("index build + score");
     // gated entries never become clusters: force them out of the target set
     for (int i = 0; i < n; ++i)
         if (gated[size_t(i)] && (r = ioc_force_decision(c, i, -2, 0)) != IOC_OK) return r;
@@ -399,6 +416,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         ad.sa = sa;
         ad.n = n;
         if ((r = ad.init()) != IOC_OK) return r;
+        tr.mark("sequence pool upload");
         v_t.assign(size_t(n) + 1, INT32_MIN);
         v_s.assign(size_t(n) + 1, 0);
         v_ties.assign(size_t(n) + 1, std::vector<uint32_t>());
@@ -411,6 +429,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         if ((r = ioc_resolve(c, &iters)) != IOC_OK) return r;
         total_iters += iters;
         if ((r = ioc_get_decisions(c, tgt.data(), str.data(), flg.data())) != IOC_OK) return r;
+        tr.mark("resolve + decisions");
         if (!aln_mode) break;
         if (round > 2 * n + 8) return ioc_fail(c, IOC_ERR_STATE, "alignment fallback did not converge");
         if ((r = ioc_get_ties(c, tcount.data(), tkeys.data())) != IOC_OK) return r;
@@ -437,9 +456,11 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
             cur.push_back(std::move(ties));
             if (ad.host_only && v_t[size_t(i)] == INT32_MIN) break;  // host aligner: no speculation beyond the first
         }
+        tr.mark("tie sets");
         if (bad.empty()) break;
         aln_rounds++;
         if ((r = ad.ensure(want)) != IOC_OK) return r;
+        tr.mark("alignment batch");
         bool changed = false;
         for (size_t b = 0; b < bad.size(); ++b) {
             const int i = bad[b];
@@ -474,6 +495,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
             v_s[size_t(i)] = vs;
             v_ties[size_t(i)] = ties;
         }
+        tr.mark("verdicts");
         if (!changed) break;
         if ((r = ioc_set_aln_verdicts(c, v_t.data(), v_s.data())) != IOC_OK) return r;
     }
@@ -513,6 +535,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         out_strand[i] = s;
         joined++;
     }
+    tr.mark("final ids + tie replays");
     if (stats) {
         stats->n_clusters = next;
         stats->n_joined = joined;
