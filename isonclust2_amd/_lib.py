@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libisonclust2_hip.so")
+LIB_PATH = os.environ.get("IOC_LIB", os.path.join(HERE, "libisonclust2_hip.so"))  # IOC_LIB: developer builds
 TABLE_PATH = os.path.join(HERE, "data", "pmin_shared.bin")
 
 

@@ -396,226 +396,293 @@ __device__ __forceinline__ uint32_t ref_byte(const uint8_t* __restrict__ r, uint
     return rc ? comp_base(r[m - 1 - j]) : r[j];
 }
 
+// The forward pass works on SLANTED scores: X*(i, j) = X(i, j) + ge * (i + j) for X in {H, E, F}, and keeps
+// Hq = H* - (go - ge) instead of H*.  Extending a gap then costs nothing (the slant pays the ge), opening
+// one is the "- (go - ge)" already folded into Hq, and a diagonal step adds match + 2 ge or mismatch + 2 ge:
+//     E*(i, j) = max(E*(i, j-1), Hq(i, j-1))          F*(i, j) = max(F*(i-1, j), Hq(i-1, j))
+//     H*(i, j) = max3(Hq(i-1, j-1) + (s + 2 ge + go - ge), E*, F*)
+// 7 VALU per cell instead of 10; true values (checkpoints, end cell) are X* - ge * (i + j).
+struct FwdConst {
+    int gd;      // go - ge
+    int cm, cx;  // match / mismatch + 2 ge + gd
+    int ge;
+};
+
+// An opaque copy of a per-lane value: address / predicate / slant arithmetic derived from it inside a
+// rarely taken block stays inside that block instead of being hoisted out of the step loop into dozens of
+// long-lived registers.
+__device__ __forceinline__ uint32_t opaque(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int C>
-__device__ __forceinline__ void fwd_cells(int (&Hp)[C], int (&F)[C], const uint32_t (&rpk)[C / 4], int& hl, int& el,
-                                          int dg, uint32_t qc, int go, const AlnParams& P)
+__device__ __forceinline__ void fwd_cells(int (&Hq)[C], int (&F)[C], const uint32_t (&rpk)[C / 4], int& hql, int& el,
+                                          int dgq, uint32_t qc, const FwdConst& K)
 {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const int E = max(hl - go, el - P.gap_extend);
-        const int Fn = max(Hp[c] - go, F[c] - P.gap_extend);
+        const int E = max(el, hql);
+        const int Fn = max(F[c], Hq[c]);
         const bool mt = qc == ((rpk[c >> 2] >> (8 * (c & 3))) & 0xFFu);
-        const int h = max(max(dg + (mt ? P.match : P.mismatch), E), Fn);
-        dg = Hp[c];
-        Hp[c] = h;
+        const int hq = max(max(dgq + (mt ? K.cm : K.cx), E), Fn) - K.gd;
+        dgq = Hq[c];
+        Hq[c] = hq;
         F[c] = Fn;
-        hl = h;
+        hql = hq;
         el = E;
     }
 }
 
-// Pass 1: scores only.  Strips are NT * FW_C columns wide, a multiple of TILE, so the right edge of a
-// strip IS a column checkpoint and the next strip reads its left edge from there.  A thread takes FW_R
-// rows per step (a FW_R x FW_C block of cells between two exchanges with its neighbours), so the DPP
-// shifts, the LDS hand-over between waves and the loop control are paid once per 64 cells.
+// Pass 1: scores only.  A strip is 64 * FW_C = 1024 columns (a multiple of TILE, so its right edge IS a
+// column checkpoint and the next strip reads its left edge from there); one WAVE walks a strip top to
+// bottom, FW_R rows per step, its lanes skewed by one step: the right edge (Hq, E*) and the query bases
+// of a lane reach the next lane by one DPP wave shift — no LDS, no barrier inside a strip.
+// The waves of a workgroup split the ROWS into bands of whole tiles and run the (band, strip) grid as a
+// pipeline: wave b does strip p in round p + b, taking its top edge from the row checkpoint band b - 1
+// wrote one round earlier.  One barrier per round (~4000 steps) instead of one per step: waves of one pair
+// share SIMDs with other pairs' waves, and per-step lockstep cost 30 % of the throughput.
 constexpr int FW_R = 4;
+static_assert(FW_C == 16, "the last-column select tree assumes 16 columns per lane");
 
-__global__ void __launch_bounds__(64 * ALN_MAXW)
-k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
-            AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow, uint64_t lrow_stride, int4* __restrict__ ends)
+#ifndef IOC_FWD_WAVES_PER_EU
+#define IOC_FWD_WAVES_PER_EU 3
+#endif
+__global__ void __launch_bounds__(64 * ALN_MAXW) __attribute__((amdgpu_waves_per_eu(IOC_FWD_WAVES_PER_EU, 8)))
+k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, uint32_t count, uint32_t wpp,
+            const uint8_t* __restrict__ pool, AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow,
+            uint64_t lrow_stride, int4* __restrict__ ends)
 {
-    // right edge of a wave for the next one, double-buffered, one barrier per step.  (An LDS ring with
-    // step counters instead of the barrier — waves free to drift up to 30 steps apart — measured 40 % SLOWER.)
-    __shared__ __attribute__((aligned(16))) uint32_t xb[2][ALN_MAXW][3][FW_R];
-    __shared__ __attribute__((aligned(16))) uint32_t s_look[3][64];
-    __shared__ int s_lc[2];
-    const uint32_t pid = order[blockIdx.x];
+    // A workgroup is 4 (or 8) waves = one per SIMD of its CU, however the dispatcher places workgroups; it
+    // carries (waves / wpp) pairs, each split over wpp waves ("bands").  (Workgroups of 2 waves were seen
+    // sharing SIMDs while others idled.)
+    __shared__ __attribute__((aligned(16))) uint32_t s_look_all[ALN_MAXW][3][64];
+    __shared__ int s_best[ALN_MAXW][2];
+    __shared__ uint32_t s_rounds;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));  // uniform: keep the band in SGPRs
+    const uint32_t slot = wv / wpp, wave = wv % wpp, nwaves = wpp;
+    const uint32_t pslot = blockIdx.x * ((blockDim.x >> 6) / wpp) + slot;  // pair of this wave, in `order`
+    const bool live = pslot < count;
+    if (threadIdx.x == 0) s_rounds = 0;
+    __syncthreads();
+    const uint32_t pid = order[live ? pslot : 0];
     const AlnPairDev pr = pairs[pid];
     const uint32_t n = pr.n, m = pr.m;
-    const int go = pr.gap_open;
+    FwdConst K;
+    K.ge = P.gap_extend;
+    K.gd = pr.gap_open - P.gap_extend;
+    K.cm = P.match + 2 * P.gap_extend + K.gd;
+    K.cx = P.mismatch + 2 * P.gap_extend + K.gd;
     const uint8_t* __restrict__ q = pool + pr.q_off;
     const uint8_t* __restrict__ r = pool + pr.r_off;
-    const uint32_t NT = blockDim.x;
-    const uint32_t g = threadIdx.x, lane = g & 63u, wave = g >> 6, nwaves = NT >> 6;
     int2* rowck = ck + cko[pid].row_off;
     int2* colck = ck + cko[pid].col_off;
-    int2* mylrow = lrow + uint64_t(blockIdx.x) * lrow_stride;
-    const uint32_t strip_cols = NT * FW_C;
+    int2* mylrow = lrow + uint64_t(live ? pslot : 0) * lrow_stride;
+    uint32_t(*s_look)[64] = s_look_all[wv];
+    constexpr uint32_t strip_cols = 64u * FW_C;
     const uint32_t nstrips = (m + strip_cols - 1) / strip_cols;
-    const uint32_t nblocks = (n + FW_R - 1) / FW_R;   // row blocks
-    const uint32_t nsteps = nblocks + NT - 1;
-    if (g == 0) {
-        s_lc[0] = ALN_NEG;
-        s_lc[1] = 0;
-    }
+    // this wave's band of rows [r_lo, r_hi), whole tiles
+    const uint32_t ntiles = (n + TILE - 1) / TILE, tpb = (ntiles + nwaves - 1) / nwaves;
+    const uint32_t r_lo = min(n, wave * tpb * TILE), r_hi = min(n, (wave + 1u) * tpb * TILE);
+    const uint32_t nblocks = (r_hi - r_lo + FW_R - 1) / FW_R;  // row blocks of the band
+    const uint32_t nsteps = nblocks + 63u;
+    const bool last_band = r_hi == n && r_lo < n;
+    int bc = ALN_NEG;  // best of the last column inside this band (true score), first row wins ties
+    uint32_t bc_i = 0;
 
-    for (uint32_t p = 0; p < nstrips; ++p) {
-        const uint32_t jb = p * strip_cols + g * FW_C;  // columns to the left of this thread's block
-        uint32_t rpk[FW_C / 4];
+    // the pairs of a workgroup may need different numbers of rounds: everybody stays for the barriers
+    if (live && lane == 0) atomicMax(&s_rounds, nstrips + nwaves - 1u);
+    __syncthreads();
+    const uint32_t rounds = s_rounds;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const int ps = int(round) - int(wave);
+        if (live && ps >= 0 && uint32_t(ps) < nstrips && nblocks > 0) {
+            const uint32_t p = uint32_t(ps);
+            const uint32_t jb = p * strip_cols + lane * FW_C;  // columns to the left of this lane's block
+            uint32_t rpk[FW_C / 4];
 #pragma unroll
-        for (int c4 = 0; c4 < FW_C / 4; ++c4) {
-            uint32_t w = 0;
+            for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+                uint32_t w = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w |= ref_byte(r, m, pr.rc, jb + c4 * 4 + e) << (8 * e);
-            rpk[c4] = w;
-        }
-        int Hp[FW_C], F[FW_C];
-#pragma unroll
-        for (int c = 0; c < FW_C; ++c) {
-            Hp[c] = 0;  // row 0: free leading gap
-            F[c] = ALN_NEG;
-        }
-        int dg = 0;  // H(0, jb)
-        const bool has_cols = jb < m;   // threads right of the matrix only take part in the barriers
-        const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
-        int bc = ALN_NEG;
-        uint32_t bc_i = 0;
-        // this thread's right edge is a column checkpoint (and, for the last thread, the next strip's input)
-        const uint32_t jr = jb + FW_C;
-        const bool wr_col = (jr % TILE) == 0 && jr < m;
-        int2* colout = wr_col ? colck + uint64_t(jr / TILE - 1) * n : colck;
-        const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * n : colck;
-
-        // wave 0 looks ahead in blocks of 64 rows — the query bytes and (strips > 0) the left-edge records
-        uint32_t qn = 0;
-        int2 en{0, 0};
-        int out_h[FW_R], out_e[FW_R];
-        uint32_t out_q[FW_R];
-#pragma unroll
-        for (int rr = 0; rr < FW_R; ++rr) {
-            out_h[rr] = 0;
-            out_e[rr] = ALN_NEG;
-            out_q[rr] = 0;
-        }
-        for (uint32_t s = 0; s < nsteps; ++s) {
-            if (wave == 0 && (s & (64 / FW_R - 1)) == 0 && s < nblocks) {
-                if (s == 0) {
-                    const uint32_t row = lane;
-                    qn = row < n ? q[row] : 0u;
-                    if (p > 0 && row < n) en = colin[row];
-                }
-                s_look[2][lane] = qn;
-                s_look[0][lane] = uint32_t(en.x);
-                s_look[1][lane] = uint32_t(en.y);
-                const uint32_t row = s * FW_R + 64u + lane;
-                qn = row < n ? q[row] : 0u;
-                if (p > 0 && row < n) en = colin[row];
+                for (int e = 0; e < 4; ++e) w |= ref_byte(r, m, pr.rc, jb + c4 * 4 + e) << (8 * e);
+                rpk[c4] = w;
             }
-            int hl[FW_R], el[FW_R];
+            // Hq and F* of the row above the band (slanted, see fwd_cells): row 0 of the matrix (free leading
+            // gap, H = 0) or the row checkpoint the band above wrote in the previous round
+            int Hp[FW_C], F[FW_C];
+            int dg;
+            if (r_lo == 0) {
+                const int base = K.ge * int(jb) - K.gd;  // per-column parts (ge * c) are scalar
+#pragma unroll
+                for (int c = 0; c < FW_C; ++c) {
+                    Hp[c] = base + K.ge * (c + 1);
+                    F[c] = ALN_NEG;
+                }
+                dg = base;
+            } else {
+                const int2* ro = rowck + uint64_t(r_lo / TILE - 1) * m;
+                const int base = K.ge * int(r_lo + jb);
+#pragma unroll
+                for (int c = 0; c < FW_C; ++c) {
+                    const int2 v = (jb + c < m) ? ro[jb + c] : int2{0, 0};
+                    Hp[c] = v.x + (base - K.gd) + K.ge * (c + 1);
+                    F[c] = v.y + base + K.ge * (c + 1);
+                }
+                const int sl = K.ge * int(r_lo + jb);
+                dg = ((jb > 0 && jb <= m) ? ro[jb - 1].x : 0) + sl - K.gd;  // column 0 holds H = 0
+            }
+            const bool has_cols = jb < m;
+            const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
+            // this lane's right edge is a column checkpoint (lane 63: the next strip's input)
+            const uint32_t jr = jb + FW_C;
+            const bool wr_col = (jr % TILE) == 0 && jr < m;
+            int2* colout = wr_col ? colck + uint64_t(jr / TILE - 1) * n : colck;
+            const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * n : colck;
+            // look-ahead in blocks of 64 rows — the query bytes and the strip's left edge (Hq, E*): column 0
+            // of the matrix (H = 0, no gap to extend) or the column checkpoint, slanted
+            const int jcol = int(p * strip_cols);
+            auto left_edge = [&](uint32_t row) {
+                int2 v{K.ge * int(row + 1) - K.gd, ALN_NEG};
+                if (p > 0 && row < r_hi) {
+                    const int2 t = colin[row];
+                    const int sl = K.ge * (int(row + 1) + jcol);
+                    v = int2{t.x + sl - K.gd, t.y + sl};
+                }
+                return v;
+            };
+            uint32_t qn = 0;
+            int2 en{0, 0};
+            int hl[FW_R], el[FW_R];  // inputs of the step from the left; after the step: this lane's right edge
             uint32_t qc[FW_R];
 #pragma unroll
             for (int rr = 0; rr < FW_R; ++rr) {
-                hl[rr] = int(from_left(uint32_t(out_h[rr])));
-                el[rr] = int(from_left(uint32_t(out_e[rr])));
-                qc[rr] = from_left(out_q[rr]);
+                hl[rr] = 0;
+                el[rr] = ALN_NEG;
+                qc[rr] = 0;
             }
-            if (lane == 0) {
-                if (wave > 0) {
-                    const uint32_t(*x)[FW_R] = xb[(s + 1) & 1u][wave - 1];
-#pragma unroll
-                    for (int rr = 0; rr < FW_R; ++rr) {
-                        hl[rr] = int(x[0][rr]);
-                        el[rr] = int(x[1][rr]);
-                        qc[rr] = x[2][rr];
+            for (uint32_t s = 0; s < nsteps; ++s) {
+                if ((s & (64 / FW_R - 1)) == 0 && s < nblocks) {
+                    if (s == 0) {
+                        const uint32_t row = r_lo + lane;
+                        qn = row < r_hi ? q[row] : 0u;
+                        en = left_edge(row);
                     }
-                } else {
+                    s_look[0][lane] = uint32_t(en.x);
+                    s_look[1][lane] = uint32_t(en.y);
+                    s_look[2][lane] = qn;
+                    const uint32_t row = r_lo + s * FW_R + 64u + lane;
+                    qn = row < r_hi ? q[row] : 0u;
+                    en = left_edge(row);
+                }
+#pragma unroll
+                for (int rr = 0; rr < FW_R; ++rr) {
+                    hl[rr] = int(from_left(uint32_t(hl[rr])));
+                    el[rr] = int(from_left(uint32_t(el[rr])));
+                    qc[rr] = from_left(qc[rr]);
+                }
+                if (lane == 0) {
                     const uint32_t sl = (s * FW_R) & 63u;
 #pragma unroll
                     for (int rr = 0; rr < FW_R; ++rr) {
+                        hl[rr] = int(s_look[0][sl + rr]);
+                        el[rr] = int(s_look[1][sl + rr]);
                         qc[rr] = s_look[2][sl + rr];
-                        hl[rr] = p == 0 ? 0 : int(s_look[0][sl + rr]);        // column 0: free leading gap
-                        el[rr] = p == 0 ? ALN_NEG : int(s_look[1][sl + rr]);
                     }
                 }
-            }
-            const int bi = int(s) - int(g);  // row block of this thread in this step
-            if (bi >= 0 && uint32_t(bi) < nblocks && has_cols) {
-                const uint32_t i0 = uint32_t(bi) * FW_R;
-                if (uint32_t(bi) + 1u < nblocks && lastc < 0) {
-                    // interior block: no per-row bookkeeping
+                const int bi = int(s) - int(lane);  // row block of this lane in this step
+                if (bi >= 0 && uint32_t(bi) < nblocks && has_cols) {
+                    const uint32_t i0 = r_lo + uint32_t(bi) * FW_R;
+                    // rows past the end (last block of the last band) run on a query byte of 0 and are never looked at
+                    const bool special = lastc >= 0 || (last_band && uint32_t(bi) + 1u == nblocks);
+                    if (!special) {
 #pragma unroll
-                    for (int rr = 0; rr < FW_R; ++rr) {
-                        const int hl_in = hl[rr];
-                        fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], go, P);
-                        dg = hl_in;
-                    }
-                    if (wr_col) {
-#pragma unroll
-                        for (int rr = 0; rr < FW_R; ++rr) colout[i0 + rr] = int2{hl[rr], el[rr]};
-                    }
-                } else {
-#pragma unroll
-                    for (int rr = 0; rr < FW_R; ++rr) {
-                        const uint32_t i = i0 + rr;  // 0-based row
-                        if (i < n) {
+                        for (int rr = 0; rr < FW_R; ++rr) {
                             const int hl_in = hl[rr];
-                            fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], go, P);
+                            fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
                             dg = hl_in;
-                            if (lastc >= 0) {  // best of the last column, first row wins ties
-                                int hm = Hp[0];
+                        }
+                    } else {
 #pragma unroll
-                                for (int c = 1; c < FW_C; ++c)
-                                    if (c == lastc) hm = Hp[c];
-                                if (hm > bc) {
-                                    bc = hm;
-                                    bc_i = i + 1u;
-                                }
-                            }
-                            if (wr_col) colout[i] = int2{hl[rr], el[rr]};
-                            if (i + 1u == n) {  // last row: this thread's best cell, first column wins ties
-                                int br = ALN_NEG;
-                                uint32_t bj = 0;
-#pragma unroll
-                                for (int c = 0; c < FW_C; ++c) {
-                                    if (jb + c < m && Hp[c] > br) {
-                                        br = Hp[c];
-                                        bj = jb + c + 1;
+                        for (int rr = 0; rr < FW_R; ++rr) {
+                            const int hl_in = hl[rr];
+                            fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                            dg = hl_in;
+                            const uint32_t i = i0 + rr;  // 0-based row
+                            if (i < r_hi) {
+                                if (lastc >= 0) {
+                                    // Hp[lastc] by a select tree over the bits of lastc (4 conditions, not 15)
+                                    const uint32_t lc = opaque(uint32_t(lastc));
+                                    // (written out: an index computed in a loop makes the compiler move Hp to LDS)
+                                    const bool b0 = lc & 1u, b1 = lc & 2u, b2 = lc & 4u, b3 = lc & 8u;
+                                    const int s0 = b0 ? Hp[1] : Hp[0], s1 = b0 ? Hp[3] : Hp[2], s2 = b0 ? Hp[5] : Hp[4],
+                                              s3 = b0 ? Hp[7] : Hp[6], s4 = b0 ? Hp[9] : Hp[8], s5 = b0 ? Hp[11] : Hp[10],
+                                              s6 = b0 ? Hp[13] : Hp[12], s7 = b0 ? Hp[15] : Hp[14];
+                                    const int u0 = b1 ? s1 : s0, u1 = b1 ? s3 : s2, u2 = b1 ? s5 : s4, u3 = b1 ? s7 : s6;
+                                    const int v0 = b2 ? u1 : u0, v1 = b2 ? u3 : u2;
+                                    int hm = b3 ? v1 : v0;
+                                    hm += K.gd - K.ge * int(opaque(i) + 1 + m);  // true H(i + 1, m)
+                                    if (hm > bc) {
+                                        bc = hm;
+                                        bc_i = i + 1u;
                                     }
                                 }
-                                mylrow[p * NT + g] = int2{br, int(bj)};
+                                if (i + 1u == n) {  // last row: this lane's best cell, first column wins ties
+                                    int br = ALN_NEG;
+                                    uint32_t bj = 0;
+                                    const uint32_t jbo = opaque(jb);
+                                    const int base = K.gd - K.ge * int(n + jbo);
+#pragma unroll
+                                    for (int c = 0; c < FW_C; ++c) {
+                                        const int ht = Hp[c] + base - K.ge * (c + 1);  // true H(n, jb + c + 1)
+                                        if (jbo + c < m && ht > br) {
+                                            br = ht;
+                                            bj = jbo + c + 1;
+                                        }
+                                    }
+                                    mylrow[jbo / FW_C] = int2{br, int(bj)};
+                                }
                             }
                         }
                     }
-                }
-                const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
-                if ((i1 % TILE) == 0 && i1 < n) {
-                    int2* ro = rowck + uint64_t(i1 / TILE - 1) * m + jb;
+                    if (wr_col) {
 #pragma unroll
-                    for (int c = 0; c < FW_C; ++c)
-                        if (jb + c < m) ro[c] = int2{Hp[c], F[c]};
-                }
-            }
+                        for (int rr = 0; rr < FW_R; ++rr) {
+                            const int sl = K.ge * int(i0 + rr + 1 + jr);
+                            if (i0 + rr < r_hi) colout[i0 + rr] = int2{hl[rr] + K.gd - sl, el[rr] - sl};
+                        }
+                    }
+                    const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
+                    if ((i1 % TILE) == 0 && i1 < n) {
+                        const uint32_t jbo = opaque(jb);
+                        int2* ro = rowck + uint64_t(i1 / TILE - 1) * m + jbo;
+                        const int base = -K.ge * int(i1 + jbo);
 #pragma unroll
-            for (int rr = 0; rr < FW_R; ++rr) {
-                out_h[rr] = hl[rr];
-                out_e[rr] = el[rr];
-                out_q[rr] = qc[rr];
-            }
-            if (lane == 63 && wave + 1 < nwaves) {
-                uint32_t(*x)[FW_R] = xb[s & 1u][wave];
-#pragma unroll
-                for (int rr = 0; rr < FW_R; ++rr) {
-                    x[0][rr] = uint32_t(hl[rr]);
-                    x[1][rr] = uint32_t(el[rr]);
-                    x[2][rr] = qc[rr];
+                        for (int c = 0; c < FW_C; ++c) {
+                            const int sl = base - K.ge * (c + 1);
+                            if (jbo + c < m) ro[c] = int2{Hp[c] + K.gd + sl, F[c] + sl};
+                        }
+                    }
                 }
             }
-            if (nwaves > 1) __syncthreads();
+            // the lane that owns the last column hands the band's best to lane 0 (a strip of the last round)
+            if (lastc >= 0) {
+                s_best[wv][0] = bc;
+                s_best[wv][1] = int(bc_i);
+            }
         }
-        if (lastc >= 0) {
-            s_lc[0] = bc;
-            s_lc[1] = int(bc_i);
-        }
-        __syncthreads();  // also orders this strip's column checkpoints before the next strip reads them
+        if (rounds > 1 || wpp > 1) __syncthreads();  // orders this round's checkpoints before the next round reads them
     }
+    __syncthreads();
 
     // end cell: best of the last column (rows ascending), replaced only by a strictly larger cell of the
     // last row (columns ascending from 0) — the host aligner's scan order (ioc_align.cpp)
-    if (wave == 0) {
+    if (live && wave == 0) {
         int br = 0;  // H(n, 0)
         uint32_t bj = 0;
-        for (uint32_t e = lane; e < nstrips * NT; e += 64) {
-            if (uint64_t(e / NT) * strip_cols + uint64_t(e % NT) * FW_C >= m) continue;  // thread right of the matrix
+        for (uint32_t e = lane; e < nstrips * 64u; e += 64) {
+            if (uint64_t(e) * FW_C >= m) continue;  // lane right of the matrix
             const int2 x = mylrow[e];
             if (x.x > br || (x.x == br && uint32_t(x.y) < bj)) {
                 br = x.x;
@@ -631,8 +698,15 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             }
         }
         if (lane == 0) {
-            int fin = s_lc[0];
-            uint32_t bi = uint32_t(s_lc[1]), bjj = m;
+            int fin = ALN_NEG;
+            uint32_t bi = 0, bjj = m;
+            for (uint32_t b2 = 0; b2 < nwaves; ++b2) {  // bands top to bottom: the first row wins ties
+                if (min(n, b2 * tpb * TILE) >= n) break;
+                if (s_best[slot * wpp + b2][0] > fin) {
+                    fin = s_best[slot * wpp + b2][0];
+                    bi = uint32_t(s_best[slot * wpp + b2][1]);
+                }
+            }
             if (br > fin) {
                 fin = br;
                 bi = n;
@@ -857,6 +931,7 @@ int ioc_align_set_pool(ioc_ctx* c, int32_t n_seqs, const char* seqs, const int64
 {
     if (!c || n_seqs < 0 || (n_seqs > 0 && (!seqs || !offs))) return IOC_ERR_ARG;
     ACHK(c, hipSetDevice(c->device));
+    c->res_pool_ready = false;
     c->aln_offs.assign(offs, offs + (n_seqs > 0 ? n_seqs + 1 : 0));
     if (n_seqs == 0) return IOC_OK;
     if (offs[0] != 0) return ioc_fail(c, IOC_ERR_ARG, "sequence pool offsets must start at 0");
@@ -933,7 +1008,14 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         if (v >= 1 && v <= ALN_MAXW) waves = uint32_t(v);
     } else {
         while (waves > 1 && uint64_t(np) * waves > 4096) waves >>= 1;
-        while (waves > 1 && uint64_t(waves / 2) * 64 * colsper >= max_m) waves >>= 1;
+        if (carry) {
+            while (waves > 1 && uint64_t(waves / 2) * 64 * colsper >= max_m) waves >>= 1;
+        } else {
+            // row bands x column strips run as a pipeline: it needs a few strips per band to fill, and
+            // whole tiles per band
+            const uint32_t strips = (max_m + 64 * FW_C - 1) / (64 * FW_C), tiles = (max_n + TILE - 1) / TILE;
+            while (waves > 1 && (strips < 2 * waves || tiles < 2 * waves)) waves >>= 1;
+        }
     }
     const uint32_t NT = waves * 64;
     int r;
@@ -973,7 +1055,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         auto ck_units = [&](const AlnPairDev& d) {
             return uint64_t((d.n - 1) / TILE) * d.m + uint64_t((d.m - 1) / TILE) * d.n;
         };
-        const uint64_t lrow_stride = uint64_t((max_m + NT * FW_C - 1) / (NT * FW_C)) * NT;  // int2 per pair
+        const uint64_t lrow_stride = uint64_t((max_m + 64 * FW_C - 1) / (64 * FW_C)) * 64;  // int2 per pair
         std::vector<AlnCk> cko(np);
         std::vector<std::pair<uint32_t, uint32_t>> slices;  // [first, count) in `order`
         uint64_t arena = 0;
@@ -1008,11 +1090,27 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             // fullest CU: cap the residency at ceil(workgroups / CUs) per CU with an LDS reservation, or the
             // dispatcher may stack 8 workgroups on some CUs and leave others with 3.
             size_t lds_pad = 0;
-            const uint32_t per_cu = (sl.second + uint32_t(n_cu) - 1) / uint32_t(n_cu);
-            if (!getenv("IOC_ALIGN_NO_CAP") && per_cu >= 3 && per_cu * waves < 32)
-                // per-workgroup LDS halfway between 160 KB / (per_cu + 1) and 160 KB / per_cu (2 KB of it static)
-                lds_pad = (size_t(160u * 1024u) * (2 * per_cu + 1) / (2 * per_cu * (per_cu + 1)) - 2048u) & ~size_t(255);
-            hipLaunchKernelGGL(k_align_fwd, dim3(sl.second), dim3(NT), lds_pad, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
+            const uint32_t wg_waves = waves > 4 ? waves : 4, ppw = wg_waves / waves;
+            const uint32_t n_wg = (sl.second + ppw - 1) / ppw;
+            const uint32_t per_cu = (n_wg + uint32_t(n_cu) - 1) / uint32_t(n_cu);
+            if (!getenv("IOC_ALIGN_NO_CAP") && per_cu * wg_waves < 32) {
+                // per-workgroup LDS halfway between 160 KB / (per_cu + 1) and 160 KB / per_cu (8 KB of it static)
+                lds_pad = (size_t(160u * 1024u) * (2 * per_cu + 1) / (2 * per_cu * (per_cu + 1)) - 8192u) & ~size_t(255);
+                // more than the default 64 KB per workgroup needs the kernel attribute (best effort)
+                if (c->aln_lds_max == 0) {
+                    int mx = 0;
+                    (void)hipDeviceGetAttribute(&mx, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
+                    c->aln_lds_max = 48 * 1024;
+                    if (mx > 72 * 1024 &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_align_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            mx - 8 * 1024) == hipSuccess)
+                        c->aln_lds_max = size_t(mx) - 8 * 1024;
+                    (void)hipGetLastError();
+                }
+                lds_pad = std::min(lds_pad, c->aln_lds_max);
+            }
+            hipLaunchKernelGGL(k_align_fwd, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
+                               static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves,
                                static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
                                static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
                                static_cast<int4*>(c->a_ends.p));

@@ -281,6 +281,8 @@ struct AlnDriver {
     {
         host_only = getenv("IOC_ALIGN_HOST") != nullptr || c->params.k > 32;
         if (host_only) return IOC_OK;
+        // resident queries: the pool was uploaded once by ioc_resident_set_sequences
+        if (c->res_pool_ready && c->L == 0 && sa->r_seq == c->res_seq.data()) return IOC_OK;
         // pool: right entries 0..n-1, then the left representatives
         const int L = c->L;
         std::vector<int64_t> off(size_t(n) + size_t(L) + 1, 0);
@@ -690,6 +692,10 @@ int ioc_resident_set_sequences(ioc_ctx* c, const char* raw_seq, const int64_t* r
     c->res_off.assign(raw_off, raw_off + n + 1);
     c->res_err.assign(raw_err, raw_err + n);
     c->have_res_seq = true;
+    // the alignment fallback's sequence pool stays in HBM with the queries (ioc_align_set_pool clears the flag)
+    int r = ioc_align_set_pool(c, n, c->res_seq.data(), c->res_off.data());
+    if (r != IOC_OK) return r;
+    c->res_pool_ready = getenv("IOC_ALIGN_HOST") == nullptr;
     return IOC_OK;
 }
 

@@ -96,6 +96,8 @@ struct ioc_ctx {
     std::vector<int64_t> res_off;
     std::vector<double> res_err;
     bool have_res_seq = false;
+    bool res_pool_ready = false;  // a_pool holds exactly res_seq
+    size_t aln_lds_max = 0;  // dynamic LDS a k_align_fwd workgroup may reserve (residency cap)
 
     // ---- instrumentation ----
     hipEvent_t ev[6]{};
