@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py — reads/s clustered on the BASELINE.json config-2 workload (3000 reads / 50 Mb, k=11 w=15,
-fast mode) on N MI355X GPUs of one node.
+"""bench.py — reads/s clustered on BASELINE.json's 3000-read / 50 Mb batch (k=11 w=15) on N MI355X GPUs.
 
-One "step" = one pass of the hot path over one sorted batch whose minimizer SoA is already resident
-in HBM: index build + shared-minimizer scoring + mapped-ratio resolve + decisions back on the host
-(ioc_cluster_resident).  Batches shard one per GPU with no data-path collective (weak scaling); ranks
-only meet at the timing barrier.  Inputs are synthetic (isonclust2_amd/synth.py, seed = 1 + rank) and
-are prepared by the product's own GPU sort stage (ioc_qual_scores / ioc_extract_minimizers), never by
-the oracle.  The oracle appears only in the cpu_baseline leg (rank 0, N=1): it is timed on the same
-batch on one host core and doubles as a full-size parity check.
+Headline (`value`) = sahlin mode, the mode BASELINE.json's metric names (configs[2]): index build +
+shared-minimizer scoring + mapped-ratio resolve + the alignment fallback (GPU, batched) + decisions back on
+the host.  The fast-mode result of the SAME resident batch (configs[1]: no alignment) rides along in
+`fast_mode`, with the HBM roofline of the scoring kernels in `roofline`; `roofline_align` is the integer-VALU
+issue roofline of the forward DP kernel that dominates a sahlin step.
+
+One "step" = one pass of the hot path (ioc_cluster_resident) over one sorted batch whose minimizer SoA and raw
+sequences are already resident in HBM.  Batches shard one per GPU with no data-path collective (weak
+scaling); ranks only meet at the timing barrier.  Inputs are synthetic (isonclust2_amd/synth.py, seed = 1 +
+rank) and are prepared by the product's own GPU sort stage (ioc_qual_scores / ioc_extract_minimizers), never
+by the oracle.  The oracle appears only in the cpu_baseline legs (rank 0, N=1): timed on one host core — the
+full batch in fast mode (doubling as a full-size parity check), a bounded sample in sahlin mode.
 
 Prints ONE JSON line on rank 0.
 """
@@ -131,15 +135,51 @@ def cpu_baseline_and_parity(rs, order, cls, strand, k, w):
     return dt, st, mism
 
 
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3 T int32 lane-ops/s: 1024 SIMDs x 16 lanes x 2.4 GHz (one
+                                               # wave64 int32 VALU instruction = 4 cycles of its SIMD)
+ALIGN_VALU_PER_CELL = 7                        # fwd_cells: cmp, cndmask, add, max, max3, sub, max (ioc_align_gpu.hip)
+
+
+def timed_steps(ctx, torch, dist, dev, steps, warmup):
+    """W untimed + K timed passes of the hot path over the resident batch; returns the last result, the
+    wall time (max over ranks) and the per-phase HIP-event averages."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(warmup):
+        cls, strand, st = ctx.cluster_resident()
+    barrier()
+    acc = dict(ms_score=0.0, ms_build=0.0, ms_resolve=0.0, ms_align_fwd=0.0, ms_align_trace=0.0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cls, strand, st = ctx.cluster_resident()
+        tm = ctx.timings()          # HIP events recorded on the launch stream around each phase
+        for k in acc:
+            acc[k] += tm[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for k in acc:
+        acc[k] /= steps
+    return cls, strand, st, tm, elapsed, acc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config2")
-    ap.add_argument("--mode", default="fast", choices=["fast", "sahlin"],
-                    help="fast = BASELINE.json configs[1] (default); sahlin = configs[2] (GPU alignment fallback)")
-    ap.add_argument("--cpu-sample", type=int, default=40, help="sahlin: reads in the CPU-baseline sample")
+    ap.add_argument("--mode", default="both", choices=["both", "fast", "sahlin"],
+                    help="both (default): headline = sahlin mode (BASELINE.json's metric, configs[2]) with the fast-mode "
+                         "result (configs[1]) of the same batch beside it; fast / sahlin = that mode only")
+    ap.add_argument("--cpu-sample", type=int, default=30, help="sahlin: reads in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--merge", action="store_true",
@@ -169,104 +209,127 @@ def main():
     dev = torch.device("cuda", dev_index) if (dist is None or a.backend == "nccl") else torch.device("cpu")
 
     ctx = api.Context(dev_index)
-    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w, a.mode)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ctx.synchronize()
-
-    for _ in range(a.warmup):
-        cls, strand, st = ctx.cluster_resident()
-    barrier()
-    ms_score = ms_build = ms_resolve = 0.0
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        cls, strand, st = ctx.cluster_resident()
-        tm = ctx.timings()          # HIP events recorded on the launch stream around each phase
-        ms_score += tm["ms_score"]
-        ms_build += tm["ms_build"]
-        ms_resolve += tm["ms_resolve"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    want_fast = a.mode in ("both", "fast")
+    want_sahlin = a.mode in ("both", "sahlin")
+    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w,
+                                              "sahlin" if want_sahlin else "fast")
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         nreads = torch.tensor([rs.n], dtype=torch.int64, device=dev)
         dist.all_reduce(nreads, op=dist.ReduceOp.SUM)
         total_reads = int(nreads.item())
     else:
         total_reads = rs.n
-    ms_score /= a.steps
-    ms_build /= a.steps
-    ms_resolve /= a.steps
+    single = world == 1 and not a.no_cpu_baseline
+
+    fast = None
+    if want_fast:
+        ctx.set_params(api.default_params(k, w, "fast"))
+        cls, strand, st, tm, elapsed, acc = timed_steps(ctx, torch, dist, dev, a.steps, a.warmup)
+        fast = {"value": total_reads * a.steps / elapsed, "unit": "reads/s", "ms_per_step": elapsed / a.steps * 1e3,
+                "phase_ms": {"index_build": acc["ms_build"], "score": acc["ms_score"], "resolve": acc["ms_resolve"],
+                             "resolve_sweeps": tm["resolve_iters"]},
+                "clusters": st["n_clusters"]}
+        fast_res = (cls, strand, st, tm, acc)
+    sah = None
+    if want_sahlin:
+        ctx.set_params(api.default_params(k, w, "sahlin"))
+        cls, strand, st, tm, elapsed, acc = timed_steps(ctx, torch, dist, dev, a.steps, a.warmup)
+        sah = {"value": total_reads * a.steps / elapsed, "unit": "reads/s", "ms_per_step": elapsed / a.steps * 1e3,
+               "phase_ms": {"index_build": acc["ms_build"], "score": acc["ms_score"], "resolve_last": acc["ms_resolve"],
+                            "align_fwd": acc["ms_align_fwd"], "align_trace": acc["ms_align_trace"]},
+               "clusters": st["n_clusters"],
+               "alignment": {"reads_aligned": st["n_aln_invoked"], "pairs": st["n_aln_pairs"],
+                             "rounds": st["aln_rounds"], "order_dependent": st["n_aln_order_dep"],
+                             "cells": tm["n_align_cells"]}}
+        sah_res = (cls, strand, st, tm, acc)
 
     if rank == 0:
-        value = total_reads * a.steps / elapsed
-        cpu = None
-        parity = None
-        M = tm["n_minimizers"]
-        # H = postings the reference's GetMinimizerHits traverses on this batch, counted on the device
-        # from the final clustering (instrumentation launch, untimed); C_s = survivor candidates
-        H = ctx.count_reference_postings()
-        Cs = tm["n_mapped_evals"]
-        h_source = "device count (ioc_count_reference_postings)"
-        if world == 1 and not a.no_cpu_baseline and a.mode == "sahlin":
-            res = cpu_baseline_sahlin_sample(rs, order, cls, strand, k, w, a.cpu_sample)
-            if res is not None:
-                dt, ost, mism, ns = res
-                cpu = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-                       "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 -msse3 with the "
-                                 "product's host aligner behind its aligner hook (parasail absent), 1 run"}
-                parity = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
-        elif world == 1 and not a.no_cpu_baseline:
-            dt, ost, mism = cpu_baseline_and_parity(rs, order, cls, strand, k, w)
-            cpu = {"value": rs.n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-                   "sample": f"the full {a.config} batch ({rs.n} reads), ClusterSortedReads region, oracle -O3 -msse3, 1 run"}
-            parity = {"entries": rs.n, "mismatches": mism, "clusters": st["n_clusters"],
-                      "tie_replays": st["n_tie_replays"], "oracle_postings": ost["postings"],
-                      "device_postings": H}
-            Cs = ost["mapped_calls"]
-            h_source += "; equals the oracle's count" if H == ost["postings"] else "; DIFFERS from the oracle's count"
-        # algorithmic bytes of one scoring launch: 12 B per minimizer probed +
-        # 8 B index row per probe + 4 B per posting traversed + 16 B per surviving candidate
-        alg_bytes = None
+        out_extra = {}
+        # ---- fast mode (configs[1]): HBM roofline of the scoring kernels + full-batch CPU baseline / parity ----
         roof = None
-        if H:
-            alg_bytes = 12 * M + 8 * M + 4 * H + 16 * Cs
-            ach = alg_bytes / (ms_score * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_score", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
-                    "kernel_ms": ms_score, "counts": {"M": M, "H": H, "C_s": Cs, "H_source": h_source}}
-            tfile = os.path.join(ROOT, "profiles", "k_score_traffic.json")
-            if os.path.exists(tfile):
-                try:
-                    roof["traffic"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
+        if fast is not None:
+            ctx.set_params(api.default_params(k, w, "fast"))
+            fcls, fstrand, fst = ctx.cluster_resident()     # untimed: leaves the fast-mode clustering on the device
+            M = fast_res[3]["n_minimizers"]
+            # H = postings the reference's GetMinimizerHits traverses on this batch, counted on the device
+            # from the final clustering (instrumentation launch, untimed); C_s = survivor candidates
+            H = ctx.count_reference_postings()
+            Cs = fast_res[3]["n_mapped_evals"]
+            h_source = "device count (ioc_count_reference_postings)"
+            if single:
+                dt, ost, mism = cpu_baseline_and_parity(rs, order, fcls, fstrand, k, w)
+                fast["cpu_baseline"] = {"value": rs.n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                                        "sample": f"the full {a.config} batch ({rs.n} reads), fast mode, ClusterSortedReads "
+                                                  "region, oracle -O3 -msse3, 1 run"}
+                fast["parity"] = {"entries": rs.n, "mismatches": mism, "clusters": fst["n_clusters"],
+                                  "tie_replays": fst["n_tie_replays"], "oracle_postings": ost["postings"],
+                                  "device_postings": H}
+                Cs = ost["mapped_calls"]
+                h_source += "; equals the oracle's count" if H == ost["postings"] else "; DIFFERS from the oracle's count"
+            # algorithmic bytes of one scoring launch: 12 B per minimizer probed +
+            # 8 B index row per probe + 4 B per posting traversed + 16 B per surviving candidate
+            if H:
+                ms_score = fast_res[4]["ms_score"]
+                alg_bytes = 12 * M + 8 * M + 4 * H + 16 * Cs
+                ach = alg_bytes / (ms_score * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": "k_score (k_partition_mins + k_score_part + k_score_compact)",
+                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
+                        "kernel_ms": ms_score, "counts": {"M": M, "H": H, "C_s": Cs, "H_source": h_source}}
+                tfile = os.path.join(ROOT, "profiles", "k_score_traffic.json")
+                if os.path.exists(tfile):
+                    try:
+                        roof["traffic"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                    except Exception:
+                        pass
+        # ---- sahlin mode (configs[2]): the step is dominated by the alignment fallback's forward DP, an
+        # integer-VALU kernel (no HBM traffic to speak of, no MFMA): its issue-rate roofline beside the HBM one ----
+        roof_aln = None
+        if sah is not None:
+            cells = sah_res[3]["n_align_cells"]
+            ms_fwd = sah_res[4]["ms_align_fwd"]
+            if cells and ms_fwd > 0:
+                ach = cells * ALIGN_VALU_PER_CELL / (ms_fwd * 1e-3) / 1e12
+                roof_aln = {"bound": "valu-int32", "kernel": "k_align_fwd", "achieved": ach, "peak": VALU_PEAK_TOPS,
+                            "unit": "T lane-op/s", "frac": ach / VALU_PEAK_TOPS, "kernel_ms": ms_fwd,
+                            "cells": cells, "valu_per_cell": ALIGN_VALU_PER_CELL,
+                            "gcells_per_s": cells / (ms_fwd * 1e-3) / 1e9}
+            if single:
+                res = cpu_baseline_sahlin_sample(rs, order, sah_res[0], sah_res[1], k, w, a.cpu_sample)
+                if res is not None:
+                    dt, ost, mism, ns = res
+                    sah["cpu_baseline"] = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                                           "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 "
+                                                     "-msse3 with the product's host aligner behind its aligner hook "
+                                                     "(parasail absent), 1 run"}
+                    sah["parity"] = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
+        head, head_mode = (sah, "sahlin") if sah is not None else (fast, "fast")
         out = {
-            "metric": f"reads/s clustered ({a.mode} mode, k=11 w=15, 3000-read / 50 Mb batch per GPU)",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": f"reads/s clustered ({head_mode} mode, k=11 w=15)",
+            "value": head["value"], "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{a.config}: {rs.tag}; one sorted batch per GPU, minimizer SoA resident in HBM",
-                       "mode": a.mode, "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
+            "config": {"workload": f"{a.config} = BASELINE.json configs[{2 if head_mode == 'sahlin' else 1}]: {rs.tag}; one sorted "
+                                   "3000-read / 50 Mb batch per GPU, minimizer SoA and sequences resident in HBM",
+                       "mode": head_mode, "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
                        "parallelism": f"batch-shard x{world}, no data-path collective"},
-            "phase_ms": {"index_build": ms_build, "score": ms_score, "resolve": ms_resolve,
-                         "resolve_sweeps": tm["resolve_iters"]},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "phase_ms": head["phase_ms"],
+            "roofline": roof if roof is not None else roof_aln,
+            "cpu_baseline": head.get("cpu_baseline"), "parity": head.get("parity"),
         }
-        if a.mode == "sahlin":
-            out["alignment"] = {"reads_aligned": st["n_aln_invoked"], "pairs": st["n_aln_pairs"],
-                                "rounds": st["aln_rounds"], "order_dependent": st["n_aln_order_dep"]}
+        if head_mode == "sahlin":
+            out["alignment"] = sah["alignment"]
+            out["roofline_align"] = roof_aln
+            if fast is not None:
+                out["fast_mode"] = fast       # BASELINE.json configs[1] on the same batch
         print(json.dumps(out), flush=True)
     if a.merge:
         # config 4: RCCL all-gather of every rank's clustered batch, then the reference's left fold
         # ((b0 + b1) + b2) ... with ioc_cluster_merge on rank 0 (untimed extra, reported on stderr)
         from isonclust2_amd import dist as idist
         from isonclust2_amd import pipeline
+        ctx.set_params(api.default_params(k, w, "fast"))
+        cls, strand, st = ctx.cluster_resident()
         cb = resident_to_clustered(ctx, api, pipeline, rs, order, cls, strand, rank)
         t1 = time.perf_counter()
         allb = idist.allgather_clustered(cb, dist)

@@ -176,6 +176,12 @@ typedef struct {
     int64_t n_candidates;      /* candidate entries written by ioc_score    */
     int64_t n_mapped_evals;    /* (query,target,strand) mapped-ratio evaluations */
     int64_t postings_traversed;/* postings read by ioc_score (if counted)   */
+    /* GPU alignment fallback, summed over the ioc_align_pairs calls since the last ioc_index_build
+     * (HIP events around the two passes on the launch stream) */
+    float ms_align_fwd;        /* k_align_fwd: score-only DP + checkpoints   */
+    float ms_align_trace;      /* k_align_trace: tiled traceback + windows   */
+    int64_t n_align_pairs;
+    int64_t n_align_cells;     /* sum of query length x reference length     */
 } ioc_timings;
 int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
 /* Instrumentation (one extra scoring launch, outside any timed region): the number of postings the

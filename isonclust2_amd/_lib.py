@@ -61,7 +61,9 @@ class Timings(C.Structure):
     _fields_ = [("ms_build", C.c_float), ("ms_score", C.c_float), ("ms_resolve", C.c_float),
                 ("resolve_iters", C.c_int32), ("n_queries", C.c_int32), ("n_minimizers", C.c_int64),
                 ("n_index_postings", C.c_int64), ("n_candidates", C.c_int64),
-                ("n_mapped_evals", C.c_int64), ("postings_traversed", C.c_int64)]
+                ("n_mapped_evals", C.c_int64), ("postings_traversed", C.c_int64),
+                ("ms_align_fwd", C.c_float), ("ms_align_trace", C.c_float), ("n_align_pairs", C.c_int64),
+                ("n_align_cells", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

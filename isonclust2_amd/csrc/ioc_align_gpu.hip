@@ -1084,6 +1084,9 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
         if (n_cu < 1) n_cu = 256;
+        std::vector<hipEvent_t> evs(slices.size() * 3, nullptr);
+        for (auto& e : evs) ACHK(c, hipEventCreate(&e));
+        size_t evi = 0;
         for (auto& sl : slices) {
             const uint32_t* ord = static_cast<const uint32_t*>(c->a_order.p) + sl.first;
             // Every workgroup lives for the whole launch (equal-sized pairs), so the launch ends with the
@@ -1109,18 +1112,30 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 }
                 lds_pad = std::min(lds_pad, c->aln_lds_max);
             }
+            ACHK(c, hipEventRecord(evs[evi++], s));
             hipLaunchKernelGGL(k_align_fwd, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
                                static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves,
                                static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
                                static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
                                static_cast<int4*>(c->a_ends.p));
             ACHK(c, hipGetLastError());
+            ACHK(c, hipEventRecord(evs[evi++], s));
             hipLaunchKernelGGL(k_align_trace, dim3(sl.second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
                                static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const int2*>(c->a_ck.p),
                                static_cast<const AlnCk*>(c->a_cko.p), static_cast<const int4*>(c->a_ends.p), d_score, d_count);
             ACHK(c, hipGetLastError());
+            ACHK(c, hipEventRecord(evs[evi++], s));
         }
+        ACHK(c, hipStreamSynchronize(s));
+        for (size_t x = 0; x + 2 < evs.size() + 0 && x < evi; x += 3) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, evs[x], evs[x + 1]) == hipSuccess) c->tm.ms_align_fwd += a;
+            if (hipEventElapsedTime(&b, evs[x + 1], evs[x + 2]) == hipSuccess) c->tm.ms_align_trace += b;
+        }
+        for (auto& e : evs) (void)hipEventDestroy(e);
     }
+    c->tm.n_align_pairs += np;
+    for (auto& d : dp) c->tm.n_align_cells += int64_t(d.n) * int64_t(d.m);
     std::vector<int32_t> hs(np);
     std::vector<uint32_t> hc(np);
     ACHK(c, hipMemcpyAsync(hs.data(), d_score, size_t(np) * 4, hipMemcpyDeviceToHost, s));

@@ -1,6 +1,7 @@
 """GPU batched aligner (ioc_align_pairs) against the host aligner (ioc_host_align + ioc_host_aln_ratio):
-score and getAlnRatio must be identical — same recurrence, tie-breaks and end-cell choice, with the
-window statistics carried forward instead of a traceback (src/cluster.cpp:408-459)."""
+score and getAlnRatio must be identical — same recurrence, tie-breaks and end-cell choice; the device
+replaces the traceback matrix by checkpoints + a tiled traceback ("trace", default) or carries the window
+statistics forward ("carry") (src/cluster.cpp:408-459)."""
 import ctypes as C
 import random
 
@@ -111,3 +112,42 @@ def test_automatic_width_and_many_pairs(ctx):
     seqs = [_mutate(rng, base[i % 6], 0.1) for i in range(60)]
     pairs = [(i, (i + 6) % 60, i % 2, 0.2) for i in range(60)] + [(i, (i + 1) % 60, 0, 0.2) for i in range(60)]
     _check(ctx, seqs, pairs, 11)
+
+
+@pytest.mark.parametrize("waves", ["1", "2", "4", "8"])
+def test_tile_boundaries(ctx, monkeypatch, waves):
+    """Lengths around the checkpoint pitch (256) and the strip width (1024): row bands that end exactly on a
+    tile, bands without rows, last column on / next to a lane edge, last row on / next to a tile edge."""
+    monkeypatch.setenv("IOC_ALIGN_WAVES", waves)
+    rng = random.Random(17)
+    base = bytes(rng.choice(b"ACGT") for _ in range(2200))
+    lens = [255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1040, 2047, 2049]
+    seqs = [_mutate(rng, base, 0.1)[:ln] for ln in lens] + [base[:1024], base[:1024]]
+    pairs = []
+    for a in range(len(lens)):
+        for b in (a, (a + 5) % len(lens), (a + 8) % len(lens)):
+            pairs.append((a, b, (a + b) % 2, rng.choice([0.05, 0.2])))
+    pairs.append((len(lens), len(lens) + 1, 0, 0.01))  # identical sequences: one long diagonal
+    _check(ctx, seqs, pairs, 11)
+
+
+def test_checkpoint_arena_slices(ctx, monkeypatch):
+    """A 1 MB checkpoint budget forces several launches (slices) over one batch."""
+    monkeypatch.setenv("IOC_ALIGN_CK_BUDGET_MB", "1")
+    rng = random.Random(23)
+    base = bytes(rng.choice(b"ACGT") for _ in range(3000))
+    seqs = [_mutate(rng, base, 0.1) for _ in range(12)]
+    pairs = [(i, (i + 1) % 12, i % 2, 0.2) for i in range(12)]
+    _check(ctx, seqs, pairs, 11)
+
+
+def test_carry_variant(ctx, monkeypatch):
+    """The single-pass kernel (window statistics carried forward) against the host aligner too: two
+    independent device formulations of the same alignment."""
+    monkeypatch.setenv("IOC_ALIGN_VARIANT", "carry")
+    rng = random.Random(29)
+    base = bytes(rng.choice(b"ACGT") for _ in range(2500))
+    seqs = [_mutate(rng, base, 0.12) for _ in range(8)] + [b"", b"A", base[:40]]
+    pairs = [(i, (i + 3) % 8, i % 2, rng.choice([0.02, 0.2, 0.95])) for i in range(8)] + [(8, 0, 0, 0.2), (9, 10, 0, 0.2), (10, 1, 1, 0.2)]
+    for k in (5, 11, 32):
+        _check(ctx, seqs, pairs, k)

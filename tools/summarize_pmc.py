@@ -23,7 +23,7 @@ def short(name):
     return n.split("<")[0]
 
 
-summary = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline", "kernels": {}}
+summary = {"tag": tag, "command": "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline (kernel trace, SQ counters); --mode fast for the TCC / HBM-traffic passes", "kernels": {}}
 st = first(f"{out}/trace/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
