@@ -17,7 +17,7 @@ def first(pattern):
 
 
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
     if n.startswith("void "):
         n = n[5:]
     return n.split("<")[0]
