@@ -96,6 +96,21 @@ int ioc_queries_bind_device(ioc_ctx* ctx, int32_t n, const int64_t* d_off_fwd, c
 int ioc_left_load(ioc_ctx* ctx, int32_t n_clusters, const uint8_t* cls_err_cell, int64_t n_keys,
                   const uint32_t* keys, const int64_t* offs, const uint32_t* postings);
 
+/* UpdateMinDB (src/minimizer.cpp:124-160, called at src/cluster.cpp:296 once a cluster's consensus replaced its
+ * representative): left cluster `cls` leaves the posting lists of the values only old_min has and enters, at
+ * its sorted place, the lists of the values only new_min has (both arrays: the representative's forward
+ * minimizer VALUES, duplicates allowed).  Lists that become empty stay as keys, unseen values open new keys
+ * (`db[m]`, :146, :156).  old_min must be what the index holds for the cluster — in the reference it always
+ * is (AddMinimizers / the previous UpdateMinDB put it there) — otherwise IOC_ERR_INPUT.  new_err_cell (1..15,
+ * 0 = unchanged) is the cell of the representative's re-weighted HPC error rate (src/consensus.cpp:56-58, 104).
+ * Device-side rewrite of the CSR; the combined index must be rebuilt afterwards (ioc_index_build). */
+int ioc_index_update(ioc_ctx* ctx, int32_t cls, const uint32_t* old_min, int64_t n_old, const uint32_t* new_min,
+                     int64_t n_new, uint8_t new_err_cell);
+/* The left MinDB as it stands on the device (after ioc_left_load / ioc_index_update), CSR with ascending keys,
+ * keys with empty lists included.  Call with keys == NULL to size. */
+int ioc_left_export(ioc_ctx* ctx, int64_t* n_keys, int64_t* n_postings, uint32_t* keys, int64_t* offs,
+                    uint32_t* postings);
+
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /* AddMinimizers for every tentative representative at once (src/minimizer.cpp:31-42): per-query
  * sorted distinct forward values, hash insert, posting lists. */
@@ -265,7 +280,8 @@ typedef struct {
 typedef struct {
     int32_t n_clusters;
     const double* cls_hpc_err; /* [n_clusters] HpcSeq->ErrorRate() of each representative */
-    int64_t n_keys;
+    int64_t n_keys;            /* -1 with keys == NULL: keep the left state that is on the device
+                                  (ioc_left_load, then any ioc_index_update); n_clusters must match it */
     const uint32_t* keys;
     const int64_t* offs;       /* [n_keys+1] */
     const uint32_t* postings;

@@ -79,6 +79,7 @@ SYMBOLS = [
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
     "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
+    "ioc_index_update", "ioc_left_export",
 ]
 
 _lib = None
@@ -114,6 +115,8 @@ def load():
     L.ioc_queries_upload.argtypes = [vp, i32, pi64, pi64, pu32, pu32, i64, pu32, pu8, pu32]
     L.ioc_queries_bind_device.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, pi64, pi64]
     L.ioc_left_load.argtypes = [vp, i32, pu8, i64, pu32, pi64, pu32]
+    L.ioc_index_update.argtypes = [vp, i32, pu32, i64, pu32, i64, C.c_uint8]
+    L.ioc_left_export.argtypes = [vp, pi64, pi64, pu32, pi64, pu32]
     L.ioc_index_build.argtypes = [vp]
     L.ioc_score.argtypes = [vp]
     L.ioc_resolve.argtypes = [vp, pi32]

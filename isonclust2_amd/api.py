@@ -99,6 +99,24 @@ class Context:
         self._chk(self.L.ioc_left_load(self.h, n_clusters, _p(cls_err_cell, C.c_uint8), len(keys),
                                        _p(keys, C.c_uint32), _p(offs, C.c_int64), _p(postings, C.c_uint32)))
 
+    def index_update(self, cls, old_min, new_min, new_err_cell=0):
+        """UpdateMinDB (src/minimizer.cpp:124-160) for left cluster `cls` on the device."""
+        old_min = np.ascontiguousarray(old_min, np.uint32)
+        new_min = np.ascontiguousarray(new_min, np.uint32)
+        self._chk(self.L.ioc_index_update(self.h, int(cls), _p(old_min, C.c_uint32), len(old_min),
+                                          _p(new_min, C.c_uint32), len(new_min), int(new_err_cell)))
+
+    def left_export(self):
+        """The left MinDB as it stands on the device: (keys, offs, postings), empty lists included."""
+        nk, npost = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.ioc_left_export(self.h, C.byref(nk), C.byref(npost), None, None, None))
+        keys = np.zeros(nk.value, np.uint32)
+        offs = np.zeros(nk.value + 1, np.int64)
+        post = np.zeros(max(1, npost.value), np.uint32)
+        self._chk(self.L.ioc_left_export(self.h, C.byref(nk), C.byref(npost), _p(keys, C.c_uint32),
+                                         _p(offs, C.c_int64), _p(post, C.c_uint32)))
+        return keys, offs, post[:npost.value]
+
     def index_build(self):
         self._chk(self.L.ioc_index_build(self.h))
 
@@ -257,7 +275,12 @@ class Context:
                       n_members=_p(nm, C.c_int32) if nm is not None else None,
                       depth=int(batch.get("depth", -1)), min_cls_size=int(batch.get("min_cls_size", 3)))
         lv = None
-        if left is not None:
+        if left is not None and left.get("resident"):
+            # the left state already on the device (left_load + index_update) is used as it is
+            le = np.ascontiguousarray(left["cls_hpc_err"], np.float64)
+            lv = LeftView(n_clusters=len(le), cls_hpc_err=_p(le, C.c_double), n_keys=-1, keys=None, offs=None,
+                          postings=None, rep_seq=None, rep_off=None, cls_raw_err=None)
+        elif left is not None:
             le = np.ascontiguousarray(left["cls_hpc_err"], np.float64)
             lk = np.ascontiguousarray(left["keys"], np.uint32)
             lo = np.ascontiguousarray(left["offs"], np.int64)

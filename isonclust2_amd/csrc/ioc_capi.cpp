@@ -283,9 +283,7 @@ int ioc_left_load(ioc_ctx* c, int32_t L, const uint8_t* cls_err_cell, int64_t n_
     c->L = L;
     c->n_left_keys = n_keys;
     c->n_left_post = np;
-    c->h_lkeys.assign(keys, keys + n_keys);
-    c->h_loffs.assign(offs, offs + (n_keys > 0 ? n_keys + 1 : 0));
-    c->h_lpost.assign(postings, postings + np);
+    c->h_lset_off = soff;
     RESERVE(c, c->b_left_err, size_t(L));
     RESERVE(c, c->b_lkeys, size_t(n_keys) * 4);
     RESERVE(c, c->b_loffs, size_t(n_keys + 1) * 8);

@@ -650,7 +650,12 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
                                need.data());
     }
     if (r != IOC_OK) return r;
-    if (L > 0) {
+    if (left && left->n_keys == -1 && !left->keys) {
+        // the left state stays as it is on the device (persisted MinDB + any ioc_index_update)
+        if (L != c->L) return ioc_fail(c, IOC_ERR_STATE, "resident left state holds a different number of clusters");
+        c->built = c->scored = c->resolved = false;
+        r = IOC_OK;
+    } else if (L > 0) {
         std::vector<uint8_t> lcell(size_t(L), 1);
         for (int i = 0; i < L; ++i) {
             lcell[size_t(i)] = ioc_host_err_cell(left->cls_hpc_err[i]);

@@ -48,9 +48,7 @@ struct ioc_ctx {
     DevBuf b_left_err, b_lkeys, b_loffs, b_lpost, b_lslot;
     // left clusters' value sets (transposed MinDB), built by ioc_left_load
     DevBuf b_lset_off, b_lset_val;
-    std::vector<uint32_t> h_lkeys;
-    std::vector<int64_t> h_loffs;
-    std::vector<uint32_t> h_lpost;
+    std::vector<int64_t> h_lset_off;  // host copy of the value-set offsets (ioc_index_update)
 
     // ---- index ----
     bool built = false;

@@ -25,7 +25,9 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <iterator>
 #include <memory>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -323,6 +325,32 @@ void add_minimizers(const MzVec& mins, unsigned cls, MinDB& db, orc_stats* st)
             v->second.emplace_back(cls);
             if (st) st->index_appends++;
         }
+    }
+}
+
+// ---- src/minimizer.cpp:124-160: UpdateMinDB ------------------------------------------------------------------------------------
+// After a consensus replaced the representative of cluster `best`: the cluster leaves the posting lists of the
+// values only the old minimizers had (the list goes through a std::set: sorted, de-duplicated, `best` erased; a
+// value without an entry gets an EMPTY one through operator[], and emptied lists are kept — the erase is
+// commented out at :150-152) and is appended + sorted into the lists of the values only the new ones have.
+void update_mindb(unsigned best, const MzVec& oldMins, const MzVec& newMins, MinDB& db)
+{
+    std::set<unsigned> oldSet, newSet, toIns, toDel;
+    for (auto& m : oldMins) oldSet.insert(m.Min);
+    for (auto& m : newMins) newSet.insert(m.Min);
+    std::set_difference(oldSet.begin(), oldSet.end(), newSet.begin(), newSet.end(), std::inserter(toDel, toDel.begin()));
+    std::set_difference(newSet.begin(), newSet.end(), oldSet.begin(), oldSet.end(), std::inserter(toIns, toIns.begin()));
+    for (auto m : toDel) {
+        auto& mins = db[m];
+        std::set<unsigned> tmp(mins.begin(), mins.end());
+        tmp.erase(best);
+        mins.clear();
+        mins.insert(mins.begin(), tmp.begin(), tmp.end());
+    }
+    for (auto m : toIns) {
+        auto& tv = db[m];
+        tv.push_back(best);
+        std::sort(tv.begin(), tv.end());
     }
 }
 
@@ -1004,6 +1032,22 @@ int64_t orc_batch_index(void* bh, uint32_t* keys, int64_t* offs, uint32_t* posti
         offs[ks.size()] = o;
     }
     return int64_t(ks.size());
+}
+
+// UpdateMinDB on a clustered batch's index; old / new minimizers are given by value only (Pos and Index play
+// no part, src/minimizer.cpp:132-137).  With mins_too != 0 the representative's forward minimizers are
+// replaced as well (values, Pos = Index = ordinal), so that a later update sees them as its old ones.
+int orc_batch_update_mindb(void* bh, int cls, const uint32_t* old_min, int64_t n_old, const uint32_t* new_min,
+                           int64_t n_new, int mins_too)
+{
+    auto b = static_cast<Batch*>(bh);
+    if (!b || cls < 0 || size_t(cls) >= b->Cls.size()) return -1;
+    MzVec o, nw;
+    for (int64_t i = 0; i < n_old; ++i) o.push_back(Mz{old_min[i], unsigned(i), unsigned(i)});
+    for (int64_t i = 0; i < n_new; ++i) nw.push_back(Mz{new_min[i], unsigned(i), unsigned(i)});
+    update_mindb(unsigned(cls), o, nw, b->Db);
+    if (mins_too && b->Cls[size_t(cls)] && !b->Cls[size_t(cls)]->empty() && b->Cls[size_t(cls)]->at(0)) b->Cls[size_t(cls)]->at(0)->Mins = nw;
+    return 0;
 }
 
 }  // extern "C"

@@ -102,6 +102,10 @@ int orc_batch_members(void* b, int32_t* cls, int32_t* orig, int32_t* strand, int
 int64_t orc_batch_index(void* b, uint32_t* keys, int64_t* offs, uint32_t* postings,
                         int64_t* n_postings);
 
+/* UpdateMinDB (src/minimizer.cpp:124-160) on the batch's index for cluster `cls`. */
+int orc_batch_update_mindb(void* b, int cls, const uint32_t* old_min, int64_t n_old, const uint32_t* new_min,
+                           int64_t n_new, int mins_too);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,7 @@ def lib():
     L.orc_batch_index.argtypes = [vp, u32p, i64p, u32p, i64p]
     L.orc_batch_index.restype = C.c_int64
     L.orc_set_aligner.argtypes = [vp]
+    L.orc_batch_update_mindb.argtypes = [vp, C.c_int, u32p, C.c_int64, u32p, C.c_int64, C.c_int]
     _lib = L
     return L
 
@@ -290,6 +291,15 @@ class Batch:
         lib().orc_batch_index(self.h, _p(keys, C.c_uint32), _p(offs, C.c_int64), _p(post, C.c_uint32),
                               C.byref(np_))
         return keys[:nk], offs, post[:np_.value]
+
+    def update_mindb(self, cls, old_min, new_min, mins_too=True):
+        """UpdateMinDB (src/minimizer.cpp:124-160) for cluster `cls` of this (clustered) batch."""
+        old_min = np.ascontiguousarray(old_min, np.uint32)
+        new_min = np.ascontiguousarray(new_min, np.uint32)
+        rc = lib().orc_batch_update_mindb(self.h, int(cls), _p(old_min, C.c_uint32), len(old_min),
+                                          _p(new_min, C.c_uint32), len(new_min), 1 if mins_too else 0)
+        if rc != 0:
+            raise ValueError("orc_batch_update_mindb failed")
 
     def __del__(self):
         if getattr(self, "h", None):
