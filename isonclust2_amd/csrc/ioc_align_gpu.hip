@@ -417,7 +417,11 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v)
     return v;
 }
 
-template <int C>
+// PROF: the diagonal increment (cm for identical bases, cx otherwise) comes as one byte per column out of
+// the lane's QUERY PROFILE in LDS — per strip, for each of A C G T (and "anything else"), the 16 increments
+// of the lane's 16 columns packed four to a word; `xw` holds the row of this query base.  One add with a
+// byte-select operand instead of compare + select + add: 5 VALU per cell.
+template <int C, bool PROF>
 __device__ __forceinline__ void fwd_cells(int (&Hq)[C], int (&F)[C], const uint32_t (&rpk)[C / 4], int& hql, int& el,
                                           int dgq, uint32_t qc, const FwdConst& K)
 {
@@ -425,8 +429,14 @@ __device__ __forceinline__ void fwd_cells(int (&Hq)[C], int (&F)[C], const uint3
     for (int c = 0; c < C; ++c) {
         const int E = max(el, hql);
         const int Fn = max(F[c], Hq[c]);
-        const bool mt = qc == ((rpk[c >> 2] >> (8 * (c & 3))) & 0xFFu);
-        const int hq = max(max(dgq + (mt ? K.cm : K.cx), E), Fn) - K.gd;
+        int inc;
+        if (PROF) {
+            inc = int((rpk[c >> 2] >> (8 * (c & 3))) & 0xFFu);  // rpk = the profile row here
+        } else {
+            const bool mt = qc == ((rpk[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+            inc = mt ? K.cm : K.cx;
+        }
+        const int hq = max(max(dgq + inc, E), Fn) - K.gd;
         dgq = Hq[c];
         Hq[c] = hq;
         F[c] = Fn;
@@ -449,9 +459,10 @@ static_assert(FW_C == 16, "the last-column select tree assumes 16 columns per la
 #ifndef IOC_FWD_WAVES_PER_EU
 #define IOC_FWD_WAVES_PER_EU 3
 #endif
+template <bool PROF>
 __global__ void __launch_bounds__(64 * ALN_MAXW) __attribute__((amdgpu_waves_per_eu(IOC_FWD_WAVES_PER_EU, 8)))
-k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, uint32_t count, uint32_t wpp,
-            const uint8_t* __restrict__ pool, AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow,
+k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, uint32_t count, uint32_t wpp_main,
+            uint32_t n_main, uint32_t wpp_tail, const uint8_t* __restrict__ pool, AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow,
             uint64_t lrow_stride, int4* __restrict__ ends)
 {
     // A workgroup is 4 (or 8) waves = one per SIMD of its CU, however the dispatcher places workgroups; it
@@ -460,10 +471,18 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     __shared__ __attribute__((aligned(16))) uint32_t s_look_all[ALN_MAXW][3][64];
     __shared__ int s_best[ALN_MAXW][2];
     __shared__ uint32_t s_rounds;
+    // PROF: query profile of the current strip, [wave][base code 0..4][lane][4 words]
+    __shared__ __attribute__((aligned(16))) uint32_t s_prof_all[PROF ? ALN_MAXW : 1][5][64][4];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));  // uniform: keep the band in SGPRs
+    // The first n_main workgroups (one resident generation of the chip) split their pairs over wpp_main waves;
+    // the ones after them — dispatched as those retire — over wpp_tail >= wpp_main waves, so that the tail
+    // generation, which runs on a half-empty chip, is over sooner.
+    const bool tail = blockIdx.x >= n_main;
+    const uint32_t wpp = tail ? wpp_tail : wpp_main, wg_waves = blockDim.x >> 6;
     const uint32_t slot = wv / wpp, wave = wv % wpp, nwaves = wpp;
-    const uint32_t pslot = blockIdx.x * ((blockDim.x >> 6) / wpp) + slot;  // pair of this wave, in `order`
+    const uint32_t pslot = tail ? n_main * (wg_waves / wpp_main) + (blockIdx.x - n_main) * (wg_waves / wpp_tail) + slot
+                                : blockIdx.x * (wg_waves / wpp_main) + slot;  // pair of this wave, in `order`
     const bool live = pslot < count;
     if (threadIdx.x == 0) s_rounds = 0;
     __syncthreads();
@@ -481,6 +500,13 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     int2* colck = ck + cko[pid].col_off;
     int2* mylrow = lrow + uint64_t(live ? pslot : 0) * lrow_stride;
     uint32_t(*s_look)[64] = s_look_all[wv];
+    uint32_t(*s_prof)[64][4] = s_prof_all[PROF ? wv : 0];
+    // what travels with a row: the query byte, or (PROF) the word offset of its profile row
+    auto qcode = [](uint32_t ch) -> uint32_t {
+        if (!PROF) return ch;
+        const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+        return code * 256u;
+    };
     constexpr uint32_t strip_cols = 64u * FW_C;
     const uint32_t nstrips = (m + strip_cols - 1) / strip_cols;
     // this wave's band of rows [r_lo, r_hi), whole tiles
@@ -508,6 +534,21 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w |= ref_byte(r, m, pr.rc, jb + c4 * 4 + e) << (8 * e);
                 rpk[c4] = w;
+            }
+            if (PROF) {
+                const uint32_t bases = 'A' | ('C' << 8) | ('G' << 16) | ('T' << 24);
+#pragma unroll
+                for (int code = 0; code < 5; ++code) {
+                    const uint32_t b = code < 4 ? (bases >> (8 * code)) & 0xFFu : 0x100u;  // 0x100: equals no byte
+#pragma unroll
+                    for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            w |= uint32_t(((rpk[c4] >> (8 * e)) & 0xFFu) == b ? K.cm : K.cx) << (8 * e);
+                        s_prof[code][lane][c4] = w;
+                    }
+                }
             }
             // Hq and F* of the row above the band (slanted, see fwd_cells): row 0 of the matrix (free leading
             // gap, H = 0) or the row checkpoint the band above wrote in the previous round
@@ -566,14 +607,14 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 if ((s & (64 / FW_R - 1)) == 0 && s < nblocks) {
                     if (s == 0) {
                         const uint32_t row = r_lo + lane;
-                        qn = row < r_hi ? q[row] : 0u;
+                        qn = qcode(row < r_hi ? q[row] : 0u);
                         en = left_edge(row);
                     }
                     s_look[0][lane] = uint32_t(en.x);
                     s_look[1][lane] = uint32_t(en.y);
                     s_look[2][lane] = qn;
                     const uint32_t row = r_lo + s * FW_R + 64u + lane;
-                    qn = row < r_hi ? q[row] : 0u;
+                    qn = qcode(row < r_hi ? q[row] : 0u);
                     en = left_edge(row);
                 }
 #pragma unroll
@@ -600,14 +641,26 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
 #pragma unroll
                         for (int rr = 0; rr < FW_R; ++rr) {
                             const int hl_in = hl[rr];
-                            fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                            if (PROF) {
+                                const uint4 x = *reinterpret_cast<const uint4*>(&s_prof[0][0][0] + qc[rr] + lane * 4u);
+                                const uint32_t xw[FW_C / 4] = {x.x, x.y, x.z, x.w};
+                                fwd_cells<FW_C, true>(Hp, F, xw, hl[rr], el[rr], dg, qc[rr], K);
+                            } else {
+                                fwd_cells<FW_C, false>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                            }
                             dg = hl_in;
                         }
                     } else {
 #pragma unroll
                         for (int rr = 0; rr < FW_R; ++rr) {
                             const int hl_in = hl[rr];
-                            fwd_cells<FW_C>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                            if (PROF) {
+                                const uint4 x = *reinterpret_cast<const uint4*>(&s_prof[0][0][0] + qc[rr] + lane * 4u);
+                                const uint32_t xw[FW_C / 4] = {x.x, x.y, x.z, x.w};
+                                fwd_cells<FW_C, true>(Hp, F, xw, hl[rr], el[rr], dg, qc[rr], K);
+                            } else {
+                                fwd_cells<FW_C, false>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                            }
                             dg = hl_in;
                             const uint32_t i = i0 + rr;  // 0-based row
                             if (i < r_hi) {
@@ -888,6 +941,25 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     }
 }
 
+// per sequence: does it hold a byte other than A C G T?  (The query-profile kernel knows four bases; a pair
+// with anything else — the host aligner matches any two equal bytes — takes the comparing kernel.)
+__global__ void __launch_bounds__(256)
+k_seq_flags(const uint8_t* __restrict__ pool, const int64_t* __restrict__ offs, uint8_t* __restrict__ flags)
+{
+    __shared__ uint32_t s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    const int64_t a = offs[blockIdx.x], b = offs[blockIdx.x + 1];
+    uint32_t any = 0;
+    for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+        const uint8_t ch = pool[i];
+        any |= (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ? 1u : 0u;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = uint8_t(s_any);
+}
+
 struct DevTmp {
     void* p = nullptr;
     ~DevTmp()
@@ -942,6 +1014,16 @@ int ioc_align_set_pool(ioc_ctx* c, int32_t n_seqs, const char* seqs, const int64
     int r = reserve(c, c->a_pool, size_t(total));
     if (r != IOC_OK) return r;
     ACHK(c, hipMemcpyAsync(c->a_pool.p, seqs, size_t(total), hipMemcpyHostToDevice, c->stream));
+    // which sequences hold something else than A C G T
+    if ((r = reserve(c, c->a_ends, size_t(n_seqs + 1) * 8 + size_t(n_seqs))) != IOC_OK) return r;
+    int64_t* d_offs = static_cast<int64_t*>(c->a_ends.p);
+    uint8_t* d_flags = reinterpret_cast<uint8_t*>(d_offs + n_seqs + 1);
+    ACHK(c, hipMemcpyAsync(d_offs, offs, size_t(n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_seq_flags, dim3(uint32_t(n_seqs)), dim3(256), 0, c->stream,
+                       static_cast<const uint8_t*>(c->a_pool.p), d_offs, d_flags);
+    ACHK(c, hipGetLastError());
+    c->aln_other.assign(size_t(n_seqs), 0);
+    ACHK(c, hipMemcpyAsync(c->aln_other.data(), d_flags, size_t(n_seqs), hipMemcpyDeviceToHost, c->stream));
     ACHK(c, hipStreamSynchronize(c->stream));
     return IOC_OK;
 }
@@ -985,6 +1067,12 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         d.gap_open = ioc_host_gap_open(a.e);
         d.ilimit = il;
         d.rc = a.ref_revcomp ? 1u : 0u;
+        {   // query-profile kernel: four-letter sequences, diagonal increments that fit a byte
+            const int gd = d.gap_open - gap_extend, cm = match + 2 * gap_extend + gd, cx = mismatch + 2 * gap_extend + gd;
+            const bool ok = !c->aln_other[size_t(a.query)] && !c->aln_other[size_t(a.ref)] && cm >= 0 && cm <= 255 &&
+                            cx >= 0 && cx <= 255 && !getenv("IOC_ALIGN_NO_PROFILE");
+            d.pad = ok ? 1u : 0u;
+        }
         dp.push_back(d);
         back.push_back(uint32_t(i));
         max_n = std::max(max_n, d.n);
@@ -998,6 +1086,8 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return uint64_t(dp[x].n) * dp[x].m > uint64_t(dp[y].n) * dp[y].m;
     });
+    // trace variant: the pairs of the query-profile kernel first, the comparing kernel's after them
+    std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return dp[x].pad != 0; });
     const char* ev = getenv("IOC_ALIGN_VARIANT");
     const bool carry = ev && strcmp(ev, "carry") == 0;
     const uint32_t colsper = carry ? ALN_C : FW_C;
@@ -1066,6 +1156,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 const AlnPairDev& d = dp[order[first + cnt]];
                 const uint64_t u = ck_units(d);
                 if (cnt > 0 && (used + u) * 8ull > budget) break;
+                if (cnt > 0 && d.pad != dp[order[first]].pad) break;  // one kernel per slice
                 cko[order[first + cnt]] = AlnCk{used, used + uint64_t((d.n - 1) / TILE) * d.m};
                 used += u;
                 ++cnt;
@@ -1078,7 +1169,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         for (auto& sl : slices) max_cnt = std::max(max_cnt, sl.second);
         if ((r = reserve(c, c->a_ck, size_t(arena) * 8)) != IOC_OK) return r;
         if ((r = reserve(c, c->a_cko, size_t(np) * sizeof(AlnCk))) != IOC_OK) return r;
-        if ((r = reserve(c, c->a_ends, size_t(np) * sizeof(int4))) != IOC_OK) return r;
+        if ((r = reserve(c, c->a_ends2, size_t(np) * sizeof(int4))) != IOC_OK) return r;
         if ((r = reserve(c, c->a_lrow, size_t(max_cnt) * lrow_stride * 8)) != IOC_OK) return r;
         ACHK(c, hipMemcpyAsync(c->a_cko.p, cko.data(), size_t(np) * sizeof(AlnCk), hipMemcpyHostToDevice, s));
         int n_cu = 256;
@@ -1092,37 +1183,61 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             // Every workgroup lives for the whole launch (equal-sized pairs), so the launch ends with the
             // fullest CU: cap the residency at ceil(workgroups / CUs) per CU with an LDS reservation, or the
             // dispatcher may stack 8 workgroups on some CUs and leave others with 3.
+            const bool prof = dp[order[sl.first]].pad != 0;
+            const void* kfn = prof ? reinterpret_cast<const void*>(k_align_fwd<true>) : reinterpret_cast<const void*>(k_align_fwd<false>);
             size_t lds_pad = 0;
             const uint32_t wg_waves = waves > 4 ? waves : 4, ppw = wg_waves / waves;
-            const uint32_t n_wg = (sl.second + ppw - 1) / ppw;
-            const uint32_t per_cu = (n_wg + uint32_t(n_cu) - 1) / uint32_t(n_cu);
+            uint32_t n_wg = (sl.second + ppw - 1) / ppw, n_main = n_wg, wpp_tail = waves;
+            {   // a second, partly filled generation of workgroups: give its pairs twice the waves
+                int occ = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, int(wg_waves * 64), 0) != hipSuccess) occ = 0;
+                (void)hipGetLastError();
+                const uint32_t gen = uint32_t(occ > 0 ? occ : 3) * uint32_t(n_cu);  // resident workgroups
+                if (!getenv("IOC_ALIGN_NO_TAIL") && n_wg > gen && n_wg < gen + gen / 2 && 2 * waves <= wg_waves) {
+                    n_main = gen;
+                    wpp_tail = 2 * waves;
+                    const uint32_t rest = sl.second - n_main * ppw, ppw_tail = wg_waves / wpp_tail;
+                    n_wg = n_main + (rest + ppw_tail - 1) / ppw_tail;
+                }
+            }
+            const uint32_t per_cu = (n_main + uint32_t(n_cu) - 1) / uint32_t(n_cu);
             if (!getenv("IOC_ALIGN_NO_CAP") && per_cu * wg_waves < 32) {
-                // per-workgroup LDS halfway between 160 KB / (per_cu + 1) and 160 KB / per_cu (8 KB of it static)
-                lds_pad = (size_t(160u * 1024u) * (2 * per_cu + 1) / (2 * per_cu * (per_cu + 1)) - 8192u) & ~size_t(255);
+                // per-workgroup LDS (static + reservation) halfway between 160 KB / (per_cu + 1) and 160 KB / per_cu
+                hipFuncAttributes fa{};
+                size_t stat = 48 * 1024;
+                if (hipFuncGetAttributes(&fa, kfn) == hipSuccess) stat = fa.sharedSizeBytes;
+                const size_t want = size_t(160u * 1024u) * (2 * per_cu + 1) / (2 * per_cu * (per_cu + 1));
+                lds_pad = want > stat + 1024 ? (want - stat - 512) & ~size_t(255) : 0;
                 // more than the default 64 KB per workgroup needs the kernel attribute (best effort)
-                if (c->aln_lds_max == 0) {
+                size_t& lim = prof ? c->aln_lds_max : c->aln_lds_max2;
+                if (lim == 0) {
                     int mx = 0;
                     (void)hipDeviceGetAttribute(&mx, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
-                    c->aln_lds_max = 48 * 1024;
-                    if (mx > 72 * 1024 &&
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_align_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            mx - 8 * 1024) == hipSuccess)
-                        c->aln_lds_max = size_t(mx) - 8 * 1024;
+                    lim = 64 * 1024 > stat ? 64 * 1024 - stat : 1;
+                    if (mx > 72 * 1024 && hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mx - int(stat)) == hipSuccess)
+                        lim = size_t(mx) - stat;
                     (void)hipGetLastError();
                 }
-                lds_pad = std::min(lds_pad, c->aln_lds_max);
+                lds_pad = std::min(lds_pad, lim > 1 ? lim : 0);
             }
             ACHK(c, hipEventRecord(evs[evi++], s));
-            hipLaunchKernelGGL(k_align_fwd, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
-                               static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves,
-                               static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
-                               static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
-                               static_cast<int4*>(c->a_ends.p));
+            if (prof)
+                hipLaunchKernelGGL(k_align_fwd<true>, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
+                                   static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
+                                   static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
+                                   static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
+                                   static_cast<int4*>(c->a_ends2.p));
+            else
+                hipLaunchKernelGGL(k_align_fwd<false>, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
+                                   static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
+                                   static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
+                                   static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
+                                   static_cast<int4*>(c->a_ends2.p));
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(evs[evi++], s));
             hipLaunchKernelGGL(k_align_trace, dim3(sl.second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
                                static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const int2*>(c->a_ck.p),
-                               static_cast<const AlnCk*>(c->a_cko.p), static_cast<const int4*>(c->a_ends.p), d_score, d_count);
+                               static_cast<const AlnCk*>(c->a_cko.p), static_cast<const int4*>(c->a_ends2.p), d_score, d_count);
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(evs[evi++], s));
         }

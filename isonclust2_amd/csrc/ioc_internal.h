@@ -83,7 +83,8 @@ struct ioc_ctx {
     std::vector<uint8_t> x_keep;
 
     // ---- GPU alignment fallback (ioc_align_gpu.hip) ----
-    DevBuf a_pool, a_pairs, a_order, a_out, a_bnd, a_lrow, a_ck, a_cko, a_ends;
+    DevBuf a_pool, a_pairs, a_order, a_out, a_bnd, a_lrow, a_ck, a_cko, a_ends, a_ends2;
+    std::vector<uint8_t> aln_other;  // per pool sequence: holds a byte other than A C G T
     std::vector<int64_t> aln_offs;
     DevBuf b_aln_t, b_aln_s, b_tie_count, b_tie_keys;
     std::vector<int32_t> h_aln_t;
@@ -95,7 +96,7 @@ struct ioc_ctx {
     std::vector<double> res_err;
     bool have_res_seq = false;
     bool res_pool_ready = false;  // a_pool holds exactly res_seq
-    size_t aln_lds_max = 0;  // dynamic LDS a k_align_fwd workgroup may reserve (residency cap)
+    size_t aln_lds_max = 0, aln_lds_max2 = 0;  // dynamic LDS a k_align_fwd<true/false> workgroup may reserve (residency cap)
 
     // ---- instrumentation ----
     hipEvent_t ev[6]{};
