@@ -137,7 +137,7 @@ def cpu_baseline_and_parity(rs, order, cls, strand, k, w):
 
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3 T int32 lane-ops/s: 1024 SIMDs x 16 lanes x 2.4 GHz (one
                                                # wave64 int32 VALU instruction = 4 cycles of its SIMD)
-ALIGN_VALU_PER_CELL = 7                        # fwd_cells: cmp, cndmask, add, max, max3, sub, max (ioc_align_gpu.hip)
+ALIGN_VALU_PER_CELL = 5                        # fwd_cells (query-profile kernel): add with byte select, max3, sub, max, max (ioc_align_gpu.hip)
 
 
 def timed_steps(ctx, torch, dist, dev, steps, warmup):

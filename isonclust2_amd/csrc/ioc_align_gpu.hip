@@ -88,6 +88,12 @@ __device__ __forceinline__ uint32_t from_left(uint32_t v)
     return uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+// same, lane 0 takes `first` (its own copy of it) instead: the strip's left edge enters the wave here
+__device__ __forceinline__ uint32_t from_left_or(uint32_t v, uint32_t first)
+{
+    return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ uint8_t comp_base(uint8_t ch)
 {
     return ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch;
@@ -382,7 +388,11 @@ k_align_carry(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
 
 // ---- "trace" variant ------------------------------------------------------------------------------
 constexpr int FW_C = 16;      // columns per thread in the forward pass
-constexpr int TILE = 256;     // checkpoint pitch = traceback tile edge
+#ifndef IOC_ALIGN_TILE
+#define IOC_ALIGN_TILE 128
+#endif
+constexpr int TILE = IOC_ALIGN_TILE;  // checkpoint pitch = traceback tile edge (128 or 256)
+static_assert(TILE == 128 || TILE == 256, "tile edge");
 constexpr int TR_C = TILE / 64;  // columns per lane in the traceback tile (one wave per pair)
 
 struct AlnCk {  // where a pair's checkpoints live in the arena, in int2 units
@@ -455,6 +465,7 @@ __device__ __forceinline__ void fwd_cells(int (&Hq)[C], int (&F)[C], const uint3
 // share SIMDs with other pairs' waves, and per-step lockstep cost 30 % of the throughput.
 constexpr int FW_R = 4;
 static_assert(FW_C == 16, "the last-column select tree assumes 16 columns per lane");
+static_assert(FW_R == 4, "the look-ahead hands 4 rows per step to lane 0 (one 16-byte LDS read per field)");
 
 #ifndef IOC_FWD_WAVES_PER_EU
 #define IOC_FWD_WAVES_PER_EU 3
@@ -468,7 +479,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     // A workgroup is 4 (or 8) waves = one per SIMD of its CU, however the dispatcher places workgroups; it
     // carries (waves / wpp) pairs, each split over wpp waves ("bands").  (Workgroups of 2 waves were seen
     // sharing SIMDs while others idled.)
-    __shared__ __attribute__((aligned(16))) uint32_t s_look_all[ALN_MAXW][3][64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_look_all[ALN_MAXW][3][128];
     __shared__ int s_best[ALN_MAXW][2];
     __shared__ uint32_t s_rounds;
     // PROF: query profile of the current strip, [wave][base code 0..4][lane][4 words]
@@ -499,7 +510,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     int2* rowck = ck + cko[pid].row_off;
     int2* colck = ck + cko[pid].col_off;
     int2* mylrow = lrow + uint64_t(live ? pslot : 0) * lrow_stride;
-    uint32_t(*s_look)[64] = s_look_all[wv];
+    uint32_t(*s_look)[128] = s_look_all[wv];
     uint32_t(*s_prof)[64][4] = s_prof_all[PROF ? wv : 0];
     // what travels with a row: the query byte, or (PROF) the word offset of its profile row
     auto qcode = [](uint32_t ch) -> uint32_t {
@@ -564,15 +575,13 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 dg = base;
             } else {
                 const int2* ro = rowck + uint64_t(r_lo / TILE - 1) * m;
-                const int base = K.ge * int(r_lo + jb);
 #pragma unroll
-                for (int c = 0; c < FW_C; ++c) {
+                for (int c = 0; c < FW_C; ++c) {  // row checkpoints hold the slanted (Hq, F*)
                     const int2 v = (jb + c < m) ? ro[jb + c] : int2{0, 0};
-                    Hp[c] = v.x + (base - K.gd) + K.ge * (c + 1);
-                    F[c] = v.y + base + K.ge * (c + 1);
+                    Hp[c] = v.x;
+                    F[c] = v.y;
                 }
-                const int sl = K.ge * int(r_lo + jb);
-                dg = ((jb > 0 && jb <= m) ? ro[jb - 1].x : 0) + sl - K.gd;  // column 0 holds H = 0
+                dg = (jb > 0 && jb <= m) ? ro[jb - 1].x : K.ge * int(r_lo) - K.gd;  // column 0 holds H = 0
             }
             const bool has_cols = jb < m;
             const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
@@ -583,14 +592,9 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * n : colck;
             // look-ahead in blocks of 64 rows — the query bytes and the strip's left edge (Hq, E*): column 0
             // of the matrix (H = 0, no gap to extend) or the column checkpoint, slanted
-            const int jcol = int(p * strip_cols);
             auto left_edge = [&](uint32_t row) {
                 int2 v{K.ge * int(row + 1) - K.gd, ALN_NEG};
-                if (p > 0 && row < r_hi) {
-                    const int2 t = colin[row];
-                    const int sl = K.ge * (int(row + 1) + jcol);
-                    v = int2{t.x + sl - K.gd, t.y + sl};
-                }
+                if (p > 0 && row < r_hi) v = colin[row];  // checkpoints hold the slanted (Hq, E*) as passed between lanes
                 return v;
             };
             uint32_t qn = 0;
@@ -603,34 +607,47 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 el[rr] = ALN_NEG;
                 qc[rr] = 0;
             }
+            // Look-ahead of the left edge + query, 64 rows at a time, one block AHEAD of its use in a 128-row
+            // ring in LDS; every lane reads the 4 rows of the NEXT step from there (one address for the whole
+            // wave, a step before they are needed) and lane 0 picks them up as the `old` operand of the DPP shift.
+            auto publish = [&](uint32_t blk) {
+                s_look[0][(blk & 1u) * 64u + lane] = uint32_t(en.x);
+                s_look[1][(blk & 1u) * 64u + lane] = uint32_t(en.y);
+                s_look[2][(blk & 1u) * 64u + lane] = qn;
+            };
+            auto fetch = [&](uint32_t blk) {
+                const uint32_t row = r_lo + blk * 64u + lane;
+                qn = qcode(row < r_hi ? q[row] : 0u);
+                en = left_edge(row);
+            };
+            fetch(0);
+            publish(0);
+            fetch(1);
+            uint4 nxh, nxe, nxq;  // inputs of lane 0 for the coming step
+            {
+                nxh = *reinterpret_cast<const uint4*>(&s_look[0][0]);
+                nxe = *reinterpret_cast<const uint4*>(&s_look[1][0]);
+                nxq = *reinterpret_cast<const uint4*>(&s_look[2][0]);
+            }
             for (uint32_t s = 0; s < nsteps; ++s) {
-                if ((s & (64 / FW_R - 1)) == 0 && s < nblocks) {
-                    if (s == 0) {
-                        const uint32_t row = r_lo + lane;
-                        qn = qcode(row < r_hi ? q[row] : 0u);
-                        en = left_edge(row);
-                    }
-                    s_look[0][lane] = uint32_t(en.x);
-                    s_look[1][lane] = uint32_t(en.y);
-                    s_look[2][lane] = qn;
-                    const uint32_t row = r_lo + s * FW_R + 64u + lane;
-                    qn = qcode(row < r_hi ? q[row] : 0u);
-                    en = left_edge(row);
+                if ((s & (64 / FW_R - 1)) == 0) {  // steps 16 b .. : publish block b + 1, fetch block b + 2
+                    const uint32_t blk = s / (64 / FW_R) + 1u;
+                    publish(blk);
+                    fetch(blk + 1u);
                 }
-#pragma unroll
-                for (int rr = 0; rr < FW_R; ++rr) {
-                    hl[rr] = int(from_left(uint32_t(hl[rr])));
-                    el[rr] = int(from_left(uint32_t(el[rr])));
-                    qc[rr] = from_left(qc[rr]);
-                }
-                if (lane == 0) {
-                    const uint32_t sl = (s * FW_R) & 63u;
+                {
+                    const uint32_t h4[FW_R] = {nxh.x, nxh.y, nxh.z, nxh.w}, e4[FW_R] = {nxe.x, nxe.y, nxe.z, nxe.w},
+                                   q4[FW_R] = {nxq.x, nxq.y, nxq.z, nxq.w};
 #pragma unroll
                     for (int rr = 0; rr < FW_R; ++rr) {
-                        hl[rr] = int(s_look[0][sl + rr]);
-                        el[rr] = int(s_look[1][sl + rr]);
-                        qc[rr] = s_look[2][sl + rr];
+                        hl[rr] = int(from_left_or(uint32_t(hl[rr]), h4[rr]));
+                        el[rr] = int(from_left_or(uint32_t(el[rr]), e4[rr]));
+                        qc[rr] = from_left_or(qc[rr], q4[rr]);
                     }
+                    const uint32_t nx = ((s + 1u) * FW_R) & 127u;  // rows of the next step
+                    nxh = *reinterpret_cast<const uint4*>(&s_look[0][nx]);
+                    nxe = *reinterpret_cast<const uint4*>(&s_look[1][nx]);
+                    nxq = *reinterpret_cast<const uint4*>(&s_look[2][nx]);
                 }
                 const int bi = int(s) - int(lane);  // row block of this lane in this step
                 if (bi >= 0 && uint32_t(bi) < nblocks && has_cols) {
@@ -700,22 +717,22 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                         }
                     }
                     if (wr_col) {
+                        if (!special) {
 #pragma unroll
-                        for (int rr = 0; rr < FW_R; ++rr) {
-                            const int sl = K.ge * int(i0 + rr + 1 + jr);
-                            if (i0 + rr < r_hi) colout[i0 + rr] = int2{hl[rr] + K.gd - sl, el[rr] - sl};
+                            for (int rr = 0; rr < FW_R; ++rr) colout[i0 + rr] = int2{hl[rr], el[rr]};
+                        } else {
+#pragma unroll
+                            for (int rr = 0; rr < FW_R; ++rr)
+                                if (i0 + rr < r_hi) colout[i0 + rr] = int2{hl[rr], el[rr]};
                         }
                     }
                     const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
                     if ((i1 % TILE) == 0 && i1 < n) {
                         const uint32_t jbo = opaque(jb);
                         int2* ro = rowck + uint64_t(i1 / TILE - 1) * m + jbo;
-                        const int base = -K.ge * int(i1 + jbo);
 #pragma unroll
-                        for (int c = 0; c < FW_C; ++c) {
-                            const int sl = base - K.ge * (c + 1);
-                            if (jbo + c < m) ro[c] = int2{Hp[c] + K.gd + sl, F[c] + sl};
-                        }
+                        for (int c = 0; c < FW_C; ++c)
+                            if (jbo + c < m) ro[c] = int2{Hp[c], F[c]};
                     }
                 }
             }
@@ -801,7 +818,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
               AlnParams P, const int2* __restrict__ ck, const AlnCk* __restrict__ cko, const int4* __restrict__ ends,
               int32_t* __restrict__ out_score, uint32_t* __restrict__ out_count)
 {
-    __shared__ uint16_t dirs[TILE][64];
+    __shared__ uint16_t dirs[TILE * TR_C / 4][64];  // TR_C nibbles per lane and row (TILE 128: two rows share a word)
     __shared__ int2 s_left[TILE];
     __shared__ uint32_t s_q[TILE];
     const uint32_t pid = order[blockIdx.x];
@@ -825,7 +842,13 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
         const uint32_t rows = i - r0, cols = j - c0;
         for (uint32_t x = lane; x < rows; x += 64) {
             s_q[x] = q[r0 + x];
-            s_left[x] = c0 ? colck[uint64_t(c0 / TILE - 1) * n + r0 + x] : int2{0, ALN_NEG};
+            int2 le{0, ALN_NEG};
+            if (c0) {  // checkpoints hold slanted values (k_align_fwd): X = X* - ge (i + j), H* = Hq + (go - ge)
+                le = colck[uint64_t(c0 / TILE - 1) * n + r0 + x];
+                const int sl = P.gap_extend * int(r0 + x + 1 + c0);
+                le = int2{le.x + (go - P.gap_extend) - sl, le.y - sl};
+            }
+            s_left[x] = le;
         }
         const uint32_t jb = c0 + lane * TR_C;  // columns to the left of this lane's block
         uint32_t rpk[1];
@@ -847,11 +870,16 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             const int2* ro = rowck + uint64_t(r0 / TILE - 1) * m;
 #pragma unroll
             for (int c = 0; c < TR_C; ++c) {
-                const int2 v = (jb + c < m) ? ro[jb + c] : int2{0, ALN_NEG};
+                int2 v{0, ALN_NEG};
+                if (jb + c < m) {
+                    v = ro[jb + c];
+                    const int sl = P.gap_extend * int(r0 + jb + c + 1);
+                    v = int2{v.x + (go - P.gap_extend) - sl, v.y - sl};
+                }
                 Hp[c] = v.x;
                 F[c] = v.y;
             }
-            if (jb > 0 && jb <= m) dg = ro[jb - 1].x;  // H(r0, jb); column 0 holds 0
+            if (jb > 0 && jb <= m) dg = ro[jb - 1].x + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);  // H(r0, jb); column 0 holds 0
         }
         __syncthreads();
         const uint32_t nact = (cols + TR_C - 1) / TR_C;
@@ -900,7 +928,10 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                     el = E;
                 }
                 dg = hl_in;
-                dirs[ri][lane] = uint16_t(bits);
+                if (TR_C == 4)
+                    dirs[ri][lane] = uint16_t(bits);
+                else
+                    reinterpret_cast<uint8_t*>(&dirs[ri >> 1][lane])[ri & 1] = uint8_t(bits);
             }
             out_h = hl;
             out_e = el;
@@ -910,7 +941,9 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
         // the host aligner's traceback loop inside this tile (identical in every lane)
         while (i > r0 && j > c0) {
             const uint32_t cj = j - c0 - 1;
-            const uint32_t t = (uint32_t(dirs[i - r0 - 1][cj / TR_C]) >> (4 * (cj % TR_C))) & 0xFu;
+            const uint32_t ri = i - r0 - 1;
+            const uint32_t t = TR_C == 4 ? (uint32_t(dirs[ri][cj / TR_C]) >> (4 * (cj % TR_C))) & 0xFu
+                                         : (uint32_t(dirs[ri >> 1][cj / TR_C]) >> (8 * (ri & 1) + 4 * (cj % TR_C))) & 0xFu;
             if (state == 0) {
                 const uint32_t from = t & 3u;
                 if (from == 1u) {
