@@ -396,9 +396,16 @@ static_assert(TILE == 128 || TILE == 256, "tile edge");
 constexpr int TR_C = TILE / 64;  // columns per lane in the traceback tile (one wave per pair)
 
 struct AlnCk {  // where a pair's checkpoints live in the arena, in int2 units
-    uint64_t row_off;  // [(n - 1) / TILE][m]  (H, F) of rows TILE, 2 TILE, ...   (DP row index, 1-based)
-    uint64_t col_off;  // [(m - 1) / TILE][n]  (H, E) of columns TILE, 2 TILE, ...
+    uint64_t row_off;  // [(n - 1) / TILE][row_pitch(m)]  (H, F) of rows TILE, 2 TILE, ...   (DP row index, 1-based)
+    uint64_t col_off;  // [(m - 1) / TILE][col_pitch(n)]  (H, E) of columns TILE, 2 TILE, ...
 };
+
+// row checkpoints are padded to whole lane blocks (16 columns): a lane stores its block without per-column
+// bounds checks — the store block runs in EVERY step of a wave (for the two lanes whose skewed row block ends a
+// tile), so its instruction count matters as much as the cells'
+__host__ __device__ __forceinline__ uint64_t row_pitch(uint32_t m) { return (uint64_t(m) + 15u) & ~uint64_t(15); }
+// column checkpoints: 4 rows (one step of a lane) go out as two 16-byte stores
+__host__ __device__ __forceinline__ uint64_t col_pitch(uint32_t n) { return (uint64_t(n) + 3u) & ~uint64_t(3); }
 
 __device__ __forceinline__ uint32_t ref_byte(const uint8_t* __restrict__ r, uint32_t m, uint32_t rc, uint32_t j)
 {
@@ -574,7 +581,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 }
                 dg = base;
             } else {
-                const int2* ro = rowck + uint64_t(r_lo / TILE - 1) * m;
+                const int2* ro = rowck + uint64_t(r_lo / TILE - 1) * row_pitch(m);
 #pragma unroll
                 for (int c = 0; c < FW_C; ++c) {  // row checkpoints hold the slanted (Hq, F*)
                     const int2 v = (jb + c < m) ? ro[jb + c] : int2{0, 0};
@@ -588,8 +595,8 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             // this lane's right edge is a column checkpoint (lane 63: the next strip's input)
             const uint32_t jr = jb + FW_C;
             const bool wr_col = (jr % TILE) == 0 && jr < m;
-            int2* colout = wr_col ? colck + uint64_t(jr / TILE - 1) * n : colck;
-            const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * n : colck;
+            int2* colout = wr_col ? colck + uint64_t(jr / TILE - 1) * col_pitch(n) : colck;
+            const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * col_pitch(n) : colck;
             // look-ahead in blocks of 64 rows — the query bytes and the strip's left edge (Hq, E*): column 0
             // of the matrix (H = 0, no gap to extend) or the column checkpoint, slanted
             auto left_edge = [&](uint32_t row) {
@@ -717,9 +724,10 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                         }
                     }
                     if (wr_col) {
-                        if (!special) {
-#pragma unroll
-                            for (int rr = 0; rr < FW_R; ++rr) colout[i0 + rr] = int2{hl[rr], el[rr]};
+                        if (!special) {  // i0 is a multiple of 4: two 16-byte stores
+                            int4* co = reinterpret_cast<int4*>(colout + i0);
+                            co[0] = int4{hl[0], el[0], hl[1], el[1]};
+                            co[1] = int4{hl[2], el[2], hl[3], el[3]};
                         } else {
 #pragma unroll
                             for (int rr = 0; rr < FW_R; ++rr)
@@ -729,10 +737,9 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                     const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
                     if ((i1 % TILE) == 0 && i1 < n) {
                         const uint32_t jbo = opaque(jb);
-                        int2* ro = rowck + uint64_t(i1 / TILE - 1) * m + jbo;
+                        int4* ro = reinterpret_cast<int4*>(rowck + uint64_t(i1 / TILE - 1) * row_pitch(m) + jbo);
 #pragma unroll
-                        for (int c = 0; c < FW_C; ++c)
-                            if (jbo + c < m) ro[c] = int2{Hp[c], F[c]};
+                        for (int c = 0; c < FW_C; c += 2) ro[c / 2] = int4{Hp[c], F[c], Hp[c + 1], F[c + 1]};
                     }
                 }
             }
@@ -844,7 +851,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             s_q[x] = q[r0 + x];
             int2 le{0, ALN_NEG};
             if (c0) {  // checkpoints hold slanted values (k_align_fwd): X = X* - ge (i + j), H* = Hq + (go - ge)
-                le = colck[uint64_t(c0 / TILE - 1) * n + r0 + x];
+                le = colck[uint64_t(c0 / TILE - 1) * col_pitch(n) + r0 + x];
                 const int sl = P.gap_extend * int(r0 + x + 1 + c0);
                 le = int2{le.x + (go - P.gap_extend) - sl, le.y - sl};
             }
@@ -867,7 +874,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 F[c] = ALN_NEG;
             }
         } else {
-            const int2* ro = rowck + uint64_t(r0 / TILE - 1) * m;
+            const int2* ro = rowck + uint64_t(r0 / TILE - 1) * row_pitch(m);
 #pragma unroll
             for (int c = 0; c < TR_C; ++c) {
                 int2 v{0, ALN_NEG};
@@ -1176,7 +1183,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         uint64_t budget = uint64_t(free_b + c->a_ck.cap) / 2;
         if (const char* e = getenv("IOC_ALIGN_CK_BUDGET_MB")) budget = uint64_t(atoll(e)) << 20;
         auto ck_units = [&](const AlnPairDev& d) {
-            return uint64_t((d.n - 1) / TILE) * d.m + uint64_t((d.m - 1) / TILE) * d.n;
+            return uint64_t((d.n - 1) / TILE) * row_pitch(d.m) + uint64_t((d.m - 1) / TILE) * col_pitch(d.n);
         };
         const uint64_t lrow_stride = uint64_t((max_m + 64 * FW_C - 1) / (64 * FW_C)) * 64;  // int2 per pair
         std::vector<AlnCk> cko(np);
@@ -1190,7 +1197,8 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 const uint64_t u = ck_units(d);
                 if (cnt > 0 && (used + u) * 8ull > budget) break;
                 if (cnt > 0 && d.pad != dp[order[first]].pad) break;  // one kernel per slice
-                cko[order[first + cnt]] = AlnCk{used, used + uint64_t((d.n - 1) / TILE) * d.m};
+                // (rows first: their pitch is a multiple of 16 int2, `used` stays 16-byte aligned for the int4 stores)
+                cko[order[first + cnt]] = AlnCk{used, used + uint64_t((d.n - 1) / TILE) * row_pitch(d.m)};
                 used += u;
                 ++cnt;
             }
