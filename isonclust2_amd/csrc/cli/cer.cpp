@@ -1,6 +1,11 @@
 // cer.cpp — binary (.cer) reader / writer for the batch record (see cer.hpp for the layout rules).
 #include "cer.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +23,11 @@ struct Writer {
     void raw(const void* p, size_t n)
     {
         const char* c = static_cast<const char*>(p);
+        if (n >= (1u << 15)) {  // sequences, quality strings, minimizer arrays: straight to the file, no staging copy
+            flush();
+            if (fwrite(c, 1, n, f) != n) ok = false;
+            return;
+        }
         buf.insert(buf.end(), c, c + n);
         if (buf.size() >= (1u << 22)) flush();
     }
@@ -199,23 +209,40 @@ bool save_batch(const Batch& b, const std::string& path, std::string& err)
 
 bool load_batch(Batch& b, const std::string& path, std::string& err)
 {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) {
+    // the archive is decoded straight out of a read-only mapping (no 460 MB staging buffer)
+    struct Mapping {
+        int fd = -1;
+        void* p = MAP_FAILED;
+        size_t n = 0;
+        ~Mapping()
+        {
+            if (p != MAP_FAILED) munmap(p, n);
+            if (fd >= 0) close(fd);
+        }
+    } mp;
+    mp.fd = open(path.c_str(), O_RDONLY);
+    if (mp.fd < 0) {
         err = "Failed to load batch " + path + ": cannot open";
         return false;
     }
-    std::vector<uint8_t> data;
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    data.resize(size_t(sz > 0 ? sz : 0));
-    if (sz > 0 && fread(data.data(), 1, size_t(sz), f) != size_t(sz)) {
-        fclose(f);
-        err = "Failed to load batch " + path + ": short read";
+    struct stat sb;
+    if (fstat(mp.fd, &sb) != 0) {
+        err = "Failed to load batch " + path + ": cannot stat";
         return false;
     }
-    fclose(f);
-    Reader r{data.data(), data.data() + data.size()};
+    mp.n = size_t(sb.st_size);
+    static const uint8_t none = 0;
+    const uint8_t* base = &none;
+    if (mp.n > 0) {
+        mp.p = mmap(nullptr, mp.n, PROT_READ, MAP_PRIVATE, mp.fd, 0);
+        if (mp.p == MAP_FAILED) {
+            err = "Failed to load batch " + path + ": short read";
+            return false;
+        }
+        (void)madvise(mp.p, mp.n, MADV_SEQUENTIAL);
+        base = static_cast<const uint8_t*>(mp.p);
+    }
+    Reader r{base, base + mp.n};
     b = Batch();
     b.BatchNr = r.pod<int32_t>();
     b.BatchStart = r.pod<uint64_t>();

@@ -11,16 +11,20 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
+#include <memory>
 #include <numeric>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -333,9 +337,19 @@ static int main_cluster(int argc, char** argv)
     if (left_path.empty()) die("Specifying left input batch is mandatory!");
     if (out_path.empty()) die("Specifying output batch file is mandatory!");
     auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    // HIP initialisation (~80 ms) runs beside the archive load
+    auto ctx_future = std::async(std::launch::async, [] {
+        const auto t0 = std::chrono::steady_clock::now();
+        ioc_ctx* cc = make_ctx();
+        return std::make_pair(cc, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    });
     Batch left, right;
     string err;
     if (!load_batch(left, left_path, err)) die(err);
+    double load_ms = ms_since(t_begin);
     if (VERBOSE) {
         cerr << "Loaded input batch from " << left_path << ":" << endl;
         print_batch_info(left);
@@ -343,6 +357,7 @@ static int main_cluster(int argc, char** argv)
     const bool single = right_path.empty();
     if (!single) {
         if (!load_batch(right, right_path, err)) die(err);
+        load_ms = ms_since(t_begin);
         cerr << "Loaded input batch from " << right_path << ":" << endl;
         right.Db.clear();
         print_batch_info(right);
@@ -401,7 +416,36 @@ static int main_cluster(int argc, char** argv)
         if (ProcSeq* r = rep_of(i)) tot += int64_t(r->RevMins.size());
     }
     orv[size_t(n)] = tot;
-    std::vector<uint32_t> mv(static_cast<size_t>(tot) + 1), mp(static_cast<size_t>(tot) + 1);
+    std::unique_ptr<uint32_t[]> mv(new uint32_t[static_cast<size_t>(tot) + 1]), mp(new uint32_t[static_cast<size_t>(tot) + 1]);
+    // AoS (Min, Pos, Index) -> SoA, entries spread over the host cores
+    {
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        std::atomic<int> bad(0);
+        for (unsigned t0 = 0; t0 < nt; ++t0)
+            th.emplace_back([&, t0] {
+                for (int i = int(t0); i < n; i += int(nt)) {
+                    ProcSeq* r = rep_of(i);
+                    if (!r) continue;
+                    uint32_t* v = mv.get() + of[size_t(i)];
+                    uint32_t* q = mp.get() + of[size_t(i)];
+                    for (size_t t = 0; t < r->Mins.size(); ++t) {
+                        if (r->Mins[t].Index != t) bad = 1;
+                        v[t] = r->Mins[t].Min;
+                        q[t] = r->Mins[t].Pos;
+                    }
+                    v = mv.get() + orv[size_t(i)];
+                    q = mp.get() + orv[size_t(i)];
+                    for (size_t t = 0; t < r->RevMins.size(); ++t) {
+                        if (r->RevMins[t].Index != t) bad = 1;
+                        v[t] = r->RevMins[t].Min;
+                        q[t] = r->RevMins[t].Pos;
+                    }
+                }
+            });
+        for (auto& x : th) x.join();
+        if (bad) die("Minimizer Index is not the ordinal");
+    }
     string rseq;
     for (int i = 0; i < n; ++i) {
         roff[size_t(i)] = rtot;
@@ -415,16 +459,6 @@ static int main_cluster(int argc, char** argv)
         score[size_t(i)] = r->RawSeq->score;
         raw_err[size_t(i)] = r->RawSeq->errorRate;
         hpc_err[size_t(i)] = r->HpcSeq->errorRate;
-        for (size_t t = 0; t < r->Mins.size(); ++t) {
-            if (r->Mins[t].Index != t) die("Minimizer Index is not the ordinal");
-            mv[size_t(of[size_t(i)]) + t] = r->Mins[t].Min;
-            mp[size_t(of[size_t(i)]) + t] = r->Mins[t].Pos;
-        }
-        for (size_t t = 0; t < r->RevMins.size(); ++t) {
-            if (r->RevMins[t].Index != t) die("Minimizer Index is not the ordinal");
-            mv[size_t(orv[size_t(i)]) + t] = r->RevMins[t].Min;
-            mp[size_t(orv[size_t(i)]) + t] = r->RevMins[t].Pos;
-        }
         if (need_seq) {
             rseq += r->RawSeq->seq;
             rtot += int64_t(r->RawSeq->seq.size());
@@ -435,8 +469,8 @@ static int main_cluster(int argc, char** argv)
     rv.n = n;
     rv.off_fwd = of.data();
     rv.off_rev = orv.data();
-    rv.min_val = mv.data();
-    rv.min_pos = mp.data();
+    rv.min_val = mv.get();
+    rv.min_pos = mp.get();
     rv.total = tot;
     rv.raw_len = raw_len.data();
     rv.hpc_len = hpc_len.data();
@@ -485,7 +519,10 @@ static int main_cluster(int argc, char** argv)
     lv.cls_raw_err = l_raw_err.data();
 
     ioc_params p{a.KmerSize, a.WindowSize, a.MinShared, mode, a.MinFraction, a.MappedThreshold, a.MinProbNoHits, a.AlignedThreshold};
-    ioc_ctx* c = make_ctx();
+    const double flatten_ms = ms_since(t_begin) - load_ms;
+    auto ctx_done = ctx_future.get();
+    ioc_ctx* c = ctx_done.first;
+    const double ctx_ms = ctx_done.second;
     std::vector<int32_t> out_cls(static_cast<size_t>(n) + 1);
     std::vector<int8_t> out_strand(static_cast<size_t>(n) + 1);
     ioc_cluster_stats st{};
@@ -495,6 +532,40 @@ static int main_cluster(int argc, char** argv)
     double core_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count();
 
     // ---- bookkeeping of the loop, cluster.cpp:115-310 ----
+    // representative copies of the fresh reads that open clusters (cluster.cpp:181-199): deep copies of
+    // ~150 kB each, made on the host cores beside each other; the loop below only links them in
+    std::vector<std::shared_ptr<ProcSeq>> rep_copy(static_cast<size_t>(n));
+    {
+        std::vector<int> fresh;
+        int next_id = int(left.Cls.size());
+        std::vector<int> new_id(static_cast<size_t>(n), -1);
+        for (int i = 0; i < n; ++i)
+            if (out_cls[size_t(i)] >= 0 && out_cls[size_t(i)] == next_id) {
+                new_id[size_t(i)] = next_id++;
+                if (right.Cls[size_t(i)] && right.Cls[size_t(i)]->size() == 1 && rep_of(i)) fresh.push_back(i);
+            }
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t0 = 0; t0 < nt; ++t0)
+            th.emplace_back([&, t0] {
+                for (size_t x = t0; x < fresh.size(); x += nt) {
+                    const int i = fresh[x];
+                    ProcSeq* r = rep_of(i);
+                    auto rep = std::make_shared<ProcSeq>();
+                    rep->RawSeq.reset(new Seq(*r->RawSeq));
+                    rep->HpcSeq.reset(new Seq(*r->HpcSeq));
+                    rep->Mins = r->Mins;
+                    rep->RevMins = r->RevMins;
+                    rep->MatchStrand = r->MatchStrand;
+                    rep->Id = r->Id;
+                    const string nm = "rep_" + std::to_string(left.BatchNr) + "_" + std::to_string(new_id[size_t(i)]);
+                    rep->RawSeq->name = nm;
+                    rep->HpcSeq->name = nm;
+                    rep_copy[size_t(i)] = rep;
+                }
+            });
+        for (auto& x : th) x.join();
+    }
     for (int i = 0; i < n; ++i) {
         auto& entry = right.Cls[size_t(i)];
         ProcSeq* r = rep_of(i);
@@ -510,17 +581,8 @@ static int main_cluster(int argc, char** argv)
         const int best = out_cls[size_t(i)];
         if (best == int(left.Cls.size())) {  // opens a new cluster (cluster.cpp:177-222)
             if (entry->size() == 1) {
-                auto rep = std::make_shared<ProcSeq>();
-                rep->RawSeq.reset(new Seq(*r->RawSeq));
-                rep->HpcSeq.reset(new Seq(*r->HpcSeq));
-                rep->Mins = r->Mins;
-                rep->RevMins = r->RevMins;
-                rep->MatchStrand = r->MatchStrand;
-                rep->Id = r->Id;
-                const string nm = "rep_" + std::to_string(left.BatchNr) + "_" + std::to_string(best);
-                rep->RawSeq->name = nm;
-                rep->HpcSeq->name = nm;
-                entry->insert(entry->begin(), rep);
+                if (!rep_copy[size_t(i)]) die("Inconsistent cluster id from the device path");
+                entry->insert(entry->begin(), rep_copy[size_t(i)]);
             }
             left.Cls.push_back(entry);
             left.NrCls++;
@@ -560,7 +622,6 @@ static int main_cluster(int argc, char** argv)
         for (int64_t i = 0; i < nk; ++i)
             left.Db.emplace_back(ek[size_t(i)], std::vector<uint32_t>(ep.begin() + eo[size_t(i)], ep.begin() + eo[size_t(i) + 1]));
     }
-    ioc_ctx_destroy(c);
     if (VERBOSE) {
         cerr << "Finished clustering!" << endl;
         cerr << "Alignment invocation count: " << st.n_aln_invoked << " (" << (n ? double(st.n_aln_invoked) / n * 100 : 0.0) << "%)" << endl;
@@ -578,13 +639,22 @@ static int main_cluster(int argc, char** argv)
         left.Db.clear();
     }
     left.NrConsGs = left.Cls.size();
+    const double book_ms = ms_since(t_core) - core_ms;
+    auto t_save = std::chrono::steady_clock::now();
     if (!save_batch(left, out_path, err)) die(err);
+    const double save_ms = ms_since(t_save);
     double cli_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (VERBOSE) cerr << "Output batch written to: " << out_path << endl;
     if (getenv("ISONCLUST2_STATS_JSON"))
-        fprintf(stderr, "{\"entries\": %d, \"clusters\": %lld, \"core_ms\": %.3f, \"cli_ms\": %.3f, \"resolve_sweeps\": %d}\n", n,
-                (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters);
-    return 0;
+        fprintf(stderr,
+                "{\"entries\": %d, \"clusters\": %lld, \"core_ms\": %.3f, \"cli_ms\": %.3f, \"resolve_sweeps\": %d, "
+                "\"load_ms\": %.3f, \"flatten_ms\": %.3f, \"ctx_ms\": %.3f, \"bookkeeping_ms\": %.3f, \"save_ms\": %.3f}\n",
+                n, (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters, load_ms, flatten_ms, ctx_ms, book_ms, save_ms);
+    // the output is on disk: leave without unwinding a gigabyte of host structures and the HIP runtime
+    fflush(nullptr);
+    std::cout.flush();
+    cerr.flush();
+    _exit(0);
 }
 
 // ===================================================================================================

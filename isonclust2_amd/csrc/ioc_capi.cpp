@@ -701,6 +701,7 @@ fprintf(stderr, "[ioc eval diag] evals %llu: total %.0f cyc/eval = clear %.0f + 
     c->tm.resolve_iters = iters;
     if (n_iter) *n_iter = iters;
     c->resolved = true;
+    c->exp_valid = false;
     return IOC_OK;
 }
 
@@ -795,12 +796,11 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
     return out;
 }
 
-int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t* keys, int64_t* offs,
-                     uint32_t* postings)
+// The export (device -> host copy of the combined index, renumbering, sort by key) is computed once per
+// resolve and kept: callers size with a first call (keys == NULL) and fetch with a second one.
+static int index_export_compute(ioc_ctx* c)
 {
-    if (!c) return IOC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
     hipStream_t s = c->stream;
     const uint32_t nslots = c->cap + 1;
     const uint32_t psize = c->post16 ? 2u : 4u;
@@ -833,27 +833,47 @@ int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t*
         rows.push_back(Row{key, sl});
     }
     std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.key < b.key; });
-    int64_t nk = 0, np = 0;
+    c->exp_keys.clear();
+    c->exp_offs.clear();
+    c->exp_post.clear();
+    c->exp_keys.reserve(rows.size());
+    c->exp_offs.reserve(rows.size() + 1);
+    c->exp_post.reserve(size_t(c->n_post));
     const uint32_t L = uint32_t(c->L);
     for (auto& r : rows) {
-        int64_t start = np;
+        const size_t start = c->exp_post.size();
         for (uint32_t p = 0; p < hc[r.slot]; ++p) {
             uint32_t t = hp[size_t(ho[r.slot]) + p];
             int32_t id = t < L ? int32_t(t) : cid[size_t(t - L)];
             if (id < 0) continue;
-            if (postings) postings[np] = uint32_t(id);
-            np++;
+            c->exp_post.push_back(uint32_t(id));
         }
         // the reference keeps keys with emptied lists only through UpdateMinDB (consensus); a key
         // whose every contributor joined another cluster was never inserted by AddMinimizers.
-        if (np == start) continue;
-        if (keys) keys[nk] = r.key;
-        if (offs) offs[nk] = start;
-        nk++;
+        if (c->exp_post.size() == start) continue;
+        c->exp_keys.push_back(r.key);
+        c->exp_offs.push_back(int64_t(start));
     }
-    if (offs) offs[nk] = np;
-    if (n_keys) *n_keys = nk;
-    if (n_postings) *n_postings = np;
+    c->exp_offs.push_back(int64_t(c->exp_post.size()));
+    c->exp_valid = true;
+    return IOC_OK;
+}
+
+int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t* keys, int64_t* offs,
+                     uint32_t* postings)
+{
+    if (!c) return IOC_ERR_ARG;
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    if (!c->exp_valid) {
+        int r = index_export_compute(c);
+        if (r != IOC_OK) return r;
+    }
+    const size_t nk = c->exp_keys.size(), np = c->exp_post.size();
+    if (keys && nk) memcpy(keys, c->exp_keys.data(), nk * 4);
+    if (offs) memcpy(offs, c->exp_offs.data(), (nk + 1) * 8);
+    if (postings && np) memcpy(postings, c->exp_post.data(), np * 4);
+    if (n_keys) *n_keys = int64_t(nk);
+    if (n_postings) *n_postings = int64_t(np);
     return IOC_OK;
 }
 

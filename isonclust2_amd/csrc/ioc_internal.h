@@ -98,6 +98,11 @@ struct ioc_ctx {
     bool res_pool_ready = false;  // a_pool holds exactly res_seq
     size_t aln_lds_max = 0, aln_lds_max2 = 0;  // dynamic LDS a k_align_fwd<true/false> workgroup may reserve (residency cap)
 
+    // ---- ioc_index_export result of the current resolve ----
+    bool exp_valid = false;
+    std::vector<uint32_t> exp_keys, exp_post;
+    std::vector<int64_t> exp_offs;
+
     // ---- instrumentation ----
     hipEvent_t ev[6]{};
     ioc_timings tm{};
