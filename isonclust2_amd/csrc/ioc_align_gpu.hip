@@ -396,7 +396,7 @@ static_assert(TILE == 128 || TILE == 256, "tile edge");
 constexpr int TR_C = TILE / 64;  // columns per lane in the traceback tile (one wave per pair)
 
 struct AlnCk {  // where a pair's checkpoints live in the arena, in int2 units
-    uint64_t row_off;  // [(n - 1) / TILE][row_pitch(m)]  (H, F) of rows TILE, 2 TILE, ...   (DP row index, 1-based)
+    uint64_t row_off;  // [(n - 1) / TILE][2][row_pitch(m)] ints: the Hq plane, then the F* plane, of rows TILE, 2 TILE, ...
     uint64_t col_off;  // [(m - 1) / TILE][col_pitch(n)]  (H, E) of columns TILE, 2 TILE, ...
 };
 
@@ -581,14 +581,15 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 }
                 dg = base;
             } else {
-                const int2* ro = rowck + uint64_t(r_lo / TILE - 1) * row_pitch(m);
+                const int* roh = reinterpret_cast<const int*>(rowck + uint64_t(r_lo / TILE - 1) * row_pitch(m));
+                const int* rof = roh + row_pitch(m);
 #pragma unroll
                 for (int c = 0; c < FW_C; ++c) {  // row checkpoints hold the slanted (Hq, F*)
-                    const int2 v = (jb + c < m) ? ro[jb + c] : int2{0, 0};
+                    const int2 v = (jb + c < m) ? int2{roh[jb + c], rof[jb + c]} : int2{0, 0};
                     Hp[c] = v.x;
                     F[c] = v.y;
                 }
-                dg = (jb > 0 && jb <= m) ? ro[jb - 1].x : K.ge * int(r_lo) - K.gd;  // column 0 holds H = 0
+                dg = (jb > 0 && jb <= m) ? roh[jb - 1] : K.ge * int(r_lo) - K.gd;  // column 0 holds H = 0
             }
             const bool has_cols = jb < m;
             const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
@@ -737,9 +738,15 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                     const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
                     if ((i1 % TILE) == 0 && i1 < n) {
                         const uint32_t jbo = opaque(jb);
-                        int4* ro = reinterpret_cast<int4*>(rowck + uint64_t(i1 / TILE - 1) * row_pitch(m) + jbo);
+                        // two planes (Hq, F*): each lane's 16 values go out as they sit in its registers
+                        int* rb = reinterpret_cast<int*>(rowck + uint64_t(i1 / TILE - 1) * row_pitch(m)) + jbo;
+                        int4* roh = reinterpret_cast<int4*>(rb);
+                        int4* rof = reinterpret_cast<int4*>(rb + row_pitch(m));
 #pragma unroll
-                        for (int c = 0; c < FW_C; c += 2) ro[c / 2] = int4{Hp[c], F[c], Hp[c + 1], F[c + 1]};
+                        for (int c = 0; c < FW_C; c += 4) {
+                            roh[c / 4] = int4{Hp[c], Hp[c + 1], Hp[c + 2], Hp[c + 3]};
+                            rof[c / 4] = int4{F[c], F[c + 1], F[c + 2], F[c + 3]};
+                        }
                     }
                 }
             }
@@ -874,19 +881,20 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 F[c] = ALN_NEG;
             }
         } else {
-            const int2* ro = rowck + uint64_t(r0 / TILE - 1) * row_pitch(m);
+            const int* roh = reinterpret_cast<const int*>(rowck + uint64_t(r0 / TILE - 1) * row_pitch(m));
+            const int* rof = roh + row_pitch(m);
 #pragma unroll
             for (int c = 0; c < TR_C; ++c) {
                 int2 v{0, ALN_NEG};
                 if (jb + c < m) {
-                    v = ro[jb + c];
+                    v = int2{roh[jb + c], rof[jb + c]};
                     const int sl = P.gap_extend * int(r0 + jb + c + 1);
                     v = int2{v.x + (go - P.gap_extend) - sl, v.y - sl};
                 }
                 Hp[c] = v.x;
                 F[c] = v.y;
             }
-            if (jb > 0 && jb <= m) dg = ro[jb - 1].x + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);  // H(r0, jb); column 0 holds 0
+            if (jb > 0 && jb <= m) dg = roh[jb - 1] + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);  // H(r0, jb); column 0 holds 0
         }
         __syncthreads();
         const uint32_t nact = (cols + TR_C - 1) / TR_C;
