@@ -151,3 +151,41 @@ def test_carry_variant(ctx, monkeypatch):
     pairs = [(i, (i + 3) % 8, i % 2, rng.choice([0.02, 0.2, 0.95])) for i in range(8)] + [(8, 0, 0, 0.2), (9, 10, 0, 0.2), (10, 1, 1, 0.2)]
     for k in (5, 11, 32):
         _check(ctx, seqs, pairs, k)
+
+
+def test_full_length_pairs_two_device_formulations_agree(ctx, monkeypatch):
+    """BASELINE-size sequences (config 2/3: 16.7 kb reads, the pairs the sahlin fallback really aligns) are too
+    slow for the host aligner in a test (~1 s per pair): the two independent device formulations — score-only
+    DP + checkpoints + tiled traceback vs window statistics carried through every DP state — must agree on
+    score and window count for every pair, same-transcript and unrelated, forward and reverse-complemented;
+    a handful of the pairs is also checked against the host aligner."""
+    from isonclust2_amd import synth
+    rs = synth.generate_config("config2", seed=1)
+    rng = random.Random(41)
+    ids = rng.sample(range(rs.n), 240)
+    seqs = [bytes(rs.read(i)[0]) for i in ids]
+    pairs = []
+    for t in range(0, 240, 2):
+        pairs.append((t, t + 1, t % 4 == 0, 0.05 + 0.2 * rng.random()))          # random partner: mostly unrelated
+    tr = {}
+    for x, i in enumerate(ids):
+        tr.setdefault(int(rs.transcript[i]), []).append(x)                         # ground truth of the generator
+    same = [v for v in tr.values() if len(v) >= 2][:60]
+    for v in same:   # same transcript: one of the two orientations is the real overlap
+        pairs.append((v[0], v[1], 0, 0.2))
+        pairs.append((v[0], v[1], 1, 0.2))
+    ctx.align_set_pool(seqs)
+    s1, w1, _ = ctx.align_pairs(pairs, 11)
+    monkeypatch.setenv("IOC_ALIGN_VARIANT", "carry")
+    s2, w2, _ = ctx.align_pairs(pairs, 11)
+    monkeypatch.delenv("IOC_ALIGN_VARIANT")
+    monkeypatch.setenv("IOC_ALIGN_NO_PROFILE", "1")
+    s3, w3, _ = ctx.align_pairs(pairs, 11)
+    assert np.array_equal(s1, s2) and np.array_equal(w1, w2)
+    assert np.array_equal(s1, s3) and np.array_equal(w1, w3)
+    assert len(set(int(x) for x in w1)) > 20          # not a degenerate comparison
+    L = _lib.load()
+    for i in (0, len(pairs) - 1, len(pairs) - 2):
+        qi, ri, rc, e = pairs[i]
+        hs, hr = _host(L, seqs[qi], seqs[ri], rc, e, 11)
+        assert s1[i] == hs and w1[i] / len(seqs[qi]) == hr
