@@ -301,6 +301,8 @@ typedef struct {
     int32_t aln_rounds;      /* verdict rounds of the alignment fallback driver */
     int64_t n_aln_pairs;     /* (read, candidate, strand) pairs actually aligned */
     int64_t n_aln_order_dep; /* verdicts that depended on the reference's candidate order */
+    int64_t n_cons_invoked;  /* representatives replaced by a consensus (CONS_INVOKED, cluster.cpp:22,295) */
+    int64_t n_cons_restarts; /* device passes of ioc_cluster_consensus (one + one per consensus event) */
 } ioc_cluster_stats;
 
 /* Initial clustering of one sorted batch (`cluster -l batch.cer`, src/main.cpp:262-275):
@@ -317,6 +319,52 @@ int ioc_cluster_batch(ioc_ctx* ctx, const ioc_params* p, const char* table_path,
 int ioc_cluster_merge(ioc_ctx* ctx, const ioc_params* p, const char* table_path, const ioc_left_view* left,
                       const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
                       ioc_cluster_stats* stats);
+/* ---- consensus mode (ConsMaxSize > 0; src/cluster.cpp:200-204, 263-309, src/consensus.cpp) -------------------- */
+/* The partial-order graphs of the consensus (spoa in the reference) stay with the caller, behind the operations
+ * the reference performs on them.  side 0 = leftBatch->ConsGs[idx] (idx = left cluster id), side 1 =
+ * rightBatch->ConsGs[idx] (idx = right entry; merges).  Every callback returns >= 0, or < 0 to abort. */
+typedef struct {
+    const char* raw_seq;      /* the consensus = new RawSeq->Str() of the representative (consensus.cpp:93) */
+    int32_t raw_len;
+    char raw_qual;            /* every quality character of it (consensus.cpp:98-100) */
+    double raw_err;           /* RawSeq->ErrorRate(): weighted mean (consensus.cpp:60-62) */
+    double raw_score;         /* RawSeq->Score() = raw_err * length (consensus.cpp:96) */
+    const char* hpc_seq;      /* HomopolymerCompress of the consensus */
+    int32_t hpc_len;
+    double hpc_err;           /* HpcSeq->ErrorRate(): weighted mean (consensus.cpp:56-58, 121) */
+    const uint32_t* fwd_min;  /* Mins (Index = ordinal), consensus.cpp:123 */
+    const uint32_t* fwd_pos;
+    int32_t n_fwd;
+    const uint32_t* rev_min;  /* RevMins, consensus.cpp:124 */
+    const uint32_t* rev_pos;
+    int32_t n_rev;
+    int32_t entry;            /* right entry whose join triggered it (the name is cons_<BatchNr>_<entry>, cluster.cpp:280-282) */
+} ioc_rep_record;
+typedef struct {
+    void* user;
+    int (*create)(void* user, int side, int idx, const char* seq, int len);                 /* new graph + AddSeqToGraph(seq, 1), cluster.cpp:200-204 */
+    int (*size)(void* user, int side, int idx);                                             /* sequences().size(); < 0: no such graph */
+    int (*add)(void* user, int side, int idx, const char* seq, int len, unsigned weight);   /* AddSeqToGraph, consensus.cpp:76-81 */
+    int (*consensus)(void* user, int side, int idx, char* out, int cap);                    /* GenerateConsensus -> length, consensus.cpp:87 */
+    int (*purge)(void* user, int side, int idx, const char* seq, int len, unsigned weight); /* ConsPurge, consensus.cpp:128-137 */
+    void (*rep_changed)(void* user, int32_t cls, const ioc_rep_record* rec);                /* optional: the pointers die with the call */
+} ioc_consensus_ops;
+typedef struct {
+    int32_t cons_min_size;      /* CmdArgs::ConsMinSize */
+    int32_t cons_max_size;      /* CmdArgs::ConsMaxSize; <= 0: no consensus (graphs are still created, as in the reference) */
+    int32_t cons_period;        /* CmdArgs::ConsPeriod */
+    int32_t left_depth;         /* leftBatch->Depth on entry: -1 for a freshly sorted batch (qualscore.cpp:102) */
+    const int32_t* left_sizes;  /* cls[c]->size() of the left clusters (ConsPeriod test, cluster.cpp:267-271); NULL = 2 each */
+} ioc_consensus_args;
+/* ClusterSortedReads with the consensus branch: same inputs and outputs as ioc_cluster_merge (left host MinDB
+ * required, right raw sequences required).  The device pipeline runs over all remaining entries; the host
+ * walks the decisions in the reference's order up to the first join that replaces a representative
+ * (UpdateClusterConsensus), re-minimizes the consensus on the GPU, applies UpdateMinDB and resumes behind that
+ * entry.  ioc_index_export afterwards returns the final MinDB (emptied lists included, minimizer.cpp:150-152). */
+int ioc_cluster_consensus(ioc_ctx* ctx, const ioc_params* p, const char* table_path, const ioc_left_view* left,
+                          const ioc_batch_view* right, const ioc_consensus_args* args, const ioc_consensus_ops* ops,
+                          int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);
+
 /* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries
  * must all be clusterable.  Fast mode, or sahlin mode after ioc_resident_set_sequences. */
 int ioc_cluster_resident(ioc_ctx* ctx, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);

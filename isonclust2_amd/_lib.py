@@ -46,10 +46,36 @@ class ClusterStats(C.Structure):
     _fields_ = [("n_clusters", C.c_int64), ("n_joined", C.c_int64), ("n_gated", C.c_int64),
                 ("n_tie_replays", C.c_int64), ("n_aln_invoked", C.c_int64),
                 ("resolve_iters", C.c_int32), ("aln_rounds", C.c_int32), ("n_aln_pairs", C.c_int64),
-                ("n_aln_order_dep", C.c_int64)]
+                ("n_aln_order_dep", C.c_int64), ("n_cons_invoked", C.c_int64), ("n_cons_restarts", C.c_int64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class RepRecord(C.Structure):  # ioc_rep_record
+    _fields_ = [("raw_seq", C.POINTER(C.c_char)), ("raw_len", C.c_int32), ("raw_qual", C.c_char), ("raw_err", C.c_double),
+                ("raw_score", C.c_double), ("hpc_seq", C.POINTER(C.c_char)), ("hpc_len", C.c_int32), ("hpc_err", C.c_double),
+                ("fwd_min", C.POINTER(C.c_uint32)), ("fwd_pos", C.POINTER(C.c_uint32)), ("n_fwd", C.c_int32),
+                ("rev_min", C.POINTER(C.c_uint32)), ("rev_pos", C.POINTER(C.c_uint32)), ("n_rev", C.c_int32),
+                ("entry", C.c_int32)]
+
+
+CONS_CREATE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+CONS_SIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+CONS_ADD = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int, C.c_uint)
+CONS_CONSENSUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+CONS_PURGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int, C.c_uint)
+CONS_REP_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(RepRecord))
+
+
+class ConsensusOps(C.Structure):  # ioc_consensus_ops (the oracle's orc_cons_ops is its first six members)
+    _fields_ = [("user", C.c_void_p), ("create", CONS_CREATE), ("size", CONS_SIZE), ("add", CONS_ADD),
+                ("consensus", CONS_CONSENSUS), ("purge", CONS_PURGE), ("rep_changed", CONS_REP_CHANGED)]
+
+
+class ConsensusArgs(C.Structure):  # ioc_consensus_args
+    _fields_ = [("cons_min_size", C.c_int32), ("cons_max_size", C.c_int32), ("cons_period", C.c_int32),
+                ("left_depth", C.c_int32), ("left_sizes", C.POINTER(C.c_int32))]
 
 
 class AlnPair(C.Structure):  # ioc_aln_pair
@@ -79,7 +105,7 @@ SYMBOLS = [
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
     "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
-    "ioc_index_update", "ioc_left_export",
+    "ioc_index_update", "ioc_left_export", "ioc_cluster_consensus",
 ]
 
 _lib = None
@@ -141,6 +167,8 @@ def load():
                                     C.POINTER(ClusterStats)]
     L.ioc_cluster_merge.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(LeftView), C.POINTER(BatchView),
                                     pi32, pi8, C.POINTER(ClusterStats)]
+    L.ioc_cluster_consensus.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(LeftView), C.POINTER(BatchView),
+                                        C.POINTER(ConsensusArgs), C.POINTER(ConsensusOps), pi32, pi8, C.POINTER(ClusterStats)]
     L.ioc_host_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, C.c_char_p, i32, pi32]
     L.ioc_host_gap_open.argtypes = [C.c_double]
     L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]

@@ -240,7 +240,7 @@ class Context:
         hpc_err, state, min_qual (the fields of ioc_batch_view).  Returns (cls, strand, stats)."""
         return self.cluster_merge(params, None, batch, table)
 
-    def cluster_merge(self, params: Params, left, batch: dict, table=_lib.TABLE_PATH):
+    def _merge_call(self, params: Params, left, batch: dict, table, cons=None):
         """ClusterSortedReads(left, right).  left: None (initial clustering) or dict with cls_hpc_err,
         keys, offs, postings (the left clusters' representative error rates + MinDB as CSR).
         batch: the right batch (ioc_batch_view fields; for a clustered right batch one record per
@@ -296,12 +296,27 @@ class Context:
                           cls_raw_err=_p(lerr, C.c_double) if lerr is not None else None)
         cls, strand = np.zeros(n, np.int32), np.zeros(n, np.int8)
         st = ClusterStats()
-        self._chk(self.L.ioc_cluster_merge(self.h, C.byref(params), table.encode(),
-                                           C.byref(lv) if lv is not None else None, C.byref(v),
-                                           _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
+        if cons is None:
+            self._chk(self.L.ioc_cluster_merge(self.h, C.byref(params), table.encode(),
+                                               C.byref(lv) if lv is not None else None, C.byref(v),
+                                               _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
+        else:
+            cargs, ops = cons
+            self._chk(self.L.ioc_cluster_consensus(self.h, C.byref(params), table.encode(),
+                                                   C.byref(lv) if lv is not None else None, C.byref(v), C.byref(cargs),
+                                                   C.byref(ops), _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
         self.n = n
         self.params = params
         return cls, strand, st.as_dict()
+
+    def cluster_merge(self, params: Params, left, batch: dict, table=_lib.TABLE_PATH):
+        """ClusterSortedReads(left, right), consensus off (see _merge_call for the views)."""
+        return self._merge_call(params, left, batch, table)
+
+    def cluster_consensus(self, params: Params, left, batch: dict, cons_args, ops, table=_lib.TABLE_PATH):
+        """ClusterSortedReads with the consensus branch (ioc_cluster_consensus): cons_args = _lib.ConsensusArgs,
+        ops = _lib.ConsensusOps (the caller's graph store); batch needs raw_seq / raw_off."""
+        return self._merge_call(params, left, batch, table, cons=(cons_args, ops))
 
     def cluster_resident(self):
         n = self.n

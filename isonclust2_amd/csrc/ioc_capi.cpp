@@ -655,7 +655,14 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     // against actual clusters only.  The result is the fixed point of the exact sweeps either way.
     int first = 0, iters = 0, sweeps = 0;
     a.lazy = env_u32("IOC_RESOLVE_LAZY", 1) == 1 ? 1 : 0;
-    while (first < n) {
+    while (n > 0) {
+        if (first >= n) {
+            // every query up to the last one is final for THIS stage: a lazy stage that ends on a change of the
+            // last query still owes the exact sweeps (decisions of provisional cluster openers are not final)
+            if (!a.lazy) break;
+            a.lazy = 0;
+            first = 0;
+        }
         uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
         uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};

@@ -1,0 +1,336 @@
+// ioc_consensus.cpp — ClusterSortedReads with the consensus branch on (src/cluster.cpp:200-204, 263-309;
+// src/consensus.cpp:34-137): SURVEY.md §8 f4.
+//
+// With ConsMaxSize > 0 a cluster's representative is REPLACED by a consensus after (almost) every join once its
+// graph holds ConsMinSize sequences, which breaks the decision-independence the parallel resolve rests on
+//  — but only at those events.  The driver therefore speculates: the device pipeline
+// (index build, scoring, resolve, alignment fallback) runs over ALL remaining entries against the current
+// left state; the host walks the decisions in the reference's order, doing its bookkeeping, until the first
+// join that replaces a representative; decisions up to there are final, everything after is recomputed
+// against the updated state.  The representative's new minimizers come from the GPU extractor (K1), the
+// index edit is UpdateMinDB.
+//
+// spoa is absent from the reference tree: the partial-order graphs stay on the caller's side, behind the five
+// operations the reference performs on them (ioc_consensus_ops), the way parasail can stay behind
+// ioc_get_ties / ioc_set_aln_verdicts.  Nothing here links the oracle; without a device every call fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ioc_internal.h"
+
+namespace {
+
+struct ClState {
+    double raw_err = 0, hpc_err = 0;
+    int64_t size = 0;                // cls[c]->size(): representative copy + members
+    std::vector<uint32_t> vals;      // sorted distinct forward minimizer values of the representative
+    std::string raw;                 // representative's raw sequence (alignment fallback / ConsPurge)
+    bool have_raw = false;
+};
+
+void sorted_unique(std::vector<uint32_t>& v)
+{
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+}  // namespace
+
+extern "C" {
+
+int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_left_view* left,
+                          const ioc_batch_view* rb, const ioc_consensus_args* ca, const ioc_consensus_ops* ops,
+                          int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+{
+    if (!c || !p || !table_path || !rb || !ca || !ops || !out_cls || !out_strand) return IOC_ERR_ARG;
+    if (!ops->create || !ops->size || !ops->add || !ops->consensus || !ops->purge)
+        return ioc_fail(c, IOC_ERR_ARG, "consensus needs all five graph operations");
+    const int n = rb->n;
+    if (n < 0) return ioc_fail(c, IOC_ERR_ARG, "negative batch size");
+    if (!rb->raw_seq || !rb->raw_off)
+        return ioc_fail(c, IOC_ERR_ARG, "consensus needs the raw sequences of the right batch (graph seeds and additions)");
+    const bool aln_mode = p->mode == IOC_MODE_SAHLIN || p->mode == IOC_MODE_FURIOUS;
+    const int32_t L0 = left ? left->n_clusters : 0;
+    if (left && left->n_keys < 0) return ioc_fail(c, IOC_ERR_ARG, "consensus takes the left MinDB as host arrays");
+    if (aln_mode && L0 > 0 && (!left->rep_seq || !left->rep_off || !left->cls_raw_err))
+        return ioc_fail(c, IOC_ERR_ARG, "sahlin/furious need the left representatives' sequences");
+
+    // ---- left state on the host: MinDB as an ordered map, one ClState per cluster ----
+    std::map<uint32_t, std::vector<uint32_t>> db;
+    std::vector<ClState> cl(static_cast<size_t>(L0));
+    for (int32_t t = 0; t < L0; ++t) {
+        cl[size_t(t)].hpc_err = left->cls_hpc_err[t];
+        cl[size_t(t)].raw_err = left->cls_raw_err ? left->cls_raw_err[t] : 0.0;
+        cl[size_t(t)].size = ca->left_sizes ? ca->left_sizes[t] : 2;
+        if (left->rep_seq && left->rep_off) {
+            cl[size_t(t)].raw.assign(left->rep_seq + left->rep_off[t], size_t(left->rep_off[t + 1] - left->rep_off[t]));
+            cl[size_t(t)].have_raw = true;
+        }
+    }
+    if (left)
+        for (int64_t i = 0; i < left->n_keys; ++i) {
+            auto& v = db[left->keys[i]];
+            v.assign(left->postings + left->offs[i], left->postings + left->offs[i + 1]);
+            for (uint32_t t : v) {
+                if (t >= uint32_t(L0)) return ioc_fail(c, IOC_ERR_ARG, "left posting >= n_clusters");
+                cl[t].vals.push_back(left->keys[i]);  // keys ascending -> vals come out sorted
+            }
+        }
+
+    // layout of the right batch's minimizer lists: the usual "all forward lists, then all reverse lists" lets a
+    // suffix of the batch be handed over by pointer arithmetic
+    bool blocked = n > 0;
+    for (int i = 0; i < n && blocked; ++i)
+        blocked = rb->off_fwd[i] <= rb->off_fwd[i + 1] && rb->off_rev[i] <= rb->off_rev[i + 1];
+    blocked = blocked && n > 0 && rb->off_fwd[n] <= rb->off_rev[0];
+    if (n > 0 && !blocked)
+        return ioc_fail(c, IOC_ERR_ARG, "consensus driver: minimizer lists must be laid out forward block, then reverse block");
+
+    ioc_cluster_stats total{};
+    std::vector<int64_t> of, orv, roff;
+    std::vector<uint32_t> keys, post;
+    std::vector<int64_t> offs;
+    std::vector<double> herr, rerr;
+    std::string lseq;
+    std::vector<int64_t> loff;
+    std::vector<int32_t> sub_cls;
+    std::vector<int8_t> sub_strand;
+    const int k = p->k, w = p->w;
+    int pos = 0;
+    while (pos < n) {
+        const int m = n - pos;
+        // ---- left view of the current state ----
+        const int32_t Lc = int32_t(cl.size());
+        keys.clear();
+        offs.clear();
+        post.clear();
+        for (auto& kv : db) {
+            if (kv.second.empty()) continue;  // lists emptied by UpdateMinDB stay in the MinDB but match nothing
+            keys.push_back(kv.first);
+            offs.push_back(int64_t(post.size()));
+            post.insert(post.end(), kv.second.begin(), kv.second.end());
+        }
+        offs.push_back(int64_t(post.size()));
+        herr.resize(size_t(Lc));
+        rerr.resize(size_t(Lc));
+        for (int32_t t = 0; t < Lc; ++t) {
+            herr[size_t(t)] = cl[size_t(t)].hpc_err;
+            rerr[size_t(t)] = cl[size_t(t)].raw_err;
+        }
+        ioc_left_view lv{};
+        lv.n_clusters = Lc;
+        lv.cls_hpc_err = herr.data();
+        lv.n_keys = int64_t(keys.size());
+        lv.keys = keys.data();
+        lv.offs = offs.data();
+        lv.postings = post.data();
+        if (aln_mode) {
+            lseq.clear();
+            loff.assign(size_t(Lc) + 1, 0);
+            for (int32_t t = 0; t < Lc; ++t) {
+                if (!cl[size_t(t)].have_raw) return ioc_fail(c, IOC_ERR_STATE, "a representative's sequence is missing");
+                lseq += cl[size_t(t)].raw;
+                loff[size_t(t) + 1] = int64_t(lseq.size());
+            }
+            lv.rep_seq = lseq.data();
+            lv.rep_off = loff.data();
+            lv.cls_raw_err = rerr.data();
+        }
+        // ---- the remaining entries [pos, n) as a batch view ----
+        const int64_t base = rb->off_fwd[pos];
+        of.resize(size_t(m) + 1);
+        orv.resize(size_t(m) + 1);
+        roff.resize(size_t(m) + 1);
+        for (int i = 0; i <= m; ++i) {
+            of[size_t(i)] = rb->off_fwd[pos + i] - base;
+            orv[size_t(i)] = rb->off_rev[pos + i] - base;
+            roff[size_t(i)] = rb->raw_off[pos + i] - rb->raw_off[pos];
+        }
+        ioc_batch_view sv = *rb;
+        sv.n = m;
+        sv.off_fwd = of.data();
+        sv.off_rev = orv.data();
+        sv.min_val = rb->min_val + base;
+        sv.min_pos = rb->min_pos + base;
+        sv.total = rb->off_rev[n] - base;
+        sv.raw_len = rb->raw_len + pos;
+        sv.hpc_len = rb->hpc_len + pos;
+        sv.score = rb->score + pos;
+        sv.raw_err = rb->raw_err + pos;
+        sv.hpc_err = rb->hpc_err + pos;
+        sv.state = rb->state ? rb->state + pos : nullptr;
+        sv.raw_seq = rb->raw_seq + rb->raw_off[pos];
+        sv.raw_off = roff.data();
+        sv.n_members = rb->n_members ? rb->n_members + pos : nullptr;
+        sub_cls.assign(size_t(m) + 1, -1);
+        sub_strand.assign(size_t(m) + 1, 0);
+        ioc_cluster_stats st{};
+        int r = ioc_cluster_merge(c, p, table_path, Lc > 0 ? &lv : nullptr, &sv, sub_cls.data(), sub_strand.data(), &st);
+        if (r != IOC_OK) return r;
+        total.resolve_iters += st.resolve_iters;
+        total.n_tie_replays += st.n_tie_replays;
+        total.aln_rounds += st.aln_rounds;
+        total.n_aln_pairs += st.n_aln_pairs;
+        total.n_cons_restarts++;
+        if (getenv("IOC_TRACE")) fprintf(stderr, "[ioc] consensus pass from entry %d (%d left clusters)\n", pos, Lc);
+
+        // ---- walk the decisions in the reference's order until a representative changes ----
+        bool restarted = false;
+        for (int x = 0; x < m; ++x) {
+            const int i = pos + x;
+            const int32_t dc = sub_cls[size_t(x)];
+            if (dc < 0) {
+                out_cls[i] = -1;
+                out_strand[i] = 0;
+                total.n_gated++;
+                continue;
+            }
+            const char* rseq = rb->raw_seq + rb->raw_off[i];
+            const int rlen = int(rb->raw_off[i + 1] - rb->raw_off[i]);
+            const int64_t entry_size = rb->n_members ? int64_t(rb->n_members[i]) + 1 : 1;  // reads[i]->size()
+            if (dc == int32_t(cl.size())) {
+                // ---- opens a new cluster (cluster.cpp:177-222) ----
+                ClState ns;
+                ns.raw_err = rb->raw_err[i];
+                ns.hpc_err = rb->hpc_err[i];
+                ns.size = entry_size == 1 ? 2 : entry_size;  // a fresh read gets a representative copy in front
+                ns.vals.assign(rb->min_val + rb->off_fwd[i], rb->min_val + rb->off_fwd[i + 1]);
+                sorted_unique(ns.vals);
+                ns.raw.assign(rseq, size_t(rlen));
+                ns.have_raw = true;
+                // AddMinimizers (minimizer.cpp:31-42): the new id is larger than every id in the lists
+                for (uint32_t v : ns.vals) db[v].push_back(uint32_t(dc));
+                if (ops->create(ops->user, 0, dc, rseq, rlen) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: create failed");
+                cl.push_back(std::move(ns));
+                out_cls[i] = dc;
+                out_strand[i] = 1;
+                total.n_aln_invoked += 0;
+                continue;
+            }
+            if (dc > int32_t(cl.size())) return ioc_fail(c, IOC_ERR_STATE, "inconsistent cluster id from the device path");
+            // ---- joins cluster dc (cluster.cpp:223-309) ----
+            ClState& b = cl[size_t(dc)];
+            out_cls[i] = dc;
+            out_strand[i] = sub_strand[size_t(x)];
+            total.n_joined++;
+            b.size += entry_size > 1 ? entry_size - 1 : 1;
+            if (ca->cons_max_size <= 0) continue;
+            if (ca->left_depth == -1 && ca->cons_period > 0 && b.size > ca->cons_period) continue;   // :267-271
+            const int cons_min = ca->left_depth != -1 ? 2 : ca->cons_min_size;                         // :284-288
+            // UpdateClusterConsensus, consensus.cpp:34-126
+            const int left_size = ops->size(ops->user, 0, dc);
+            if (left_size < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: the cluster has no graph");
+            const int rsz = ops->size(ops->user, 1, i);
+            const bool have_right = rsz >= 0;
+            const int right_size = have_right ? rsz : 1;
+            const double hpc_err = (b.hpc_err * double(left_size) + rb->hpc_err[i] * double(right_size)) / double(left_size + right_size);
+            const double raw_err = (b.raw_err * double(left_size) + rb->raw_err[i] * double(right_size)) / double(left_size + right_size);
+            // (the reference reverse-complements a copy and throws it away, consensus.cpp:47-49: the read goes in as it is)
+            if (ops->add(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u) < 0)
+                return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: add failed");
+            if (ops->size(ops->user, 0, dc) < cons_min) continue;
+            std::vector<char> buf(size_t(1) << 22);
+            const int clen = ops->consensus(ops->user, 0, dc, buf.data(), int(buf.size()));
+            if (clen < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: consensus failed");
+            std::string cons(buf.data(), size_t(clen));
+            // the new representative: fixed quality character, HPC, minimizers (K1 on the GPU)
+            const char qraw = std::to_string(int(-10 * log10(raw_err)) + 33)[0];  // :98-99: first CHARACTER of the number
+            if (!(cons.size() > size_t(2 * k) || cons.size() >= size_t(w)))
+                return ioc_fail(c, IOC_ERR_INPUT, "consensus shorter than 2k and w (the reference re-minimizes an empty sequence here)");
+            const std::string qual(cons.size(), qraw);
+            const int64_t xoff[2] = {0, int64_t(cons.size())};
+            uint32_t hlen = 0;
+            double herr_k1 = 0;
+            int64_t xf[2] = {0, 0}, xr[2] = {0, 0};
+            int32_t xst = 0;
+            r = ioc_extract_minimizers(c, 1, xoff, reinterpret_cast<const uint8_t*>(cons.data()),
+                                       reinterpret_cast<const uint8_t*>(qual.data()), k, w, &hlen, &herr_k1, xf, xr, &xst);
+            if (r != IOC_OK) return r;
+            if (xst != 0)
+                return ioc_fail(c, IOC_ERR_INPUT, "consensus with a non-ACGT base or an HPC length below 2k / w");
+            const int64_t nmin = xr[1];
+            std::vector<uint32_t> mv(size_t(nmin) + 1), mp(size_t(nmin) + 1);
+            if ((r = ioc_extracted_download(c, mv.data(), mp.data(), nmin)) != IOC_OK) return r;
+            std::vector<char> hs(cons.size() + 1), hq(cons.size() + 1);
+            if ((r = ioc_extracted_hpc_download(c, hs.data(), hq.data(), int64_t(cons.size()))) != IOC_OK) return r;
+            // UpdateMinDB (minimizer.cpp:124-160) on the host MinDB
+            std::vector<uint32_t> nv(mv.begin() + xf[0], mv.begin() + xf[1]);
+            sorted_unique(nv);
+            {
+                std::vector<uint32_t> to_del, to_ins;
+                std::set_difference(b.vals.begin(), b.vals.end(), nv.begin(), nv.end(), std::back_inserter(to_del));
+                std::set_difference(nv.begin(), nv.end(), b.vals.begin(), b.vals.end(), std::back_inserter(to_ins));
+                for (uint32_t v : to_del) {
+                    auto& lst = db[v];
+                    std::vector<uint32_t> t2(lst);
+                    sorted_unique(t2);
+                    t2.erase(std::remove(t2.begin(), t2.end(), uint32_t(dc)), t2.end());
+                    lst.swap(t2);
+                }
+                for (uint32_t v : to_ins) {
+                    auto& lst = db[v];
+                    lst.push_back(uint32_t(dc));
+                    std::sort(lst.begin(), lst.end());
+                }
+            }
+            b.vals.swap(nv);
+            b.raw_err = raw_err;
+            b.hpc_err = hpc_err;  // consensus.cpp:121 — also when the 0.9999 branch (:112-117) fired
+            b.raw = cons;
+            b.have_raw = true;
+            total.n_cons_invoked++;
+            if (ops->rep_changed) {
+                ioc_rep_record rec{};
+                rec.raw_seq = cons.data();
+                rec.raw_len = int32_t(cons.size());
+                rec.raw_qual = qraw;
+                rec.raw_err = raw_err;
+                rec.raw_score = raw_err * double(cons.size());
+                rec.hpc_seq = hs.data();
+                rec.hpc_len = int32_t(hlen);
+                rec.hpc_err = hpc_err;
+                rec.fwd_min = mv.data() + xf[0];
+                rec.fwd_pos = mp.data() + xf[0];
+                rec.n_fwd = int32_t(xf[1] - xf[0]);
+                rec.rev_min = mv.data() + xr[0];
+                rec.rev_pos = mp.data() + xr[0];
+                rec.n_rev = int32_t(xr[1] - xr[0]);
+                rec.entry = i;
+                ops->rep_changed(ops->user, dc, &rec);
+            }
+            const int gsz = ops->size(ops->user, 0, dc);
+            if (gsz > ca->cons_max_size) {  // ConsPurge, consensus.cpp:128-137
+                if (ops->purge(ops->user, 0, dc, cons.data(), int(cons.size()), unsigned(gsz)) < 0)
+                    return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: purge failed");
+            }
+            // everything after entry i has to see the new representative
+            pos = i + 1;
+            restarted = true;
+            break;
+        }
+        if (!restarted) break;
+    }
+    // the final MinDB is what ioc_index_export returns
+    c->exp_keys.clear();
+    c->exp_offs.clear();
+    c->exp_post.clear();
+    for (auto& kv : db) {
+        c->exp_keys.push_back(kv.first);
+        c->exp_offs.push_back(int64_t(c->exp_post.size()));
+        c->exp_post.insert(c->exp_post.end(), kv.second.begin(), kv.second.end());
+    }
+    c->exp_offs.push_back(int64_t(c->exp_post.size()));
+    c->exp_valid = true;
+    c->resolved = true;
+    total.n_clusters = int64_t(cl.size());
+    if (stats) *stats = total;
+    return IOC_OK;
+}
+
+}  // extern "C"

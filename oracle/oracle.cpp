@@ -572,7 +572,75 @@ bool same_sort_args(const orc_params& a, const orc_params& b)
            a.mode == b.mode;
 }
 
-// ---- src/cluster.cpp:67-322 (consensus branch :263-309 not restated: ConsMaxSize <= 0) ------------------------------------------
+// ---- consensus (src/consensus.cpp, src/cluster.cpp:200-204, 263-309) --------------------------------------------------------
+// spoa is absent from /root/reference: the per-cluster partial-order graphs live behind a hook with exactly the
+// operations the reference performs on them (create + seed, sequences().size(), AddSeqToGraph, GenerateConsensus,
+// ConsPurge).  Everything around them — when a consensus is taken, the weighted error rates, the quirks of
+// UpdateClusterConsensus, the re-minimizing of the new representative, UpdateMinDB — is restated here.
+orc_cons_ops g_cons{};
+bool g_cons_set = false;
+int g_cons_min_size = 50, g_cons_period = 500;  // CmdArgs defaults, src/args.h:18-20
+
+// src/consensus.cpp:34-126.  Returns 1 if the representative was replaced, 0 if not, < 0 on hook errors.
+int update_cluster_consensus(const std::string& consName, Cluster& cl, int best, int rightEntry, const std::string& readSeq,
+                             double readRawErr, double readHpcErr, int matchStrand, int consMinSize, int k, int w)
+{
+    const int leftSize = g_cons.size(g_cons.user, 0, best);                          // :41
+    if (leftSize < 0) return -30;
+    int rightSize = 1;                                                              // :42-43
+    std::string rs = readSeq;
+    if (matchStrand == -1) {
+        std::string dropped;
+        revcomp(rs, dropped);  // :47-49: RevComp(rs) returns a new string that is discarded — rs stays as it is
+    }
+    const int rsz = g_cons.size(g_cons.user, 1, rightEntry);
+    const bool haveRight = rsz >= 0;
+    if (haveRight) rightSize = rsz;                                                 // :51-53
+    ProcSeq* clsRep = cl.at(0).get();
+    const double hpcErr = (clsRep->Hpc->err * double(leftSize) + readHpcErr * double(rightSize)) / double(leftSize + rightSize);
+    const double rawErr = (clsRep->Raw->err * double(leftSize) + readRawErr * double(rightSize)) / double(leftSize + rightSize);
+    if (g_cons.add(g_cons.user, 0, best, rs.data(), int(rs.size()), haveRight ? unsigned(rightSize) : 1u) < 0) return -31;  // :76-81
+    if (g_cons.size(g_cons.user, 0, best) < consMinSize) return 0;                  // :83-85
+    std::string cons;
+    {
+        std::vector<char> buf(size_t(1) << 22);
+        int n = g_cons.consensus(g_cons.user, 0, best, buf.data(), int(buf.size()));
+        if (n < 0) return -32;
+        cons.assign(buf.data(), size_t(n));
+    }
+    auto& rep = cl[0];
+    rep->Raw->seq = cons;                                                           // :93-97
+    rep->Raw->name = consName;
+    rep->Raw->err = rawErr;
+    rep->Raw->score = rawErr * double(cons.length());
+    const char fixedQualRaw = std::to_string(int(-10 * log10(rawErr)) + 33)[0];     // :98-99: first CHARACTER of the number
+    rep->Raw->qual = std::string(cons.length(), fixedQualRaw);
+    std::unique_ptr<Seq> hpcSeq(new Seq);
+    if (cons.length() > unsigned(2 * k) || cons.length() >= unsigned(w)) {          // :104-118
+        hpcSeq->name = rep->Raw->name;
+        hpc(rep->Raw->seq, rep->Raw->qual, hpcSeq->seq, hpcSeq->qual);
+        hpcSeq->err = hpcErr;
+        hpcSeq->score = hpcErr * double(hpcSeq->seq.length());
+        if (hpcSeq->seq.length() < unsigned(2 * k) || hpcSeq->seq.length() < unsigned(w)) {
+            hpcSeq->score = -1.0;
+            rep->Raw->score = -1.0;
+            rep->Raw->err = 0.9999;
+            hpcSeq->err = 0.9999;
+        }
+    }
+    if (hpcSeq->seq.length() <= unsigned(w - k)) return -33;  // GetKmerMinimizers would read past its input
+    auto kmerSeq = kmer_encode(hpcSeq->seq, unsigned(k));                            // :119-120
+    std::string rc;
+    if (!revcomp(hpcSeq->seq, rc)) return -34;
+    auto revKmerSeq = kmer_encode(rc, unsigned(k));
+    hpcSeq->err = hpcErr;                                                           // :121
+    rep->Hpc = std::move(hpcSeq);
+    rep->Mins = minimizers(kmerSeq, k, w);                                          // :123-124
+    rep->RevMins = minimizers(revKmerSeq, k, w);
+    return 1;
+}
+
+// ---- src/cluster.cpp:67-322 ------------------------------------------------------------------------------------------------
 int cluster_sorted_reads(Batch& left, Batch& right, const char* binpath, orc_stats* st)
 {
     if (!same_sort_args(left.Args, right.Args)) return -10;
@@ -581,7 +649,8 @@ int cluster_sorted_reads(Batch& left, Batch& right, const char* binpath, orc_sta
     if (left.Depth > 0 && right.Depth > left.Depth) return -12;
     if (left.Db.size() == 0) left.Db = MinDB(1000000, IdHash());
     right.Db = MinDB(0, IdHash());
-    if (args.cons_max_size > 0) return -13;  // consensus is outside the oracle
+    const int consMaxSize = args.cons_max_size;
+    if (consMaxSize > 0 && !g_cons_set) return -13;  // consensus needs the graph hook (orc_set_consensus)
     auto& cls = left.Cls;
     auto& reads = right.Cls;
     PTab tab;
@@ -633,12 +702,18 @@ int cluster_sorted_reads(Batch& left, Batch& right, const char* binpath, orc_sta
                 n->Hpc->name = nm;
                 reads[i]->insert(reads[i]->begin(), 1, n);
             }
+            if (g_cons_set) {  // cluster.cpp:200-204: a graph seeded with the representative, whatever ConsMaxSize is
+                const std::string& rseq = reads[i]->at(0)->Raw->seq;
+                if (g_cons.create(g_cons.user, 0, int(newId), rseq.data(), int(rseq.size())) < 0) return -35;
+            }
             cls.emplace_back(reads[i]);
             if (nr == 1 && cls[newId]->size() != 2) return -16;
             left.NrCls++;
             if (st) st->new_clusters++;
         } else {
             auto startIt = reads[i]->begin();
+            const std::string readSeq = (*startIt)->Raw->seq;  // cluster.cpp:172-175: taken before the members are cleared
+            const double readRawErr = (*startIt)->Raw->err, readHpcErr = (*startIt)->Hpc->err;
             for (unsigned j = 0; j < reads[i]->size(); j++) {
                 auto& s = reads[i]->at(j);
                 if (s == nullptr) return -17;
@@ -656,6 +731,25 @@ int cluster_sorted_reads(Batch& left, Batch& right, const char* binpath, orc_sta
             if (reads[i]->size() > 1) startIt++;
             std::move(startIt, std::end(*(reads[i])), std::back_inserter(*(cls[size_t(best)])));
             if (st) st->joins++;
+            // ---- consensus branch, cluster.cpp:263-309 ----
+            if (consMaxSize <= 0) continue;
+            if ((left.Depth == -1) && (g_cons_period > 0) && (int(cls[size_t(best)]->size()) > g_cons_period)) continue;
+            const std::string consName = "cons_" + std::to_string(left.BatchNr) + "_" + std::to_string(i);
+            const MzVec oldMins = cls.at(size_t(best))->at(0)->Mins;
+            int consMinSize = g_cons_min_size;
+            if (left.Depth != -1) consMinSize = 2;  // FIXME of the reference, :286-288
+            const int ok = update_cluster_consensus(consName, *(cls[size_t(best)]), best, int(i), readSeq, readRawErr, readHpcErr,
+                                                    st_match.second, consMinSize, args.k, args.w);
+            if (ok < 0) return ok;
+            if (ok) {
+                if (st) st->cons_invoked++;
+                update_mindb(unsigned(best), oldMins, cls[size_t(best)]->at(0)->Mins, left.Db);
+            }
+            if (ok && g_cons.size(g_cons.user, 0, best) > consMaxSize) {  // ConsPurge, consensus.cpp:128-137
+                const std::string& repSeq = cls[size_t(best)]->at(0)->Raw->seq;
+                const int wgt = g_cons.size(g_cons.user, 0, best);
+                if (g_cons.purge(g_cons.user, 0, best, repSeq.data(), int(repSeq.size()), unsigned(wgt)) < 0) return -36;
+            }
         }
     }
     left.Depth++;
@@ -670,6 +764,14 @@ int cluster_sorted_reads(Batch& left, Batch& right, const char* binpath, orc_sta
 extern "C" {
 
 void orc_set_aligner(void* fn) { g_aligner = reinterpret_cast<aligner_fn>(fn); }
+
+void orc_set_consensus(const orc_cons_ops* ops, int cons_min_size, int cons_period)
+{
+    g_cons_set = ops != nullptr;
+    if (ops) g_cons = *ops;
+    g_cons_min_size = cons_min_size;
+    g_cons_period = cons_period;
+}
 
 int orc_hpc(const char* seq, const char* qual, int n, char* oseq, char* oqual)
 {

@@ -43,7 +43,22 @@ typedef struct {
     uint64_t index_appends;  /* postings appended by AddMinimizers */
     uint64_t aln_invoked;
     uint64_t tie_reads;      /* queries with >=2 passing candidates tied at the winning Size */
+    uint64_t cons_invoked;   /* CONS_INVOKED, cluster.cpp:22,295 */
 } orc_stats;
+
+/* The partial-order graphs of the consensus (spoa, absent from the reference tree) behind the operations the
+ * reference performs on them.  side 0 = leftBatch->ConsGs[idx] (idx = left cluster id), side 1 =
+ * rightBatch->ConsGs[idx] (idx = right entry).  size: sequences().size(), < 0 if there is no such graph. */
+typedef struct {
+    void* user;
+    int (*create)(void* user, int side, int idx, const char* seq, int len);                 /* new graph + AddSeqToGraph(seq, 1) */
+    int (*size)(void* user, int side, int idx);
+    int (*add)(void* user, int side, int idx, const char* seq, int len, unsigned weight);   /* AddSeqToGraph */
+    int (*consensus)(void* user, int side, int idx, char* out, int cap);                    /* GenerateConsensus -> length */
+    int (*purge)(void* user, int side, int idx, const char* seq, int len, unsigned weight); /* ConsPurge */
+} orc_cons_ops;
+/* ops == NULL switches the hook off; cons_min_size / cons_period = CmdArgs::ConsMinSize / ConsPeriod */
+void orc_set_consensus(const orc_cons_ops* ops, int cons_min_size, int cons_period);
 
 /* ---- primitives ---------------------------------------------------------------- */
 int orc_hpc(const char* seq, const char* qual, int n, char* oseq, char* oqual);

@@ -24,7 +24,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("probes", "postings", "mapped_calls", "queries",
                                           "new_clusters", "joins", "index_appends", "aln_invoked",
-                                          "tie_reads")]
+                                          "tie_reads", "cons_invoked")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -98,6 +98,8 @@ def lib():
     L.orc_batch_index.restype = C.c_int64
     L.orc_set_aligner.argtypes = [vp]
     L.orc_batch_update_mindb.argtypes = [vp, C.c_int, u32p, C.c_int64, u32p, C.c_int64, C.c_int]
+    L.orc_set_consensus.argtypes = [vp, C.c_int, C.c_int]
+    L.orc_set_consensus.restype = None
     _lib = L
     return L
 

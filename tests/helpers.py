@@ -36,3 +36,71 @@ def fnv1a(cls, strand):
             h ^= b
             h = (h * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+class ToyGraphs:
+    """A stand-in for the per-cluster spoa graphs of the consensus (spoa is absent from the reference tree):
+    the same five operations, deterministic and cheap — a "graph" is the list of (sequence, weight) it was fed,
+    its consensus the heaviest sequence (ties: the latest), truncated by one base per call so that the
+    representative really changes.  The SAME store semantics serve the oracle (orc_set_consensus) and the
+    product (ioc_cluster_consensus): what the tests pin is everything AROUND the graphs."""
+
+    def __init__(self, right_sizes=None):
+        import ctypes as C
+        from isonclust2_amd import _lib
+        self.g = {0: {}, 1: {}}
+        self.calls = 0
+        self.rep_events = []
+        self.log = []          # (operation, side, idx, sequence length / weight): compared between the two sides
+        for i, s in (right_sizes or {}).items():
+            self.g[1][i] = [(b"", 1)] * s
+        self._C = C
+
+        def create(user, side, idx, seq, n):
+            self.g[side][idx] = [(C.string_at(seq, n), 1)]
+            self.log.append(("create", side, idx, n))
+            return 0
+
+        def size(user, side, idx):
+            return len(self.g[side][idx]) if idx in self.g[side] else -1
+
+        def add(user, side, idx, seq, n, weight):
+            if idx not in self.g[side]:
+                return -1
+            self.g[side][idx].append((C.string_at(seq, n), int(weight)))
+            self.log.append(("add", side, idx, n, int(weight)))
+            return 0
+
+        def consensus(user, side, idx, out, cap):
+            self.calls += 1
+            items = self.g[side][idx]
+            best = max(range(len(items)), key=lambda t: (items[t][1], t))
+            s = items[best][0]
+            s = s[: max(64, len(s) - (self.calls % 7))]
+            if len(s) > cap:
+                return -1
+            C.memmove(out, s, len(s))
+            self.log.append(("consensus", side, idx, len(s)))
+            return len(s)
+
+        def purge(user, side, idx, seq, n, weight):
+            self.g[side][idx] = [(C.string_at(seq, n), int(weight))]
+            self.log.append(("purge", side, idx, n, int(weight)))
+            return 0
+
+        def rep_changed(user, cls, rec):
+            r = rec.contents
+            self.rep_events.append((int(cls), int(r.entry), C.string_at(r.raw_seq, r.raw_len), float(r.raw_err), float(r.hpc_err),
+                                    int(r.hpc_len), int(r.n_fwd), int(r.n_rev)))
+
+        self._keep = (_lib.CONS_CREATE(create), _lib.CONS_SIZE(size), _lib.CONS_ADD(add), _lib.CONS_CONSENSUS(consensus),
+                      _lib.CONS_PURGE(purge), _lib.CONS_REP_CHANGED(rep_changed))
+        self.ops = _lib.ConsensusOps(None, *self._keep)
+
+    def reset(self, right_sizes=None):
+        self.g = {0: {}, 1: {}}
+        self.calls = 0
+        self.rep_events = []
+        self.log = []
+        for i, s in (right_sizes or {}).items():
+            self.g[1][i] = [(b"", 1)] * s

@@ -1,0 +1,110 @@
+"""Consensus mode (ConsMaxSize > 0; src/cluster.cpp:200-204, 263-309, src/consensus.cpp): SURVEY.md §8 f4.
+
+spoa is absent from the reference tree, so the graphs themselves are a toy store with the reference's five
+operations (tests/helpers.py::ToyGraphs), shared by the oracle (which restates when a consensus is taken,
+the weighted error rates, UpdateClusterConsensus' quirks, the re-minimizing and UpdateMinDB) and the product
+(speculative device passes + host walk + K1 on the GPU + index update).  Pinned here: the control flow and
+every number around the graphs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import synth
+from oracle import pyoracle as po
+from tests.helpers import ToyGraphs
+
+
+def _oracle_run(rs, cons_max, cons_min, period, mode="fast", k=11, w=15, graphs=None):
+    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+    R.score_sort(k, w)
+    p = po.default_params(k, w)
+    p.cons_max_size = cons_max
+    B = po.Batch(R, 0, rs.n - 1, p)
+    info, off_f, off_r, mn, ps = B.minimizer_soa()
+    view = dict(off_fwd=off_f, off_rev=off_r, min_val=mn, min_pos=ps, raw_len=info["raw_len"], hpc_len=info["hpc_len"],
+                score=info["score"], raw_err=info["raw_err"], hpc_err=info["hpc_err"], state=info["state"].astype(np.uint8),
+                min_qual=p.min_qual, orig=info["orig"])
+    g = graphs or ToyGraphs()
+    po.lib().orc_set_consensus(C.cast(C.pointer(g.ops), C.c_void_p), cons_min, period)
+    try:
+        st = B.cluster(mode=mode)
+    finally:
+        po.lib().orc_set_consensus(None, 50, 500)
+    return B, view, st, g
+
+
+def test_oracle_consensus_branch_runs_and_updates_the_index():
+    rs = synth.generate(300, 6, 900, 12, 22, seed=3)
+    B, view, st, g = _oracle_run(rs, cons_max=8, cons_min=3, period=500)
+    assert st["cons_invoked"] > 10
+    assert g.calls == st["cons_invoked"]
+    # ConsPurge keeps every graph at or below ConsMaxSize + 1 sequences
+    assert max(len(v) for v in g.g[0].values()) <= 9
+    keys, offs, post = B.index()
+    assert np.any(np.diff(offs) == 0), "UpdateMinDB leaves emptied lists in the index"
+    # consensus off: same data, no event, and the graphs are still created (cluster.cpp:200-204)
+    B0, _, st0, g0 = _oracle_run(rs, cons_max=-150, cons_min=3, period=500)
+    assert st0["cons_invoked"] == 0 and len(g0.g[0]) == B0.n_clusters()
+
+
+def test_cons_period_stops_the_updates_of_large_clusters():
+    rs = synth.generate(300, 3, 900, 14, 22, seed=5)
+    _, _, st_all, _ = _oracle_run(rs, cons_max=50, cons_min=3, period=500)
+    _, _, st_lim, _ = _oracle_run(rs, cons_max=50, cons_min=3, period=20)
+    assert 0 < st_lim["cons_invoked"] < st_all["cons_invoked"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,shape,seed,cmax,cmin,period", [
+    ("fast", (300, 6, 900), 3, 8, 3, 500),
+    ("fast", (400, 10, 700), 4, 6, 2, 25),
+    ("sahlin", (160, 5, 900), 6, 8, 3, 500),
+])
+def test_device_consensus_equals_oracle(mode, shape, seed, cmax, cmin, period):
+    from isonclust2_amd import _lib, api
+    rs = synth.generate(shape[0], shape[1], shape[2], 11 if mode == "sahlin" else 12, 21, seed=seed)
+    hook = None
+    if mode == "sahlin":   # the oracle's aligner hook calls the product's host aligner (parasail absent)
+        L = _lib.load()
+        CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+        hook = CB(lambda read, nread, rep, nrep, go, ge, out, cap:
+                  L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None))
+        po.lib().orc_set_aligner(C.cast(hook, C.c_void_p))
+    try:
+        B, view, ost, og = _oracle_run(rs, cmax, cmin, period, mode=mode)
+    finally:
+        po.lib().orc_set_aligner(None)
+    assert ost["cons_invoked"] > 3
+    acl, ast = B.assignments(rs.n)
+    ocl, ostr = acl[view["orig"]], ast[view["orig"]]
+
+    seqs = [rs.read(int(i))[0] for i in view["orig"]]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    v = dict(view)
+    v.update(raw_seq=b"".join(seqs), raw_off=off)
+    g = ToyGraphs()
+    ctx = api.Context(0)
+    cargs = _lib.ConsensusArgs(cons_min_size=cmin, cons_max_size=cmax, cons_period=period, left_depth=-1, left_sizes=None)
+    cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, mode), None, v, cargs, g.ops)
+    first = next((x for x in range(min(len(g.log), len(og.log))) if g.log[x] != og.log[x]), None)
+    assert first is None, (first, g.log[first - 2:first + 2], og.log[first - 2:first + 2])
+    assert len(g.log) == len(og.log)
+    assert st["n_cons_invoked"] == ost["cons_invoked"]
+    assert st["n_cons_restarts"] == st["n_cons_invoked"] + 1 or st["n_cons_restarts"] == st["n_cons_invoked"]
+    bad = np.nonzero((cls != ocl) | (strand != ostr))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
+    # the graphs saw the same operations in the same order
+    assert g.calls == og.calls
+    assert {kk: [(len(s), wt) for s, wt in vv] for kk, vv in g.g[0].items()} == \
+           {kk: [(len(s), wt) for s, wt in vv] for kk, vv in og.g[0].items()}
+    # final MinDB (emptied lists included) equals the oracle's
+    keys, offs, post = ctx.index_export()
+    okeys, ooffs, opost = B.index()
+    assert np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)
+    # every replaced representative was reported with the reference's numbers
+    assert len(g.rep_events) == st["n_cons_invoked"]
+    for cl_id, entry, raw, raw_err, hpc_err, hpc_len, n_fwd, n_rev in g.rep_events[-3:]:
+        assert 0 < raw_err < 1 and 0 < hpc_err < 1 and hpc_len <= len(raw) and n_fwd > 0 and n_rev > 0
+    ctx.close()

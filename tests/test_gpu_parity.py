@@ -103,3 +103,24 @@ def test_mode_none_opens_one_cluster_per_read(ctx):
     ocl, ost, _ = oracle_entry_assignments(B, view, mode="none")
     cls, strand, st = ctx.cluster_batch(api.default_params(11, 15, "none"), view)
     assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
+
+
+def test_every_prefix_of_a_batch(ctx):
+    """The greedy loop on the first m reads for every m: batches that END in a join, in a new cluster, in a
+    read whose best candidates fail.  (The resolve's lazy stage used to end without its exact sweeps when the
+    LAST query was the first one whose cluster flag changed; the consensus driver's short re-runs found it and
+    tests/test_consensus.py::test_device_consensus_equals_oracle[fast-shape1-...] is its regression test.)"""
+    rs = synth.generate(140, 7, 600, 11, 21, seed=9)
+    B, view = oracle_sorted_batch(rs)
+    order = view["orig"]
+    p = api.default_params(11, 15, "fast")
+    joins_at_end = 0
+    for m in range(1, rs.n + 1):
+        sub = rs.subset(order[:m])                     # the m best reads, already in sorted order
+        Bm, vm = oracle_sorted_batch(sub)
+        assert np.array_equal(vm["orig"], np.arange(m))
+        ocl, ost, _ = oracle_entry_assignments(Bm, vm)
+        cls, strand, st = ctx.cluster_batch(p, vm)
+        assert np.array_equal(cls, ocl) and np.array_equal(strand, ost), m
+        joins_at_end += int(m > 1 and cls[m - 1] < cls[:m].max())
+    assert joins_at_end > 20
