@@ -24,7 +24,8 @@ def test_oracle_digest(key):
     cls, strand, st = oracle_entry_assignments(B, view)
     assert B.n_clusters() == GOLD[key]["clusters"]
     assert f"{fnv1a(cls, strand):016x}" == GOLD[key]["fnv1a"]
-    assert st == GOLD[key]["stats"]
+    assert {kk: st[kk] for kk in GOLD[key]["stats"]} == GOLD[key]["stats"]   # (the golden file predates cons_invoked)
+    assert st["cons_invoked"] == 0
 
 
 def test_properties_clean_reads_recover_transcripts():
