@@ -108,3 +108,91 @@ def test_device_consensus_equals_oracle(mode, shape, seed, cmax, cmin, period):
     for cl_id, entry, raw, raw_err, hpc_err, hpc_len, n_fwd, n_rev in g.rep_events[-3:]:
         assert 0 < raw_err < 1 and 0 < hpc_err < 1 and hpc_len <= len(raw) and n_fwd > 0 and n_rev > 0
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_merge_with_consensus_equals_oracle():
+    """`cluster -l L -r R` with consensus on: leftBatch->Depth != -1, so ConsMinSize is 2 and ConsPeriod is
+    ignored (cluster.cpp:267-288); a right cluster's graph only contributes its sequence count as the weight
+    of the addition (consensus.cpp:51-53, 76-81).  Stage 1 (two initial clusterings, ConsMinSize too high for
+    any event, graphs growing) is shared; the merge is run by the oracle and by the product on copies of the
+    same graphs."""
+    import copy
+    from isonclust2_amd import _lib, api, pipeline
+    rs = synth.generate(360, 8, 800, 12, 21, seed=11)
+    k, w = 11, 15
+    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+    R.score_sort(k, w)
+    p = po.default_params(k, w)
+    p.cons_max_size = 12
+    cuts = [0, 200, 360]
+    obs, sbs, graphs = [], [], []
+    for b in range(2):
+        Bo = po.Batch(R, cuts[b], cuts[b + 1] - 1, p, batch_nr=b)
+        info, off_f, off_r, mn, ps = Bo.minimizer_soa()
+        view = dict(off_fwd=off_f, off_rev=off_r, min_val=mn, min_pos=ps, raw_len=info["raw_len"], hpc_len=info["hpc_len"],
+                    score=info["score"], raw_err=info["raw_err"], hpc_err=info["hpc_err"],
+                    state=info["state"].astype(np.uint8), min_qual=p.min_qual)
+        sbs.append(pipeline.SortedBatch(view=view, read_ids=info["orig"].astype(np.int64), batch_nr=b,
+                                        batch_start=cuts[b], batch_end=cuts[b + 1] - 1))
+        g = ToyGraphs()
+        po.lib().orc_set_consensus(C.cast(C.pointer(g.ops), C.c_void_p), 1000, 500)   # no event in stage 1
+        try:
+            st = Bo.cluster(mode="fast")
+        finally:
+            po.lib().orc_set_consensus(None, 50, 500)
+        assert st["cons_invoked"] == 0 and max(len(v) for v in g.g[0].values()) > 3
+        obs.append(Bo)
+        graphs.append(g)
+    ctx = api.Context(0)
+    pp = api.default_params(k, w, "fast")
+    cbs = [pipeline.cluster_single(ctx, pp, sb) for sb in sbs]        # stage 1 on the product (no events: plain path)
+    for cb, Bo in zip(cbs, obs):
+        assert cb.n_clusters == Bo.n_clusters()
+
+    def merged_graphs():
+        gm = ToyGraphs()
+        gm.g[0] = copy.deepcopy(graphs[0].g[0])
+        gm.g[1] = copy.deepcopy(graphs[1].g[0])       # right batch's graphs, indexed by right cluster = right entry
+        return gm
+
+    # ---- oracle merge ----
+    og = merged_graphs()
+    po.lib().orc_set_consensus(C.cast(C.pointer(og.ops), C.c_void_p), 50, 500)
+    try:
+        ost = obs[0].cluster(right=obs[1], mode="fast")
+    finally:
+        po.lib().orc_set_consensus(None, 50, 500)
+    assert ost["cons_invoked"] > 5
+    # ---- product merge ----
+    left, right = cbs[0], cbs[1]
+    counts = np.bincount(right.member_cls, minlength=right.n_clusters).astype(np.int32)
+    lsizes = (np.bincount(left.member_cls, minlength=left.n_clusters) + 1).astype(np.int32)   # + the representative copy
+    rep_reads = np.full(right.n_clusters, -1, np.int64)
+    for c_id, r_id in zip(right.member_cls[::-1], right.member_read[::-1]):
+        rep_reads[c_id] = r_id                                                       # first member = creator = representative
+    seqs = [rs.read(int(i))[0] for i in rep_reads]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    rv = dict(right.rep_view)
+    rv.update(n_members=counts, depth=right.depth, min_cls_size=3, raw_seq=b"".join(seqs), raw_off=off)
+    lv = dict(cls_hpc_err=left.rep_view["hpc_err"], keys=left.mindb[0], offs=left.mindb[1], postings=left.mindb[2])
+    pg = merged_graphs()
+    cargs = _lib.ConsensusArgs(cons_min_size=50, cons_max_size=12, cons_period=500, left_depth=left.depth,
+                               left_sizes=lsizes.ctypes.data_as(C.POINTER(C.c_int32)))
+    cls, strand, st = ctx.cluster_consensus(pp, lv, rv, cargs, pg.ops)
+    first = next((x for x in range(min(len(pg.log), len(og.log))) if pg.log[x] != og.log[x]), None)
+    assert first is None and len(pg.log) == len(og.log), (first, pg.log[max(0, (first or 0) - 2):(first or 0) + 2],
+                                                            og.log[max(0, (first or 0) - 2):(first or 0) + 2])
+    assert st["n_cons_invoked"] == ost["cons_invoked"]
+    ocl, ostr = obs[0].assignments(rs.n)
+    rcl, rst = right.assignments(rs.n)
+    reads = np.nonzero(rcl >= 0)[0]
+    keep = cls[rcl[reads]] >= 0
+    assert np.array_equal(cls[rcl[reads]][keep], ocl[reads][keep])
+    assert np.array_equal((strand[rcl[reads]].astype(np.int32) * rst[reads])[keep], ostr[reads][keep])
+    assert np.array_equal(ocl[reads][~keep], np.full(int((~keep).sum()), -1))         # size-filtered right clusters
+    keys, offs, post = ctx.index_export()
+    okeys, ooffs, opost = obs[0].index()
+    assert np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)
+    ctx.close()
