@@ -365,6 +365,21 @@ int ioc_cluster_consensus(ioc_ctx* ctx, const ioc_params* p, const char* table_p
                           const ioc_batch_view* right, const ioc_consensus_args* args, const ioc_consensus_ops* ops,
                           int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);
 
+/* ---- a POA engine of its own behind those five operations (spoa is absent from the reference tree: parity with
+ * spoa's alignments and consensus tie-breaks is unpinned).  Graphs and heaviest-bundle consensus on the host, the
+ * sequence-to-graph DP (local alignment, convex gaps as two affine pieces, src/main.cpp:285-324: m 4, n -8, g -8, e -4,
+ * q -20, c -1) on the GPU.  Limits: sequences <= 29 999 bases, <= 127 predecessors per node. ------------------- */
+typedef struct ioc_poa ioc_poa;
+int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int32_t q, int32_t c, ioc_poa** out);
+void ioc_poa_destroy(ioc_poa* poa);
+/* fills user + create / size / add / consensus / purge of *ops (rep_changed is left to the caller) */
+void ioc_poa_bind(ioc_poa* poa, ioc_consensus_ops* ops);
+/* inspection: a graph's nodes (letter, topological order) and weighted edges; the alignment (node id or -1,
+ * position or -1, forward order) and score of the last `add`.  Returns the number of pairs. */
+int ioc_poa_graph_export(ioc_poa* poa, int side, int idx, int32_t* n_nodes, int32_t* n_edges, char* bases, int32_t* rank,
+                         int32_t* edge_from, int32_t* edge_to, int64_t* edge_w);
+int ioc_poa_last_alignment(ioc_poa* poa, int32_t cap, int32_t* nodes, int32_t* pos, int32_t* score);
+
 /* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries
  * must all be clusterable.  Fast mode, or sahlin mode after ioc_resident_set_sequences. */
 int ioc_cluster_resident(ioc_ctx* ctx, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);

@@ -106,6 +106,7 @@ SYMBOLS = [
     "ioc_cluster_batch", "ioc_cluster_merge", "ioc_cluster_resident", "ioc_host_align", "ioc_host_gap_open",
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
     "ioc_index_update", "ioc_left_export", "ioc_cluster_consensus",
+    "ioc_poa_create", "ioc_poa_destroy", "ioc_poa_bind", "ioc_poa_graph_export", "ioc_poa_last_alignment",
 ]
 
 _lib = None
@@ -169,6 +170,13 @@ def load():
                                     pi32, pi8, C.POINTER(ClusterStats)]
     L.ioc_cluster_consensus.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(LeftView), C.POINTER(BatchView),
                                         C.POINTER(ConsensusArgs), C.POINTER(ConsensusOps), pi32, pi8, C.POINTER(ClusterStats)]
+    L.ioc_poa_create.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.ioc_poa_destroy.argtypes = [vp]
+    L.ioc_poa_destroy.restype = None
+    L.ioc_poa_bind.argtypes = [vp, C.POINTER(ConsensusOps)]
+    L.ioc_poa_bind.restype = None
+    L.ioc_poa_graph_export.argtypes = [vp, C.c_int, C.c_int, pi32, pi32, C.c_char_p, pi32, pi32, pi32, pi64]
+    L.ioc_poa_last_alignment.argtypes = [vp, i32, pi32, pi32, pi32]
     L.ioc_host_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, C.c_char_p, i32, pi32]
     L.ioc_host_gap_open.argtypes = [C.c_double]
     L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]

@@ -1,0 +1,673 @@
+// ioc_poa.hip — partial-order alignment for the consensus of a cluster.
+//
+// The reference keeps one spoa::Graph per cluster and performs five operations on it (src/consensus.cpp:15-32,
+// 41, 87, 128-137; src/cluster.cpp:200-204): seed, size, AddSeqToGraph (align + AddAlignment), GenerateConsensus,
+// ConsPurge, with spoa::AlignmentEngine::Create(kSW, m=4, n=-8, g=-8, e=-4, q=-20, c=-1) (src/main.cpp:285-324).
+// spoa is a third-party library ABSENT from /root/reference (.gitmodules:13-15): this is an engine of its own
+// after the published algorithm (Lee, Grasso & Sharlow 2002: sequence-to-graph DP over the topologically sorted
+// nodes; convex gaps as two affine pieces; heaviest-bundle consensus) — PARITY WITH spoa IS UNPINNED:
+// alignments of equal score and the consensus' tie-breaks may differ.
+//
+// What runs where: the graphs (nodes, weighted edges, aligned-node groups, topological order) and the consensus
+// live on the host — they are small.  The sequence-to-graph DP is the heavy part (|graph| x |read| cells, 3*10^8
+// for a 16.7 kb read) and runs on the GPU:
+//   k_poa_forward  rows = graph nodes in topological order, one workgroup of 1024 threads per alignment.  The
+//                  columns of a row are independent once its predecessor rows are known, except for the
+//                  horizontal gap states, which are a max-plus prefix scan along the row:
+//                  E[j] = max_{x<j} Hn[x] + open + (j-1-x) ext, Hn = H without E (opening a gap right after a gap
+//                  never beats extending it, and switching between the two pieces of the convex gap never pays
+//                  when open <= ext for both pieces, which is checked).  Stores H, F1, F2 (later rows need them)
+//                  and one direction word per cell.
+//   k_poa_trace    one lane walks back from the best cell over the direction words.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ioc_internal.h"
+
+namespace {
+
+constexpr int POA_NEG = INT32_MIN / 4;
+constexpr int POA_THREADS = 1024;
+constexpr int POA_MAX_COLS = 30000;   // one row of Hn stays in LDS
+constexpr int POA_MAX_PREDS = 127;
+
+// direction word: [1:0] source of Hn (0 stop, 1 diagonal, 2 F1, 3 F2)  [4:2] source of H (those, 4 E1, 5 E2)
+// [5] E1 extended  [6] E2 extended  [7] F1 extended  [8] F2 extended
+// [15:9] / [22:16] / [29:23] predecessor (index into the row's predecessor list) of the diagonal / F1 / F2 move
+enum : uint32_t { SRC_STOP = 0, SRC_DIAG = 1, SRC_F1 = 2, SRC_F2 = 3, SRC_E1 = 4, SRC_E2 = 5 };
+
+struct PoaScores {
+    int m, n, g, e, q, c;
+};
+
+__device__ __forceinline__ int2 max2(int2 a, int2 b) { return int2{max(a.x, b.x), max(a.y, b.y)}; }
+
+// rows 1..R = nodes in topological order, row 0 = virtual source (H = 0: local alignment); columns 0..L.
+// pred_off[r] .. pred_off[r+1]: predecessor ROWS of row r (row 0 for a node without in-edges).
+__global__ void __launch_bounds__(POA_THREADS)
+k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __restrict__ pred_off,
+              const int32_t* __restrict__ pred, const uint8_t* __restrict__ seq, PoaScores S, int* H, int* F1, int* F2,
+              uint32_t* dirs, int* __restrict__ best /* score, row, col */)
+{
+    extern __shared__ int s_hn[];  // W ints: Hn of the current row
+    __shared__ int2 s_wave[POA_THREADS / 64];
+    __shared__ int2 s_inc[POA_THREADS];
+    __shared__ int s_red[3 * (POA_THREADS / 64)];
+    const int W = L + 1;                                   // row pitch
+    const int per = (W + POA_THREADS - 1) / POA_THREADS;   // consecutive columns per thread
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = min(W, tid * per), j1 = min(W, j0 + per);
+    for (int j = tid; j < W; j += POA_THREADS) {  // row 0
+        H[j] = 0;
+        F1[j] = POA_NEG;
+        F2[j] = POA_NEG;
+        dirs[j] = SRC_STOP;
+    }
+    __syncthreads();
+    int my_best = 0, my_r = 0, my_j = 0;
+    for (int r = 1; r <= R; ++r) {
+        const int pb = pred_off[r], pe = pred_off[r + 1];
+        const uint8_t b = base[r];
+        int* Hr = H + int64_t(r) * W;
+        int* F1r = F1 + int64_t(r) * W;
+        int* F2r = F2 + int64_t(r) * W;
+        uint32_t* Dr = dirs + int64_t(r) * W;
+        // ---- phase A: Hn (everything but the horizontal gaps), F1, F2, and this thread's scan totals ----
+        int2 tot{POA_NEG, POA_NEG};
+        for (int j = j0; j < j1; ++j) {
+            int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
+            uint32_t d = SRC_STOP;
+            uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
+            int diag = POA_NEG;
+            const int sc = j > 0 ? ((b == seq[j - 1]) ? S.m : S.n) : 0;
+            for (int x = pb; x < pe; ++x) {
+                const int64_t po = int64_t(pred[x]) * W;
+                if (j > 0) {
+                    const int hd = H[po + j - 1] + sc;
+                    if (hd > diag) {
+                        diag = hd;
+                        dp = uint32_t(x - pb);
+                    }
+                }
+                const int hu = H[po + j];
+                const int o1 = hu + S.g, x1 = F1[po + j] + S.e;
+                const int v1 = max(o1, x1);
+                if (v1 > f1) {
+                    f1 = v1;
+                    f1p = uint32_t(x - pb);
+                    f1x = x1 > o1 ? 1u : 0u;
+                }
+                const int o2 = hu + S.q, x2 = F2[po + j] + S.c;
+                const int v2 = max(o2, x2);
+                if (v2 > f2) {
+                    f2 = v2;
+                    f2p = uint32_t(x - pb);
+                    f2x = x2 > o2 ? 1u : 0u;
+                }
+            }
+            if (diag > hn) {
+                hn = diag;
+                d = SRC_DIAG;
+            }
+            if (f1 > hn) {
+                hn = f1;
+                d = SRC_F1;
+            }
+            if (f2 > hn) {
+                hn = f2;
+                d = SRC_F2;
+            }
+            d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
+            s_hn[j] = hn;
+            F1r[j] = f1;
+            F2r[j] = f2;
+            Dr[j] = d;
+            tot = max2(tot, int2{hn - S.e * j, hn - S.c * j});
+        }
+        // ---- inclusive block scan of the thread totals: prefix maxima of Hn[x] - e x and Hn[x] - c x ----
+        int2 v = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tx = __shfl_up(v.x, o), ty = __shfl_up(v.y, o);
+            if (lane >= o) v = max2(v, int2{tx, ty});
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();  // (also: s_hn of this row is complete)
+        if (wave == 0) {
+            int2 w = lane < POA_THREADS / 64 ? s_wave[lane] : int2{POA_NEG, POA_NEG};
+#pragma unroll
+            for (int o = 1; o < POA_THREADS / 64; o <<= 1) {
+                const int tx = __shfl_up(w.x, o), ty = __shfl_up(w.y, o);
+                if (lane >= o) w = max2(w, int2{tx, ty});
+            }
+            if (lane < POA_THREADS / 64) s_wave[lane] = w;
+        }
+        __syncthreads();
+        if (wave > 0) v = max2(v, s_wave[wave - 1]);
+        s_inc[tid] = v;
+        __syncthreads();
+        int2 run = tid > 0 ? s_inc[tid - 1] : int2{POA_NEG, POA_NEG};  // over the columns left of j0
+        // ---- phase B: E1, E2, H ----
+        for (int j = j0; j < j1; ++j) {
+            const int hn = s_hn[j];
+            int h = hn;
+            uint32_t d = Dr[j];
+            uint32_t src = d & 3u;
+            if (j > 0) {
+                const int e1 = run.x > POA_NEG / 2 ? run.x + S.g + (j - 1) * S.e : POA_NEG;
+                const int e2 = run.y > POA_NEG / 2 ? run.y + S.q + (j - 1) * S.c : POA_NEG;
+                const int left = s_hn[j - 1];
+                const uint32_t e1x = e1 > left + S.g ? 1u : 0u;   // opened iff the maximum sits at x = j - 1
+                const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
+                if (e1 > h) {
+                    h = e1;
+                    src = SRC_E1;
+                }
+                if (e2 > h) {
+                    h = e2;
+                    src = SRC_E2;
+                }
+                d |= (e1x << 5) | (e2x << 6);
+            }
+            d |= src << 2;
+            Hr[j] = h;
+            Dr[j] = d;
+            run = max2(run, int2{hn - S.e * j, hn - S.c * j});
+            if (h > my_best) {  // first row, then first column, wins ties (rows ascend in time, columns inside a thread too)
+                my_best = h;
+                my_r = r;
+                my_j = j;
+            }
+        }
+        __syncthreads();  // row r is complete (and s_hn free) before row r + 1
+    }
+    // ---- best cell: maximum score, ties to the smallest row, then the smallest column ----
+    auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
+        return s1 > s2 || (s1 == s2 && (r1 < r2 || (r1 == r2 && c1 < c2)));
+    };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int s2 = __shfl_xor(my_best, o), r2 = __shfl_xor(my_r, o), c2 = __shfl_xor(my_j, o);
+        if (better(s2, r2, c2, my_best, my_r, my_j)) {
+            my_best = s2;
+            my_r = r2;
+            my_j = c2;
+        }
+    }
+    if (lane == 0) {
+        s_red[3 * wave] = my_best;
+        s_red[3 * wave + 1] = my_r;
+        s_red[3 * wave + 2] = my_j;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int bs = s_red[0], br = s_red[1], bc = s_red[2];
+        for (int w2 = 1; w2 < POA_THREADS / 64; ++w2)
+            if (better(s_red[3 * w2], s_red[3 * w2 + 1], s_red[3 * w2 + 2], bs, br, bc)) {
+                bs = s_red[3 * w2];
+                br = s_red[3 * w2 + 1];
+                bc = s_red[3 * w2 + 2];
+            }
+        best[0] = bs;
+        best[1] = br;
+        best[2] = bc;
+    }
+}
+
+// Walk back from the best cell.  out_node / out_pos receive the alignment in REVERSE order: (row, column - 1)
+// for a diagonal move, (row, -1) for a node against a gap, (-1, column - 1) for a base against a gap;
+// out_n = number of pairs.
+__global__ void k_poa_trace(int L, const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred,
+                            const uint32_t* __restrict__ dirs, const int* __restrict__ best, int32_t* __restrict__ out_node,
+                            int32_t* __restrict__ out_pos, int32_t* __restrict__ out_n, int cap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t W = L + 1;
+    int r = best[1], j = best[2], n = 0;
+    int state = 0;  // 0 H, 1 Hn (H without the horizontal sources), 2 F1, 3 F2, 4 E1, 5 E2
+    while (r > 0 && n < cap) {
+        const uint32_t d = dirs[int64_t(r) * W + j];
+        const int pb = pred_off[r];
+        if (state == 0 || state == 1) {
+            const uint32_t src = state == 0 ? (d >> 2) & 7u : d & 3u;
+            if (src == SRC_STOP) break;
+            if (src == SRC_DIAG) {
+                out_node[n] = r;
+                out_pos[n] = j - 1;
+                ++n;
+                r = pred[pb + int((d >> 9) & 127u)];
+                --j;
+                state = 0;
+            } else {
+                state = int(src);  // F1 / F2 / E1 / E2: same cell, other matrix
+            }
+        } else if (state == 2 || state == 3) {
+            out_node[n] = r;
+            out_pos[n] = -1;
+            ++n;
+            const bool ext = state == 2 ? (d >> 7) & 1u : (d >> 8) & 1u;
+            r = pred[pb + int(state == 2 ? (d >> 16) & 127u : (d >> 23) & 127u)];
+            if (!ext) state = 0;
+        } else {
+            out_node[n] = -1;
+            out_pos[n] = j - 1;
+            ++n;
+            const bool ext = state == 4 ? (d >> 5) & 1u : (d >> 6) & 1u;
+            --j;
+            if (!ext) state = 1;  // the gap was opened from Hn of the column to the left
+        }
+    }
+    *out_n = n;
+}
+
+// ---- host side: the graph ----------------------------------------------------------------------------------
+struct PNode {
+    char base = 0;
+    std::vector<int> in, out;      // edge ids
+    std::vector<int> aligned;      // nodes at the same position with another letter
+};
+struct PEdge {
+    int from = 0, to = 0;
+    int64_t w = 0;
+};
+struct PGraph {
+    std::vector<PNode> nodes;
+    std::vector<PEdge> edges;
+    std::vector<int> rank;  // topological order: rank[i] = node id
+    int nseq = 0;
+
+    int add_node(char b)
+    {
+        nodes.emplace_back();
+        nodes.back().base = b;
+        return int(nodes.size()) - 1;
+    }
+    void add_edge(int u, int v, int64_t w)
+    {
+        for (int e : nodes[size_t(u)].out)
+            if (edges[size_t(e)].to == v) {
+                edges[size_t(e)].w += w;
+                return;
+            }
+        edges.push_back(PEdge{u, v, w});
+        nodes[size_t(u)].out.push_back(int(edges.size()) - 1);
+        nodes[size_t(v)].in.push_back(int(edges.size()) - 1);
+    }
+    int add_chain(const char* s, int a, int b, int64_t w)  // nodes for s[a..b), returns the first; last in *tail
+    {
+        int first = -1, prev = -1;
+        for (int i = a; i < b; ++i) {
+            const int v = add_node(s[i]);
+            if (first < 0) first = v;
+            if (prev >= 0) add_edge(prev, v, w);
+            prev = v;
+        }
+        return first;
+    }
+    void toposort()
+    {
+        // Kahn, smallest node id first: deterministic, independent of edge insertion order
+        const size_t n = nodes.size();
+        std::vector<int> indeg(n);
+        for (size_t i = 0; i < n; ++i) indeg[i] = int(nodes[i].in.size());
+        std::vector<int> heap;
+        auto cmp = [](int a, int b) { return a > b; };
+        for (size_t i = 0; i < n; ++i)
+            if (!indeg[i]) heap.push_back(int(i));
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        rank.clear();
+        rank.reserve(n);
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            const int u = heap.back();
+            heap.pop_back();
+            rank.push_back(u);
+            for (int e : nodes[size_t(u)].out) {
+                const int v = edges[size_t(e)].to;
+                if (--indeg[size_t(v)] == 0) {
+                    heap.push_back(v);
+                    std::push_heap(heap.begin(), heap.end(), cmp);
+                }
+            }
+        }
+    }
+    // AddAlignment: aln = (node id or -1, position or -1) in forward order; an empty alignment adds a chain
+    void add_alignment(const std::vector<std::pair<int, int>>& aln, const char* s, int len, int64_t w)
+    {
+        if (len <= 0) return;
+        std::vector<int> pos_of;
+        for (auto& a : aln)
+            if (a.second >= 0) pos_of.push_back(a.second);
+        if (pos_of.empty()) {
+            add_chain(s, 0, len, w);
+            ++nseq;
+            toposort();
+            return;
+        }
+        const int first_pos = pos_of.front(), last_pos = pos_of.back();
+        int head = -1;
+        if (first_pos > 0) {
+            add_chain(s, 0, first_pos, w);
+            head = int(nodes.size()) - 1;
+        }
+        for (auto& a : aln) {
+            if (a.second < 0) continue;
+            const char letter = s[a.second];
+            int cur;
+            if (a.first < 0) {
+                cur = add_node(letter);
+            } else if (nodes[size_t(a.first)].base == letter) {
+                cur = a.first;
+            } else {
+                cur = -1;
+                for (int x : nodes[size_t(a.first)].aligned)
+                    if (nodes[size_t(x)].base == letter) {
+                        cur = x;
+                        break;
+                    }
+                if (cur < 0) {
+                    cur = add_node(letter);
+                    std::vector<int> grp = nodes[size_t(a.first)].aligned;
+                    grp.push_back(a.first);
+                    for (int x : grp) {
+                        nodes[size_t(x)].aligned.push_back(cur);
+                        nodes[size_t(cur)].aligned.push_back(x);
+                    }
+                }
+            }
+            if (head >= 0) add_edge(head, cur, w);
+            head = cur;
+        }
+        if (last_pos + 1 < len) {
+            const int f = add_chain(s, last_pos + 1, len, w);
+            if (head >= 0) add_edge(head, f, w);
+        }
+        ++nseq;
+        toposort();
+    }
+    // heaviest bundle: per node the heaviest in-edge (ties: the predecessor with the higher score), the best
+    // end node, then forward along the heaviest out-edges to a sink
+    std::string consensus() const
+    {
+        const size_t n = nodes.size();
+        if (n == 0) return std::string();
+        std::vector<int64_t> score(n, 0);
+        std::vector<int> from(n, -1);
+        int best = rank.empty() ? 0 : rank[0];
+        for (int u : rank) {
+            int64_t bw = -1;
+            for (int e : nodes[size_t(u)].in) {
+                const PEdge& ed = edges[size_t(e)];
+                if (from[size_t(u)] < 0 || ed.w > bw || (ed.w == bw && score[size_t(ed.from)] > score[size_t(from[size_t(u)])])) {
+                    bw = ed.w;
+                    from[size_t(u)] = ed.from;
+                }
+            }
+            if (from[size_t(u)] >= 0) score[size_t(u)] = bw + score[size_t(from[size_t(u)])];
+            if (score[size_t(u)] > score[size_t(best)]) best = u;
+        }
+        std::vector<int> path;
+        for (int u = best; u >= 0; u = from[size_t(u)]) path.push_back(u);
+        std::reverse(path.begin(), path.end());
+        for (int u = best; !nodes[size_t(u)].out.empty();) {
+            int be = nodes[size_t(u)].out[0];
+            for (int e : nodes[size_t(u)].out)
+                if (edges[size_t(e)].w > edges[size_t(be)].w) be = e;
+            u = edges[size_t(be)].to;
+            path.push_back(u);
+        }
+        std::string s;
+        s.reserve(path.size());
+        for (int u : path) s.push_back(nodes[size_t(u)].base);
+        return s;
+    }
+};
+
+}  // namespace
+
+struct ioc_poa {
+    ioc_ctx* ctx = nullptr;
+    PoaScores S{4, -8, -8, -4, -20, -1};
+    std::map<int, PGraph> g[2];
+    DevBuf d_h, d_f1, d_f2, d_dirs, d_small, d_aln;
+    // the alignment of the last ioc_poa_add (tests / inspection): node ids, positions, score
+    std::vector<int32_t> last_node, last_pos;
+    int32_t last_score = 0;
+    std::string err;
+};
+
+namespace {
+
+int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes)
+{
+    if (b.cap >= bytes) return IOC_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        (void)hipGetLastError();
+        return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: hipMalloc of the DP matrices failed");
+    }
+    b.cap = want;
+    return IOC_OK;
+}
+
+#define PCHK(p, call)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess) return ioc_fail((p)->ctx, IOC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// align seq to graph on the device; aln in forward order with NODE IDS
+int poa_align(ioc_poa* p, const PGraph& G, const char* seq, int len, std::vector<std::pair<int, int>>& aln, int32_t& score)
+{
+    aln.clear();
+    score = 0;
+    const int R = int(G.nodes.size()), L = len;
+    if (R == 0 || L == 0) return IOC_OK;
+    if (L + 1 > POA_MAX_COLS) return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: sequences above 30 000 bases are not supported");
+    ioc_ctx* c = p->ctx;
+    PCHK(p, hipSetDevice(c->device));
+    std::vector<int> row_of(static_cast<size_t>(R), 0);
+    for (int i = 0; i < R; ++i) row_of[size_t(G.rank[size_t(i)])] = i + 1;
+    std::vector<uint8_t> base(size_t(R) + 1, 0);
+    std::vector<int32_t> poff(size_t(R) + 2, 0), pred;
+    for (int i = 0; i < R; ++i) {
+        const PNode& nd = G.nodes[size_t(G.rank[size_t(i)])];
+        base[size_t(i) + 1] = uint8_t(nd.base);
+        poff[size_t(i) + 1] = int32_t(pred.size());
+        if (nd.in.empty()) pred.push_back(0);
+        if (nd.in.size() > size_t(POA_MAX_PREDS)) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
+        for (int e : nd.in) pred.push_back(row_of[size_t(G.edges[size_t(e)].from)]);
+    }
+    poff[size_t(R) + 1] = int32_t(pred.size());
+    const size_t cells = size_t(R + 1) * size_t(L + 1);
+    int r;
+    if ((r = poa_reserve(p, p->d_h, cells * 4)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_f1, cells * 4)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_f2, cells * 4)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_dirs, cells * 4)) != IOC_OK) return r;
+    const size_t o_base = 0, o_poff = (o_base + base.size() + 15) & ~size_t(15), o_pred = o_poff + poff.size() * 4,
+                 o_seq = o_pred + pred.size() * 4, o_best = (o_seq + size_t(L) + 15) & ~size_t(15), o_n = o_best + 16;
+    if ((r = poa_reserve(p, p->d_small, o_n + 16)) != IOC_OK) return r;
+    const int cap = R + L + 2;
+    if ((r = poa_reserve(p, p->d_aln, size_t(cap) * 8)) != IOC_OK) return r;
+    hipStream_t s = c->stream;
+    uint8_t* sm = static_cast<uint8_t*>(p->d_small.p);
+    PCHK(p, hipMemcpyAsync(sm + o_base, base.data(), base.size(), hipMemcpyHostToDevice, s));
+    PCHK(p, hipMemcpyAsync(sm + o_poff, poff.data(), poff.size() * 4, hipMemcpyHostToDevice, s));
+    PCHK(p, hipMemcpyAsync(sm + o_pred, pred.data(), pred.size() * 4, hipMemcpyHostToDevice, s));
+    PCHK(p, hipMemcpyAsync(sm + o_seq, seq, size_t(L), hipMemcpyHostToDevice, s));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_poa_forward), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  POA_MAX_COLS * 4);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_poa_forward, dim3(1), dim3(POA_THREADS), size_t(L + 1) * 4, s, R, L, sm + o_base,
+                       reinterpret_cast<const int32_t*>(sm + o_poff), reinterpret_cast<const int32_t*>(sm + o_pred), sm + o_seq,
+                       p->S, static_cast<int*>(p->d_h.p), static_cast<int*>(p->d_f1.p), static_cast<int*>(p->d_f2.p),
+                       static_cast<uint32_t*>(p->d_dirs.p), reinterpret_cast<int*>(sm + o_best));
+    PCHK(p, hipGetLastError());
+    int32_t* d_node = static_cast<int32_t*>(p->d_aln.p);
+    int32_t* d_pos = d_node + cap;
+    hipLaunchKernelGGL(k_poa_trace, dim3(1), dim3(64), 0, s, L, reinterpret_cast<const int32_t*>(sm + o_poff),
+                       reinterpret_cast<const int32_t*>(sm + o_pred), static_cast<const uint32_t*>(p->d_dirs.p),
+                       reinterpret_cast<const int*>(sm + o_best), d_node, d_pos, reinterpret_cast<int32_t*>(sm + o_n), cap);
+    PCHK(p, hipGetLastError());
+    int32_t hb[3] = {0, 0, 0}, hn = 0;
+    PCHK(p, hipMemcpyAsync(hb, sm + o_best, 12, hipMemcpyDeviceToHost, s));
+    PCHK(p, hipMemcpyAsync(&hn, sm + o_n, 4, hipMemcpyDeviceToHost, s));
+    PCHK(p, hipStreamSynchronize(s));
+    std::vector<int32_t> hnode(size_t(hn) + 1), hpos(size_t(hn) + 1);
+    if (hn > 0) {
+        PCHK(p, hipMemcpyAsync(hnode.data(), d_node, size_t(hn) * 4, hipMemcpyDeviceToHost, s));
+        PCHK(p, hipMemcpyAsync(hpos.data(), d_pos, size_t(hn) * 4, hipMemcpyDeviceToHost, s));
+        PCHK(p, hipStreamSynchronize(s));
+    }
+    score = hb[0];
+    aln.reserve(size_t(hn));
+    for (int i = hn - 1; i >= 0; --i)
+        aln.emplace_back(hnode[size_t(i)] > 0 ? G.rank[size_t(hnode[size_t(i)]) - 1] : -1, hpos[size_t(i)]);
+    return IOC_OK;
+}
+
+int op_create(void* u, int side, int idx, const char* seq, int len)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1 || len < 0) return -1;
+    PGraph G;
+    G.add_alignment({}, seq, len, 1);
+    p->g[side][idx] = std::move(G);
+    return 0;
+}
+int op_size(void* u, int side, int idx)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1) return -1;
+    auto it = p->g[side].find(idx);
+    return it == p->g[side].end() ? -1 : it->second.nseq;
+}
+int op_add(void* u, int side, int idx, const char* seq, int len, unsigned weight)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1) return -1;
+    auto it = p->g[side].find(idx);
+    if (it == p->g[side].end()) return -1;
+    std::vector<std::pair<int, int>> aln;
+    int32_t score = 0;
+    if (poa_align(p, it->second, seq, len, aln, score) != IOC_OK) return -1;
+    p->last_node.clear();
+    p->last_pos.clear();
+    for (auto& a : aln) {
+        p->last_node.push_back(a.first);
+        p->last_pos.push_back(a.second);
+    }
+    p->last_score = score;
+    it->second.add_alignment(aln, seq, len, int64_t(weight));
+    return 0;
+}
+int op_consensus(void* u, int side, int idx, char* out, int cap)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1) return -1;
+    auto it = p->g[side].find(idx);
+    if (it == p->g[side].end()) return -1;
+    const std::string s = it->second.consensus();
+    if (int(s.size()) > cap) return -1;
+    memcpy(out, s.data(), s.size());
+    return int(s.size());
+}
+int op_purge(void* u, int side, int idx, const char* seq, int len, unsigned weight)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1) return -1;
+    PGraph G;
+    G.add_alignment({}, seq, len, int64_t(weight));  // ConsPurge: the representative alone, with the old count as weight
+    p->g[side][idx] = std::move(G);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int32_t q, int32_t c, ioc_poa** out)
+{
+    if (!ctx || !out) return IOC_ERR_ARG;
+    // the row scan computes horizontal gaps from H-without-gaps: valid when opening is no cheaper than extending
+    if (!(g <= e && e <= 0 && q <= c && c <= 0 && n <= 0 && m >= 0))
+        return ioc_fail(ctx, IOC_ERR_ARG, "POA scores: need m >= 0, n <= 0, g <= e <= 0, q <= c <= 0");
+    ioc_poa* p = new ioc_poa;
+    p->ctx = ctx;
+    p->S = PoaScores{m, n, g, e, q, c};
+    *out = p;
+    return IOC_OK;
+}
+
+void ioc_poa_destroy(ioc_poa* p)
+{
+    if (!p) return;
+    for (DevBuf* b : {&p->d_h, &p->d_f1, &p->d_f2, &p->d_dirs, &p->d_small, &p->d_aln})
+        if (b->p) (void)hipFree(b->p);
+    delete p;
+}
+
+void ioc_poa_bind(ioc_poa* p, ioc_consensus_ops* ops)
+{
+    if (!p || !ops) return;
+    ops->user = p;
+    ops->create = op_create;
+    ops->size = op_size;
+    ops->add = op_add;
+    ops->consensus = op_consensus;
+    ops->purge = op_purge;
+}
+
+int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_t* n_edges, char* bases, int32_t* rank,
+                         int32_t* edge_from, int32_t* edge_to, int64_t* edge_w)
+{
+    if (!p || side < 0 || side > 1) return IOC_ERR_ARG;
+    auto it = p->g[side].find(idx);
+    if (it == p->g[side].end()) return IOC_ERR_ARG;
+    const PGraph& G = it->second;
+    if (n_nodes) *n_nodes = int32_t(G.nodes.size());
+    if (n_edges) *n_edges = int32_t(G.edges.size());
+    for (size_t i = 0; i < G.nodes.size(); ++i) {
+        if (bases) bases[i] = G.nodes[i].base;
+        if (rank) rank[i] = G.rank[i];
+    }
+    for (size_t i = 0; i < G.edges.size(); ++i) {
+        if (edge_from) edge_from[i] = G.edges[i].from;
+        if (edge_to) edge_to[i] = G.edges[i].to;
+        if (edge_w) edge_w[i] = G.edges[i].w;
+    }
+    return IOC_OK;
+}
+
+int ioc_poa_last_alignment(ioc_poa* p, int32_t cap, int32_t* nodes, int32_t* pos, int32_t* score)
+{
+    if (!p) return IOC_ERR_ARG;
+    const int n = int(p->last_node.size());
+    if (score) *score = p->last_score;
+    if (nodes && pos) {
+        if (cap < n) return IOC_ERR_CAPACITY;
+        for (int i = 0; i < n; ++i) {
+            nodes[i] = p->last_node[size_t(i)];
+            pos[i] = p->last_pos[size_t(i)];
+        }
+    }
+    return n;
+}
+
+}  // extern "C"

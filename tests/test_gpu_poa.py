@@ -1,0 +1,243 @@
+"""The POA engine behind the consensus operations (ioc_poa_*).  spoa is absent from the
+reference tree, so there is no reference answer to pin: checked here are (a) the GPU sequence-to-graph DP
+against a plain-Python restatement of the same recurrence on the exported graph (score; the returned path is a
+valid walk through the graph whose own score equals it), (b) that the consensus of noisy copies recovers the
+sequence they came from, (c) the whole consensus-mode pipeline with this engine on both sides (oracle control
+flow vs product driver)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import _lib, api
+
+pytestmark = pytest.mark.gpu
+
+SC = dict(m=4, n=-8, g=-8, e=-4, q=-20, c=-1)   # src/main.cpp:285-290
+NEG = -10 ** 9
+
+
+class Poa:
+    def __init__(self, ctx):
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        rc = self.L.ioc_poa_create(ctx.h, SC["m"], SC["n"], SC["g"], SC["e"], SC["q"], SC["c"], C.byref(self.h))
+        assert rc == 0
+        self.ops = _lib.ConsensusOps()
+        self.L.ioc_poa_bind(self.h, C.byref(self.ops))
+
+    def create(self, idx, s, side=0):
+        assert self.ops.create(self.ops.user, side, idx, C.cast(C.c_char_p(s), C.POINTER(C.c_char)), len(s)) == 0
+
+    def add(self, idx, s, w=1, side=0):
+        assert self.ops.add(self.ops.user, side, idx, C.cast(C.c_char_p(s), C.POINTER(C.c_char)), len(s), w) == 0
+
+    def size(self, idx, side=0):
+        return self.ops.size(self.ops.user, side, idx)
+
+    def consensus(self, idx, side=0):
+        buf = C.create_string_buffer(1 << 20)
+        n = self.ops.consensus(self.ops.user, side, idx, C.cast(buf, C.POINTER(C.c_char)), len(buf))
+        assert n >= 0
+        return buf.raw[:n]
+
+    def graph(self, idx, side=0):
+        nn, ne = C.c_int32(), C.c_int32()
+        assert self.L.ioc_poa_graph_export(self.h, side, idx, C.byref(nn), C.byref(ne), None, None, None, None, None) == 0
+        bases = C.create_string_buffer(nn.value + 1)
+        rank = np.zeros(max(1, nn.value), np.int32)
+        ef, et = np.zeros(max(1, ne.value), np.int32), np.zeros(max(1, ne.value), np.int32)
+        ew = np.zeros(max(1, ne.value), np.int64)
+        p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        assert self.L.ioc_poa_graph_export(self.h, side, idx, C.byref(nn), C.byref(ne), bases, p32(rank), p32(ef), p32(et),
+                                           ew.ctypes.data_as(C.POINTER(C.c_int64))) == 0
+        return bases.raw[:nn.value], rank[:nn.value], ef[:ne.value], et[:ne.value], ew[:ne.value]
+
+    def last_alignment(self):
+        sc = C.c_int32()
+        n = self.L.ioc_poa_last_alignment(self.h, 0, None, None, C.byref(sc))
+        nodes, pos = np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+        p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        assert self.L.ioc_poa_last_alignment(self.h, n, p32(nodes), p32(pos), C.byref(sc)) == n
+        return nodes[:n], pos[:n], sc.value
+
+    def close(self):
+        self.L.ioc_poa_destroy(self.h)
+
+
+def _ref_score(bases, rank, ef, et, seq):
+    """Local sequence-to-graph alignment, convex gap = best of two affine pieces (plain loops)."""
+    n, L = len(bases), len(seq)
+    preds = {v: [] for v in range(n)}
+    for a, b in zip(ef, et):
+        preds[int(b)].append(int(a))
+    H = {-1: [0] * (L + 1)}
+    F1 = {-1: [NEG] * (L + 1)}
+    F2 = {-1: [NEG] * (L + 1)}
+    best = 0
+    for v in [int(x) for x in rank]:
+        ps = preds[v] or [-1]
+        h, f1, f2 = [0] * (L + 1), [NEG] * (L + 1), [NEG] * (L + 1)
+        e1 = e2 = NEG
+        for j in range(L + 1):
+            f1[j] = max(max(H[p][j] + SC["g"], F1[p][j] + SC["e"]) for p in ps)
+            f2[j] = max(max(H[p][j] + SC["q"], F2[p][j] + SC["c"]) for p in ps)
+            if j == 0:
+                h[j] = 0
+                continue
+            e1 = max(h[j - 1] + SC["g"], e1 + SC["e"])
+            e2 = max(h[j - 1] + SC["q"], e2 + SC["c"])
+            s = SC["m"] if bases[v] == seq[j - 1] else SC["n"]
+            h[j] = max(0, max(H[p][j - 1] for p in ps) + s, f1[j], f2[j], e1, e2)
+            best = max(best, h[j])
+        H[v], F1[v], F2[v] = h, f1, f2
+    return best
+
+
+def _path_score(bases, ef, et, seq, nodes, pos):
+    """Score of an alignment path, checking that it IS a walk through the graph and the read."""
+    edges = set(zip(ef.tolist(), et.tolist()))
+    total, run_kind, run_len = 0, None, 0
+    last_node, last_pos = None, None
+
+    def close():
+        nonlocal total, run_kind, run_len
+        if run_len:
+            total += max(SC["g"] + (run_len - 1) * SC["e"], SC["q"] + (run_len - 1) * SC["c"])
+        run_kind, run_len = None, 0
+
+    for v, p in zip(nodes.tolist(), pos.tolist()):
+        if v >= 0:
+            assert last_node is None or (last_node, v) in edges, "consecutive path nodes must be joined by an edge"
+            last_node = v
+        if p >= 0:
+            assert last_pos is None or p == last_pos + 1, "read positions must be consecutive"
+            last_pos = p
+        kind = "diag" if v >= 0 and p >= 0 else ("vert" if v >= 0 else "horz")
+        if kind == "diag":
+            close()
+            total += SC["m"] if bases[v] == seq[p] else SC["n"]
+        else:
+            if kind != run_kind:
+                close()
+            run_kind, run_len = kind, run_len + 1
+    close()
+    return total
+
+
+def _mutate(rng, s, rate):
+    out = bytearray()
+    for ch in s:
+        x = rng.random()
+        if x < rate / 3:
+            out.append(rng.choice(b"ACGT"))
+        elif x < 2 * rate / 3:
+            continue
+        elif x < rate:
+            out += bytes([ch, rng.choice(b"ACGT")])
+        else:
+            out.append(ch)
+    return bytes(out)
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, y in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y))
+        prev = cur
+    return prev[-1]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def test_graph_dp_equals_the_plain_recurrence(ctx):
+    rng = random.Random(7)
+    poa = Poa(ctx)
+    truth = bytes(rng.choice(b"ACGT") for _ in range(180))
+    poa.create(0, _mutate(rng, truth, 0.1))
+    for t in range(9):
+        read = _mutate(rng, truth, 0.15)
+        if t == 4:
+            read = read[40:120]                     # a fragment: local alignment, prefix/suffix unaligned
+        if t == 6:
+            read = bytes(rng.choice(b"ACGT") for _ in range(60)) + read[:100]   # unrelated head
+        bases, rank, ef, et, ew = poa.graph(0)      # the graph the read is aligned to
+        want = _ref_score(bases, rank, ef, et, read)
+        poa.add(0, read, w=1 + t % 3)
+        nodes, pos, score = poa.last_alignment()
+        assert score == want, (t, score, want)
+        assert _path_score(bases, ef, et, read, nodes, pos) == score, t
+    assert poa.size(0) == 10
+    bases, rank, ef, et, ew = poa.graph(0)
+    assert sorted(rank.tolist()) == list(range(len(bases)))                      # a permutation
+    order = {int(v): i for i, v in enumerate(rank)}
+    assert all(order[int(a)] < order[int(b)] for a, b in zip(ef, et))            # topological
+    poa.close()
+
+
+def test_consensus_recovers_the_source_sequence(ctx):
+    rng = random.Random(3)
+    poa = Poa(ctx)
+    truth = bytes(rng.choice(b"ACGT") for _ in range(900))
+    reads = [_mutate(rng, truth, 0.12) for _ in range(14)]
+    poa.create(5, reads[0])
+    d0 = _edit_distance(reads[0], truth)
+    for r in reads[1:]:
+        poa.add(5, r)
+    cons = poa.consensus(5)
+    d = _edit_distance(cons, truth)
+    assert d <= 0.03 * len(truth) and d < d0 / 3, (d, d0)
+    # purge: the graph restarts from one sequence carrying the old count as weight
+    ops = poa.ops
+    assert ops.purge(ops.user, 0, 5, C.cast(C.c_char_p(cons), C.POINTER(C.c_char)), len(cons), 14) == 0
+    assert poa.size(5) == 1 and poa.consensus(5) == cons
+    poa.close()
+
+
+def test_consensus_mode_pipeline_with_the_poa_engine(ctx):
+    """ioc_cluster_consensus with this engine against the oracle's consensus branch driving a second instance of
+    the same engine: assignments, event counts and the final MinDB."""
+    from isonclust2_amd import synth
+    from oracle import pyoracle as po
+    rs = synth.generate(120, 4, 700, 12, 21, seed=2)
+    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+    R.score_sort(11, 15)
+    p = po.default_params(11, 15)
+    p.cons_max_size = 10
+    B = po.Batch(R, 0, rs.n - 1, p)
+    info, off_f, off_r, mn, ps = B.minimizer_soa()
+    view = dict(off_fwd=off_f, off_rev=off_r, min_val=mn, min_pos=ps, raw_len=info["raw_len"], hpc_len=info["hpc_len"],
+                score=info["score"], raw_err=info["raw_err"], hpc_err=info["hpc_err"], state=info["state"].astype(np.uint8),
+                min_qual=p.min_qual, orig=info["orig"])
+    o_poa = Poa(ctx)
+    po.lib().orc_set_consensus(C.cast(C.pointer(o_poa.ops), C.c_void_p), 3, 500)
+    try:
+        ost = B.cluster(mode="fast")
+    finally:
+        po.lib().orc_set_consensus(None, 50, 500)
+    assert ost["cons_invoked"] > 10
+    acl, ast = B.assignments(rs.n)
+    ocl, ostr = acl[view["orig"]], ast[view["orig"]]
+    seqs = [rs.read(int(i))[0] for i in view["orig"]]
+    off = np.zeros(len(seqs) + 1, np.int64)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    v = dict(view)
+    v.update(raw_seq=b"".join(seqs), raw_off=off)
+    p_poa = Poa(ctx)
+    cargs = _lib.ConsensusArgs(cons_min_size=3, cons_max_size=10, cons_period=500, left_depth=-1, left_sizes=None)
+    cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, "fast"), None, v, cargs, p_poa.ops)
+    assert st["n_cons_invoked"] == ost["cons_invoked"]
+    assert np.array_equal(cls, ocl) and np.array_equal(strand, ostr)
+    keys, offs, post = ctx.index_export()
+    okeys, ooffs, opost = B.index()
+    assert np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)
+    o_poa.close()
+    p_poa.close()
