@@ -11,13 +11,15 @@
 // What runs where: the graphs (nodes, weighted edges, aligned-node groups, topological order) and the consensus
 // live on the host — they are small.  The sequence-to-graph DP is the heavy part (|graph| x |read| cells, 3*10^8
 // for a 16.7 kb read) and runs on the GPU:
-//   k_poa_forward  rows = graph nodes in topological order, one workgroup of 1024 threads per alignment.  The
-//                  columns of a row are independent once its predecessor rows are known, except for the
-//                  horizontal gap states, which are a max-plus prefix scan along the row:
-//                  E[j] = max_{x<j} Hn[x] + open + (j-1-x) ext, Hn = H without E (opening a gap right after a gap
-//                  never beats extending it, and switching between the two pieces of the convex gap never pays
-//                  when open <= ext for both pieces, which is checked).  Stores H, F1, F2 (later rows need them)
-//                  and one direction word per cell.
+//   k_poa_tile     rows = graph nodes in topological order.  The columns of a row are independent once its
+//                  predecessor rows are known, except for the horizontal gap states, which are a max-plus
+//                  prefix scan along the row: E[j] = max_{x<j} Hn[x] + open + (j-1-x) ext, Hn = H without E (opening
+//                  a gap right after a gap never beats extending it, and switching between the two pieces of the
+//                  convex gap never pays when open <= ext for both pieces, which is checked).  The matrix is cut
+//                  into tiles of 64 rows x 1024 columns (one column per thread) and swept one anti-diagonal of
+//                  tiles per launch: tiles of a diagonal are independent, a tile takes its row carries and
+//                  its boundary column from the tile on its left.  Stores H, F1, F2 (later rows need them), a
+//                  direction word and an E byte per cell.
 //   k_poa_trace    one lane walks back from the best cell over the direction words.
 #include <hip/hip_runtime.h>
 
@@ -35,11 +37,11 @@ namespace {
 
 constexpr int POA_NEG = INT32_MIN / 4;
 constexpr int POA_THREADS = 1024;
-constexpr int POA_MAX_COLS = 30000;   // one row of Hn stays in LDS
+constexpr int POA_MAX_COLS = 1 << 20;
 constexpr int POA_MAX_PREDS = 127;
 
-// direction word: [1:0] source of Hn (0 stop, 1 diagonal, 2 F1, 3 F2)  [4:2] source of H (those, 4 E1, 5 E2)
-// [5] E1 extended  [6] E2 extended  [7] F1 extended  [8] F2 extended
+// direction word: [1:0] source of Hn (0 stop, 1 diagonal, 2 F1, 3 F2)  [7] F1 extended  [8] F2 extended
+// (a horizontal gap winning H is in the cell's E byte: [2:0] 4 E1 / 5 E2 / 0, [3] E1 extended, [4] E2 extended)
 // [15:9] / [22:16] / [29:23] predecessor (index into the row's predecessor list) of the diagonal / F1 / F2 move
 enum : uint32_t { SRC_STOP = 0, SRC_DIAG = 1, SRC_F1 = 2, SRC_F2 = 3, SRC_E1 = 4, SRC_E2 = 5 };
 
@@ -49,50 +51,64 @@ struct PoaScores {
 
 __device__ __forceinline__ int2 max2(int2 a, int2 b) { return int2{max(a.x, b.x), max(a.y, b.y)}; }
 
-// rows 1..R = nodes in topological order, row 0 = virtual source (H = 0: local alignment); columns 0..L.
-// pred_off[r] .. pred_off[r+1]: predecessor ROWS of row r (row 0 for a node without in-edges).
-__global__ void __launch_bounds__(POA_THREADS)
-k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __restrict__ pred_off,
-              const int32_t* __restrict__ pred, const uint8_t* __restrict__ seq, PoaScores S, int* H, int* F1, int* F2,
-              uint32_t* dirs, int* __restrict__ best /* score, row, col */)
+constexpr int POA_CB = POA_THREADS;  // columns per tile: one per thread
+constexpr int POA_RB = 64;           // rows per tile
+
+// row 0 = virtual source (H = 0: local alignment)
+__global__ void k_poa_init(int W, int* H, int* F1, int* F2, uint32_t* dirs, uint8_t* ebits)
 {
-    extern __shared__ int s_hn[];  // W ints: Hn of the current row
-    __shared__ int2 s_wave[POA_THREADS / 64];
-    __shared__ int2 s_inc[POA_THREADS];
-    __shared__ int s_red[3 * (POA_THREADS / 64)];
-    const int W = L + 1;                                   // row pitch
-    const int per = (W + POA_THREADS - 1) / POA_THREADS;   // consecutive columns per thread
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = min(W, tid * per), j1 = min(W, j0 + per);
-    for (int j = tid; j < W; j += POA_THREADS) {  // row 0
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < W) {
         H[j] = 0;
         F1[j] = POA_NEG;
         F2[j] = POA_NEG;
         dirs[j] = SRC_STOP;
+        ebits[j] = 0;
     }
-    __syncthreads();
+}
+
+// One anti-diagonal of tiles per launch (tile = POA_RB rows x POA_CB columns): the tiles of a diagonal are
+// independent, kernel boundaries are the only synchronisation between tiles (no flags, no cross-workgroup
+// coherence games), and a row inside a tile costs one memory latency and one block scan for 1024 columns.
+// rows 1..R = nodes in topological order; pred_off[r] .. pred_off[r+1]: predecessor ROWS of row r (row 0 for a
+// node without in-edges).  carry[cb][r] = (prefix max of Hn[x] - e x, of Hn[x] - c x, over all columns up to the
+// tile's last one; Hn of that last column): what the tile to the right needs of row r.
+__global__ void __launch_bounds__(POA_THREADS)
+k_poa_tile(int R, int L, int diag, int cb_first, int nrb, const uint8_t* __restrict__ base,
+           const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred, const uint8_t* __restrict__ seq,
+           PoaScores S, int* H, int* F1, int* F2, uint32_t* __restrict__ dirs, uint8_t* __restrict__ ebits, int4* carry,
+           int4* __restrict__ tile_best)
+{
+    __shared__ int2 s_wave[POA_THREADS / 64];
+    __shared__ int2 s_inc[POA_THREADS];
+    __shared__ int s_hn[POA_THREADS];
+    __shared__ int s_red[3 * (POA_THREADS / 64)];
+    const int W = L + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = cb_first + blockIdx.x, rb = diag - cb;
+    const int j = cb * POA_CB + tid;
+    const bool active = j < W;
+    const int r_lo = rb * POA_RB + 1, r_hi = min(R, r_lo + POA_RB - 1);
+    const int4* cin_row = cb > 0 ? carry + int64_t(cb - 1) * (R + 1) : nullptr;
+    int4* cout_row = carry + int64_t(cb) * (R + 1);
     int my_best = 0, my_r = 0, my_j = 0;
-    for (int r = 1; r <= R; ++r) {
+    for (int r = r_lo; r <= r_hi; ++r) {
         const int pb = pred_off[r], pe = pred_off[r + 1];
         const uint8_t b = base[r];
-        int* Hr = H + int64_t(r) * W;
-        int* F1r = F1 + int64_t(r) * W;
-        int* F2r = F2 + int64_t(r) * W;
-        uint32_t* Dr = dirs + int64_t(r) * W;
-        // ---- phase A: Hn (everything but the horizontal gaps), F1, F2, and this thread's scan totals ----
-        int2 tot{POA_NEG, POA_NEG};
-        for (int j = j0; j < j1; ++j) {
-            int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
-            uint32_t d = SRC_STOP;
+        const int64_t ro = int64_t(r) * W;
+        const int4 cin = cin_row ? cin_row[r] : int4{POA_NEG, POA_NEG, 0, 0};  // (issued first: not needed before the scan)
+        int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
+        uint32_t d = SRC_STOP;
+        if (active) {
             uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
-            int diag = POA_NEG;
+            int dg = POA_NEG;
             const int sc = j > 0 ? ((b == seq[j - 1]) ? S.m : S.n) : 0;
             for (int x = pb; x < pe; ++x) {
                 const int64_t po = int64_t(pred[x]) * W;
                 if (j > 0) {
                     const int hd = H[po + j - 1] + sc;
-                    if (hd > diag) {
-                        diag = hd;
+                    if (hd > dg) {
+                        dg = hd;
                         dp = uint32_t(x - pb);
                     }
                 }
@@ -112,8 +128,8 @@ k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __r
                     f2x = x2 > o2 ? 1u : 0u;
                 }
             }
-            if (diag > hn) {
-                hn = diag;
+            if (dg > hn) {
+                hn = dg;
                 d = SRC_DIAG;
             }
             if (f1 > hn) {
@@ -125,21 +141,17 @@ k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __r
                 d = SRC_F2;
             }
             d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
-            s_hn[j] = hn;
-            F1r[j] = f1;
-            F2r[j] = f2;
-            Dr[j] = d;
-            tot = max2(tot, int2{hn - S.e * j, hn - S.c * j});
         }
-        // ---- inclusive block scan of the thread totals: prefix maxima of Hn[x] - e x and Hn[x] - c x ----
-        int2 v = tot;
+        s_hn[tid] = hn;
+        // ---- inclusive block scan: prefix maxima of Hn[x] - e x and Hn[x] - c x over the tile's columns ----
+        int2 v = active ? int2{hn - S.e * j, hn - S.c * j} : int2{POA_NEG, POA_NEG};
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int tx = __shfl_up(v.x, o), ty = __shfl_up(v.y, o);
             if (lane >= o) v = max2(v, int2{tx, ty});
         }
         if (lane == 63) s_wave[wave] = v;
-        __syncthreads();  // (also: s_hn of this row is complete)
+        __syncthreads();
         if (wave == 0) {
             int2 w = lane < POA_THREADS / 64 ? s_wave[lane] : int2{POA_NEG, POA_NEG};
 #pragma unroll
@@ -153,42 +165,44 @@ k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __r
         if (wave > 0) v = max2(v, s_wave[wave - 1]);
         s_inc[tid] = v;
         __syncthreads();
-        int2 run = tid > 0 ? s_inc[tid - 1] : int2{POA_NEG, POA_NEG};  // over the columns left of j0
-        // ---- phase B: E1, E2, H ----
-        for (int j = j0; j < j1; ++j) {
-            const int hn = s_hn[j];
+        int2 run = max2(tid > 0 ? s_inc[tid - 1] : int2{POA_NEG, POA_NEG}, int2{cin.x, cin.y});  // all columns left of j
+        if (active) {
             int h = hn;
-            uint32_t d = Dr[j];
-            uint32_t src = d & 3u;
+            uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
             if (j > 0) {
                 const int e1 = run.x > POA_NEG / 2 ? run.x + S.g + (j - 1) * S.e : POA_NEG;
                 const int e2 = run.y > POA_NEG / 2 ? run.y + S.q + (j - 1) * S.c : POA_NEG;
-                const int left = s_hn[j - 1];
-                const uint32_t e1x = e1 > left + S.g ? 1u : 0u;   // opened iff the maximum sits at x = j - 1
+                const int left = tid > 0 ? s_hn[tid - 1] : cin.z;
+                const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
                 const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
                 if (e1 > h) {
                     h = e1;
-                    src = SRC_E1;
+                    eb = SRC_E1;
                 }
                 if (e2 > h) {
                     h = e2;
-                    src = SRC_E2;
+                    eb = SRC_E2;
                 }
-                d |= (e1x << 5) | (e2x << 6);
+                eb |= (e1x << 3) | (e2x << 4);
             }
-            d |= src << 2;
-            Hr[j] = h;
-            Dr[j] = d;
-            run = max2(run, int2{hn - S.e * j, hn - S.c * j});
-            if (h > my_best) {  // first row, then first column, wins ties (rows ascend in time, columns inside a thread too)
+            H[ro + j] = h;
+            F1[ro + j] = f1;
+            F2[ro + j] = f2;
+            dirs[ro + j] = d;
+            ebits[ro + j] = uint8_t(eb);
+            if (h > my_best) {  // rows ascend in time: the first row wins ties
                 my_best = h;
                 my_r = r;
                 my_j = j;
             }
+            if (tid == POA_CB - 1 || j == W - 1) {
+                const int2 all = max2(v, int2{cin.x, cin.y});
+                cout_row[r] = int4{all.x, all.y, hn, 0};
+            }
         }
-        __syncthreads();  // row r is complete (and s_hn free) before row r + 1
+        __syncthreads();  // row r of this tile is in memory (and the LDS arrays are free) before row r + 1
     }
-    // ---- best cell: maximum score, ties to the smallest row, then the smallest column ----
+    // ---- the tile's best cell: maximum score, ties to the smallest row, then the smallest column ----
     auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
         return s1 > s2 || (s1 == s2 && (r1 < r2 || (r1 == r2 && c1 < c2)));
     };
@@ -215,9 +229,7 @@ k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __r
                 br = s_red[3 * w2 + 1];
                 bc = s_red[3 * w2 + 2];
             }
-        best[0] = bs;
-        best[1] = br;
-        best[2] = bc;
+        tile_best[int64_t(cb) * nrb + rb] = int4{bs, br, bc, 0};
     }
 }
 
@@ -225,7 +237,8 @@ k_poa_forward(int R, int L, const uint8_t* __restrict__ base, const int32_t* __r
 // for a diagonal move, (row, -1) for a node against a gap, (-1, column - 1) for a base against a gap;
 // out_n = number of pairs.
 __global__ void k_poa_trace(int L, const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred,
-                            const uint32_t* __restrict__ dirs, const int* __restrict__ best, int32_t* __restrict__ out_node,
+                            const uint32_t* __restrict__ dirs, const uint8_t* __restrict__ ebits, const int* __restrict__ best,
+                            int32_t* __restrict__ out_node,
                             int32_t* __restrict__ out_pos, int32_t* __restrict__ out_n, int cap)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -234,9 +247,10 @@ __global__ void k_poa_trace(int L, const int32_t* __restrict__ pred_off, const i
     int state = 0;  // 0 H, 1 Hn (H without the horizontal sources), 2 F1, 3 F2, 4 E1, 5 E2
     while (r > 0 && n < cap) {
         const uint32_t d = dirs[int64_t(r) * W + j];
+        const uint32_t eb = ebits[int64_t(r) * W + j];
         const int pb = pred_off[r];
         if (state == 0 || state == 1) {
-            const uint32_t src = state == 0 ? (d >> 2) & 7u : d & 3u;
+            const uint32_t src = (state == 0 && (eb & 7u)) ? eb & 7u : d & 3u;
             if (src == SRC_STOP) break;
             if (src == SRC_DIAG) {
                 out_node[n] = r;
@@ -259,7 +273,7 @@ __global__ void k_poa_trace(int L, const int32_t* __restrict__ pred_off, const i
             out_node[n] = -1;
             out_pos[n] = j - 1;
             ++n;
-            const bool ext = state == 4 ? (d >> 5) & 1u : (d >> 6) & 1u;
+            const bool ext = state == 4 ? (eb >> 3) & 1u : (eb >> 4) & 1u;
             --j;
             if (!ext) state = 1;  // the gap was opened from Hn of the column to the left
         }
@@ -436,7 +450,7 @@ struct ioc_poa {
     ioc_ctx* ctx = nullptr;
     PoaScores S{4, -8, -8, -4, -20, -1};
     std::map<int, PGraph> g[2];
-    DevBuf d_h, d_f1, d_f2, d_dirs, d_small, d_aln;
+    DevBuf d_h, d_f1, d_f2, d_dirs, d_eb, d_carry, d_tbest, d_small, d_aln;
     // the alignment of the last ioc_poa_add (tests / inspection): node ids, positions, score
     std::vector<int32_t> last_node, last_pos;
     int32_t last_score = 0;
@@ -474,7 +488,7 @@ int poa_align(ioc_poa* p, const PGraph& G, const char* seq, int len, std::vector
     score = 0;
     const int R = int(G.nodes.size()), L = len;
     if (R == 0 || L == 0) return IOC_OK;
-    if (L + 1 > POA_MAX_COLS) return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: sequences above 30 000 bases are not supported");
+    if (L + 1 > POA_MAX_COLS) return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: sequences above 2^20 bases are not supported");
     ioc_ctx* c = p->ctx;
     PCHK(p, hipSetDevice(c->device));
     std::vector<int> row_of(static_cast<size_t>(R), 0);
@@ -507,23 +521,39 @@ int poa_align(ioc_poa* p, const PGraph& G, const char* seq, int len, std::vector
     PCHK(p, hipMemcpyAsync(sm + o_poff, poff.data(), poff.size() * 4, hipMemcpyHostToDevice, s));
     PCHK(p, hipMemcpyAsync(sm + o_pred, pred.data(), pred.size() * 4, hipMemcpyHostToDevice, s));
     PCHK(p, hipMemcpyAsync(sm + o_seq, seq, size_t(L), hipMemcpyHostToDevice, s));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_poa_forward), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  POA_MAX_COLS * 4);
-        (void)hipGetLastError();
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_poa_forward, dim3(1), dim3(POA_THREADS), size_t(L + 1) * 4, s, R, L, sm + o_base,
-                       reinterpret_cast<const int32_t*>(sm + o_poff), reinterpret_cast<const int32_t*>(sm + o_pred), sm + o_seq,
-                       p->S, static_cast<int*>(p->d_h.p), static_cast<int*>(p->d_f1.p), static_cast<int*>(p->d_f2.p),
-                       static_cast<uint32_t*>(p->d_dirs.p), reinterpret_cast<int*>(sm + o_best));
+    const int W = L + 1, ncb = (W + POA_CB - 1) / POA_CB, nrb = (R + POA_RB - 1) / POA_RB;
+    if ((r = poa_reserve(p, p->d_eb, cells)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_carry, size_t(ncb) * size_t(R + 1) * sizeof(int4))) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_tbest, size_t(ncb) * size_t(nrb) * sizeof(int4))) != IOC_OK) return r;
+    hipLaunchKernelGGL(k_poa_init, dim3(unsigned((W + 255) / 256)), dim3(256), 0, s, W, static_cast<int*>(p->d_h.p),
+                       static_cast<int*>(p->d_f1.p), static_cast<int*>(p->d_f2.p), static_cast<uint32_t*>(p->d_dirs.p),
+                       static_cast<uint8_t*>(p->d_eb.p));
     PCHK(p, hipGetLastError());
+    for (int dg = 0; dg < nrb + ncb - 1; ++dg) {  // one anti-diagonal of tiles per launch
+        const int cb_first = std::max(0, dg - nrb + 1), cb_last = std::min(ncb - 1, dg);
+        hipLaunchKernelGGL(k_poa_tile, dim3(unsigned(cb_last - cb_first + 1)), dim3(POA_THREADS), 0, s, R, L, dg, cb_first, nrb,
+                           sm + o_base, reinterpret_cast<const int32_t*>(sm + o_poff), reinterpret_cast<const int32_t*>(sm + o_pred),
+                           sm + o_seq, p->S, static_cast<int*>(p->d_h.p), static_cast<int*>(p->d_f1.p), static_cast<int*>(p->d_f2.p),
+                           static_cast<uint32_t*>(p->d_dirs.p), static_cast<uint8_t*>(p->d_eb.p), static_cast<int4*>(p->d_carry.p),
+                           static_cast<int4*>(p->d_tbest.p));
+        PCHK(p, hipGetLastError());
+    }
+    {   // best cell over the tiles: maximum score, ties to the smallest row, then the smallest column
+        std::vector<int4> tb(size_t(ncb) * size_t(nrb));
+        PCHK(p, hipMemcpyAsync(tb.data(), p->d_tbest.p, tb.size() * sizeof(int4), hipMemcpyDeviceToHost, s));
+        PCHK(p, hipStreamSynchronize(s));
+        int4 bst{0, 0, 0, 0};
+        for (const int4& t : tb)
+            if (t.x > bst.x || (t.x == bst.x && t.x > 0 && (t.y < bst.y || (t.y == bst.y && t.z < bst.z)))) bst = t;
+        const int32_t hb3[3] = {bst.x, bst.y, bst.z};
+        PCHK(p, hipMemcpyAsync(sm + o_best, hb3, 12, hipMemcpyHostToDevice, s));
+    }
     int32_t* d_node = static_cast<int32_t*>(p->d_aln.p);
     int32_t* d_pos = d_node + cap;
     hipLaunchKernelGGL(k_poa_trace, dim3(1), dim3(64), 0, s, L, reinterpret_cast<const int32_t*>(sm + o_poff),
                        reinterpret_cast<const int32_t*>(sm + o_pred), static_cast<const uint32_t*>(p->d_dirs.p),
-                       reinterpret_cast<const int*>(sm + o_best), d_node, d_pos, reinterpret_cast<int32_t*>(sm + o_n), cap);
+                       static_cast<const uint8_t*>(p->d_eb.p), reinterpret_cast<const int*>(sm + o_best), d_node, d_pos,
+                       reinterpret_cast<int32_t*>(sm + o_n), cap);
     PCHK(p, hipGetLastError());
     int32_t hb[3] = {0, 0, 0}, hn = 0;
     PCHK(p, hipMemcpyAsync(hb, sm + o_best, 12, hipMemcpyDeviceToHost, s));
@@ -618,7 +648,7 @@ int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int
 void ioc_poa_destroy(ioc_poa* p)
 {
     if (!p) return;
-    for (DevBuf* b : {&p->d_h, &p->d_f1, &p->d_f2, &p->d_dirs, &p->d_small, &p->d_aln})
+    for (DevBuf* b : {&p->d_h, &p->d_f1, &p->d_f2, &p->d_dirs, &p->d_eb, &p->d_carry, &p->d_tbest, &p->d_small, &p->d_aln})
         if (b->p) (void)hipFree(b->p);
     delete p;
 }

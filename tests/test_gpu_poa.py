@@ -241,3 +241,21 @@ def test_consensus_mode_pipeline_with_the_poa_engine(ctx):
     assert np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)
     o_poa.close()
     p_poa.close()
+
+
+def test_graph_dp_across_tiles(ctx):
+    """Reads longer than one tile column (1024 columns) against a graph deeper than one tile row (64 nodes): row
+    carries and boundary columns cross tiles, a long deletion spans a tile edge."""
+    rng = random.Random(19)
+    poa = Poa(ctx)
+    truth = bytes(rng.choice(b"ACGT") for _ in range(2150))
+    poa.create(0, _mutate(rng, truth, 0.08))
+    reads = [_mutate(rng, truth, 0.1), _mutate(rng, truth[:1000] + truth[1060:], 0.05)]   # the second lacks 60 bases at the tile edge
+    for t, read in enumerate(reads):
+        bases, rank, ef, et, ew = poa.graph(0)
+        want = _ref_score(bases, rank, ef, et, read)
+        poa.add(0, read)
+        nodes, pos, score = poa.last_alignment()
+        assert score == want, (t, score, want)
+        assert _path_score(bases, ef, et, read, nodes, pos) == score, t
+    poa.close()
