@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Developer run of consensus mode at scale: a synthetic batch through ioc_cluster_consensus with the product's POA
+engine behind the graph operations (CLI defaults ConsMinSize 20, ConsMaxSize 100, ConsPeriod 400)."""
+import argparse
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from isonclust2_amd import _lib, api, synth  # noqa: E402
+from tests.helpers import oracle_sorted_batch  # noqa: E402
+from tests.test_gpu_poa import Poa  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="600,30,4000", help="n_reads,n_transcripts,length")
+ap.add_argument("--mode", default="fast")
+ap.add_argument("--cons", default="20,100,400", help="ConsMinSize,ConsMaxSize,ConsPeriod")
+a = ap.parse_args()
+n, g, ln = (int(x) for x in a.shape.split(","))
+cmin, cmax, per = (int(x) for x in a.cons.split(","))
+rs = synth.generate(n, g, ln, 10, 21, seed=1)
+B, view = oracle_sorted_batch(rs)     # (sort stage only: the oracle does not cluster here)
+seqs = [rs.read(int(i))[0] for i in view["orig"]]
+off = np.zeros(len(seqs) + 1, np.int64)
+off[1:] = np.cumsum([len(x) for x in seqs])
+v = dict(view)
+v.update(raw_seq=b"".join(seqs), raw_off=off)
+ctx = api.Context(0)
+poa = Poa(ctx)
+cargs = _lib.ConsensusArgs(cons_min_size=cmin, cons_max_size=cmax, cons_period=per, left_depth=-1, left_sizes=None)
+t = time.time()
+cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, a.mode), None, v, cargs, poa.ops)
+dt = time.time() - t
+print(f"{rs.tag} {a.mode}: {dt:.2f} s ({rs.n / dt:.0f} reads/s); {st}")
