@@ -379,6 +379,10 @@ void ioc_poa_bind(ioc_poa* poa, ioc_consensus_ops* ops);
 int ioc_poa_graph_export(ioc_poa* poa, int side, int idx, int32_t* n_nodes, int32_t* n_edges, char* bases, int32_t* rank,
                          int32_t* edge_from, int32_t* edge_to, int64_t* edge_w);
 int ioc_poa_last_alignment(ioc_poa* poa, int32_t cap, int32_t* nodes, int32_t* pos, int32_t* score);
+/* persistence across `.cer` files (one graph per cluster, src/serialize.h:21,37; the blob layout is this build's
+ * own): save returns the size (out == NULL to size), load replaces graph (side, idx). */
+int64_t ioc_poa_graph_save(ioc_poa* poa, int side, int idx, uint8_t* out, int64_t cap);
+int ioc_poa_graph_load(ioc_poa* poa, int side, int idx, const uint8_t* in, int64_t len);
 
 /* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries
  * must all be clusterable.  Fast mode, or sahlin mode after ioc_resident_set_sequences. */

@@ -107,6 +107,7 @@ SYMBOLS = [
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
     "ioc_index_update", "ioc_left_export", "ioc_cluster_consensus",
     "ioc_poa_create", "ioc_poa_destroy", "ioc_poa_bind", "ioc_poa_graph_export", "ioc_poa_last_alignment",
+    "ioc_poa_graph_save", "ioc_poa_graph_load",
 ]
 
 _lib = None
@@ -177,6 +178,9 @@ def load():
     L.ioc_poa_bind.restype = None
     L.ioc_poa_graph_export.argtypes = [vp, C.c_int, C.c_int, pi32, pi32, C.c_char_p, pi32, pi32, pi32, pi64]
     L.ioc_poa_last_alignment.argtypes = [vp, i32, pi32, pi32, pi32]
+    L.ioc_poa_graph_save.argtypes = [vp, C.c_int, C.c_int, pu8, i64]
+    L.ioc_poa_graph_save.restype = C.c_int64
+    L.ioc_poa_graph_load.argtypes = [vp, C.c_int, C.c_int, pu8, i64]
     L.ioc_host_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, C.c_char_p, i32, pi32]
     L.ioc_host_gap_open.argtypes = [C.c_double]
     L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]

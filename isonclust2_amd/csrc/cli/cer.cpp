@@ -200,7 +200,15 @@ bool save_batch(const Batch& b, const std::string& path, std::string& err)
         }
     }
     w.pod<uint64_t>(b.NrConsGs);
-    for (uint64_t i = 0; i < b.NrConsGs; ++i) w.pod<uint8_t>(0);  // null unique_ptr<spoa::Graph>
+    for (uint64_t i = 0; i < b.NrConsGs; ++i) {
+        if (i < b.ConsGs.size() && !b.ConsGs[i].empty()) {
+            w.pod<uint8_t>(1);
+            w.pod<uint64_t>(b.ConsGs[i].size());
+            w.raw(b.ConsGs[i].data(), b.ConsGs[i].size());
+        } else {
+            w.pod<uint8_t>(0);  // null unique_ptr<spoa::Graph>
+        }
+    }
     w.flush();
     bool ok = w.ok && fclose(f) == 0;
     if (!ok) err = "Failed to write " + path + "!";
@@ -307,11 +315,18 @@ bool load_batch(Batch& b, const std::string& path, std::string& err)
         b.Cls.push_back(c);
     }
     b.NrConsGs = r.pod<uint64_t>();
-    for (uint64_t i = 0; r.ok && i < b.NrConsGs; ++i)
-        if (r.pod<uint8_t>() != 0) {
-            err = "Failed to load batch " + path + ": consensus graphs are not supported by this build";
-            return false;
+    b.ConsGs.clear();
+    for (uint64_t i = 0; r.ok && i < b.NrConsGs; ++i) {
+        b.ConsGs.emplace_back();
+        if (r.pod<uint8_t>() == 0) continue;
+        const uint64_t n = r.pod<uint64_t>();
+        if (!r.ok || uint64_t(r.e - r.p) < n) {
+            r.ok = false;
+            break;
         }
+        b.ConsGs.back().assign(r.p, r.p + n);
+        r.p += n;
+    }
     if (!r.ok) {
         err = "Failed to load batch " + path + ": truncated or corrupt archive";
         return false;

@@ -7,7 +7,8 @@
 // value) pairs, unique_ptr = u8 valid flag, shared_ptr = u32 id with the MSB set on first occurrence).
 // cereal itself is absent from the reference tree (vendor/cereal is an empty submodule), so the byte
 // layout is UNVERIFIED against a reference-written file: it is self-consistent between this tool's
-// sort / cluster / dump / info.  spoa graphs (ConsGs) are written as null entries.
+// sort / cluster / dump / info.  spoa graphs (ConsGs) are written as null entries, or — consensus mode — as the
+// graph blobs of this build's POA engine.
 #ifndef IOC_CER_HPP
 #define IOC_CER_HPP
 
@@ -61,6 +62,9 @@ struct Batch {  // src/serialize.h:23-43
     MinDB Db;
     Clusters Cls;
     uint64_t NrConsGs = 0;
+    // ConsGs (src/serialize.h:21,37): one graph per cluster.  spoa's own cereal layout is not in the tree; a graph is
+    // written as unique_ptr flag + u64 length + the blob of ioc_poa_graph_save (empty vector entry = null pointer).
+    std::vector<std::vector<uint8_t>> ConsGs;
 };
 
 bool save_batch(const Batch& b, const std::string& path, std::string& err);

@@ -20,6 +20,7 @@
 #include <fstream>
 #include <future>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <numeric>
 #include <sstream>
@@ -160,7 +161,6 @@ static int main_sort(int argc, char** argv)
     // src/args.cpp:135-148
     if (a.KmerSize < 10 || a.KmerSize > 31) die("Invalid kmer size (must be in [10,31])!");
     if (a.KmerSize > a.WindowSize) die("The window size must be larger than or equal to the kmer size!");
-    if (a.ConsMaxSize > 0) die("Consensus (-c > 0) is not supported by this build (spoa is out of scope)");
     if (optind >= argc) die("No input fastq specified!");
     a.InFastq = argv[optind];
     VERBOSE = a.Verbose;
@@ -388,10 +388,10 @@ static int main_cluster(int argc, char** argv)
             die("The left and right batches have been sorted with different parameters! \nRefusing to carry on with clustering as results would not make sense! ");
         if (right.Depth > 0 && right.BatchStart != left.BatchEnd + 1) die("Trying to merge non-consecutive batches! Giving up!");
         if (left.Depth > 0 && right.Depth > left.Depth) die("The left input batch must have higher depth!");
-        if (x.ConsMaxSize > 0) die("Consensus (ConsMaxSize > 0) is not supported by this build");
     }
     const CmdArgs& a = left.SortArgs;
-    const bool need_seq = (mode == Sahlin || mode == Furious);
+    const bool cons_on = left.SortArgs.ConsMaxSize > 0;  // consensus mode: frozen at sort time (-c), cluster.cpp:101
+    const bool need_seq = cons_on || ((mode == Sahlin || mode == Furious));
 
     // ---- right batch -> ioc_batch_view ----
     const int n = int(right.Cls.size());
@@ -527,8 +527,69 @@ static int main_cluster(int argc, char** argv)
     std::vector<int8_t> out_strand(static_cast<size_t>(n) + 1);
     ioc_cluster_stats st{};
     auto t_core = std::chrono::steady_clock::now();
-    check(c, ioc_cluster_merge(c, &p, table_path().c_str(), L > 0 ? &lv : nullptr, &rv, out_cls.data(), out_strand.data(), &st),
-          "clustering");
+    // consensus mode: the graphs live in this build's POA engine (spoa is not in the reference tree); representatives
+    // replaced by a consensus are collected and written into the clusters after the bookkeeping below
+    struct RepEvent {
+        int32_t entry = -1;
+        string raw, hpc;
+        char qual = '!';
+        double raw_err = 0, raw_score = 0, hpc_err = 0;
+        std::vector<cer::Minimizer> mins, rev;
+    };
+    std::map<int32_t, RepEvent> rep_events;
+    ioc_poa* poa = nullptr;
+    if (cons_on) {
+        if (mode == None) die("Invalid clustering mode: 3");
+        check(c, ioc_poa_create(c, 4, -8, -8, -4, -20, -1, &poa), "consensus engine");  // src/main.cpp:285-290
+        for (size_t i = 0; i < left.ConsGs.size() && i < size_t(L); ++i)
+            if (!left.ConsGs[i].empty())
+                check(c, ioc_poa_graph_load(poa, 0, int(i), left.ConsGs[i].data(), int64_t(left.ConsGs[i].size())), "left consensus graph");
+        for (size_t i = 0; i < right.ConsGs.size() && i < size_t(n); ++i)
+            if (!right.ConsGs[i].empty())
+                check(c, ioc_poa_graph_load(poa, 1, int(i), right.ConsGs[i].data(), int64_t(right.ConsGs[i].size())), "right consensus graph");
+        // left clusters without a stored graph (batches clustered without consensus): seeded with the representative
+        for (int i = 0; i < L; ++i)
+            if (size_t(i) >= left.ConsGs.size() || left.ConsGs[size_t(i)].empty()) {
+                ioc_consensus_ops seed{};
+                ioc_poa_bind(poa, &seed);
+                const string& rs0 = left.Cls[size_t(i)]->at(0)->RawSeq->seq;
+                seed.create(seed.user, 0, i, rs0.data(), int(rs0.size()));
+            }
+        ioc_consensus_ops ops{};
+        ioc_poa_bind(poa, &ops);
+        struct Ctx {
+            std::map<int32_t, RepEvent>* ev;
+            void* poa;
+        } cbctx{&rep_events, poa};
+        // the five graph operations go to the engine; rep_changed is ours (different `user`): wrap
+        static Ctx* g_cb = nullptr;
+        g_cb = &cbctx;
+        ops.user = poa;
+        ops.rep_changed = [](void*, int32_t cls, const ioc_rep_record* rec) {
+            RepEvent& e = (*g_cb->ev)[cls];
+            e.entry = rec->entry;
+            e.raw.assign(rec->raw_seq, size_t(rec->raw_len));
+            e.hpc.assign(rec->hpc_seq, size_t(rec->hpc_len));
+            e.qual = rec->raw_qual;
+            e.raw_err = rec->raw_err;
+            e.raw_score = rec->raw_score;
+            e.hpc_err = rec->hpc_err;
+            e.mins.resize(size_t(rec->n_fwd));
+            for (int32_t t = 0; t < rec->n_fwd; ++t) e.mins[size_t(t)] = cer::Minimizer{rec->fwd_min[t], rec->fwd_pos[t], uint32_t(t)};
+            e.rev.resize(size_t(rec->n_rev));
+            for (int32_t t = 0; t < rec->n_rev; ++t) e.rev[size_t(t)] = cer::Minimizer{rec->rev_min[t], rec->rev_pos[t], uint32_t(t)};
+        };
+        std::vector<int32_t> lsizes(static_cast<size_t>(L) + 1, 2);
+        for (int i = 0; i < L; ++i) lsizes[size_t(i)] = int32_t(left.Cls[size_t(i)]->size());
+        const CmdArgs& la = left.SortArgs;
+        ioc_consensus_args ca{la.ConsMinSize, la.ConsMaxSize, la.ConsPeriod, left.Depth, lsizes.data()};
+        check(c, ioc_cluster_consensus(c, &p, table_path().c_str(), L > 0 ? &lv : nullptr, &rv, &ca, &ops, out_cls.data(),
+                                       out_strand.data(), &st),
+              "clustering (consensus mode)");
+    } else {
+        check(c, ioc_cluster_merge(c, &p, table_path().c_str(), L > 0 ? &lv : nullptr, &rv, out_cls.data(), out_strand.data(), &st),
+              "clustering");
+    }
     double core_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count();
 
     // ---- bookkeeping of the loop, cluster.cpp:115-310 ----
@@ -639,6 +700,38 @@ static int main_cluster(int argc, char** argv)
         left.Db.clear();
     }
     left.NrConsGs = left.Cls.size();
+    left.ConsGs.clear();
+    if (cons_on) {
+        // UpdateClusterConsensus' effect on the representatives (consensus.cpp:93-124), last event per cluster
+        for (auto& kv : rep_events) {
+            if (kv.first < 0 || size_t(kv.first) >= left.Cls.size()) die("Inconsistent cluster id from the consensus path");
+            auto& rep = left.Cls[size_t(kv.first)]->at(0);
+            const RepEvent& e = kv.second;
+            const string nm = "cons_" + std::to_string(left.BatchNr) + "_" + std::to_string(e.entry);
+            rep->RawSeq.reset(new Seq);
+            rep->RawSeq->name = nm;
+            rep->RawSeq->seq = e.raw;
+            rep->RawSeq->qual = string(e.raw.size(), e.qual);
+            rep->RawSeq->score = e.raw_score;
+            rep->RawSeq->errorRate = e.raw_err;
+            rep->HpcSeq.reset(new Seq);
+            rep->HpcSeq->name = nm;
+            rep->HpcSeq->seq = e.hpc;
+            rep->HpcSeq->qual = string(e.hpc.size(), e.qual);
+            rep->HpcSeq->score = e.hpc_err * double(e.hpc.size());
+            rep->HpcSeq->errorRate = e.hpc_err;
+            rep->Mins = e.mins;
+            rep->RevMins = e.rev;
+        }
+        left.ConsGs.resize(left.Cls.size());
+        for (size_t i = 0; i < left.Cls.size(); ++i) {
+            const int64_t sz = ioc_poa_graph_save(poa, 0, int(i), nullptr, 0);
+            if (sz <= 0) continue;
+            left.ConsGs[i].resize(size_t(sz));
+            if (ioc_poa_graph_save(poa, 0, int(i), left.ConsGs[i].data(), sz) != sz) die("Failed to serialize a consensus graph");
+        }
+        if (VERBOSE) cerr << "Consensus invocation count: " << st.n_cons_invoked << endl;
+    }
     const double book_ms = ms_since(t_core) - core_ms;
     auto t_save = std::chrono::steady_clock::now();
     if (!save_batch(left, out_path, err)) die(err);

@@ -685,6 +685,97 @@ int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_
     return IOC_OK;
 }
 
+// ---- persistence (the .cer batch files carry one graph per cluster, src/serialize.h:21,37) ----------------------
+// blob: "IOCPOA1\0" | i32 nseq | i32 n_nodes | i32 n_edges | n_nodes x (u8 base, i32 n_aligned, n_aligned x i32) |
+// n_edges x (i32 from, i32 to, i64 weight).  The layout is this build's own (spoa's cereal layout is not in the tree).
+int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t cap)
+{
+    if (!p || side < 0 || side > 1) return IOC_ERR_ARG;
+    auto it = p->g[side].find(idx);
+    if (it == p->g[side].end()) return IOC_ERR_ARG;
+    const PGraph& G = it->second;
+    std::vector<uint8_t> b;
+    auto put = [&](const void* v, size_t n) { b.insert(b.end(), static_cast<const uint8_t*>(v), static_cast<const uint8_t*>(v) + n); };
+    auto put32 = [&](int32_t v) { put(&v, 4); };
+    put("IOCPOA1", 8);
+    put32(G.nseq);
+    put32(int32_t(G.nodes.size()));
+    put32(int32_t(G.edges.size()));
+    for (auto& nd : G.nodes) {
+        put(&nd.base, 1);
+        put32(int32_t(nd.aligned.size()));
+        for (int x : nd.aligned) put32(x);
+    }
+    for (auto& e : G.edges) {
+        put32(e.from);
+        put32(e.to);
+        put(&e.w, 8);
+    }
+    if (out) {
+        if (cap < int64_t(b.size())) return IOC_ERR_CAPACITY;
+        memcpy(out, b.data(), b.size());
+    }
+    return int64_t(b.size());
+}
+
+int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t len)
+{
+    if (!p || side < 0 || side > 1 || !in) return IOC_ERR_ARG;
+    const uint8_t* q = in;
+    const uint8_t* e = in + len;
+    bool ok = true;
+    auto get = [&](void* v, size_t n) {
+        if (size_t(e - q) < n) {
+            ok = false;
+            memset(v, 0, n);
+            return;
+        }
+        memcpy(v, q, n);
+        q += n;
+    };
+    auto get32 = [&]() {
+        int32_t v = 0;
+        get(&v, 4);
+        return v;
+    };
+    char magic[8];
+    get(magic, 8);
+    if (!ok || memcmp(magic, "IOCPOA1", 8) != 0) return ioc_fail(p->ctx, IOC_ERR_INPUT, "not a graph written by this build");
+    PGraph G;
+    G.nseq = get32();
+    const int32_t nn = get32(), ne = get32();
+    if (!ok || nn < 0 || ne < 0) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");
+    G.nodes.resize(size_t(nn));
+    for (int32_t i = 0; ok && i < nn; ++i) {
+        get(&G.nodes[size_t(i)].base, 1);
+        const int32_t na = get32();
+        if (na < 0 || na > nn) ok = false;
+        for (int32_t x = 0; ok && x < na; ++x) {
+            const int32_t a = get32();
+            if (a < 0 || a >= nn) ok = false;
+            G.nodes[size_t(i)].aligned.push_back(a);
+        }
+    }
+    for (int32_t i = 0; ok && i < ne; ++i) {
+        PEdge ed;
+        ed.from = get32();
+        ed.to = get32();
+        get(&ed.w, 8);
+        if (ed.from < 0 || ed.from >= nn || ed.to < 0 || ed.to >= nn) {
+            ok = false;
+            break;
+        }
+        G.edges.push_back(ed);
+        G.nodes[size_t(ed.from)].out.push_back(i);
+        G.nodes[size_t(ed.to)].in.push_back(i);
+    }
+    if (!ok) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");
+    G.toposort();
+    if (G.rank.size() != G.nodes.size()) return ioc_fail(p->ctx, IOC_ERR_INPUT, "graph with a cycle");
+    p->g[side][idx] = std::move(G);
+    return IOC_OK;
+}
+
 int ioc_poa_last_alignment(ioc_poa* p, int32_t cap, int32_t* nodes, int32_t* pos, int32_t* score)
 {
     if (!p) return IOC_ERR_ARG;

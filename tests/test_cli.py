@@ -98,3 +98,83 @@ def test_sort_cluster_merge_dump_matches_oracle(tmp_path, mode):
     assert names == [f"r{i}" for i, s in zip(order, score) if s >= 0]
     info = open(tmp_path / "dump" / "clusters_info.tsv").read().splitlines()
     assert len(info) - 1 == A.n_clusters()
+
+
+@pytest.mark.gpu
+def test_consensus_mode_sort_cluster_merge_dump(tmp_path):
+    """`sort -g 3 -c 8 -P 400` freezes the consensus parameters; `cluster` then keeps one POA graph per cluster
+    (this build's engine, graphs carried in the .cer files), replaces representatives by consensus sequences
+    and updates the MinDB; the merge runs with the Depth != -1 rules.  The oracle runs the same three steps with
+    a second instance of the engine behind its consensus hook (the graphs of step 2 serve as the right batch's in
+    the merge)."""
+    import ctypes as C
+    from isonclust2_amd import api
+    from oracle import pyoracle as po
+    from tests.test_gpu_poa import Poa
+    rs = synth.generate(200, 6, 800, 12, 21, seed=31)
+    half = rs.n // 2
+    fq = tmp_path / "reads.fq"
+    _write_fastq(rs, fq)
+    out = tmp_path / "sorted"
+    r = run("sort", "-B", "1000000", "-M", str(half), "-g", "3", "-c", "8", "-P", "400", "-o", str(out), str(fq))
+    assert r.returncode == 0, r.stderr
+    b0, b1 = out / "batches" / "isONbatch_0.cer", out / "batches" / "isONbatch_1.cer"
+    for b, o in ((b0, "c0.cer"), (b1, "c1.cer")):
+        r = run("cluster", "-v", "-l", str(b), "-o", str(tmp_path / o), "-x", "fast")
+        assert r.returncode == 0, r.stderr
+        assert "Consensus invocation count" in r.stderr
+    r = run("cluster", "-l", str(tmp_path / "c0.cer"), "-r", str(tmp_path / "c1.cer"), "-o", str(tmp_path / "m.cer"), "-x", "fast")
+    assert r.returncode == 0, r.stderr
+    r = run("dump", "-i", str(out / "sorted_reads_idx.cer"), "-o", str(tmp_path / "dump"), str(tmp_path / "m.cer"))
+    assert r.returncode == 0, r.stderr
+
+    # ---- oracle with the same engine behind its hook ----
+    ctx = api.Context(0)
+    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+    R.score_sort(11, 15)
+    p = po.default_params(11, 15)
+    p.cons_max_size = 8
+    A, B = po.Batch(R, 0, half - 1, p, 0), po.Batch(R, half, rs.n - 1, p, 1)
+    ga, gb = Poa(ctx), Poa(ctx)
+    events = 0
+    for Bo, g in ((A, ga), (B, gb)):
+        po.lib().orc_set_consensus(C.cast(C.pointer(g.ops), C.c_void_p), 3, 400)
+        try:
+            events += Bo.cluster(mode="fast")["cons_invoked"]
+        finally:
+            po.lib().orc_set_consensus(None, 50, 500)
+    assert events > 5
+    # merge: left graphs = ga's side 0, right graphs = gb's side 0 presented as side 1
+    gm = Poa(ctx)
+    L = gm.L
+    for src, dst_side in ((ga, 0), (gb, 1)):
+        ncl = (A if src is ga else B).n_clusters()
+        for c_id in range(ncl):
+            sz = L.ioc_poa_graph_save(src.h, 0, c_id, None, 0)
+            assert sz > 0
+            buf = (C.c_uint8 * sz)()
+            assert L.ioc_poa_graph_save(src.h, 0, c_id, buf, sz) == sz
+            assert L.ioc_poa_graph_load(gm.h, dst_side, c_id, buf, sz) == 0
+    po.lib().orc_set_consensus(C.cast(C.pointer(gm.ops), C.c_void_p), 3, 400)
+    try:
+        A.cluster(right=B, mode="fast")
+    finally:
+        po.lib().orc_set_consensus(None, 50, 500)
+    ocl, ost = A.assignments(rs.n)
+    got = {}
+    for line in open(tmp_path / "dump" / "clusters.tsv").read().splitlines()[1:]:
+        c, st, name = line.split("\t")
+        got[int(name[1:])] = (int(c), int(st))
+    assigned = np.nonzero(ocl >= 0)[0]
+    assert sorted(got) == assigned.tolist()
+    m = {}
+    for i in assigned:
+        assert got[int(i)][1] == ost[i]
+        assert m.setdefault(int(ocl[i]), got[int(i)][0]) == got[int(i)][0]
+    assert len(set(m.values())) == len(m)
+    # representatives replaced by a consensus carry the reference's name pattern in the consensus FASTQ
+    cons = open(tmp_path / "dump" / "cluster_cons.fq").read()
+    assert "cons_" in cons
+    for g in (ga, gb, gm):
+        g.close()
+    ctx.close()
