@@ -54,9 +54,37 @@ __device__ __forceinline__ int2 max2(int2 a, int2 b) { return int2{max(a.x, b.x)
 constexpr int POA_CB = POA_THREADS;  // columns per tile: one per thread
 constexpr int POA_RB = 64;           // rows per tile
 
+// One alignment of a batch (blockIdx.y): a read against one graph.  Graphs are independent, so the pending
+// additions of MANY clusters are aligned by the same launches (a single alignment offers at most 17 tiles per
+// diagonal to 256 CUs).
+struct PoaJob {
+    int R, L, nrb, ncb;
+    const uint8_t* base;
+    const int32_t* pred_off;
+    const int32_t* pred;
+    const uint8_t* seq;
+    int* H;
+    int* F1;
+    int* F2;
+    uint32_t* dirs;
+    uint8_t* ebits;
+    int4* carry;
+    int4* tile_best;
+    int* best;  // score, row, column
+    int32_t* out_node;
+    int32_t* out_pos;
+    int32_t* out_n;
+    int cap;
+};
+
 // row 0 = virtual source (H = 0: local alignment)
-__global__ void k_poa_init(int W, int* H, int* F1, int* F2, uint32_t* dirs, uint8_t* ebits)
+__global__ void k_poa_init(const PoaJob* __restrict__ jobs)
 {
+    const PoaJob J = jobs[blockIdx.y];
+    const int W = J.L + 1;
+    int *H = J.H, *F1 = J.F1, *F2 = J.F2;
+    uint32_t* dirs = J.dirs;
+    uint8_t* ebits = J.ebits;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < W) {
         H[j] = 0;
@@ -74,15 +102,25 @@ __global__ void k_poa_init(int W, int* H, int* F1, int* F2, uint32_t* dirs, uint
 // node without in-edges).  carry[cb][r] = (prefix max of Hn[x] - e x, of Hn[x] - c x, over all columns up to the
 // tile's last one; Hn of that last column): what the tile to the right needs of row r.
 __global__ void __launch_bounds__(POA_THREADS)
-k_poa_tile(int R, int L, int diag, int cb_first, int nrb, const uint8_t* __restrict__ base,
-           const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred, const uint8_t* __restrict__ seq,
-           PoaScores S, int* H, int* F1, int* F2, uint32_t* __restrict__ dirs, uint8_t* __restrict__ ebits, int4* carry,
-           int4* __restrict__ tile_best)
+k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
 {
     __shared__ int2 s_wave[POA_THREADS / 64];
     __shared__ int2 s_inc[POA_THREADS];
     __shared__ int s_hn[POA_THREADS];
     __shared__ int s_red[3 * (POA_THREADS / 64)];
+    const PoaJob J = jobs[blockIdx.y];
+    const int R = J.R, L = J.L, nrb = J.nrb;
+    const int cb_first = max(0, diag - nrb + 1), cb_last = min(J.ncb - 1, diag);
+    if (cb_first + int(blockIdx.x) > cb_last) return;  // this job has fewer tiles on the diagonal (or is finished)
+    const uint8_t* __restrict__ base = J.base;
+    const int32_t* __restrict__ pred_off = J.pred_off;
+    const int32_t* __restrict__ pred = J.pred;
+    const uint8_t* __restrict__ seq = J.seq;
+    int *H = J.H, *F1 = J.F1, *F2 = J.F2;
+    uint32_t* __restrict__ dirs = J.dirs;
+    uint8_t* __restrict__ ebits = J.ebits;
+    int4* carry = J.carry;
+    int4* __restrict__ tile_best = J.tile_best;
     const int W = L + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cb = cb_first + blockIdx.x, rb = diag - cb;
@@ -233,16 +271,50 @@ k_poa_tile(int R, int L, int diag, int cb_first, int nrb, const uint8_t* __restr
     }
 }
 
+// best cell of each job over its tiles: maximum score, ties to the smallest row, then the smallest column
+__global__ void __launch_bounds__(256) k_poa_best(const PoaJob* __restrict__ jobs)
+{
+    __shared__ int4 s_b[256];
+    const PoaJob J = jobs[blockIdx.x];
+    const int nt = J.nrb * J.ncb;
+    int4 b{0, 0, 0, 0};
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        const int4 x = J.tile_best[t];
+        if (x.x > b.x || (x.x == b.x && x.x > 0 && (x.y < b.y || (x.y == b.y && x.z < b.z)))) b = x;
+    }
+    s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (int(threadIdx.x) < o) {
+            const int4 x = s_b[threadIdx.x + o], y = s_b[threadIdx.x];
+            if (x.x > y.x || (x.x == y.x && x.x > 0 && (x.y < y.y || (x.y == y.y && x.z < y.z)))) s_b[threadIdx.x] = x;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        J.best[0] = s_b[0].x;
+        J.best[1] = s_b[0].y;
+        J.best[2] = s_b[0].z;
+    }
+}
+
 // Walk back from the best cell.  out_node / out_pos receive the alignment in REVERSE order: (row, column - 1)
 // for a diagonal move, (row, -1) for a node against a gap, (-1, column - 1) for a base against a gap;
 // out_n = number of pairs.
-__global__ void k_poa_trace(int L, const int32_t* __restrict__ pred_off, const int32_t* __restrict__ pred,
-                            const uint32_t* __restrict__ dirs, const uint8_t* __restrict__ ebits, const int* __restrict__ best,
-                            int32_t* __restrict__ out_node,
-                            int32_t* __restrict__ out_pos, int32_t* __restrict__ out_n, int cap)
+__global__ void k_poa_trace(const PoaJob* __restrict__ jobs)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int64_t W = L + 1;
+    if (threadIdx.x != 0) return;
+    const PoaJob J = jobs[blockIdx.x];
+    const int32_t* __restrict__ pred_off = J.pred_off;
+    const int32_t* __restrict__ pred = J.pred;
+    const uint32_t* __restrict__ dirs = J.dirs;
+    const uint8_t* __restrict__ ebits = J.ebits;
+    const int* __restrict__ best = J.best;
+    int32_t* __restrict__ out_node = J.out_node;
+    int32_t* __restrict__ out_pos = J.out_pos;
+    int32_t* __restrict__ out_n = J.out_n;
+    const int cap = J.cap;
+    const int64_t W = J.L + 1;
     int r = best[1], j = best[2], n = 0;
     int state = 0;  // 0 H, 1 Hn (H without the horizontal sources), 2 F1, 3 F2, 4 E1, 5 E2
     while (r > 0 && n < cap) {
@@ -446,14 +518,24 @@ struct PGraph {
 
 }  // namespace
 
+struct PoaPending {
+    std::string seq;
+    int64_t weight = 1;
+};
+
 struct ioc_poa {
     ioc_ctx* ctx = nullptr;
     PoaScores S{4, -8, -8, -4, -20, -1};
     std::map<int, PGraph> g[2];
-    DevBuf d_h, d_f1, d_f2, d_dirs, d_eb, d_carry, d_tbest, d_small, d_aln;
-    // the alignment of the last ioc_poa_add (tests / inspection): node ids, positions, score
+    // additions not aligned yet: graphs are independent until somebody reads one, so additions are queued and the
+    // queues of all graphs are worked off together, one addition per graph and round, in batched launches
+    std::map<int, std::vector<PoaPending>> pending[2];
+    bool lazy = true;
+    DevBuf d_int, d_dirs, d_eb, d_carry, d_tbest, d_small, d_aln, d_jobs;
+    // the alignment of the last addition worked off (tests / inspection): node ids, positions, score
     std::vector<int32_t> last_node, last_pos;
     int32_t last_score = 0;
+    int64_t n_batches = 0, n_aligned = 0;
     std::string err;
 };
 
@@ -481,95 +563,215 @@ int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes)
         if (e__ != hipSuccess) return ioc_fail((p)->ctx, IOC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
-// align seq to graph on the device; aln in forward order with NODE IDS
-int poa_align(ioc_poa* p, const PGraph& G, const char* seq, int len, std::vector<std::pair<int, int>>& aln, int32_t& score)
+struct HostJob {
+    PGraph* G = nullptr;
+    const PoaPending* item = nullptr;
+    std::vector<std::pair<int, int>> aln;  // out: forward order, NODE IDS
+    int32_t score = 0;
+};
+
+size_t job_cells(const HostJob& j) { return size_t(j.G->nodes.size() + 1) * size_t(j.item->seq.size() + 1); }
+
+// align every job's read to its graph: one batch of launches
+int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
 {
-    aln.clear();
-    score = 0;
-    const int R = int(G.nodes.size()), L = len;
-    if (R == 0 || L == 0) return IOC_OK;
-    if (L + 1 > POA_MAX_COLS) return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: sequences above 2^20 bases are not supported");
     ioc_ctx* c = p->ctx;
     PCHK(p, hipSetDevice(c->device));
-    std::vector<int> row_of(static_cast<size_t>(R), 0);
-    for (int i = 0; i < R; ++i) row_of[size_t(G.rank[size_t(i)])] = i + 1;
-    std::vector<uint8_t> base(size_t(R) + 1, 0);
-    std::vector<int32_t> poff(size_t(R) + 2, 0), pred;
-    for (int i = 0; i < R; ++i) {
-        const PNode& nd = G.nodes[size_t(G.rank[size_t(i)])];
-        base[size_t(i) + 1] = uint8_t(nd.base);
-        poff[size_t(i) + 1] = int32_t(pred.size());
-        if (nd.in.empty()) pred.push_back(0);
-        if (nd.in.size() > size_t(POA_MAX_PREDS)) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
-        for (int e : nd.in) pred.push_back(row_of[size_t(G.edges[size_t(e)].from)]);
-    }
-    poff[size_t(R) + 1] = int32_t(pred.size());
-    const size_t cells = size_t(R + 1) * size_t(L + 1);
-    int r;
-    if ((r = poa_reserve(p, p->d_h, cells * 4)) != IOC_OK) return r;
-    if ((r = poa_reserve(p, p->d_f1, cells * 4)) != IOC_OK) return r;
-    if ((r = poa_reserve(p, p->d_f2, cells * 4)) != IOC_OK) return r;
-    if ((r = poa_reserve(p, p->d_dirs, cells * 4)) != IOC_OK) return r;
-    const size_t o_base = 0, o_poff = (o_base + base.size() + 15) & ~size_t(15), o_pred = o_poff + poff.size() * 4,
-                 o_seq = o_pred + pred.size() * 4, o_best = (o_seq + size_t(L) + 15) & ~size_t(15), o_n = o_best + 16;
-    if ((r = poa_reserve(p, p->d_small, o_n + 16)) != IOC_OK) return r;
-    const int cap = R + L + 2;
-    if ((r = poa_reserve(p, p->d_aln, size_t(cap) * 8)) != IOC_OK) return r;
+    const size_t K = jobs.size();
+    if (K == 0) return IOC_OK;
     hipStream_t s = c->stream;
+    // ---- layout of the batch in the arenas ----
+    struct Lay {
+        size_t cells, o_cells, o_carry, o_tbest, o_small, o_base, o_poff, o_pred, o_seq, o_best, o_n, o_aln;
+        int R, L, nrb, ncb, cap;
+    };
+    std::vector<Lay> lay(K);
+    std::vector<uint8_t> small;
+    size_t tot_cells = 0, tot_carry = 0, tot_tbest = 0, tot_aln = 0;
+    int max_w = 1, max_diag = 0, max_ncb = 1;
+    for (size_t x = 0; x < K; ++x) {
+        const PGraph& G = *jobs[x].G;
+        const std::string& seq = jobs[x].item->seq;
+        Lay& l = lay[x];
+        l.R = int(G.nodes.size());
+        l.L = int(seq.size());
+        if (l.L + 1 > POA_MAX_COLS) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: sequences above 2^20 bases are not supported");
+        l.ncb = (l.L + 1 + POA_CB - 1) / POA_CB;
+        l.nrb = (l.R + POA_RB - 1) / POA_RB;
+        l.cap = l.R + l.L + 2;
+        l.cells = size_t(l.R + 1) * size_t(l.L + 1);
+        l.o_cells = tot_cells;
+        tot_cells += (l.cells + 63) & ~size_t(63);
+        l.o_carry = tot_carry;
+        tot_carry += size_t(l.ncb) * size_t(l.R + 1);
+        l.o_tbest = tot_tbest;
+        tot_tbest += size_t(l.ncb) * size_t(l.nrb);
+        l.o_aln = tot_aln;
+        tot_aln += size_t(l.cap) * 2;
+        max_w = std::max(max_w, l.L + 1);
+        max_diag = std::max(max_diag, l.nrb + l.ncb - 1);
+        max_ncb = std::max(max_ncb, l.ncb);
+        // small arrays: bases in topological order, predecessor rows, the read
+        std::vector<int> row_of(static_cast<size_t>(l.R), 0);
+        for (int i = 0; i < l.R; ++i) row_of[size_t(G.rank[size_t(i)])] = i + 1;
+        auto align16 = [&]() { small.resize((small.size() + 15) & ~size_t(15)); };
+        align16();
+        l.o_base = small.size();
+        small.resize(small.size() + size_t(l.R) + 1, 0);
+        std::vector<int32_t> poff(size_t(l.R) + 2, 0), pred;
+        for (int i = 0; i < l.R; ++i) {
+            const PNode& nd = G.nodes[size_t(G.rank[size_t(i)])];
+            small[l.o_base + size_t(i) + 1] = uint8_t(nd.base);
+            poff[size_t(i) + 1] = int32_t(pred.size());
+            if (nd.in.empty()) pred.push_back(0);
+            if (nd.in.size() > size_t(POA_MAX_PREDS)) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
+            for (int e : nd.in) pred.push_back(row_of[size_t(G.edges[size_t(e)].from)]);
+        }
+        poff[size_t(l.R) + 1] = int32_t(pred.size());
+        align16();
+        l.o_poff = small.size();
+        small.insert(small.end(), reinterpret_cast<uint8_t*>(poff.data()), reinterpret_cast<uint8_t*>(poff.data() + poff.size()));
+        l.o_pred = small.size();
+        small.insert(small.end(), reinterpret_cast<uint8_t*>(pred.data()), reinterpret_cast<uint8_t*>(pred.data() + pred.size()));
+        l.o_seq = small.size();
+        small.insert(small.end(), seq.begin(), seq.end());
+        align16();
+        l.o_best = small.size();
+        small.resize(small.size() + 16, 0);
+        l.o_n = small.size();
+        small.resize(small.size() + 16, 0);
+    }
+    int r;
+    if ((r = poa_reserve(p, p->d_int, tot_cells * 12)) != IOC_OK) return r;   // H, F1, F2 planes
+    if ((r = poa_reserve(p, p->d_dirs, tot_cells * 4)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_eb, tot_cells)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_carry, tot_carry * sizeof(int4))) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_tbest, tot_tbest * sizeof(int4))) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_small, small.size())) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_aln, tot_aln * 4)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_jobs, K * sizeof(PoaJob))) != IOC_OK) return r;
     uint8_t* sm = static_cast<uint8_t*>(p->d_small.p);
-    PCHK(p, hipMemcpyAsync(sm + o_base, base.data(), base.size(), hipMemcpyHostToDevice, s));
-    PCHK(p, hipMemcpyAsync(sm + o_poff, poff.data(), poff.size() * 4, hipMemcpyHostToDevice, s));
-    PCHK(p, hipMemcpyAsync(sm + o_pred, pred.data(), pred.size() * 4, hipMemcpyHostToDevice, s));
-    PCHK(p, hipMemcpyAsync(sm + o_seq, seq, size_t(L), hipMemcpyHostToDevice, s));
-    const int W = L + 1, ncb = (W + POA_CB - 1) / POA_CB, nrb = (R + POA_RB - 1) / POA_RB;
-    if ((r = poa_reserve(p, p->d_eb, cells)) != IOC_OK) return r;
-    if ((r = poa_reserve(p, p->d_carry, size_t(ncb) * size_t(R + 1) * sizeof(int4))) != IOC_OK) return r;
-    if ((r = poa_reserve(p, p->d_tbest, size_t(ncb) * size_t(nrb) * sizeof(int4))) != IOC_OK) return r;
-    hipLaunchKernelGGL(k_poa_init, dim3(unsigned((W + 255) / 256)), dim3(256), 0, s, W, static_cast<int*>(p->d_h.p),
-                       static_cast<int*>(p->d_f1.p), static_cast<int*>(p->d_f2.p), static_cast<uint32_t*>(p->d_dirs.p),
-                       static_cast<uint8_t*>(p->d_eb.p));
+    int* ints = static_cast<int*>(p->d_int.p);
+    std::vector<PoaJob> dj(K);
+    for (size_t x = 0; x < K; ++x) {
+        const Lay& l = lay[x];
+        PoaJob& j = dj[x];
+        j.R = l.R;
+        j.L = l.L;
+        j.nrb = l.nrb;
+        j.ncb = l.ncb;
+        j.base = sm + l.o_base;
+        j.pred_off = reinterpret_cast<const int32_t*>(sm + l.o_poff);
+        j.pred = reinterpret_cast<const int32_t*>(sm + l.o_pred);
+        j.seq = sm + l.o_seq;
+        j.H = ints + l.o_cells;
+        j.F1 = ints + tot_cells + l.o_cells;
+        j.F2 = ints + 2 * tot_cells + l.o_cells;
+        j.dirs = static_cast<uint32_t*>(p->d_dirs.p) + l.o_cells;
+        j.ebits = static_cast<uint8_t*>(p->d_eb.p) + l.o_cells;
+        j.carry = static_cast<int4*>(p->d_carry.p) + l.o_carry;
+        j.tile_best = static_cast<int4*>(p->d_tbest.p) + l.o_tbest;
+        j.best = reinterpret_cast<int*>(sm + l.o_best);
+        j.out_node = static_cast<int32_t*>(p->d_aln.p) + l.o_aln;
+        j.out_pos = j.out_node + l.cap;
+        j.out_n = reinterpret_cast<int32_t*>(sm + l.o_n);
+        j.cap = l.cap;
+    }
+    PCHK(p, hipMemcpyAsync(sm, small.data(), small.size(), hipMemcpyHostToDevice, s));
+    PCHK(p, hipMemcpyAsync(p->d_jobs.p, dj.data(), K * sizeof(PoaJob), hipMemcpyHostToDevice, s));
+    const PoaJob* djobs = static_cast<const PoaJob*>(p->d_jobs.p);
+    hipLaunchKernelGGL(k_poa_init, dim3(unsigned((max_w + 255) / 256), unsigned(K)), dim3(256), 0, s, djobs);
     PCHK(p, hipGetLastError());
-    for (int dg = 0; dg < nrb + ncb - 1; ++dg) {  // one anti-diagonal of tiles per launch
-        const int cb_first = std::max(0, dg - nrb + 1), cb_last = std::min(ncb - 1, dg);
-        hipLaunchKernelGGL(k_poa_tile, dim3(unsigned(cb_last - cb_first + 1)), dim3(POA_THREADS), 0, s, R, L, dg, cb_first, nrb,
-                           sm + o_base, reinterpret_cast<const int32_t*>(sm + o_poff), reinterpret_cast<const int32_t*>(sm + o_pred),
-                           sm + o_seq, p->S, static_cast<int*>(p->d_h.p), static_cast<int*>(p->d_f1.p), static_cast<int*>(p->d_f2.p),
-                           static_cast<uint32_t*>(p->d_dirs.p), static_cast<uint8_t*>(p->d_eb.p), static_cast<int4*>(p->d_carry.p),
-                           static_cast<int4*>(p->d_tbest.p));
+    for (int dg = 0; dg < max_diag; ++dg) {  // one anti-diagonal of tiles (of every job) per launch
+        hipLaunchKernelGGL(k_poa_tile, dim3(unsigned(std::min(max_ncb, dg + 1)), unsigned(K)), dim3(POA_THREADS), 0, s, djobs, dg, p->S);
         PCHK(p, hipGetLastError());
     }
-    {   // best cell over the tiles: maximum score, ties to the smallest row, then the smallest column
-        std::vector<int4> tb(size_t(ncb) * size_t(nrb));
-        PCHK(p, hipMemcpyAsync(tb.data(), p->d_tbest.p, tb.size() * sizeof(int4), hipMemcpyDeviceToHost, s));
-        PCHK(p, hipStreamSynchronize(s));
-        int4 bst{0, 0, 0, 0};
-        for (const int4& t : tb)
-            if (t.x > bst.x || (t.x == bst.x && t.x > 0 && (t.y < bst.y || (t.y == bst.y && t.z < bst.z)))) bst = t;
-        const int32_t hb3[3] = {bst.x, bst.y, bst.z};
-        PCHK(p, hipMemcpyAsync(sm + o_best, hb3, 12, hipMemcpyHostToDevice, s));
-    }
-    int32_t* d_node = static_cast<int32_t*>(p->d_aln.p);
-    int32_t* d_pos = d_node + cap;
-    hipLaunchKernelGGL(k_poa_trace, dim3(1), dim3(64), 0, s, L, reinterpret_cast<const int32_t*>(sm + o_poff),
-                       reinterpret_cast<const int32_t*>(sm + o_pred), static_cast<const uint32_t*>(p->d_dirs.p),
-                       static_cast<const uint8_t*>(p->d_eb.p), reinterpret_cast<const int*>(sm + o_best), d_node, d_pos,
-                       reinterpret_cast<int32_t*>(sm + o_n), cap);
+    hipLaunchKernelGGL(k_poa_best, dim3(unsigned(K)), dim3(256), 0, s, djobs);
     PCHK(p, hipGetLastError());
-    int32_t hb[3] = {0, 0, 0}, hn = 0;
-    PCHK(p, hipMemcpyAsync(hb, sm + o_best, 12, hipMemcpyDeviceToHost, s));
-    PCHK(p, hipMemcpyAsync(&hn, sm + o_n, 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_poa_trace, dim3(unsigned(K)), dim3(64), 0, s, djobs);
+    PCHK(p, hipGetLastError());
+    std::vector<uint8_t> back(small.size());
+    std::vector<int32_t> haln(tot_aln);
+    PCHK(p, hipMemcpyAsync(back.data(), sm, small.size(), hipMemcpyDeviceToHost, s));
+    PCHK(p, hipMemcpyAsync(haln.data(), p->d_aln.p, tot_aln * 4, hipMemcpyDeviceToHost, s));
     PCHK(p, hipStreamSynchronize(s));
-    std::vector<int32_t> hnode(size_t(hn) + 1), hpos(size_t(hn) + 1);
-    if (hn > 0) {
-        PCHK(p, hipMemcpyAsync(hnode.data(), d_node, size_t(hn) * 4, hipMemcpyDeviceToHost, s));
-        PCHK(p, hipMemcpyAsync(hpos.data(), d_pos, size_t(hn) * 4, hipMemcpyDeviceToHost, s));
-        PCHK(p, hipStreamSynchronize(s));
+    for (size_t x = 0; x < K; ++x) {
+        const Lay& l = lay[x];
+        const PGraph& G = *jobs[x].G;
+        int32_t hb[3], hn;
+        memcpy(hb, back.data() + l.o_best, 12);
+        memcpy(&hn, back.data() + l.o_n, 4);
+        jobs[x].score = hb[0];
+        jobs[x].aln.clear();
+        jobs[x].aln.reserve(size_t(hn));
+        const int32_t* nd = haln.data() + l.o_aln;
+        const int32_t* ps = nd + l.cap;
+        for (int i = hn - 1; i >= 0; --i) jobs[x].aln.emplace_back(nd[i] > 0 ? G.rank[size_t(nd[i]) - 1] : -1, ps[i]);
     }
-    score = hb[0];
-    aln.reserve(size_t(hn));
-    for (int i = hn - 1; i >= 0; --i)
-        aln.emplace_back(hnode[size_t(i)] > 0 ? G.rank[size_t(hnode[size_t(i)]) - 1] : -1, hpos[size_t(i)]);
+    p->n_batches++;
+    p->n_aligned += int64_t(K);
     return IOC_OK;
+}
+
+// work off every queue: one addition per graph and round, as many graphs per batch as the memory budget allows
+int poa_flush(ioc_poa* p)
+{
+    for (;;) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
+        const size_t have = p->d_int.cap + p->d_dirs.cap + p->d_eb.cap;
+        size_t budget = (free_b + have) / 2;
+        if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
+        std::vector<HostJob> jobs;
+        std::vector<std::pair<int, int>> who;
+        size_t used = 0;
+        for (int side = 0; side < 2; ++side)
+            for (auto& kv : p->pending[side]) {
+                if (kv.second.empty()) continue;
+                auto it = p->g[side].find(kv.first);
+                if (it == p->g[side].end()) return ioc_fail(p->ctx, IOC_ERR_STATE, "POA: addition to a graph that does not exist");
+                HostJob j;
+                j.G = &it->second;
+                j.item = &kv.second.front();
+                if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
+                    jobs.push_back(j);
+                    who.emplace_back(side, kv.first);
+                    continue;
+                }
+                const size_t need = job_cells(j) * 17 + (size_t(1) << 20);
+                if (!jobs.empty() && (used + need > budget || jobs.size() >= 256)) continue;  // next round
+                used += need;
+                jobs.push_back(j);
+                who.emplace_back(side, kv.first);
+            }
+        if (jobs.empty()) return IOC_OK;
+        std::vector<HostJob> run;
+        std::vector<size_t> run_ix;
+        for (size_t x = 0; x < jobs.size(); ++x)
+            if (!jobs[x].G->nodes.empty() && !jobs[x].item->seq.empty()) {
+                run.push_back(jobs[x]);
+                run_ix.push_back(x);
+            }
+        int r = poa_align_batch(p, run);
+        if (r != IOC_OK) return r;
+        for (size_t y = 0; y < run.size(); ++y) {
+            jobs[run_ix[y]].aln = std::move(run[y].aln);
+            jobs[run_ix[y]].score = run[y].score;
+        }
+        for (size_t x = 0; x < jobs.size(); ++x) {
+            HostJob& j = jobs[x];
+            p->last_node.clear();
+            p->last_pos.clear();
+            for (auto& a : j.aln) {
+                p->last_node.push_back(a.first);
+                p->last_pos.push_back(a.second);
+            }
+            p->last_score = j.score;
+            j.G->add_alignment(j.aln, j.item->seq.data(), int(j.item->seq.size()), j.item->weight);
+            auto& q = p->pending[who[x].first][who[x].second];
+            q.erase(q.begin());
+        }
+    }
 }
 
 int op_create(void* u, int side, int idx, const char* seq, int len)
@@ -579,6 +781,7 @@ int op_create(void* u, int side, int idx, const char* seq, int len)
     PGraph G;
     G.add_alignment({}, seq, len, 1);
     p->g[side][idx] = std::move(G);
+    p->pending[side].erase(idx);
     return 0;
 }
 int op_size(void* u, int side, int idx)
@@ -586,31 +789,28 @@ int op_size(void* u, int side, int idx)
     ioc_poa* p = static_cast<ioc_poa*>(u);
     if (side < 0 || side > 1) return -1;
     auto it = p->g[side].find(idx);
-    return it == p->g[side].end() ? -1 : it->second.nseq;
+    if (it == p->g[side].end()) return -1;
+    auto pq = p->pending[side].find(idx);
+    return it->second.nseq + (pq == p->pending[side].end() ? 0 : int(pq->second.size()));  // queued additions count
 }
 int op_add(void* u, int side, int idx, const char* seq, int len, unsigned weight)
 {
     ioc_poa* p = static_cast<ioc_poa*>(u);
-    if (side < 0 || side > 1) return -1;
-    auto it = p->g[side].find(idx);
-    if (it == p->g[side].end()) return -1;
-    std::vector<std::pair<int, int>> aln;
-    int32_t score = 0;
-    if (poa_align(p, it->second, seq, len, aln, score) != IOC_OK) return -1;
-    p->last_node.clear();
-    p->last_pos.clear();
-    for (auto& a : aln) {
-        p->last_node.push_back(a.first);
-        p->last_pos.push_back(a.second);
-    }
-    p->last_score = score;
-    it->second.add_alignment(aln, seq, len, int64_t(weight));
+    if (side < 0 || side > 1 || len < 0) return -1;
+    if (p->g[side].find(idx) == p->g[side].end()) return -1;
+    if (len == 0) return 0;  // AddAlignment ignores an empty sequence
+    PoaPending it;
+    it.seq.assign(seq, size_t(len));
+    it.weight = int64_t(weight);
+    p->pending[side][idx].push_back(std::move(it));
+    if (!p->lazy && poa_flush(p) != IOC_OK) return -1;
     return 0;
 }
 int op_consensus(void* u, int side, int idx, char* out, int cap)
 {
     ioc_poa* p = static_cast<ioc_poa*>(u);
     if (side < 0 || side > 1) return -1;
+    if (poa_flush(p) != IOC_OK) return -1;  // this graph must be up to date; everybody else's queue rides along
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return -1;
     const std::string s = it->second.consensus();
@@ -625,6 +825,7 @@ int op_purge(void* u, int side, int idx, const char* seq, int len, unsigned weig
     PGraph G;
     G.add_alignment({}, seq, len, int64_t(weight));  // ConsPurge: the representative alone, with the old count as weight
     p->g[side][idx] = std::move(G);
+    p->pending[side].erase(idx);
     return 0;
 }
 
@@ -648,7 +849,7 @@ int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int
 void ioc_poa_destroy(ioc_poa* p)
 {
     if (!p) return;
-    for (DevBuf* b : {&p->d_h, &p->d_f1, &p->d_f2, &p->d_dirs, &p->d_eb, &p->d_carry, &p->d_tbest, &p->d_small, &p->d_aln})
+    for (DevBuf* b : {&p->d_int, &p->d_dirs, &p->d_eb, &p->d_carry, &p->d_tbest, &p->d_small, &p->d_aln, &p->d_jobs})
         if (b->p) (void)hipFree(b->p);
     delete p;
 }
@@ -668,6 +869,10 @@ int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_
                          int32_t* edge_from, int32_t* edge_to, int64_t* edge_w)
 {
     if (!p || side < 0 || side > 1) return IOC_ERR_ARG;
+    {
+        int fr = poa_flush(p);
+        if (fr != IOC_OK) return fr;
+    }
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return IOC_ERR_ARG;
     const PGraph& G = it->second;
@@ -691,6 +896,10 @@ int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_
 int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t cap)
 {
     if (!p || side < 0 || side > 1) return IOC_ERR_ARG;
+    {
+        int fr = poa_flush(p);
+        if (fr != IOC_OK) return int64_t(fr);
+    }
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return IOC_ERR_ARG;
     const PGraph& G = it->second;
@@ -779,6 +988,10 @@ int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t
 int ioc_poa_last_alignment(ioc_poa* p, int32_t cap, int32_t* nodes, int32_t* pos, int32_t* score)
 {
     if (!p) return IOC_ERR_ARG;
+    {
+        int fr = poa_flush(p);
+        if (fr != IOC_OK) return fr;
+    }
     const int n = int(p->last_node.size());
     if (score) *score = p->last_score;
     if (nodes && pos) {
