@@ -14,6 +14,7 @@
 // operations the reference performs on them (ioc_consensus_ops), the way parasail can stay behind
 // ioc_get_ties / ioc_set_aln_verdicts.  Nothing here links the oracle; without a device every call fails.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +28,7 @@
 namespace {
 
 struct ClState {
+    uint64_t seq_id = 0;             // identity of the representative's sequence (alignment results are kept by identity)
     double raw_err = 0, hpc_err = 0;
     int64_t size = 0;                // cls[c]->size(): representative copy + members
     std::vector<uint32_t> vals;      // sorted distinct forward minimizer values of the representative
@@ -64,7 +66,20 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     // ---- left state on the host: MinDB as an ordered map, one ClState per cluster ----
     std::map<uint32_t, std::vector<uint32_t>> db;
     std::vector<ClState> cl(static_cast<size_t>(L0));
+    // sequence identities: right entry i -> i; left representatives and consensus sequences -> n, n + 1, ...
+    uint64_t next_seq_id = uint64_t(n);
+    c->aln_cache.clear();
+    struct IdsGuard {
+        ioc_ctx* c;
+        ~IdsGuard()
+        {
+            c->aln_qid.clear();
+            c->aln_lid.clear();
+            c->aln_cache.clear();
+        }
+    } ids_guard{c};
     for (int32_t t = 0; t < L0; ++t) {
+        cl[size_t(t)].seq_id = next_seq_id++;
         cl[size_t(t)].hpc_err = left->cls_hpc_err[t];
         cl[size_t(t)].raw_err = left->cls_raw_err ? left->cls_raw_err[t] : 0.0;
         cl[size_t(t)].size = ca->left_sizes ? ca->left_sizes[t] : 2;
@@ -103,8 +118,12 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     std::vector<int8_t> sub_strand;
     const int k = p->k, w = p->w;
     int pos = 0;
+    // phase clock for IOC_TRACE: [0] left view, [1] device pass, [2] graph hooks, [3] new representative
+    double ph[4] = {0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (pos < n) {
         const int m = n - pos;
+        double t0 = now();
         // ---- left view of the current state ----
         const int32_t Lc = int32_t(cl.size());
         keys.clear();
@@ -119,10 +138,14 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         offs.push_back(int64_t(post.size()));
         herr.resize(size_t(Lc));
         rerr.resize(size_t(Lc));
+        c->aln_lid.resize(size_t(Lc));
         for (int32_t t = 0; t < Lc; ++t) {
             herr[size_t(t)] = cl[size_t(t)].hpc_err;
             rerr[size_t(t)] = cl[size_t(t)].raw_err;
+            c->aln_lid[size_t(t)] = cl[size_t(t)].seq_id;
         }
+        c->aln_qid.resize(size_t(m));
+        for (int i = 0; i < m; ++i) c->aln_qid[size_t(i)] = uint64_t(pos + i);
         ioc_left_view lv{};
         lv.n_clusters = Lc;
         lv.cls_hpc_err = herr.data();
@@ -171,8 +194,11 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         sub_cls.assign(size_t(m) + 1, -1);
         sub_strand.assign(size_t(m) + 1, 0);
         ioc_cluster_stats st{};
+        ph[0] += now() - t0;
+        t0 = now();
         int r = ioc_cluster_merge(c, p, table_path, Lc > 0 ? &lv : nullptr, &sv, sub_cls.data(), sub_strand.data(), &st);
         if (r != IOC_OK) return r;
+        ph[1] += now() - t0;
         total.resolve_iters += st.resolve_iters;
         total.n_tie_replays += st.n_tie_replays;
         total.aln_rounds += st.aln_rounds;
@@ -197,6 +223,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             if (dc == int32_t(cl.size())) {
                 // ---- opens a new cluster (cluster.cpp:177-222) ----
                 ClState ns;
+                ns.seq_id = uint64_t(i);  // the representative is this read
                 ns.raw_err = rb->raw_err[i];
                 ns.hpc_err = rb->hpc_err[i];
                 ns.size = entry_size == 1 ? 2 : entry_size;  // a fresh read gets a representative copy in front
@@ -232,12 +259,17 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             const double hpc_err = (b.hpc_err * double(left_size) + rb->hpc_err[i] * double(right_size)) / double(left_size + right_size);
             const double raw_err = (b.raw_err * double(left_size) + rb->raw_err[i] * double(right_size)) / double(left_size + right_size);
             // (the reference reverse-complements a copy and throws it away, consensus.cpp:47-49: the read goes in as it is)
+            t0 = now();
             if (ops->add(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u) < 0)
                 return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: add failed");
+            ph[2] += now() - t0;
             if (ops->size(ops->user, 0, dc) < cons_min) continue;
+            t0 = now();
             std::vector<char> buf(size_t(1) << 22);
             const int clen = ops->consensus(ops->user, 0, dc, buf.data(), int(buf.size()));
             if (clen < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: consensus failed");
+            ph[2] += now() - t0;
+            t0 = now();
             std::string cons(buf.data(), size_t(clen));
             // the new representative: fixed quality character, HPC, minimizers (K1 on the GPU)
             const char qraw = std::to_string(int(-10 * log10(raw_err)) + 33)[0];  // :98-99: first CHARACTER of the number
@@ -284,6 +316,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             b.hpc_err = hpc_err;  // consensus.cpp:121 — also when the 0.9999 branch (:112-117) fired
             b.raw = cons;
             b.have_raw = true;
+            b.seq_id = next_seq_id++;
             total.n_cons_invoked++;
             if (ops->rep_changed) {
                 ioc_rep_record rec{};
@@ -309,6 +342,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 if (ops->purge(ops->user, 0, dc, cons.data(), int(cons.size()), unsigned(gsz)) < 0)
                     return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: purge failed");
             }
+            ph[3] += now() - t0;
             // everything after entry i has to see the new representative
             pos = i + 1;
             restarted = true;
@@ -316,6 +350,9 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         }
         if (!restarted) break;
     }
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc] consensus phases: left view %.1f ms, device passes %.1f ms, graph hooks %.1f ms, new representatives %.1f ms\n",
+                ph[0], ph[1], ph[2], ph[3]);
     // the final MinDB is what ioc_index_export returns
     c->exp_keys.clear();
     c->exp_offs.clear();

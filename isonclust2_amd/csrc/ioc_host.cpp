@@ -315,14 +315,36 @@ struct AlnDriver {
         return IOC_OK;
     }
 
+    // Sequence identities across calls (ioc_cluster_consensus re-runs the pipeline over the remaining entries after
+    // every consensus event): with c->aln_qid / c->aln_lid set, an alignment result is also kept in the context,
+    // keyed by (read identity, representative identity, strand) — the same pair is never aligned twice.
+    bool persistent_key(int q, uint32_t tie, std::pair<uint64_t, uint64_t>& k) const
+    {
+        if (c->aln_qid.size() != size_t(n) || c->aln_lid.size() != size_t(c->L)) return false;
+        const int32_t target = int32_t(tie >> 1);
+        const uint64_t rid = target < c->L ? c->aln_lid[size_t(target)] : c->aln_qid[size_t(target - c->L)];
+        k = std::make_pair(c->aln_qid[size_t(q)], (rid << 1) | (tie & 1u));
+        return true;
+    }
+
     // make sure every (query, tie key) of `want` is in the cache
     int ensure(std::vector<std::pair<int, uint32_t>>& want)
     {
         std::sort(want.begin(), want.end());
         want.erase(std::unique(want.begin(), want.end()), want.end());
         std::vector<std::pair<int, uint32_t>> todo;
-        for (auto& w : want)
-            if (!cache.count(key(w.first, w.second))) todo.push_back(w);
+        for (auto& w : want) {
+            if (cache.count(key(w.first, w.second))) continue;
+            std::pair<uint64_t, uint64_t> pk;
+            if (persistent_key(w.first, w.second, pk)) {
+                auto it = c->aln_cache.find(pk);
+                if (it != c->aln_cache.end()) {
+                    cache[key(w.first, w.second)] = it->second;
+                    continue;
+                }
+            }
+            todo.push_back(w);
+        }
         if (todo.empty()) return IOC_OK;
         if (host_only) {
             for (auto& w : todo) {
@@ -345,7 +367,11 @@ struct AlnDriver {
         std::vector<double> ratio(todo.size());
         int r = ioc_align_pairs(c, int32_t(pairs.size()), pairs.data(), c->params.k, 2, -2, 1, nullptr, nullptr, ratio.data());
         if (r != IOC_OK) return r;
-        for (size_t i = 0; i < todo.size(); ++i) cache[key(todo[i].first, todo[i].second)] = ratio[i];
+        for (size_t i = 0; i < todo.size(); ++i) {
+            cache[key(todo[i].first, todo[i].second)] = ratio[i];
+            std::pair<uint64_t, uint64_t> pk;
+            if (persistent_key(todo[i].first, todo[i].second, pk)) c->aln_cache[pk] = ratio[i];
+        }
         return IOC_OK;
     }
 };

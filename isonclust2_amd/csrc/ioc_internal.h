@@ -6,7 +6,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "isonclust2_hip.h"
@@ -97,6 +99,10 @@ struct ioc_ctx {
     bool have_res_seq = false;
     bool res_pool_ready = false;  // a_pool holds exactly res_seq
     size_t aln_lds_max = 0, aln_lds_max2 = 0;  // dynamic LDS a k_align_fwd<true/false> workgroup may reserve (residency cap)
+
+    // ---- alignment results kept across the device passes of ioc_cluster_consensus (see AlnDriver) ----
+    std::vector<uint64_t> aln_qid, aln_lid;  // sequence identity of every right entry / left representative
+    std::map<std::pair<uint64_t, uint64_t>, double> aln_cache;
 
     // ---- ioc_index_export result of the current resolve ----
     bool exp_valid = false;
