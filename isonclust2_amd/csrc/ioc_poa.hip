@@ -16,11 +16,11 @@
 //                  prefix scan along the row: E[j] = max_{x<j} Hn[x] + open + (j-1-x) ext, Hn = H without E (opening
 //                  a gap right after a gap never beats extending it, and switching between the two pieces of the
 //                  convex gap never pays when open <= ext for both pieces, which is checked).  The matrix is cut
-//                  into tiles of 64 rows x 1024 columns (one column per thread) and swept one anti-diagonal of
+//                  into tiles of 64 rows x 256 columns (one column per thread) and swept one anti-diagonal of
 //                  tiles per launch: tiles of a diagonal are independent, a tile takes its row carries and
-//                  its boundary column from the tile on its left.  Stores H, F1, F2 (later rows need them), a
-//                  direction word and an E byte per cell.
-//   k_poa_trace    one lane walks back from the best cell over the direction words.
+//                  its boundary column from the tile on its left and keeps its last 16 rows in LDS.  Stores
+//                  H, F1, F2 (later rows need them), a direction word and an E byte per cell.
+//   k_poa_trace    one wave walks back from the best cell over the direction words, 64 cells of look-ahead.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,7 +36,7 @@
 namespace {
 
 constexpr int POA_NEG = INT32_MIN / 4;
-constexpr int POA_THREADS = 1024;
+constexpr int POA_THREADS = 256;
 constexpr int POA_MAX_COLS = 1 << 20;
 constexpr int POA_MAX_PREDS = 127;
 
@@ -49,13 +49,14 @@ struct PoaScores {
     int m, n, g, e, q, c;
 };
 
-__device__ __forceinline__ int2 max2(int2 a, int2 b) { return int2{max(a.x, b.x), max(a.y, b.y)}; }
-
 constexpr int POA_CB = POA_THREADS;  // columns per tile: one per thread
 constexpr int POA_RB = 64;           // rows per tile
+constexpr int POA_WAVES = POA_THREADS / 64;
+constexpr int POA_RING = 16;         // rows of the tile kept in LDS behind the current one
+constexpr int POA_PRED_LDS = 448;    // predecessor entries of a tile staged in LDS (the rest is read from memory)
 
 // One alignment of a batch (blockIdx.y): a read against one graph.  Graphs are independent, so the pending
-// additions of MANY clusters are aligned by the same launches (a single alignment offers at most 17 tiles per
+// additions of MANY clusters are aligned by the same launches (a single alignment offers at most 66 tiles per
 // diagonal to 256 CUs).
 struct PoaJob {
     int R, L, nrb, ncb;
@@ -95,70 +96,140 @@ __global__ void k_poa_init(const PoaJob* __restrict__ jobs)
     }
 }
 
+using GI32 = __attribute__((address_space(1))) int32_t;
+using GU32 = __attribute__((address_space(1))) uint32_t;
+using GU8 = __attribute__((address_space(1))) uint8_t;
+
+// lanes without a source (and rows masked off) receive POA_NEG, the identity of max
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_or_neg(int v)
+{
+    return __builtin_amdgcn_update_dpp(POA_NEG, v, CTRL, ROW_MASK, 0xf, false);
+}
+// inclusive prefix maximum over the 64 lanes of a wave: row_shr 1 2 4 8, then row_bcast 15 and 31
+__device__ __forceinline__ int wave_prefix_max(int v)
+{
+    v = max(v, dpp_or_neg<0x111>(v));
+    v = max(v, dpp_or_neg<0x112>(v));
+    v = max(v, dpp_or_neg<0x114>(v));
+    v = max(v, dpp_or_neg<0x118>(v));
+    v = max(v, dpp_or_neg<0x142, 0xa>(v));
+    v = max(v, dpp_or_neg<0x143, 0xc>(v));
+    return v;
+}
+// LDS traffic of this wave done, then the workgroup barrier: global stores stay in flight (a __syncthreads
+// would wait for the five stores of every row)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One anti-diagonal of tiles per launch (tile = POA_RB rows x POA_CB columns): the tiles of a diagonal are
 // independent, kernel boundaries are the only synchronisation between tiles (no flags, no cross-workgroup
-// coherence games), and a row inside a tile costs one memory latency and one block scan for 1024 columns.
+// coherence games).  Inside a tile the rows are sequential and latency is everything, so nothing a row needs
+// comes from memory in the common case: the tile's predecessor lists, bases and left carries are staged in LDS
+// once, the last POA_RING rows of H / F1 / F2 stay in an LDS ring (a predecessor further back, or above the
+// tile, is read from memory), and the row scan is DPP within a wave plus one LDS exchange between the 4 waves.
 // rows 1..R = nodes in topological order; pred_off[r] .. pred_off[r+1]: predecessor ROWS of row r (row 0 for a
 // node without in-edges).  carry[cb][r] = (prefix max of Hn[x] - e x, of Hn[x] - c x, over all columns up to the
-// tile's last one; Hn of that last column): what the tile to the right needs of row r.
+// tile's last one; Hn and H of that last column): what the tile to the right needs of row r.
 __global__ void __launch_bounds__(POA_THREADS)
 k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
 {
-    __shared__ int2 s_wave[POA_THREADS / 64];
-    __shared__ int2 s_inc[POA_THREADS];
-    __shared__ int s_hn[POA_THREADS];
-    __shared__ int s_red[3 * (POA_THREADS / 64)];
+    __shared__ int sH[POA_RING][POA_CB], sF1[POA_RING][POA_CB], sF2[POA_RING][POA_CB];
+    __shared__ int4 s_cin[POA_RB];
+    __shared__ int4 s_wave[POA_WAVES];
+    __shared__ int s_poff[POA_RB + 1];
+    __shared__ int s_pred[POA_PRED_LDS];
+    __shared__ uint8_t s_base[POA_RB];
+    __shared__ int s_red[3 * POA_WAVES];
     const PoaJob J = jobs[blockIdx.y];
     const int R = J.R, L = J.L, nrb = J.nrb;
     const int cb_first = max(0, diag - nrb + 1), cb_last = min(J.ncb - 1, diag);
     if (cb_first + int(blockIdx.x) > cb_last) return;  // this job has fewer tiles on the diagonal (or is finished)
-    const uint8_t* __restrict__ base = J.base;
-    const int32_t* __restrict__ pred_off = J.pred_off;
-    const int32_t* __restrict__ pred = J.pred;
-    const uint8_t* __restrict__ seq = J.seq;
-    int *H = J.H, *F1 = J.F1, *F2 = J.F2;
-    uint32_t* __restrict__ dirs = J.dirs;
-    uint8_t* __restrict__ ebits = J.ebits;
-    int4* carry = J.carry;
-    int4* __restrict__ tile_best = J.tile_best;
+    // (pointers out of the job record are generic to the compiler: say that they are global memory, or every
+    // access becomes a FLAT one, which waits on the LDS and the memory counters together)
+    const GI32* __restrict__ pred_off = (const GI32*)(J.pred_off);
+    const GI32* __restrict__ pred = (const GI32*)(J.pred);
+    const GU8* __restrict__ seq = (const GU8*)(J.seq);
+    GI32 *H = (GI32*)(J.H), *F1 = (GI32*)(J.F1), *F2 = (GI32*)(J.F2);
+    GU32* __restrict__ dirs = (GU32*)(J.dirs);
+    GU8* __restrict__ ebits = (GU8*)(J.ebits);
+    GI32* carry = (GI32*)(J.carry);  // 4 values per (column tile, row)
+    GI32* __restrict__ tile_best = (GI32*)(J.tile_best);
     const int W = L + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = cb_first + blockIdx.x, rb = diag - cb;
     const int j = cb * POA_CB + tid;
     const bool active = j < W;
+    const int jj = min(j, W - 1);  // threads past the last column run along (uniform barriers) and store nothing
     const int r_lo = rb * POA_RB + 1, r_hi = min(R, r_lo + POA_RB - 1);
-    const int4* cin_row = cb > 0 ? carry + int64_t(cb - 1) * (R + 1) : nullptr;
-    int4* cout_row = carry + int64_t(cb) * (R + 1);
+    const GI32* cin_row = carry + int64_t(max(cb, 1) - 1) * (R + 1) * 4;
+    GI32* cout_row = carry + int64_t(cb) * (R + 1) * 4;
+    // ---- the tile's rows: predecessor lists, bases, carries of the tile on the left ----
+    const int nrows = r_hi - r_lo + 1;
+    const int pb0 = pred_off[r_lo];
+    for (int t = tid; t <= nrows; t += POA_THREADS) s_poff[t] = pred_off[r_lo + t];
+    for (int t = tid; t < nrows; t += POA_THREADS) {
+        s_base[t] = ((const GU8*)J.base)[r_lo + t];
+        const GI32* ci = cin_row + int64_t(r_lo + t) * 4;
+        s_cin[t] = cb > 0 ? int4{ci[0], ci[1], ci[2], ci[3]} : int4{POA_NEG, POA_NEG, 0, 0};
+    }
+    {
+        const int np = min(pred_off[r_hi + 1] - pb0, POA_PRED_LDS);
+        for (int t = tid; t < np; t += POA_THREADS) s_pred[t] = pred[pb0 + t];
+    }
+    __syncthreads();
+    int my_base = j > 0 ? seq[jj - 1] : 0;
+    asm volatile("" : "+v"(my_base));  // loaded before the row loop starts: no memory-counter wait inside it
     int my_best = 0, my_r = 0, my_j = 0;
     for (int r = r_lo; r <= r_hi; ++r) {
-        const int pb = pred_off[r], pe = pred_off[r + 1];
-        const uint8_t b = base[r];
-        const int64_t ro = int64_t(r) * W;
-        const int4 cin = cin_row ? cin_row[r] : int4{POA_NEG, POA_NEG, 0, 0};  // (issued first: not needed before the scan)
+        const int t = r - r_lo;
+        const int pb = s_poff[t], pe = s_poff[t + 1];
+        const int4 cin = s_cin[t];
         int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
         uint32_t d = SRC_STOP;
-        if (active) {
+        {
             uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
             int dg = POA_NEG;
-            const int sc = j > 0 ? ((b == seq[j - 1]) ? S.m : S.n) : 0;
+            const int sc = j > 0 ? ((s_base[t] == my_base) ? S.m : S.n) : 0;
             for (int x = pb; x < pe; ++x) {
-                const int64_t po = int64_t(pred[x]) * W;
+                int prv = s_pred[min(x - pb0, POA_PRED_LDS - 1)];
+                if (x - pb0 >= POA_PRED_LDS) {  // (uniform: a tile with very many edges)
+                    prv = pred[x];
+                    asm volatile("" : "+v"(prv));  // waited for here, not at the join (see below)
+                }
+                const int pr = __builtin_amdgcn_readfirstlane(prv);
+                int hu, u1, u2, hl;
+                if (pr >= r_lo && r - pr <= POA_RING) {
+                    const int sl = pr & (POA_RING - 1);
+                    hu = sH[sl][tid];
+                    u1 = sF1[sl][tid];
+                    u2 = sF2[sl][tid];
+                    hl = tid > 0 ? sH[sl][tid - 1] : s_cin[pr - r_lo].w;
+                } else {
+                    if (pr >= r_lo) __syncthreads();  // a row of this tile that left the ring: its stores must have landed
+                    const int64_t po = int64_t(pr) * W;
+                    hu = H[po + jj];
+                    u1 = F1[po + jj];
+                    u2 = F2[po + jj];
+                    hl = jj > 0 ? H[po + jj - 1] : 0;
+                    // the loads are waited for HERE: at the join the compiler would wait for the memory counter on
+                    // the LDS path too, and that counter also holds the previous row's stores
+                    asm volatile("" : "+v"(hu), "+v"(u1), "+v"(u2), "+v"(hl));
+                }
                 if (j > 0) {
-                    const int hd = H[po + j - 1] + sc;
+                    const int hd = hl + sc;
                     if (hd > dg) {
                         dg = hd;
                         dp = uint32_t(x - pb);
                     }
                 }
-                const int hu = H[po + j];
-                const int o1 = hu + S.g, x1 = F1[po + j] + S.e;
+                const int o1 = hu + S.g, x1 = u1 + S.e;
                 const int v1 = max(o1, x1);
                 if (v1 > f1) {
                     f1 = v1;
                     f1p = uint32_t(x - pb);
                     f1x = x1 > o1 ? 1u : 0u;
                 }
-                const int o2 = hu + S.q, x2 = F2[po + j] + S.c;
+                const int o2 = hu + S.q, x2 = u2 + S.c;
                 const int v2 = max(o2, x2);
                 if (v2 > f2) {
                     f2 = v2;
@@ -180,49 +251,48 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
             }
             d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
         }
-        s_hn[tid] = hn;
-        // ---- inclusive block scan: prefix maxima of Hn[x] - e x and Hn[x] - c x over the tile's columns ----
-        int2 v = active ? int2{hn - S.e * j, hn - S.c * j} : int2{POA_NEG, POA_NEG};
+        // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
+        const int vx = wave_prefix_max(active ? hn - S.e * j : POA_NEG);
+        const int vy = wave_prefix_max(active ? hn - S.c * j : POA_NEG);
+        int ex = dpp_or_neg<0x138>(vx), ey = dpp_or_neg<0x138>(vy);  // wave_shr:1: the lane on the left
+        int left = dpp_or_neg<0x138>(hn);
+        if (lane == 63) s_wave[wave] = int4{vx, vy, hn, 0};
+        lds_barrier();
+        int px = cin.x, py = cin.y;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int tx = __shfl_up(v.x, o), ty = __shfl_up(v.y, o);
-            if (lane >= o) v = max2(v, int2{tx, ty});
-        }
-        if (lane == 63) s_wave[wave] = v;
-        __syncthreads();
-        if (wave == 0) {
-            int2 w = lane < POA_THREADS / 64 ? s_wave[lane] : int2{POA_NEG, POA_NEG};
-#pragma unroll
-            for (int o = 1; o < POA_THREADS / 64; o <<= 1) {
-                const int tx = __shfl_up(w.x, o), ty = __shfl_up(w.y, o);
-                if (lane >= o) w = max2(w, int2{tx, ty});
+        for (int w2 = 0; w2 < POA_WAVES - 1; ++w2)
+            if (w2 < wave) {
+                const int4 o = s_wave[w2];
+                px = max(px, o.x);
+                py = max(py, o.y);
+                if (lane == 0 && w2 == wave - 1) left = o.z;
             }
-            if (lane < POA_THREADS / 64) s_wave[lane] = w;
+        if (tid == 0) left = cin.z;
+        ex = max(ex, px);
+        ey = max(ey, py);
+        int h = hn;
+        uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
+        if (j > 0) {
+            const int e1 = ex > POA_NEG / 2 ? ex + S.g + (j - 1) * S.e : POA_NEG;
+            const int e2 = ey > POA_NEG / 2 ? ey + S.q + (j - 1) * S.c : POA_NEG;
+            const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
+            const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
+            if (e1 > h) {
+                h = e1;
+                eb = SRC_E1;
+            }
+            if (e2 > h) {
+                h = e2;
+                eb = SRC_E2;
+            }
+            eb |= (e1x << 3) | (e2x << 4);
         }
-        __syncthreads();
-        if (wave > 0) v = max2(v, s_wave[wave - 1]);
-        s_inc[tid] = v;
-        __syncthreads();
-        int2 run = max2(tid > 0 ? s_inc[tid - 1] : int2{POA_NEG, POA_NEG}, int2{cin.x, cin.y});  // all columns left of j
+        const int sl = r & (POA_RING - 1);
+        sH[sl][tid] = h;
+        sF1[sl][tid] = f1;
+        sF2[sl][tid] = f2;
         if (active) {
-            int h = hn;
-            uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
-            if (j > 0) {
-                const int e1 = run.x > POA_NEG / 2 ? run.x + S.g + (j - 1) * S.e : POA_NEG;
-                const int e2 = run.y > POA_NEG / 2 ? run.y + S.q + (j - 1) * S.c : POA_NEG;
-                const int left = tid > 0 ? s_hn[tid - 1] : cin.z;
-                const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
-                const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
-                if (e1 > h) {
-                    h = e1;
-                    eb = SRC_E1;
-                }
-                if (e2 > h) {
-                    h = e2;
-                    eb = SRC_E2;
-                }
-                eb |= (e1x << 3) | (e2x << 4);
-            }
+            const int64_t ro = int64_t(r) * W;
             H[ro + j] = h;
             F1[ro + j] = f1;
             F2[ro + j] = f2;
@@ -234,11 +304,14 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
                 my_j = j;
             }
             if (tid == POA_CB - 1 || j == W - 1) {
-                const int2 all = max2(v, int2{cin.x, cin.y});
-                cout_row[r] = int4{all.x, all.y, hn, 0};
+                GI32* co = cout_row + int64_t(r) * 4;
+                co[0] = max(vx, px);
+                co[1] = max(vy, py);
+                co[2] = hn;
+                co[3] = h;
             }
         }
-        __syncthreads();  // row r of this tile is in memory (and the LDS arrays are free) before row r + 1
+        lds_barrier();  // the ring holds row r (and s_wave is free) before row r + 1
     }
     // ---- the tile's best cell: maximum score, ties to the smallest row, then the smallest column ----
     auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
@@ -261,13 +334,17 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
     __syncthreads();
     if (tid == 0) {
         int bs = s_red[0], br = s_red[1], bc = s_red[2];
-        for (int w2 = 1; w2 < POA_THREADS / 64; ++w2)
+        for (int w2 = 1; w2 < POA_WAVES; ++w2)
             if (better(s_red[3 * w2], s_red[3 * w2 + 1], s_red[3 * w2 + 2], bs, br, bc)) {
                 bs = s_red[3 * w2];
                 br = s_red[3 * w2 + 1];
                 bc = s_red[3 * w2 + 2];
             }
-        tile_best[int64_t(cb) * nrb + rb] = int4{bs, br, bc, 0};
+        GI32* tb = tile_best + (int64_t(cb) * nrb + rb) * 4;
+        tb[0] = bs;
+        tb[1] = br;
+        tb[2] = bc;
+        tb[3] = 0;
     }
 }
 
@@ -300,10 +377,12 @@ __global__ void __launch_bounds__(256) k_poa_best(const PoaJob* __restrict__ job
 
 // Walk back from the best cell.  out_node / out_pos receive the alignment in REVERSE order: (row, column - 1)
 // for a diagonal move, (row, -1) for a node against a gap, (-1, column - 1) for a base against a gap;
-// out_n = number of pairs.
-__global__ void k_poa_trace(const PoaJob* __restrict__ jobs)
+// out_n = number of pairs.  One wave per alignment: every step is a chain of dependent loads (direction word,
+// then the predecessor it names), so the 64 lanes read the cells (r - k, j - k) ahead of the walk and the run of
+// plain diagonal steps through consecutive rows they confirm is emitted at once; whatever else comes next is
+// one ordinary step.
+__global__ void __launch_bounds__(64) k_poa_trace(const PoaJob* __restrict__ jobs)
 {
-    if (threadIdx.x != 0) return;
     const PoaJob J = jobs[blockIdx.x];
     const int32_t* __restrict__ pred_off = J.pred_off;
     const int32_t* __restrict__ pred = J.pred;
@@ -312,12 +391,37 @@ __global__ void k_poa_trace(const PoaJob* __restrict__ jobs)
     const int* __restrict__ best = J.best;
     int32_t* __restrict__ out_node = J.out_node;
     int32_t* __restrict__ out_pos = J.out_pos;
-    int32_t* __restrict__ out_n = J.out_n;
     const int cap = J.cap;
     const int64_t W = J.L + 1;
+    const int lane = threadIdx.x;
     int r = best[1], j = best[2], n = 0;
     int state = 0;  // 0 H, 1 Hn (H without the horizontal sources), 2 F1, 3 F2, 4 E1, 5 E2
     while (r > 0 && n < cap) {
+        if (state == 0) {
+            const int rr = r - lane, jl = j - lane;
+            bool ok = rr > 0 && jl > 0;
+            int pr = 0;
+            if (ok) {
+                const uint32_t d = dirs[int64_t(rr) * W + jl];
+                const uint32_t eb = ebits[int64_t(rr) * W + jl];
+                ok = (eb & 7u) == 0 && (d & 3u) == SRC_DIAG;
+                if (ok) pr = pred[pred_off[rr] + int((d >> 9) & 127u)];
+            }
+            const uint64_t okm = __ballot(ok), contm = __ballot(ok && pr == rr - 1);
+            const int fc = ~contm ? __builtin_ctzll(~contm) : 64;             // first lane that leaves the diagonal run
+            int m = (fc < 64 && ((okm >> fc) & 1ull)) ? fc + 1 : fc;           // its own step is still a diagonal one
+            m = min(m, cap - n);
+            if (m > 0) {
+                if (lane < m) {
+                    out_node[n + lane] = rr;
+                    out_pos[n + lane] = jl - 1;
+                }
+                r = __shfl(pr, m - 1);
+                j -= m;
+                n += m;
+                continue;
+            }
+        }
         const uint32_t d = dirs[int64_t(r) * W + j];
         const uint32_t eb = ebits[int64_t(r) * W + j];
         const int pb = pred_off[r];
@@ -325,8 +429,10 @@ __global__ void k_poa_trace(const PoaJob* __restrict__ jobs)
             const uint32_t src = (state == 0 && (eb & 7u)) ? eb & 7u : d & 3u;
             if (src == SRC_STOP) break;
             if (src == SRC_DIAG) {
-                out_node[n] = r;
-                out_pos[n] = j - 1;
+                if (lane == 0) {
+                    out_node[n] = r;
+                    out_pos[n] = j - 1;
+                }
                 ++n;
                 r = pred[pb + int((d >> 9) & 127u)];
                 --j;
@@ -335,22 +441,26 @@ __global__ void k_poa_trace(const PoaJob* __restrict__ jobs)
                 state = int(src);  // F1 / F2 / E1 / E2: same cell, other matrix
             }
         } else if (state == 2 || state == 3) {
-            out_node[n] = r;
-            out_pos[n] = -1;
+            if (lane == 0) {
+                out_node[n] = r;
+                out_pos[n] = -1;
+            }
             ++n;
             const bool ext = state == 2 ? (d >> 7) & 1u : (d >> 8) & 1u;
             r = pred[pb + int(state == 2 ? (d >> 16) & 127u : (d >> 23) & 127u)];
             if (!ext) state = 0;
         } else {
-            out_node[n] = -1;
-            out_pos[n] = j - 1;
+            if (lane == 0) {
+                out_node[n] = -1;
+                out_pos[n] = j - 1;
+            }
             ++n;
             const bool ext = state == 4 ? (eb >> 3) & 1u : (eb >> 4) & 1u;
             --j;
             if (!ext) state = 1;  // the gap was opened from Hn of the column to the left
         }
     }
-    *out_n = n;
+    if (lane == 0) *J.out_n = n;
 }
 
 // ---- host side: the graph ----------------------------------------------------------------------------------
@@ -738,7 +848,7 @@ int poa_flush(ioc_poa* p)
                     who.emplace_back(side, kv.first);
                     continue;
                 }
-                const size_t need = job_cells(j) * 17 + (size_t(1) << 20);
+                const size_t need = job_cells(j) * 17 + (j.item->seq.size() / POA_CB + 1) * (j.G->nodes.size() + 1) * sizeof(int4) + (size_t(1) << 20);
                 if (!jobs.empty() && (used + need > budget || jobs.size() >= 256)) continue;  // next round
                 used += need;
                 jobs.push_back(j);

@@ -18,8 +18,8 @@ for i in range(n):
     r = _mutate(rng, truth, 0.1)
     t = time.time()
     poa.add(0, r)
+    nodes = len(poa.graph(0)[0])  # additions are queued: reading the graph works the queue off
     dt = time.time() - t
-    nodes = len(poa.graph(0)[0])
     print(f"add {i}: {dt * 1e3:.1f} ms, graph {nodes} nodes, {nodes * len(r) / dt / 1e9:.2f} Gcells/s", flush=True)
 t = time.time()
 c = poa.consensus(0)
