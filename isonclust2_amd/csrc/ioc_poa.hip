@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -63,6 +64,8 @@ struct PoaJob {
     const uint8_t* base;
     const int32_t* pred_off;
     const int32_t* pred;
+    const int32_t* pred_slot;  // per predecessor entry: the plane row of that predecessor's H / F1 / F2, -1 if not kept
+    const int32_t* slot;       // per row: its plane row, -1 if no later row reads it from memory
     const uint8_t* seq;
     int* H;
     int* F1;
@@ -123,10 +126,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // One anti-diagonal of tiles per launch (tile = POA_RB rows x POA_CB columns): the tiles of a diagonal are
 // independent, kernel boundaries are the only synchronisation between tiles (no flags, no cross-workgroup
-// coherence games).  Inside a tile the rows are sequential and latency is everything, so nothing a row needs
-// comes from memory in the common case: the tile's predecessor lists, bases and left carries are staged in LDS
-// once, the last POA_RING rows of H / F1 / F2 stay in an LDS ring (a predecessor further back, or above the
-// tile, is read from memory), and the row scan is DPP within a wave plus one LDS exchange between the 4 waves.
+// coherence games).  Inside a tile the rows are sequential and latency is everything:
+//   * the 4 waves of the workgroup own 64 columns each and run one row apart (wave w is on row s - w in step s),
+//     so the only thing that crosses waves is the row carry of the wave on the left, written one step earlier:
+//     one LDS barrier per step, and the row scan itself is DPP inside the wave;
+//   * nothing a row needs comes from memory in the common case: the tile's predecessor lists, bases and left
+//     carries are staged in LDS once, the last POA_RING rows of H / F1 / F2 stay in an LDS ring that only the
+//     owning lane touches (a predecessor further back, or above the tile, is read from memory), and the next
+//     row's list head is fetched while the current row computes.
 // rows 1..R = nodes in topological order; pred_off[r] .. pred_off[r+1]: predecessor ROWS of row r (row 0 for a
 // node without in-edges).  carry[cb][r] = (prefix max of Hn[x] - e x, of Hn[x] - c x, over all columns up to the
 // tile's last one; Hn and H of that last column): what the tile to the right needs of row r.
@@ -134,11 +141,10 @@ __global__ void __launch_bounds__(POA_THREADS)
 k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
 {
     __shared__ int sH[POA_RING][POA_CB], sF1[POA_RING][POA_CB], sF2[POA_RING][POA_CB];
-    __shared__ int4 s_cin[POA_RB];
-    __shared__ int4 s_wave[POA_WAVES];
-    __shared__ int s_poff[POA_RB + 1];
-    __shared__ int s_pred[POA_PRED_LDS];
-    __shared__ uint8_t s_base[POA_RB];
+    __shared__ int4 s_carry[POA_WAVES][POA_RB];  // [0]: from the tile on the left; [w]: from wave w - 1
+    __shared__ int s_poff[POA_RB + 2];
+    __shared__ int s_pred[POA_PRED_LDS], s_pslot[POA_PRED_LDS];
+    __shared__ int s_base[POA_RB + 1], s_slot[POA_RB + 1];  // (one past the last row: read ahead, never used)
     __shared__ int s_red[3 * POA_WAVES];
     const PoaJob J = jobs[blockIdx.y];
     const int R = J.R, L = J.L, nrb = J.nrb;
@@ -148,6 +154,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
     // access becomes a FLAT one, which waits on the LDS and the memory counters together)
     const GI32* __restrict__ pred_off = (const GI32*)(J.pred_off);
     const GI32* __restrict__ pred = (const GI32*)(J.pred);
+    const GI32* __restrict__ pred_slot = (const GI32*)(J.pred_slot);
     const GU8* __restrict__ seq = (const GU8*)(J.seq);
     GI32 *H = (GI32*)(J.H), *F1 = (GI32*)(J.F1), *F2 = (GI32*)(J.F2);
     GU32* __restrict__ dirs = (GU32*)(J.dirs);
@@ -159,7 +166,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
     const int cb = cb_first + blockIdx.x, rb = diag - cb;
     const int j = cb * POA_CB + tid;
     const bool active = j < W;
-    const int jj = min(j, W - 1);  // threads past the last column run along (uniform barriers) and store nothing
+    const int jj = min(j, W - 1);  // threads past the last column run along and store nothing
     const int r_lo = rb * POA_RB + 1, r_hi = min(R, r_lo + POA_RB - 1);
     const GI32* cin_row = carry + int64_t(max(cb, 1) - 1) * (R + 1) * 4;
     GI32* cout_row = carry + int64_t(cb) * (R + 1) * 4;
@@ -167,151 +174,185 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
     const int nrows = r_hi - r_lo + 1;
     const int pb0 = pred_off[r_lo];
     for (int t = tid; t <= nrows; t += POA_THREADS) s_poff[t] = pred_off[r_lo + t];
+    if (tid == 0) s_poff[nrows + 1] = 0;
     for (int t = tid; t < nrows; t += POA_THREADS) {
         s_base[t] = ((const GU8*)J.base)[r_lo + t];
+        s_slot[t] = ((const GI32*)J.slot)[r_lo + t];
         const GI32* ci = cin_row + int64_t(r_lo + t) * 4;
-        s_cin[t] = cb > 0 ? int4{ci[0], ci[1], ci[2], ci[3]} : int4{POA_NEG, POA_NEG, 0, 0};
+        s_carry[0][t] = cb > 0 ? int4{ci[0], ci[1], ci[2], ci[3]} : int4{POA_NEG, POA_NEG, 0, 0};
     }
     {
         const int np = min(pred_off[r_hi + 1] - pb0, POA_PRED_LDS);
-        for (int t = tid; t < np; t += POA_THREADS) s_pred[t] = pred[pb0 + t];
+        for (int t = tid; t < np; t += POA_THREADS) {
+            s_pred[t] = pred[pb0 + t];
+            s_pslot[t] = pred_slot[pb0 + t];
+        }
     }
-    __syncthreads();
     int my_base = j > 0 ? seq[jj - 1] : 0;
     asm volatile("" : "+v"(my_base));  // loaded before the row loop starts: no memory-counter wait inside it
+    __syncthreads();
     int my_best = 0, my_r = 0, my_j = 0;
-    for (int r = r_lo; r <= r_hi; ++r) {
-        const int t = r - r_lo;
-        const int pb = s_poff[t], pe = s_poff[t + 1];
-        const int4 cin = s_cin[t];
-        int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
-        uint32_t d = SRC_STOP;
-        {
-            uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
-            int dg = POA_NEG;
-            const int sc = j > 0 ? ((s_base[t] == my_base) ? S.m : S.n) : 0;
-            for (int x = pb; x < pe; ++x) {
-                int prv = s_pred[min(x - pb0, POA_PRED_LDS - 1)];
-                if (x - pb0 >= POA_PRED_LDS) {  // (uniform: a tile with very many edges)
-                    prv = pred[x];
-                    asm volatile("" : "+v"(prv));  // waited for here, not at the join (see below)
-                }
-                const int pr = __builtin_amdgcn_readfirstlane(prv);
-                int hu, u1, u2, hl;
-                if (pr >= r_lo && r - pr <= POA_RING) {
-                    const int sl = pr & (POA_RING - 1);
-                    hu = sH[sl][tid];
-                    u1 = sF1[sl][tid];
-                    u2 = sF2[sl][tid];
-                    hl = tid > 0 ? sH[sl][tid - 1] : s_cin[pr - r_lo].w;
-                } else {
-                    if (pr >= r_lo) __syncthreads();  // a row of this tile that left the ring: its stores must have landed
-                    const int64_t po = int64_t(pr) * W;
-                    hu = H[po + jj];
-                    u1 = F1[po + jj];
-                    u2 = F2[po + jj];
-                    hl = jj > 0 ? H[po + jj - 1] : 0;
-                    // the loads are waited for HERE: at the join the compiler would wait for the memory counter on
-                    // the LDS path too, and that counter also holds the previous row's stores
-                    asm volatile("" : "+v"(hu), "+v"(u1), "+v"(u2), "+v"(hl));
-                }
-                if (j > 0) {
-                    const int hd = hl + sc;
-                    if (hd > dg) {
-                        dg = hd;
-                        dp = uint32_t(x - pb);
+    // what the wave's next row starts with, fetched one step ahead: list bounds, base, first predecessor
+    int pb = __builtin_amdgcn_readfirstlane(s_poff[0]), pe = __builtin_amdgcn_readfirstlane(s_poff[1]), bs = s_base[0], pr0 = s_pred[0];
+    int my_slot = s_slot[0];
+    for (int s = 0; s < nrows + POA_WAVES - 1; ++s) {
+        const int t = s - wave;
+        if (t >= 0 && t < nrows) {  // (uniform in the wave)
+            const int r = r_lo + t;
+            const int4 cin = s_carry[wave][t];
+            const int pe_n = __builtin_amdgcn_readfirstlane(s_poff[t + 2]);
+            const int bs_n = s_base[t + 1];
+            const int slot_n = s_slot[t + 1];
+            const int pr0_n = s_pred[min(pe - pb0, POA_PRED_LDS - 1)];
+            int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
+            uint32_t d = SRC_STOP;
+            {
+                uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
+                int dg = POA_NEG;
+                const int sc = (bs == my_base) ? S.m : S.n;
+                // plane row of predecessor entry x (only the memory paths ask: a row read from memory is a kept one)
+                auto pslot_of = [&](int x) {
+                    int v = s_pslot[min(x - pb0, POA_PRED_LDS - 1)];
+                    if (x - pb0 >= POA_PRED_LDS) v = pred_slot[x];
+                    return __builtin_amdgcn_readfirstlane(v);
+                };
+                for (int x = pb; x < pe; ++x) {
+                    int prv = pr0;
+                    if (x > pb) {
+                        prv = s_pred[min(x - pb0, POA_PRED_LDS - 1)];
+                        if (x - pb0 >= POA_PRED_LDS) {  // (a tile with very many edges)
+                            prv = pred[x];
+                            asm volatile("" : "+v"(prv));  // waited for here, not at the join (see below)
+                        }
+                    } else if (x - pb0 >= POA_PRED_LDS) {
+                        prv = pred[x];
+                        asm volatile("" : "+v"(prv));
+                    }
+                    const int pr = __builtin_amdgcn_readfirstlane(prv);
+                    int hu, u1, u2, hl;
+                    if (pr >= r_lo) {
+                        const int edge = s_carry[wave][pr - r_lo].w;  // H of the column left of this wave's first
+                        if (r - pr <= POA_RING) {
+                            const int sl = pr & (POA_RING - 1);
+                            hu = sH[sl][tid];
+                            u1 = sF1[sl][tid];
+                            u2 = sF2[sl][tid];
+                        } else {
+                            // a row of this tile that left the ring: this wave's own stores, once they have landed,
+                            // read past the L1 (lines of it may have come in before the stores)
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            const int64_t po = int64_t(pslot_of(x)) * W + jj;
+                            hu = __hip_atomic_load((int*)(H + po), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            u1 = __hip_atomic_load((int*)(F1 + po), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            u2 = __hip_atomic_load((int*)(F2 + po), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("" : "+v"(hu), "+v"(u1), "+v"(u2));
+                        }
+                        hl = __builtin_amdgcn_update_dpp(edge, hu, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    } else {
+                        const int64_t po = int64_t(pslot_of(x)) * W;
+                        hu = H[po + jj];
+                        u1 = F1[po + jj];
+                        u2 = F2[po + jj];
+                        hl = jj > 0 ? H[po + jj - 1] : 0;
+                        // the loads are waited for HERE: at the join the compiler would wait for the memory counter
+                        // on the LDS path too, and that counter also holds the previous rows' stores
+                        asm volatile("" : "+v"(hu), "+v"(u1), "+v"(u2), "+v"(hl));
+                    }
+                    if (j > 0) {
+                        const int hd = hl + sc;
+                        if (hd > dg) {
+                            dg = hd;
+                            dp = uint32_t(x - pb);
+                        }
+                    }
+                    const int o1 = hu + S.g, x1 = u1 + S.e;
+                    const int v1 = max(o1, x1);
+                    if (v1 > f1) {
+                        f1 = v1;
+                        f1p = uint32_t(x - pb);
+                        f1x = x1 > o1 ? 1u : 0u;
+                    }
+                    const int o2 = hu + S.q, x2 = u2 + S.c;
+                    const int v2 = max(o2, x2);
+                    if (v2 > f2) {
+                        f2 = v2;
+                        f2p = uint32_t(x - pb);
+                        f2x = x2 > o2 ? 1u : 0u;
                     }
                 }
-                const int o1 = hu + S.g, x1 = u1 + S.e;
-                const int v1 = max(o1, x1);
-                if (v1 > f1) {
-                    f1 = v1;
-                    f1p = uint32_t(x - pb);
-                    f1x = x1 > o1 ? 1u : 0u;
+                if (dg > hn) {
+                    hn = dg;
+                    d = SRC_DIAG;
                 }
-                const int o2 = hu + S.q, x2 = u2 + S.c;
-                const int v2 = max(o2, x2);
-                if (v2 > f2) {
-                    f2 = v2;
-                    f2p = uint32_t(x - pb);
-                    f2x = x2 > o2 ? 1u : 0u;
+                if (f1 > hn) {
+                    hn = f1;
+                    d = SRC_F1;
+                }
+                if (f2 > hn) {
+                    hn = f2;
+                    d = SRC_F2;
+                }
+                d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
+            }
+            // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
+            const int vx = max(wave_prefix_max(active ? hn - S.e * j : POA_NEG), cin.x);
+            const int vy = max(wave_prefix_max(active ? hn - S.c * j : POA_NEG), cin.y);
+            const int ex = __builtin_amdgcn_update_dpp(cin.x, vx, 0x138, 0xf, 0xf, false);  // wave_shr:1: the lane on the left
+            const int ey = __builtin_amdgcn_update_dpp(cin.y, vy, 0x138, 0xf, 0xf, false);
+            const int left = __builtin_amdgcn_update_dpp(cin.z, hn, 0x138, 0xf, 0xf, false);
+            int h = hn;
+            uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
+            if (j > 0) {
+                const int e1 = ex > POA_NEG / 2 ? ex + S.g + (j - 1) * S.e : POA_NEG;
+                const int e2 = ey > POA_NEG / 2 ? ey + S.q + (j - 1) * S.c : POA_NEG;
+                const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
+                const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
+                if (e1 > h) {
+                    h = e1;
+                    eb = SRC_E1;
+                }
+                if (e2 > h) {
+                    h = e2;
+                    eb = SRC_E2;
+                }
+                eb |= (e1x << 3) | (e2x << 4);
+            }
+            const int sl = r & (POA_RING - 1);
+            sH[sl][tid] = h;
+            sF1[sl][tid] = f1;
+            sF2[sl][tid] = f2;
+            if (lane == 63 && wave < POA_WAVES - 1) s_carry[wave + 1][t] = int4{vx, vy, hn, h};
+            if (active) {
+                const int64_t ro = int64_t(r) * W;
+                const int ks = __builtin_amdgcn_readfirstlane(my_slot);
+                if (ks >= 0) {  // some later row reads this one from memory (it is above that row's tile or out of its ring)
+                    const int64_t ko = int64_t(ks) * W;
+                    H[ko + j] = h;
+                    F1[ko + j] = f1;
+                    F2[ko + j] = f2;
+                }
+                dirs[ro + j] = d;
+                ebits[ro + j] = uint8_t(eb);
+                if (h > my_best) {  // rows ascend in time: the first row wins ties
+                    my_best = h;
+                    my_r = r;
+                    my_j = j;
+                }
+                if (tid == POA_CB - 1 || j == W - 1) {
+                    GI32* co = cout_row + int64_t(r) * 4;
+                    co[0] = vx;
+                    co[1] = vy;
+                    co[2] = hn;
+                    co[3] = h;
                 }
             }
-            if (dg > hn) {
-                hn = dg;
-                d = SRC_DIAG;
-            }
-            if (f1 > hn) {
-                hn = f1;
-                d = SRC_F1;
-            }
-            if (f2 > hn) {
-                hn = f2;
-                d = SRC_F2;
-            }
-            d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
+            pb = pe;
+            pe = pe_n;
+            bs = bs_n;
+            pr0 = pr0_n;
+            my_slot = slot_n;
         }
-        // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
-        const int vx = wave_prefix_max(active ? hn - S.e * j : POA_NEG);
-        const int vy = wave_prefix_max(active ? hn - S.c * j : POA_NEG);
-        int ex = dpp_or_neg<0x138>(vx), ey = dpp_or_neg<0x138>(vy);  // wave_shr:1: the lane on the left
-        int left = dpp_or_neg<0x138>(hn);
-        if (lane == 63) s_wave[wave] = int4{vx, vy, hn, 0};
-        lds_barrier();
-        int px = cin.x, py = cin.y;
-#pragma unroll
-        for (int w2 = 0; w2 < POA_WAVES - 1; ++w2)
-            if (w2 < wave) {
-                const int4 o = s_wave[w2];
-                px = max(px, o.x);
-                py = max(py, o.y);
-                if (lane == 0 && w2 == wave - 1) left = o.z;
-            }
-        if (tid == 0) left = cin.z;
-        ex = max(ex, px);
-        ey = max(ey, py);
-        int h = hn;
-        uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
-        if (j > 0) {
-            const int e1 = ex > POA_NEG / 2 ? ex + S.g + (j - 1) * S.e : POA_NEG;
-            const int e2 = ey > POA_NEG / 2 ? ey + S.q + (j - 1) * S.c : POA_NEG;
-            const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
-            const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
-            if (e1 > h) {
-                h = e1;
-                eb = SRC_E1;
-            }
-            if (e2 > h) {
-                h = e2;
-                eb = SRC_E2;
-            }
-            eb |= (e1x << 3) | (e2x << 4);
-        }
-        const int sl = r & (POA_RING - 1);
-        sH[sl][tid] = h;
-        sF1[sl][tid] = f1;
-        sF2[sl][tid] = f2;
-        if (active) {
-            const int64_t ro = int64_t(r) * W;
-            H[ro + j] = h;
-            F1[ro + j] = f1;
-            F2[ro + j] = f2;
-            dirs[ro + j] = d;
-            ebits[ro + j] = uint8_t(eb);
-            if (h > my_best) {  // rows ascend in time: the first row wins ties
-                my_best = h;
-                my_r = r;
-                my_j = j;
-            }
-            if (tid == POA_CB - 1 || j == W - 1) {
-                GI32* co = cout_row + int64_t(r) * 4;
-                co[0] = max(vx, px);
-                co[1] = max(vy, py);
-                co[2] = hn;
-                co[3] = h;
-            }
-        }
-        lds_barrier();  // the ring holds row r (and s_wave is free) before row r + 1
+        lds_barrier();  // the carries of this step's rows are in LDS before the waves on the right start them
     }
     // ---- the tile's best cell: maximum score, ties to the smallest row, then the smallest column ----
     auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
@@ -478,6 +519,27 @@ struct PGraph {
     std::vector<PEdge> edges;
     std::vector<int> rank;  // topological order: rank[i] = node id
     int nseq = 0;
+    // a graph seeded with one sequence is a chain: it is built when somebody first looks at it (most clusters of a
+    // batch stay singletons, and 16.7 k nodes with their edge lists are not free)
+    std::string seed;
+    int64_t seed_w = 0;
+    bool seeded = false;
+    void seed_with(const char* s, int len, int64_t w)
+    {
+        if (len <= 0) return;
+        seed.assign(s, size_t(len));
+        seed_w = w;
+        seeded = true;
+        nseq = 1;
+    }
+    void ensure()
+    {
+        if (!seeded) return;
+        seeded = false;
+        nseq = 0;
+        add_alignment({}, seed.data(), int(seed.size()), seed_w);
+        std::string().swap(seed);
+    }
 
     int add_node(char b)
     {
@@ -646,6 +708,7 @@ struct ioc_poa {
     std::vector<int32_t> last_node, last_pos;
     int32_t last_score = 0;
     int64_t n_batches = 0, n_aligned = 0;
+    double ms_layout = 0, ms_alloc = 0, ms_gpu = 0, ms_graph = 0;  // IOC_TRACE: host layout of the batches, launches + copies, AddAlignment
     std::string err;
 };
 
@@ -678,9 +741,43 @@ struct HostJob {
     const PoaPending* item = nullptr;
     std::vector<std::pair<int, int>> aln;  // out: forward order, NODE IDS
     int32_t score = 0;
+    // rows = nodes in topological order (+1: row 0 is the virtual source); predecessor rows; which rows keep their
+    // H / F1 / F2 in memory: those a later row cannot find in its tile's LDS ring (it sits in a lower tile or more
+    // than POA_RING rows on).  On a chain that is one row in 64.
+    std::vector<int32_t> poff, pred, slot;
+    int32_t nkeep = 1;
+    void plan()
+    {
+        const int R = int(G->nodes.size());
+        std::vector<int> row_of(static_cast<size_t>(R), 0);
+        for (int i = 0; i < R; ++i) row_of[size_t(G->rank[size_t(i)])] = i + 1;
+        poff.assign(size_t(R) + 2, 0);
+        pred.clear();
+        std::vector<uint8_t> keep(size_t(R) + 1, 0);
+        keep[0] = 1;
+        for (int i = 0; i < R; ++i) {
+            const PNode& nd = G->nodes[size_t(G->rank[size_t(i)])];
+            const int q = i + 1;
+            poff[size_t(q)] = int32_t(pred.size());
+            if (nd.in.empty()) pred.push_back(0);
+            for (int e : nd.in) {
+                const int pr = row_of[size_t(G->edges[size_t(e)].from)];
+                pred.push_back(pr);
+                if ((pr - 1) / POA_RB != (q - 1) / POA_RB || q - pr > POA_RING) keep[size_t(pr)] = 1;
+            }
+        }
+        poff[size_t(R) + 1] = int32_t(pred.size());
+        slot.assign(size_t(R) + 1, -1);
+        nkeep = 0;
+        for (int r = 0; r <= R; ++r)
+            if (keep[size_t(r)]) slot[size_t(r)] = nkeep++;
+    }
+    size_t bytes() const  // device memory of the alignment: direction word + E byte per cell, 3 planes of kept rows
+    {
+        const size_t W = item->seq.size() + 1, R1 = G->nodes.size() + 1;
+        return R1 * W * 5 + size_t(nkeep) * W * 12 + (W / POA_CB + 1) * R1 * sizeof(int4) + (size_t(1) << 20);
+    }
 };
-
-size_t job_cells(const HostJob& j) { return size_t(j.G->nodes.size() + 1) * size_t(j.item->seq.size() + 1); }
 
 // align every job's read to its graph: one batch of launches
 int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
@@ -690,14 +787,16 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     const size_t K = jobs.size();
     if (K == 0) return IOC_OK;
     hipStream_t s = c->stream;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_in = now();
     // ---- layout of the batch in the arenas ----
     struct Lay {
-        size_t cells, o_cells, o_carry, o_tbest, o_small, o_base, o_poff, o_pred, o_seq, o_best, o_n, o_aln;
+        size_t cells, o_cells, o_plane, o_pslot, o_slot, o_carry, o_tbest, o_small, o_base, o_poff, o_pred, o_seq, o_best, o_n, o_aln;
         int R, L, nrb, ncb, cap;
     };
     std::vector<Lay> lay(K);
     std::vector<uint8_t> small;
-    size_t tot_cells = 0, tot_carry = 0, tot_tbest = 0, tot_aln = 0;
+    size_t tot_cells = 0, tot_plane = 0, tot_carry = 0, tot_tbest = 0, tot_aln = 0;
     int max_w = 1, max_diag = 0, max_ncb = 1;
     for (size_t x = 0; x < K; ++x) {
         const PGraph& G = *jobs[x].G;
@@ -712,6 +811,8 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         l.cells = size_t(l.R + 1) * size_t(l.L + 1);
         l.o_cells = tot_cells;
         tot_cells += (l.cells + 63) & ~size_t(63);
+        l.o_plane = tot_plane;
+        tot_plane += (size_t(jobs[x].nkeep) * size_t(l.L + 1) + 63) & ~size_t(63);
         l.o_carry = tot_carry;
         tot_carry += size_t(l.ncb) * size_t(l.R + 1);
         l.o_tbest = tot_tbest;
@@ -721,28 +822,29 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         max_w = std::max(max_w, l.L + 1);
         max_diag = std::max(max_diag, l.nrb + l.ncb - 1);
         max_ncb = std::max(max_ncb, l.ncb);
-        // small arrays: bases in topological order, predecessor rows, the read
-        std::vector<int> row_of(static_cast<size_t>(l.R), 0);
-        for (int i = 0; i < l.R; ++i) row_of[size_t(G.rank[size_t(i)])] = i + 1;
+        // small arrays: bases in topological order, predecessor rows and their plane rows, the read
         auto align16 = [&]() { small.resize((small.size() + 15) & ~size_t(15)); };
+        auto put32 = [&](const std::vector<int32_t>& v) {
+            align16();
+            const size_t o = small.size();
+            small.insert(small.end(), reinterpret_cast<const uint8_t*>(v.data()), reinterpret_cast<const uint8_t*>(v.data() + v.size()));
+            return o;
+        };
         align16();
         l.o_base = small.size();
         small.resize(small.size() + size_t(l.R) + 1, 0);
-        std::vector<int32_t> poff(size_t(l.R) + 2, 0), pred;
         for (int i = 0; i < l.R; ++i) {
             const PNode& nd = G.nodes[size_t(G.rank[size_t(i)])];
             small[l.o_base + size_t(i) + 1] = uint8_t(nd.base);
-            poff[size_t(i) + 1] = int32_t(pred.size());
-            if (nd.in.empty()) pred.push_back(0);
             if (nd.in.size() > size_t(POA_MAX_PREDS)) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
-            for (int e : nd.in) pred.push_back(row_of[size_t(G.edges[size_t(e)].from)]);
         }
-        poff[size_t(l.R) + 1] = int32_t(pred.size());
-        align16();
-        l.o_poff = small.size();
-        small.insert(small.end(), reinterpret_cast<uint8_t*>(poff.data()), reinterpret_cast<uint8_t*>(poff.data() + poff.size()));
-        l.o_pred = small.size();
-        small.insert(small.end(), reinterpret_cast<uint8_t*>(pred.data()), reinterpret_cast<uint8_t*>(pred.data() + pred.size()));
+        const HostJob& hj = jobs[x];
+        std::vector<int32_t> pslot(hj.pred.size());
+        for (size_t y = 0; y < hj.pred.size(); ++y) pslot[y] = hj.slot[size_t(hj.pred[y])];
+        l.o_poff = put32(hj.poff);
+        l.o_pred = put32(hj.pred);
+        l.o_pslot = put32(pslot);
+        l.o_slot = put32(hj.slot);
         l.o_seq = small.size();
         small.insert(small.end(), seq.begin(), seq.end());
         align16();
@@ -752,7 +854,8 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         small.resize(small.size() + 16, 0);
     }
     int r;
-    if ((r = poa_reserve(p, p->d_int, tot_cells * 12)) != IOC_OK) return r;   // H, F1, F2 planes
+    const double t_res = now();
+    if ((r = poa_reserve(p, p->d_int, tot_plane * 12)) != IOC_OK) return r;   // H, F1, F2 planes of the kept rows
     if ((r = poa_reserve(p, p->d_dirs, tot_cells * 4)) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_eb, tot_cells)) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_carry, tot_carry * sizeof(int4))) != IOC_OK) return r;
@@ -760,6 +863,7 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     if ((r = poa_reserve(p, p->d_small, small.size())) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_aln, tot_aln * 4)) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_jobs, K * sizeof(PoaJob))) != IOC_OK) return r;
+    p->ms_alloc += now() - t_res;
     uint8_t* sm = static_cast<uint8_t*>(p->d_small.p);
     int* ints = static_cast<int*>(p->d_int.p);
     std::vector<PoaJob> dj(K);
@@ -773,10 +877,12 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         j.base = sm + l.o_base;
         j.pred_off = reinterpret_cast<const int32_t*>(sm + l.o_poff);
         j.pred = reinterpret_cast<const int32_t*>(sm + l.o_pred);
+        j.pred_slot = reinterpret_cast<const int32_t*>(sm + l.o_pslot);
+        j.slot = reinterpret_cast<const int32_t*>(sm + l.o_slot);
         j.seq = sm + l.o_seq;
-        j.H = ints + l.o_cells;
-        j.F1 = ints + tot_cells + l.o_cells;
-        j.F2 = ints + 2 * tot_cells + l.o_cells;
+        j.H = ints + l.o_plane;
+        j.F1 = ints + tot_plane + l.o_plane;
+        j.F2 = ints + 2 * tot_plane + l.o_plane;
         j.dirs = static_cast<uint32_t*>(p->d_dirs.p) + l.o_cells;
         j.ebits = static_cast<uint8_t*>(p->d_eb.p) + l.o_cells;
         j.carry = static_cast<int4*>(p->d_carry.p) + l.o_carry;
@@ -787,6 +893,8 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         j.out_n = reinterpret_cast<int32_t*>(sm + l.o_n);
         j.cap = l.cap;
     }
+    const double t_gpu = now();
+    p->ms_layout += t_gpu - t_in;
     PCHK(p, hipMemcpyAsync(sm, small.data(), small.size(), hipMemcpyHostToDevice, s));
     PCHK(p, hipMemcpyAsync(p->d_jobs.p, dj.data(), K * sizeof(PoaJob), hipMemcpyHostToDevice, s));
     const PoaJob* djobs = static_cast<const PoaJob*>(p->d_jobs.p);
@@ -805,6 +913,7 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     PCHK(p, hipMemcpyAsync(back.data(), sm, small.size(), hipMemcpyDeviceToHost, s));
     PCHK(p, hipMemcpyAsync(haln.data(), p->d_aln.p, tot_aln * 4, hipMemcpyDeviceToHost, s));
     PCHK(p, hipStreamSynchronize(s));
+    p->ms_gpu += now() - t_gpu;
     for (size_t x = 0; x < K; ++x) {
         const Lay& l = lay[x];
         const PGraph& G = *jobs[x].G;
@@ -830,7 +939,8 @@ int poa_flush(ioc_poa* p)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
         const size_t have = p->d_int.cap + p->d_dirs.cap + p->d_eb.cap;
-        size_t budget = (free_b + have) / 2;
+        // (device allocations of 100 GB take seconds: more, smaller batches cost less than that)
+        size_t budget = std::min((free_b + have) / 2, size_t(48) << 30);
         if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
         std::vector<HostJob> jobs;
         std::vector<std::pair<int, int>> who;
@@ -841,6 +951,7 @@ int poa_flush(ioc_poa* p)
                 auto it = p->g[side].find(kv.first);
                 if (it == p->g[side].end()) return ioc_fail(p->ctx, IOC_ERR_STATE, "POA: addition to a graph that does not exist");
                 HostJob j;
+                it->second.ensure();
                 j.G = &it->second;
                 j.item = &kv.second.front();
                 if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
@@ -848,10 +959,11 @@ int poa_flush(ioc_poa* p)
                     who.emplace_back(side, kv.first);
                     continue;
                 }
-                const size_t need = job_cells(j) * 17 + (j.item->seq.size() / POA_CB + 1) * (j.G->nodes.size() + 1) * sizeof(int4) + (size_t(1) << 20);
+                j.plan();
+                const size_t need = j.bytes();
                 if (!jobs.empty() && (used + need > budget || jobs.size() >= 256)) continue;  // next round
                 used += need;
-                jobs.push_back(j);
+                jobs.push_back(std::move(j));
                 who.emplace_back(side, kv.first);
             }
         if (jobs.empty()) return IOC_OK;
@@ -868,6 +980,7 @@ int poa_flush(ioc_poa* p)
             jobs[run_ix[y]].aln = std::move(run[y].aln);
             jobs[run_ix[y]].score = run[y].score;
         }
+        const auto tg0 = std::chrono::steady_clock::now();
         for (size_t x = 0; x < jobs.size(); ++x) {
             HostJob& j = jobs[x];
             p->last_node.clear();
@@ -881,6 +994,7 @@ int poa_flush(ioc_poa* p)
             auto& q = p->pending[who[x].first][who[x].second];
             q.erase(q.begin());
         }
+        p->ms_graph += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
     }
 }
 
@@ -889,7 +1003,7 @@ int op_create(void* u, int side, int idx, const char* seq, int len)
     ioc_poa* p = static_cast<ioc_poa*>(u);
     if (side < 0 || side > 1 || len < 0) return -1;
     PGraph G;
-    G.add_alignment({}, seq, len, 1);
+    G.seed_with(seq, len, 1);
     p->g[side][idx] = std::move(G);
     p->pending[side].erase(idx);
     return 0;
@@ -923,6 +1037,7 @@ int op_consensus(void* u, int side, int idx, char* out, int cap)
     if (poa_flush(p) != IOC_OK) return -1;  // this graph must be up to date; everybody else's queue rides along
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return -1;
+    it->second.ensure();
     const std::string s = it->second.consensus();
     if (int(s.size()) > cap) return -1;
     memcpy(out, s.data(), s.size());
@@ -933,7 +1048,7 @@ int op_purge(void* u, int side, int idx, const char* seq, int len, unsigned weig
     ioc_poa* p = static_cast<ioc_poa*>(u);
     if (side < 0 || side > 1) return -1;
     PGraph G;
-    G.add_alignment({}, seq, len, int64_t(weight));  // ConsPurge: the representative alone, with the old count as weight
+    G.seed_with(seq, len, int64_t(weight));  // ConsPurge: the representative alone, with the old count as weight
     p->g[side][idx] = std::move(G);
     p->pending[side].erase(idx);
     return 0;
@@ -959,6 +1074,9 @@ int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int
 void ioc_poa_destroy(ioc_poa* p)
 {
     if (!p) return;
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc] POA: %lld alignments in %lld batches; batch layout %.1f ms (%.1f ms of it device allocations), launches + copies %.1f ms, graph updates %.1f ms\n",
+                (long long)p->n_aligned, (long long)p->n_batches, p->ms_layout, p->ms_alloc, p->ms_gpu, p->ms_graph);
     for (DevBuf* b : {&p->d_int, &p->d_dirs, &p->d_eb, &p->d_carry, &p->d_tbest, &p->d_small, &p->d_aln, &p->d_jobs})
         if (b->p) (void)hipFree(b->p);
     delete p;
@@ -985,6 +1103,7 @@ int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_
     }
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return IOC_ERR_ARG;
+    it->second.ensure();
     const PGraph& G = it->second;
     if (n_nodes) *n_nodes = int32_t(G.nodes.size());
     if (n_edges) *n_edges = int32_t(G.edges.size());
@@ -1012,6 +1131,7 @@ int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t 
     }
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return IOC_ERR_ARG;
+    it->second.ensure();
     const PGraph& G = it->second;
     std::vector<uint8_t> b;
     auto put = [&](const void* v, size_t n) { b.insert(b.end(), static_cast<const uint8_t*>(v), static_cast<const uint8_t*>(v) + n); };

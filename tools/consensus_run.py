@@ -36,3 +36,4 @@ t = time.time()
 poa.graph(0)      # (a .cer writer would save every graph now: works off whatever additions are still queued)
 dt_flush = time.time() - t
 print(f"{rs.tag} {a.mode}: {dt:.2f} s + {dt_flush:.2f} s for the queued graph additions ({rs.n / (dt + dt_flush):.0f} reads/s); {st}")
+poa.close()
