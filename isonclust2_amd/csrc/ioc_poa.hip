@@ -138,7 +138,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // node without in-edges).  carry[cb][r] = (prefix max of Hn[x] - e x, of Hn[x] - c x, over all columns up to the
 // tile's last one; Hn and H of that last column): what the tile to the right needs of row r.
 __global__ void __launch_bounds__(POA_THREADS)
-k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
+k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
 {
     __shared__ int sH[POA_RING][POA_CB], sF1[POA_RING][POA_CB], sF2[POA_RING][POA_CB];
     __shared__ int4 s_carry[POA_WAVES][POA_RB];  // [0]: from the tile on the left; [w]: from wave w - 1
@@ -182,7 +182,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
         s_carry[0][t] = cb > 0 ? int4{ci[0], ci[1], ci[2], ci[3]} : int4{POA_NEG, POA_NEG, 0, 0};
     }
     {
-        const int np = min(pred_off[r_hi + 1] - pb0, POA_PRED_LDS);
+        const int np = min(pred_off[r_hi + 1] - pb0, pred_lds);
         for (int t = tid; t < np; t += POA_THREADS) {
             s_pred[t] = pred[pb0 + t];
             s_pslot[t] = pred_slot[pb0 + t];
@@ -203,7 +203,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
             const int pe_n = __builtin_amdgcn_readfirstlane(s_poff[t + 2]);
             const int bs_n = s_base[t + 1];
             const int slot_n = s_slot[t + 1];
-            const int pr0_n = s_pred[min(pe - pb0, POA_PRED_LDS - 1)];
+            const int pr0_n = s_pred[min(pe - pb0, pred_lds - 1)];
             int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
             uint32_t d = SRC_STOP;
             {
@@ -212,19 +212,19 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S)
                 const int sc = (bs == my_base) ? S.m : S.n;
                 // plane row of predecessor entry x (only the memory paths ask: a row read from memory is a kept one)
                 auto pslot_of = [&](int x) {
-                    int v = s_pslot[min(x - pb0, POA_PRED_LDS - 1)];
-                    if (x - pb0 >= POA_PRED_LDS) v = pred_slot[x];
+                    int v = s_pslot[min(x - pb0, pred_lds - 1)];
+                    if (x - pb0 >= pred_lds) v = pred_slot[x];
                     return __builtin_amdgcn_readfirstlane(v);
                 };
                 for (int x = pb; x < pe; ++x) {
                     int prv = pr0;
                     if (x > pb) {
-                        prv = s_pred[min(x - pb0, POA_PRED_LDS - 1)];
-                        if (x - pb0 >= POA_PRED_LDS) {  // (a tile with very many edges)
+                        prv = s_pred[min(x - pb0, pred_lds - 1)];
+                        if (x - pb0 >= pred_lds) {  // (a tile with very many edges)
                             prv = pred[x];
                             asm volatile("" : "+v"(prv));  // waited for here, not at the join (see below)
                         }
-                    } else if (x - pb0 >= POA_PRED_LDS) {
+                    } else if (x - pb0 >= pred_lds) {
                         prv = pred[x];
                         asm volatile("" : "+v"(prv));
                     }
@@ -698,6 +698,7 @@ struct PoaPending {
 struct ioc_poa {
     ioc_ctx* ctx = nullptr;
     PoaScores S{4, -8, -8, -4, -20, -1};
+    int pred_lds = POA_PRED_LDS;  // IOC_POA_PRED_LDS: a smaller staging area, for the tests of the overflow path
     std::map<int, PGraph> g[2];
     // additions not aligned yet: graphs are independent until somebody reads one, so additions are queued and the
     // queues of all graphs are worked off together, one addition per graph and round, in batched launches
@@ -901,7 +902,7 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     hipLaunchKernelGGL(k_poa_init, dim3(unsigned((max_w + 255) / 256), unsigned(K)), dim3(256), 0, s, djobs);
     PCHK(p, hipGetLastError());
     for (int dg = 0; dg < max_diag; ++dg) {  // one anti-diagonal of tiles (of every job) per launch
-        hipLaunchKernelGGL(k_poa_tile, dim3(unsigned(std::min(max_ncb, dg + 1)), unsigned(K)), dim3(POA_THREADS), 0, s, djobs, dg, p->S);
+        hipLaunchKernelGGL(k_poa_tile, dim3(unsigned(std::min(max_ncb, dg + 1)), unsigned(K)), dim3(POA_THREADS), 0, s, djobs, dg, p->S, p->pred_lds);
         PCHK(p, hipGetLastError());
     }
     hipLaunchKernelGGL(k_poa_best, dim3(unsigned(K)), dim3(256), 0, s, djobs);
@@ -1067,6 +1068,7 @@ int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int
     ioc_poa* p = new ioc_poa;
     p->ctx = ctx;
     p->S = PoaScores{m, n, g, e, q, c};
+    if (const char* e2 = getenv("IOC_POA_PRED_LDS")) p->pred_lds = std::max(1, std::min(POA_PRED_LDS, atoi(e2)));
     *out = p;
     return IOC_OK;
 }

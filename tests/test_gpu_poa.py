@@ -259,3 +259,42 @@ def test_graph_dp_across_tiles(ctx):
         assert score == want, (t, score, want)
         assert _path_score(bases, ef, et, read, nodes, pos) == score, t
     poa.close()
+
+
+def _check_adds(poa, idx, reads):
+    for t, read in enumerate(reads):
+        bases, rank, ef, et, ew = poa.graph(idx)
+        want = _ref_score(bases, rank, ef, et, read)
+        poa.add(idx, read)
+        nodes, pos, score = poa.last_alignment()
+        assert score == want, (t, score, want)
+        assert _path_score(bases, ef, et, read, nodes, pos) == score, t
+
+
+def test_graph_dp_predecessors_out_of_the_lds_ring(ctx):
+    """Deletions of 20-45 bases put edges into the graph whose source is more than 16 rows above the target inside
+    one 64-row tile (read back from memory, past the L1) or in the tile above; later reads use those edges."""
+    rng = random.Random(23)
+    poa = Poa(ctx)
+    truth = bytes(rng.choice(b"ACGT") for _ in range(420))
+    poa.create(0, truth)
+    cut = lambda s, a, n: s[:a] + s[a + n:]
+    reads = [cut(truth, 70, 24), cut(cut(truth, 70, 24), 200, 45), _mutate(rng, cut(truth, 70, 24), 0.05),
+             cut(truth, 130, 20), _mutate(rng, cut(cut(truth, 130, 20), 290, 33), 0.04), _mutate(rng, truth, 0.08)]
+    _check_adds(poa, 0, reads)
+    bases, rank, ef, et, ew = poa.graph(0)
+    order = {int(v): i for i, v in enumerate(rank)}
+    spans = [order[int(b)] - order[int(a)] for a, b in zip(ef, et)]
+    assert max(spans) > 16                                           # the case is in the graph
+    poa.close()
+
+
+def test_graph_dp_with_a_tiny_predecessor_staging_area(ctx, monkeypatch):
+    """IOC_POA_PRED_LDS = 5: all but the first predecessor entries of a tile come from memory, not from LDS."""
+    monkeypatch.setenv("IOC_POA_PRED_LDS", "5")
+    rng = random.Random(29)
+    poa = Poa(ctx)
+    truth = bytes(rng.choice(b"ACGT") for _ in range(300))
+    poa.create(0, _mutate(rng, truth, 0.1))
+    _check_adds(poa, 0, [_mutate(rng, truth, 0.15) for _ in range(5)] + [truth[:120] + truth[150:]])
+    poa.close()
