@@ -240,7 +240,8 @@ def main():
                "clusters": st["n_clusters"],
                "alignment": {"reads_aligned": st["n_aln_invoked"], "pairs": st["n_aln_pairs"],
                              "rounds": st["aln_rounds"], "order_dependent": st["n_aln_order_dep"],
-                             "cells": tm["n_align_cells"]}}
+                             "cells": tm["n_align_cells"],
+                             "refused_by_packed_kernel": tm.get("n_align_refused", 0)}}
         sah_res = (cls, strand, st, tm, acc)
 
     if rank == 0:

@@ -197,6 +197,7 @@ typedef struct {
     float ms_align_trace;      /* k_align_trace: tiled traceback + windows   */
     int64_t n_align_pairs;
     int64_t n_align_cells;     /* sum of query length x reference length     */
+    int64_t n_align_refused;   /* pairs the packed 16-bit forward pass handed to the 32-bit one */
 } ioc_timings;
 int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
 /* Instrumentation (one extra scoring launch, outside any timed region): the number of postings the

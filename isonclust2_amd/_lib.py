@@ -89,7 +89,8 @@ class Timings(C.Structure):
                 ("n_index_postings", C.c_int64), ("n_candidates", C.c_int64),
                 ("n_mapped_evals", C.c_int64), ("postings_traversed", C.c_int64),
                 ("ms_align_fwd", C.c_float), ("ms_align_trace", C.c_float), ("n_align_pairs", C.c_int64),
-                ("n_align_cells", C.c_int64)]
+                ("n_align_cells", C.c_int64),
+                ("n_align_refused", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -404,6 +404,25 @@ struct AlnCk {  // where a pair's checkpoints live in the arena, in int2 units
 // bounds checks — the store block runs in EVERY step of a wave (for the two lanes whose skewed row block ends a
 // tile), so its instruction count matters as much as the cells'
 __host__ __device__ __forceinline__ uint64_t row_pitch(uint32_t m) { return (uint64_t(m) + 15u) & ~uint64_t(15); }
+// Packed forward pass (k_align_fwd16): a wave stores the row checkpoints of its two bands as they sit in its
+// registers, 16-bit values relative to a base, and the base of each block of 16 columns next to them.  The two
+// bands are on different strips, so each has planes of its own (of which only "its" half of a word counts).
+// Entry e = wave * tiles_per_band + tile_in_band, in uint32 units: planes [Hq low band][F* low][Hq high][F* high]
+// of `pitch` words, then pitch / 16 bases of the low band's blocks and pitch / 16 of the high band's (+ padding).
+__host__ __device__ __forceinline__ uint64_t row16_stride(uint32_t m) { return 4u * row_pitch(m) + row_pitch(m) / 4u; }  // (16-byte multiples)
+// int2 units the row region needs at most, whatever the number of waves (<= 4) a pair gets
+__host__ __device__ __forceinline__ uint64_t row16_units(uint32_t n, uint32_t m)
+{
+    const uint64_t ntiles = (uint64_t(n) + TILE - 1) / TILE;
+    return ((ntiles / 2u + 5u) * row16_stride(m) + 1u) / 2u;
+}
+// one value of a packed row checkpoint: band half hs of entry `ent`, plane pl (0 Hq, 1 F*), column j
+__device__ __forceinline__ int row16_get(const uint32_t* __restrict__ ent, uint32_t m, int hs, int pl, uint32_t j)
+{
+    const uint32_t w = ent[uint64_t(2 * hs + pl) * row_pitch(m) + j];
+    const int base = int(ent[4u * row_pitch(m) + uint32_t(hs) * (row_pitch(m) / 16u) + j / 16u]);
+    return (hs ? (int(w) >> 16) : int(short(w & 0xFFFFu))) + base;
+}
 // column checkpoints: 4 rows (one step of a lane) go out as two 16-byte stores
 __host__ __device__ __forceinline__ uint64_t col_pitch(uint32_t n) { return (uint64_t(n) + 3u) & ~uint64_t(3); }
 
@@ -801,6 +820,497 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     }
 }
 
+// =====================================================================================================
+// Pass 1, packed: the same pipeline with TWO row bands per wave, one in each 16-bit half of every register
+// (v_pk_add_i16 / v_pk_max_i16 run at the rate of their 32-bit cousins: two cells per lane and instruction).
+// Wave w owns bands 2w (low halves) and 2w + 1 (high halves); in round t the low half is on strip t - 2w and
+// the high half one strip behind — on the strip whose bottom row the low half wrote as a row checkpoint one
+// round earlier.  Everything that leaves the wave (checkpoints, end cells) is a full 32-bit value, so pass 2
+// and the results are those of the 32-bit kernel bit for bit.
+//
+// 16 bits hold a score RELATIVE to a base that is uniform in the wave (one per half) and moves with the sweep:
+// every 16 steps the base is advanced by the value of a live lane and all registers are rebased.  What is live
+// in a wave at one time — 64 lanes x 16 columns, rows a few hundred apart — differs by a few thousand at most:
+// two cells of that window are joined through a common ancestor by gaps / diagonals no longer than the window,
+// and the slant adds ge per row and column.  A guard checks |relative H| < 28000 at every rebase and flags the
+// pair (ends.w) for the 32-bit kernel otherwise.  "No score" (E at column 0, F at row 0) is -32768: it only
+// ever enters a max, and the rebase subtracts with saturation.
+// =====================================================================================================
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ v2s pmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2s pmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s psubs(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767); }
+__device__ __forceinline__ v2s pack2(int lo, int hi) { return v2s{short(lo), short(hi)}; }
+template <int H>
+__device__ __forceinline__ int half_of(v2s x)
+{
+    return H ? int(x.y) : int(x.x);
+}
+__device__ __forceinline__ int half_of_rt(int word, int h) { return h ? (word >> 16) : int(short(word & 0xFFFF)); }
+__device__ __forceinline__ v2s dpp_left_or(v2s v, v2s first) { return as_v2s(from_left_or(as_u32(v), as_u32(first))); }
+
+constexpr int P16_GUARD = 28000;
+
+// one row of 16 columns, both halves: 7 packed VALU per column (the 32-bit kernel's 5, without a max3, plus
+// the byte pair of the two profiles).  xl / xh: this row's profile words of the low / high half's strip.
+// Dependent packed instructions cost a wait state each, so everything that does not hang on the left
+// neighbour — T = max(diagonal + increment, F*) — is computed for the 16 columns first; what is left in the
+// chain along the row is E* = max(E*, Hq), H* = max(T, E*), Hq = H* - gd.
+__device__ __forceinline__ void fwd16_cells(v2s (&Hq)[FW_C], v2s (&F)[FW_C], const uint32_t (&xl)[FW_C / 4],
+                                            const uint32_t (&xh)[FW_C / 4], v2s& hql, v2s& el, v2s dgq, v2s gd2)
+{
+    v2s T[FW_C];
+#pragma unroll
+    for (int c = 0; c < FW_C; ++c) {
+        const v2s Fn = pmax(F[c], Hq[c]);
+        // bytes (c & 3) of xl and xh, zero-extended into the two halves
+        const uint32_t sel = 0x0c000c00u | uint32_t(4 + (c & 3)) << 16 | uint32_t(c & 3);
+        const v2s inc = as_v2s(__builtin_amdgcn_perm(xh[c >> 2], xl[c >> 2], sel));
+        T[c] = pmax((c ? Hq[c - 1] : dgq) + inc, Fn);
+        F[c] = Fn;
+    }
+    // (Hq[c - 1] above is still the row before: the chain below overwrites Hq only now)
+    v2s e = el, h = hql;
+#pragma unroll
+    for (int c = 0; c < FW_C; ++c) {
+        e = pmax(e, h);
+        h = pmax(T[c], e) - gd2;
+        Hq[c] = h;
+    }
+    hql = h;
+    el = e;
+}
+
+constexpr int P16_MAXW = 4;  // waves per workgroup (8 bands): the two profile buffers of a wave are 10 KB
+__global__ void __launch_bounds__(64 * P16_MAXW) __attribute__((amdgpu_waves_per_eu(IOC_FWD_WAVES_PER_EU, 8)))
+k_align_fwd16(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, uint32_t count, uint32_t wpp_main,
+              uint32_t n_main, uint32_t wpp_tail, const uint8_t* __restrict__ pool, AlnParams P, int2* ck, const AlnCk* __restrict__ cko,
+              int2* lrow, uint64_t lrow_stride, int4* __restrict__ ends)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_look_all[P16_MAXW][3][128];
+    __shared__ int s_best[2 * P16_MAXW][2];
+    __shared__ uint32_t s_rounds;
+    __shared__ uint32_t s_ovf[P16_MAXW];
+    // query profiles of two strips (strip & 1), [wave][buffer][base code 0..4][lane][4 words]
+    __shared__ __attribute__((aligned(16))) uint32_t s_prof_all[P16_MAXW][2][5][64][4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+    const bool tail = blockIdx.x >= n_main;
+    const uint32_t wpp = tail ? wpp_tail : wpp_main, wg_waves = blockDim.x >> 6;
+    const uint32_t slot = wv / wpp, wave = wv % wpp, nwaves = wpp, nbands = 2u * wpp;
+    const uint32_t pslot = tail ? n_main * (wg_waves / wpp_main) + (blockIdx.x - n_main) * (wg_waves / wpp_tail) + slot
+                                : blockIdx.x * (wg_waves / wpp_main) + slot;
+    const bool live = pslot < count;
+    if (threadIdx.x == 0) s_rounds = 0;
+    if (lane == 0) s_ovf[wv] = 0;
+    __syncthreads();
+    const uint32_t pid = order[live ? pslot : 0];
+    const AlnPairDev pr = pairs[pid];
+    const uint32_t n = pr.n, m = pr.m;
+    const int ge = P.gap_extend, gd = pr.gap_open - P.gap_extend;
+    const int cm = P.match + 2 * ge + gd, cx = P.mismatch + 2 * ge + gd;
+    const v2s gd2 = pack2(gd, gd);
+    const uint8_t* __restrict__ q = pool + pr.q_off;
+    const uint8_t* __restrict__ r = pool + pr.r_off;
+    int2* rowck = ck + cko[pid].row_off;
+    int2* colck = ck + cko[pid].col_off;
+    int2* mylrow = lrow + uint64_t(live ? pslot : 0) * lrow_stride;
+    uint32_t(*s_look)[128] = s_look_all[wv];
+    // byte offset of a query base's profile row
+    auto qcode = [](uint32_t ch) -> uint32_t {
+        const uint32_t code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+        return code * 1024u;
+    };
+    constexpr uint32_t strip_cols = 64u * FW_C;
+    const uint32_t nstrips = (m + strip_cols - 1) / strip_cols;
+    const uint32_t ntiles = (n + TILE - 1) / TILE, tpb = (ntiles + nbands - 1) / nbands;
+    uint32_t r_lo[2], r_hi[2], nblk[2];
+    bool last_band[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t band = 2u * wave + uint32_t(h);
+        r_lo[h] = min(n, band * tpb * TILE);
+        r_hi[h] = min(n, (band + 1u) * tpb * TILE);
+        nblk[h] = (r_hi[h] - r_lo[h] + FW_R - 1) / FW_R;
+        last_band[h] = r_hi[h] == n && r_lo[h] < n;
+    }
+    const uint32_t nsteps = nblk[0] + 63u;  // (bands are equal but for the trailing ones: nblk[1] <= nblk[0])
+    int bc[2] = {ALN_NEG, ALN_NEG};  // best of the last column inside each band (true score), first row wins ties
+    uint32_t bc_i[2] = {0, 0};
+    uint32_t ovf = 0;
+
+    if (live && lane == 0) atomicMax(&s_rounds, nstrips + nbands - 1u);
+    __syncthreads();
+    const uint32_t rounds = s_rounds;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        int ps[2];
+        ps[0] = int(round) - 2 * int(wave);
+        ps[1] = ps[0] - 1;
+        bool vh[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) vh[h] = live && ps[h] >= 0 && uint32_t(ps[h]) < nstrips && nblk[h] > 0;
+        if (vh[0] || vh[1]) {
+            uint32_t jb[2];
+            bool has_cols[2], wr_col[2];
+            int lastc[2];
+            int2* colout[2];
+            const int2* colin[2];
+            const uint32_t* profb[2];  // this lane's 4 words of profile row 0, per half
+            int base[2];               // what relative 0 stands for (wave-uniform)
+            uint32_t ncl[2];           // lanes that own columns of the strip
+            v2s Hp[FW_C], F[FW_C];
+            v2s dg;
+            {
+                int Ha[2][FW_C], Fa[2][FW_C], dga[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t p = uint32_t(vh[h] ? ps[h] : 0);
+                    jb[h] = p * strip_cols + lane * FW_C;
+                    has_cols[h] = vh[h] && jb[h] < m;
+                    ncl[h] = vh[h] ? min(64u, (m - p * strip_cols + FW_C - 1) / FW_C) : 0u;
+                    lastc[h] = (vh[h] && m - 1 >= jb[h] && m - 1 < jb[h] + FW_C) ? int(m - 1 - jb[h]) : -1;
+                    const uint32_t jr = jb[h] + FW_C;
+                    wr_col[h] = vh[h] && (jr % TILE) == 0 && jr < m;
+                    colout[h] = wr_col[h] ? colck + uint64_t(jr / TILE - 1) * col_pitch(n) : colck;
+                    colin[h] = p ? colck + uint64_t(p * strip_cols / TILE - 1) * col_pitch(n) : colck;
+                    profb[h] = &s_prof_all[wv][p & 1u][0][lane][0];
+                    if (!vh[h]) {
+#pragma unroll
+                        for (int c = 0; c < FW_C; ++c) {
+                            Ha[h][c] = 0;
+                            Fa[h][c] = 0;
+                        }
+                        dga[h] = 0;
+                    } else if (r_lo[h] == 0) {
+                        const int b0 = ge * int(jb[h]) - gd;
+#pragma unroll
+                        for (int c = 0; c < FW_C; ++c) {
+                            Ha[h][c] = b0 + ge * (c + 1);
+                            Fa[h][c] = ALN_NEG;
+                        }
+                        dga[h] = b0;
+                    } else {
+                        // the last row of the band above: band - 1 = (wave w', half h') wrote entry w' * tpb + tpb - 1
+                        const uint32_t bp = 2u * wave + uint32_t(h) - 1u;
+                        const uint32_t* ent = reinterpret_cast<const uint32_t*>(rowck) + uint64_t((bp >> 1) * tpb + tpb - 1u) * row16_stride(m);
+                        const int hs = int(bp & 1u);
+#pragma unroll
+                        for (int c = 0; c < FW_C; ++c) {
+                            int2 v{0, 0};
+                            if (jb[h] + c < m) v = int2{row16_get(ent, m, hs, 0, jb[h] + c), row16_get(ent, m, hs, 1, jb[h] + c)};
+                            Ha[h][c] = v.x;
+                            Fa[h][c] = v.y;
+                        }
+                        dga[h] = (jb[h] > 0 && jb[h] <= m) ? row16_get(ent, m, hs, 0, jb[h] - 1) : ge * int(r_lo[h]) - gd;  // column 0 holds H = 0
+                    }
+                    base[h] = __builtin_amdgcn_readfirstlane(Ha[h][0]);  // lane 0, first column of the strip
+                }
+#pragma unroll
+                for (int c = 0; c < FW_C; ++c) {
+                    // (columns right of the matrix: relative 0, they only ever follow their left neighbours)
+                    const bool in0 = jb[0] + c < m, in1 = jb[1] + c < m;
+                    Hp[c] = pack2(in0 ? clamp16(Ha[0][c] - base[0]) : 0, in1 ? clamp16(Ha[1][c] - base[1]) : 0);
+                    F[c] = pack2(in0 ? clamp16(Fa[0][c] - base[0]) : 0, in1 ? clamp16(Fa[1][c] - base[1]) : 0);
+                }
+                dg = pack2(clamp16(dga[0] - base[0]), clamp16(dga[1] - base[1]));
+            }
+            // the low half's strip is new: its profile goes to buffer (strip & 1); the high half's strip was
+            // the low half's one round ago
+            if (vh[0]) {
+                uint32_t rpk[FW_C / 4];
+#pragma unroll
+                for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w |= ref_byte(r, m, pr.rc, jb[0] + c4 * 4 + e) << (8 * e);
+                    rpk[c4] = w;
+                }
+                uint32_t(*pf)[64][4] = s_prof_all[wv][uint32_t(ps[0]) & 1u];
+                const uint32_t bases = 'A' | ('C' << 8) | ('G' << 16) | ('T' << 24);
+#pragma unroll
+                for (int code = 0; code < 5; ++code) {
+                    const uint32_t b = code < 4 ? (bases >> (8 * code)) & 0xFFu : 0x100u;  // 0x100: equals no byte
+#pragma unroll
+                    for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w |= uint32_t(((rpk[c4] >> (8 * e)) & 0xFFu) == b ? cm : cx) << (8 * e);
+                        pf[code][lane][c4] = w;
+                    }
+                }
+            }
+            // left edge of a strip (absolute, slanted): column 0 of the matrix or the column checkpoint
+            auto left_edge = [&](int h, uint32_t row) {
+                int2 v{ge * int(row + 1) - gd, ALN_NEG};
+                if (vh[h] && ps[h] > 0 && row < r_hi[h]) v = colin[h][row];
+                return v;
+            };
+            uint32_t qn = 0;
+            int2 en[2] = {{0, 0}, {0, 0}};
+            v2s hl[FW_R], el[FW_R];
+            uint32_t qc[FW_R];
+#pragma unroll
+            for (int rr = 0; rr < FW_R; ++rr) {
+                hl[rr] = pack2(0, 0);
+                el[rr] = pack2(-32768, -32768);
+                qc[rr] = 0;
+            }
+            auto publish = [&](uint32_t blk) {  // relative to the bases of NOW (the rebase keeps the ring current)
+                s_look[0][(blk & 1u) * 64u + lane] = as_u32(pack2(clamp16(en[0].x - base[0]), clamp16(en[1].x - base[1])));
+                s_look[1][(blk & 1u) * 64u + lane] = as_u32(pack2(clamp16(en[0].y - base[0]), clamp16(en[1].y - base[1])));
+                s_look[2][(blk & 1u) * 64u + lane] = qn;
+            };
+            auto fetch = [&](uint32_t blk) {
+                uint32_t qq[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t row = r_lo[h] + blk * 64u + lane;
+                    qq[h] = qcode((vh[h] && row < r_hi[h]) ? q[row] : 0u);
+                    en[h] = left_edge(h, row);
+                }
+                qn = qq[0] | (qq[1] << 16);
+            };
+            fetch(0);
+            publish(0);
+            fetch(1);
+            uint4 nxh, nxe, nxq;
+            {
+                nxh = *reinterpret_cast<const uint4*>(&s_look[0][0]);
+                nxe = *reinterpret_cast<const uint4*>(&s_look[1][0]);
+                nxq = *reinterpret_cast<const uint4*>(&s_look[2][0]);
+            }
+            for (uint32_t s = 0; s < nsteps; ++s) {
+                if ((s & (64 / FW_R - 1)) == 0) {
+                    if (s) {
+                        // ---- rebase: advance each base by the first column of a lane that is inside its band ----
+                        int dl[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            // (the lowest lane still inside the band; lanes right of the matrix own no columns)
+                            const uint32_t lr = s + 1u > nblk[h] ? min(63u, s + 1u - nblk[h]) : 0u;
+                            const int ref = __builtin_amdgcn_readlane(int(as_u32(Hp[0])), int(lr));
+                            dl[h] = max(half_of_rt(ref, h), 0);
+                            if (!vh[h] || lr >= ncl[h]) dl[h] = 0;
+                            base[h] += dl[h];
+                        }
+                        const v2s d2 = pack2(dl[0], dl[1]);
+                        // guard (lanes inside a band only: the registers of the others are idle)
+                        {
+                            v2s mx = Hp[0], mn = Hp[0];
+#pragma unroll
+                            for (int c = 1; c < FW_C; ++c) {
+                                mx = pmax(mx, Hp[c]);
+                                mn = pmin(mn, Hp[c]);
+                            }
+                            const int bi = int(s) - int(lane);
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int hi_v = h ? int(mx.y) : int(mx.x), lo_v = h ? int(mn.y) : int(mn.x);
+                                if (has_cols[h] && bi >= 0 && uint32_t(bi) < nblk[h] && (hi_v > P16_GUARD || lo_v < -P16_GUARD)) ovf = 1;
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < FW_C; ++c) {
+                            Hp[c] = psubs(Hp[c], d2);
+                            F[c] = psubs(F[c], d2);
+                        }
+                        dg = psubs(dg, d2);
+#pragma unroll
+                        for (int rr = 0; rr < FW_R; ++rr) {
+                            hl[rr] = psubs(hl[rr], d2);
+                            el[rr] = psubs(el[rr], d2);
+                        }
+                        nxh = uint4{as_u32(psubs(as_v2s(nxh.x), d2)), as_u32(psubs(as_v2s(nxh.y), d2)), as_u32(psubs(as_v2s(nxh.z), d2)),
+                                    as_u32(psubs(as_v2s(nxh.w), d2))};
+                        nxe = uint4{as_u32(psubs(as_v2s(nxe.x), d2)), as_u32(psubs(as_v2s(nxe.y), d2)), as_u32(psubs(as_v2s(nxe.z), d2)),
+                                    as_u32(psubs(as_v2s(nxe.w), d2))};
+                        // the block of the ring that is being consumed
+                        const uint32_t cur = ((s / (64 / FW_R)) & 1u) * 64u + lane;
+                        s_look[0][cur] = as_u32(psubs(as_v2s(s_look[0][cur]), d2));
+                        s_look[1][cur] = as_u32(psubs(as_v2s(s_look[1][cur]), d2));
+                    }
+                    const uint32_t blk = s / (64 / FW_R) + 1u;
+                    publish(blk);
+                    fetch(blk + 1u);
+                }
+                {
+                    const uint32_t h4[FW_R] = {nxh.x, nxh.y, nxh.z, nxh.w}, e4[FW_R] = {nxe.x, nxe.y, nxe.z, nxe.w},
+                                   q4[FW_R] = {nxq.x, nxq.y, nxq.z, nxq.w};
+#pragma unroll
+                    for (int rr = 0; rr < FW_R; ++rr) {
+                        hl[rr] = dpp_left_or(hl[rr], as_v2s(h4[rr]));
+                        el[rr] = dpp_left_or(el[rr], as_v2s(e4[rr]));
+                        qc[rr] = from_left_or(qc[rr], q4[rr]);
+                    }
+                    const uint32_t nx = ((s + 1u) * FW_R) & 127u;
+                    nxh = *reinterpret_cast<const uint4*>(&s_look[0][nx]);
+                    nxe = *reinterpret_cast<const uint4*>(&s_look[1][nx]);
+                    nxq = *reinterpret_cast<const uint4*>(&s_look[2][nx]);
+                }
+                const int bi = int(s) - int(lane);
+                bool act[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) act[h] = has_cols[h] && bi >= 0 && uint32_t(bi) < nblk[h];
+                if (act[0] || act[1]) {
+                    const bool special = (act[0] && (lastc[0] >= 0 || (last_band[0] && uint32_t(bi) + 1u == nblk[0]))) ||
+                                         (act[1] && (lastc[1] >= 0 || (last_band[1] && uint32_t(bi) + 1u == nblk[1])));
+                    auto row_step = [&](int rr) {
+                        const v2s hl_in = hl[rr];
+                        const uint4 xa = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(profb[0]) + (qc[rr] & 0xFFFFu));
+                        const uint4 xb = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(profb[1]) + (qc[rr] >> 16));
+                        const uint32_t xl[FW_C / 4] = {xa.x, xa.y, xa.z, xa.w}, xh[FW_C / 4] = {xb.x, xb.y, xb.z, xb.w};
+                        fwd16_cells(Hp, F, xl, xh, hl[rr], el[rr], dg, gd2);
+                        dg = hl_in;
+                    };
+                    if (!special) {
+#pragma unroll
+                        for (int rr = 0; rr < FW_R; ++rr) row_step(rr);
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < FW_R; ++rr) {
+                            row_step(rr);
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t i = r_lo[h] + uint32_t(bi) * FW_R + rr;  // 0-based row
+                                if (act[h] && i < r_hi[h]) {
+                                    if (lastc[h] >= 0) {
+                                        const uint32_t lc = opaque(uint32_t(lastc[h]));
+                                        const bool b0 = lc & 1u, b1 = lc & 2u, b2 = lc & 4u, b3 = lc & 8u;
+                                        const uint32_t s0 = b0 ? as_u32(Hp[1]) : as_u32(Hp[0]), s1 = b0 ? as_u32(Hp[3]) : as_u32(Hp[2]),
+                                                       s2 = b0 ? as_u32(Hp[5]) : as_u32(Hp[4]), s3 = b0 ? as_u32(Hp[7]) : as_u32(Hp[6]),
+                                                       s4 = b0 ? as_u32(Hp[9]) : as_u32(Hp[8]), s5 = b0 ? as_u32(Hp[11]) : as_u32(Hp[10]),
+                                                       s6 = b0 ? as_u32(Hp[13]) : as_u32(Hp[12]), s7 = b0 ? as_u32(Hp[15]) : as_u32(Hp[14]);
+                                        const uint32_t u0 = b1 ? s1 : s0, u1 = b1 ? s3 : s2, u2 = b1 ? s5 : s4, u3 = b1 ? s7 : s6;
+                                        const uint32_t v0 = b2 ? u1 : u0, v1 = b2 ? u3 : u2;
+                                        int hm = half_of_rt(int(b3 ? v1 : v0), h) + base[h];
+                                        hm += gd - ge * int(opaque(i) + 1 + m);  // true H(i + 1, m)
+                                        if (hm > bc[h]) {
+                                            bc[h] = hm;
+                                            bc_i[h] = i + 1u;
+                                        }
+                                    }
+                                    if (i + 1u == n) {  // last row: this lane's best cell, first column wins ties
+                                        int br = ALN_NEG;
+                                        uint32_t bj = 0;
+                                        const uint32_t jbo = opaque(jb[h]);
+                                        const int b0 = base[h] + gd - ge * int(n + jbo);
+#pragma unroll
+                                        for (int c = 0; c < FW_C; ++c) {
+                                            const int ht = (h ? int(Hp[c].y) : int(Hp[c].x)) + b0 - ge * (c + 1);  // true H(n, jb + c + 1)
+                                            if (jbo + c < m && ht > br) {
+                                                br = ht;
+                                                bj = jbo + c + 1;
+                                            }
+                                        }
+                                        mylrow[jbo / FW_C] = int2{br, int(bj)};
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t i0 = r_lo[h] + uint32_t(bi) * FW_R;
+                        if (act[h] && wr_col[h]) {
+                            int ha[FW_R], ea[FW_R];
+#pragma unroll
+                            for (int rr = 0; rr < FW_R; ++rr) {
+                                ha[rr] = (h ? int(hl[rr].y) : int(hl[rr].x)) + base[h];
+                                ea[rr] = (h ? int(el[rr].y) : int(el[rr].x)) + base[h];
+                            }
+                            if (!special) {  // i0 is a multiple of 4: two 16-byte stores
+                                int4* co = reinterpret_cast<int4*>(colout[h] + i0);
+                                co[0] = int4{ha[0], ea[0], ha[1], ea[1]};
+                                co[1] = int4{ha[2], ea[2], ha[3], ea[3]};
+                            } else {
+#pragma unroll
+                                for (int rr = 0; rr < FW_R; ++rr)
+                                    if (i0 + rr < r_hi[h]) colout[h][i0 + rr] = int2{ha[rr], ea[rr]};
+                            }
+                        }
+                    }
+                    // row checkpoint: the block's last row closes a tile (in both bands at once: bands start on tile
+                    // boundaries).  The registers go out as they are, with the bases of the moment.
+                    {
+                        const uint32_t i1 = uint32_t(bi + 1) * FW_R;  // rows of the band that are done
+                        if ((i1 % TILE) == 0) {
+                            uint32_t* ent = reinterpret_cast<uint32_t*>(rowck) + uint64_t(wave * tpb + (i1 / TILE - 1u)) * row16_stride(m);
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                if (act[h] && r_lo[h] + i1 < n) {
+                                    const uint32_t jbo = opaque(jb[h]);
+                                    uint4* oh = reinterpret_cast<uint4*>(ent + uint64_t(2 * h) * row_pitch(m) + jbo);
+                                    uint4* of = reinterpret_cast<uint4*>(ent + uint64_t(2 * h + 1) * row_pitch(m) + jbo);
+#pragma unroll
+                                    for (int c = 0; c < FW_C; c += 4) {
+                                        oh[c / 4] = uint4{as_u32(Hp[c]), as_u32(Hp[c + 1]), as_u32(Hp[c + 2]), as_u32(Hp[c + 3])};
+                                        of[c / 4] = uint4{as_u32(F[c]), as_u32(F[c + 1]), as_u32(F[c + 2]), as_u32(F[c + 3])};
+                                    }
+                                    ent[4u * row_pitch(m) + uint32_t(h) * uint32_t(row_pitch(m) / 16u) + jbo / FW_C] = uint32_t(base[h]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (lastc[h] >= 0) {
+                    s_best[2u * wv + uint32_t(h)][0] = bc[h];
+                    s_best[2u * wv + uint32_t(h)][1] = int(bc_i[h]);
+                }
+        }
+        __syncthreads();  // orders this round's checkpoints before the next round reads them
+    }
+    if (ovf) s_ovf[wv] = 1;
+    __syncthreads();
+
+    // end cell: best of the last column (rows ascending), replaced only by a strictly larger cell of the
+    // last row (columns ascending from 0) — the host aligner's scan order (ioc_align.cpp)
+    if (live && wave == 0) {
+        int br = 0;  // H(n, 0)
+        uint32_t bj = 0;
+        for (uint32_t e = lane; e < nstrips * 64u; e += 64) {
+            if (uint64_t(e) * FW_C >= m) continue;
+            const int2 x = mylrow[e];
+            if (x.x > br || (x.x == br && uint32_t(x.y) < bj)) {
+                br = x.x;
+                bj = uint32_t(x.y);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int s = __shfl_xor(br, o);
+            const uint32_t j = __shfl_xor(bj, o);
+            if (s > br || (s == br && j < bj)) {
+                br = s;
+                bj = j;
+            }
+        }
+        if (lane == 0) {
+            int fin = ALN_NEG;
+            uint32_t bi = 0, bjj = m;
+            uint32_t bad = 0;
+            for (uint32_t w2 = 0; w2 < nwaves; ++w2) bad |= s_ovf[slot * wpp + w2];
+            for (uint32_t b2 = 0; b2 < nbands; ++b2) {  // bands top to bottom: the first row wins ties
+                if (min(n, b2 * tpb * TILE) >= n) break;
+                if (s_best[2u * slot * wpp + b2][0] > fin) {
+                    fin = s_best[2u * slot * wpp + b2][0];
+                    bi = uint32_t(s_best[2u * slot * wpp + b2][1]);
+                }
+            }
+            if (br > fin) {
+                fin = br;
+                bi = n;
+                bjj = bj;
+            }
+            ends[pid] = int4{fin, int(bi), int(bjj), int(bad | 2u | (nbands << 8))};  // [0] refused  [1] packed row checkpoints  [15:8] bands
+        }
+    }
+}
+
 // sliding k-window counter over the comparison string, fed in REVERSE order: getAlnRatio counts the
 // windows [i, i + k) for i = 0 .. len - k - 1, i.e. every window but the last one — in reverse order,
 // every window but the first one to complete.
@@ -846,6 +1356,13 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     const uint32_t lane = threadIdx.x;
     const uint32_t k = P.k, kmask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const int4 en = ends[pid];
+    if (en.w & 1) {  // the packed forward pass left its 16-bit window: the host sends the pair to the 32-bit kernel
+        if (lane == 0) {
+            out_score[pid] = INT32_MIN;
+            out_count[pid] = 0xFFFFFFFFu;
+        }
+        return;
+    }
     uint32_t i = uint32_t(en.y), j = uint32_t(en.z);
     int state = 0;  // 0 = H, 1 = E, 2 = F
     WinStat ws;
@@ -880,6 +1397,22 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 Hp[c] = 0;
                 F[c] = ALN_NEG;
             }
+        } else if (en.w & 2) {  // written by k_align_fwd16: 16-bit values + bases, by (wave, tile of the band)
+            const uint32_t nb = uint32_t(en.w) >> 8, tpb = ((n + TILE - 1) / TILE + nb - 1) / nb;
+            const uint32_t band = (r0 / TILE - 1) / tpb, kt = (r0 / TILE - 1) % tpb;
+            const uint32_t* ent = reinterpret_cast<const uint32_t*>(rowck) + uint64_t((band >> 1) * tpb + kt) * row16_stride(m);
+            const int hs = int(band & 1u);
+#pragma unroll
+            for (int c = 0; c < TR_C; ++c) {
+                int2 v{0, ALN_NEG};
+                if (jb + c < m) {
+                    const int sl = P.gap_extend * int(r0 + jb + c + 1);
+                    v = int2{row16_get(ent, m, hs, 0, jb + c) + (go - P.gap_extend) - sl, row16_get(ent, m, hs, 1, jb + c) - sl};
+                }
+                Hp[c] = v.x;
+                F[c] = v.y;
+            }
+            if (jb > 0 && jb <= m) dg = row16_get(ent, m, hs, 0, jb - 1) + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);
         } else {
             const int* roh = reinterpret_cast<const int*>(rowck + uint64_t(r0 / TILE - 1) * row_pitch(m));
             const int* rof = roh + row_pitch(m);
@@ -1045,6 +1578,9 @@ int reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
             return ioc_fail((c), IOC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// set while pairs the packed kernel gave up on are re-run
+static thread_local bool g_force32 = false;
+
 extern "C" {
 
 int ioc_align_set_pool(ioc_ctx* c, int32_t n_seqs, const char* seqs, const int64_t* offs)
@@ -1138,6 +1674,9 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return dp[x].pad != 0; });
     const char* ev = getenv("IOC_ALIGN_VARIANT");
     const bool carry = ev && strcmp(ev, "carry") == 0;
+    // IOC_ALIGN_PACKED=1: the query-profile pairs go through the packed 16-bit kernel (two row bands per wave).
+    // Bit-identical and 30 % fewer VALU instructions, but no faster yet on MI355X: opt-in.
+    const bool packed = !carry && !g_force32 && getenv("IOC_ALIGN_PACKED") && !getenv("IOC_ALIGN_NO_PACKED");
     const uint32_t colsper = carry ? ALN_C : FW_C;
     // waves per pair: few pairs -> wide workgroups (latency), many pairs -> narrow ones (no fill/drain waste)
     uint32_t waves = ALN_MAXW;
@@ -1153,8 +1692,10 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             // whole tiles per band
             const uint32_t strips = (max_m + 64 * FW_C - 1) / (64 * FW_C), tiles = (max_n + TILE - 1) / TILE;
             while (waves > 1 && (strips < 2 * waves || tiles < 2 * waves)) waves >>= 1;
+            if (packed) while (waves > 1 && (strips < 4 * waves || tiles < 4 * waves)) waves >>= 1;  // 2 bands per wave
         }
     }
+    if (packed && waves > uint32_t(P16_MAXW)) waves = P16_MAXW;
     const uint32_t NT = waves * 64;
     int r;
     if ((r = reserve(c, c->a_pairs, size_t(np) * sizeof(AlnPairDev))) != IOC_OK) return r;
@@ -1190,9 +1731,12 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         ACHK(c, hipMemGetInfo(&free_b, &total_b));
         uint64_t budget = uint64_t(free_b + c->a_ck.cap) / 2;
         if (const char* e = getenv("IOC_ALIGN_CK_BUDGET_MB")) budget = uint64_t(atoll(e)) << 20;
-        auto ck_units = [&](const AlnPairDev& d) {
-            return uint64_t((d.n - 1) / TILE) * row_pitch(d.m) + uint64_t((d.m - 1) / TILE) * col_pitch(d.n);
+        // (row region: the larger of the two forward kernels' formats, so that a refused pair can be re-run in place)
+        auto row_units = [&](const AlnPairDev& d) {
+            const uint64_t plain = uint64_t((d.n - 1) / TILE) * row_pitch(d.m);
+            return (packed && d.pad) ? std::max(plain, (row16_units(d.n, d.m) + 15u) & ~uint64_t(15)) : plain;
         };
+        auto ck_units = [&](const AlnPairDev& d) { return row_units(d) + uint64_t((d.m - 1) / TILE) * col_pitch(d.n); };
         const uint64_t lrow_stride = uint64_t((max_m + 64 * FW_C - 1) / (64 * FW_C)) * 64;  // int2 per pair
         std::vector<AlnCk> cko(np);
         std::vector<std::pair<uint32_t, uint32_t>> slices;  // [first, count) in `order`
@@ -1206,7 +1750,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 if (cnt > 0 && (used + u) * 8ull > budget) break;
                 if (cnt > 0 && d.pad != dp[order[first]].pad) break;  // one kernel per slice
                 // (rows first: their pitch is a multiple of 16 int2, `used` stays 16-byte aligned for the int4 stores)
-                cko[order[first + cnt]] = AlnCk{used, used + uint64_t((d.n - 1) / TILE) * row_pitch(d.m)};
+                cko[order[first + cnt]] = AlnCk{used, used + row_units(d)};
                 used += u;
                 ++cnt;
             }
@@ -1233,7 +1777,8 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             // fullest CU: cap the residency at ceil(workgroups / CUs) per CU with an LDS reservation, or the
             // dispatcher may stack 8 workgroups on some CUs and leave others with 3.
             const bool prof = dp[order[sl.first]].pad != 0;
-            const void* kfn = prof ? reinterpret_cast<const void*>(k_align_fwd<true>) : reinterpret_cast<const void*>(k_align_fwd<false>);
+            const void* kfn = prof ? (packed ? reinterpret_cast<const void*>(k_align_fwd16) : reinterpret_cast<const void*>(k_align_fwd<true>))
+                                   : reinterpret_cast<const void*>(k_align_fwd<false>);
             size_t lds_pad = 0;
             const uint32_t wg_waves = waves > 4 ? waves : 4, ppw = wg_waves / waves;
             uint32_t n_wg = (sl.second + ppw - 1) / ppw, n_main = n_wg, wpp_tail = waves;
@@ -1258,7 +1803,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 const size_t want = size_t(160u * 1024u) * (2 * per_cu + 1) / (2 * per_cu * (per_cu + 1));
                 lds_pad = want > stat + 1024 ? (want - stat - 512) & ~size_t(255) : 0;
                 // more than the default 64 KB per workgroup needs the kernel attribute (best effort)
-                size_t& lim = prof ? c->aln_lds_max : c->aln_lds_max2;
+                size_t& lim = prof ? (packed ? c->aln_lds_max3 : c->aln_lds_max) : c->aln_lds_max2;
                 if (lim == 0) {
                     int mx = 0;
                     (void)hipDeviceGetAttribute(&mx, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
@@ -1270,7 +1815,13 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 lds_pad = std::min(lds_pad, lim > 1 ? lim : 0);
             }
             ACHK(c, hipEventRecord(evs[evi++], s));
-            if (prof)
+            if (prof && packed)
+                hipLaunchKernelGGL(k_align_fwd16, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
+                                   static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
+                                   static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
+                                   static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
+                                   static_cast<int4*>(c->a_ends2.p));
+            else if (prof)
                 hipLaunchKernelGGL(k_align_fwd<true>, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
                                    static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
                                    static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
@@ -1305,11 +1856,33 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     ACHK(c, hipMemcpyAsync(hs.data(), d_score, size_t(np) * 4, hipMemcpyDeviceToHost, s));
     ACHK(c, hipMemcpyAsync(hc.data(), d_count, size_t(np) * 4, hipMemcpyDeviceToHost, s));
     ACHK(c, hipStreamSynchronize(s));
+    std::vector<int32_t> again;  // pairs the packed kernel flagged: scores outside its 16-bit window
     for (uint32_t x = 0; x < np; ++x) {
         const uint32_t i = back[x];
+        if (packed && hc[x] == 0xFFFFFFFFu && hs[x] == INT32_MIN) {
+            again.push_back(int32_t(i));
+            continue;
+        }
         if (out_score) out_score[i] = hs[x];
         if (out_windows) out_windows[i] = int64_t(hc[x]);
         if (out_ratio) out_ratio[i] = double(hc[x]) / double(dp[x].n);  // getAlnRatio: aligned / slen
+    }
+    if (!again.empty()) {
+        std::vector<ioc_aln_pair> sub(again.size());
+        std::vector<int32_t> sc(again.size());
+        std::vector<int64_t> sw(again.size());
+        std::vector<double> sr(again.size());
+        for (size_t x = 0; x < again.size(); ++x) sub[x] = pairs[again[x]];
+        g_force32 = true;
+        const int rr = ioc_align_pairs(c, int32_t(sub.size()), sub.data(), k, match, mismatch, gap_extend, sc.data(), sw.data(), sr.data());
+        g_force32 = false;
+        if (rr != IOC_OK) return rr;
+        c->tm.n_align_refused += int64_t(again.size());
+        for (size_t x = 0; x < again.size(); ++x) {
+            if (out_score) out_score[again[x]] = sc[x];
+            if (out_windows) out_windows[again[x]] = sw[x];
+            if (out_ratio) out_ratio[again[x]] = sr[x];
+        }
     }
     return IOC_OK;
 }

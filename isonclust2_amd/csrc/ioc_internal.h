@@ -98,7 +98,7 @@ struct ioc_ctx {
     std::vector<double> res_err;
     bool have_res_seq = false;
     bool res_pool_ready = false;  // a_pool holds exactly res_seq
-    size_t aln_lds_max = 0, aln_lds_max2 = 0;  // dynamic LDS a k_align_fwd<true/false> workgroup may reserve (residency cap)
+    size_t aln_lds_max = 0, aln_lds_max2 = 0, aln_lds_max3 = 0;  // dynamic LDS a k_align_fwd<true/false> workgroup may reserve (residency cap)
 
     // ---- alignment results kept across the device passes of ioc_cluster_consensus (see AlnDriver) ----
     std::vector<uint64_t> aln_qid, aln_lid;  // sequence identity of every right entry / left representative

@@ -181,11 +181,37 @@ def test_full_length_pairs_two_device_formulations_agree(ctx, monkeypatch):
     monkeypatch.delenv("IOC_ALIGN_VARIANT")
     monkeypatch.setenv("IOC_ALIGN_NO_PROFILE", "1")
     s3, w3, _ = ctx.align_pairs(pairs, 11)
+    monkeypatch.delenv("IOC_ALIGN_NO_PROFILE")
+    monkeypatch.setenv("IOC_ALIGN_PACKED", "1")           # the packed 16-bit forward pass (opt-in)
+    s4, w4, _ = ctx.align_pairs(pairs, 11)
+    assert ctx.timings()["n_align_refused"] == 0          # every pair stayed inside the 16-bit window
+    monkeypatch.delenv("IOC_ALIGN_PACKED")
     assert np.array_equal(s1, s2) and np.array_equal(w1, w2)
     assert np.array_equal(s1, s3) and np.array_equal(w1, w3)
+    assert np.array_equal(s1, s4) and np.array_equal(w1, w4)
     assert len(set(int(x) for x in w1)) > 20          # not a degenerate comparison
     L = _lib.load()
     for i in (0, len(pairs) - 1, len(pairs) - 2):
         qi, ri, rc, e = pairs[i]
         hs, hr = _host(L, seqs[qi], seqs[ri], rc, e, 11)
         assert s1[i] == hs and w1[i] / len(seqs[qi]) == hr
+
+
+@pytest.mark.parametrize("waves", ["1", "2", "4"])
+def test_packed_forward_pass(ctx, monkeypatch, waves):
+    """IOC_ALIGN_PACKED=1: two row bands per wave in the 16-bit halves of the registers, relative scores with a
+    moving base, packed row checkpoints.  Same pairs as the tile-boundary, multi-strip and small-pair cases:
+    bands without rows, a high half that idles, last column / last row in either half."""
+    monkeypatch.setenv("IOC_ALIGN_PACKED", "1")
+    monkeypatch.setenv("IOC_ALIGN_WAVES", waves)
+    rng = random.Random(23 + int(waves))
+    base = bytes(rng.choice(b"ACGT") for _ in range(5200))
+    lens = [1, 3, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1024, 1025, 1040, 2047, 2049, 3100, 4097, 5100]
+    seqs = [_mutate(rng, base, 0.1)[:ln] for ln in lens] + [base[:1024], base[:1024], bytes(rng.choice(b"ACGT") for _ in range(3000))]
+    pairs = []
+    for a in range(len(lens)):
+        for b in (a, (a + 5) % len(lens), (a + 8) % len(lens), (a + 13) % len(lens)):
+            pairs.append((a, b, (a + b) % 2, rng.choice([0.05, 0.2, 0.95])))
+    pairs += [(len(lens), len(lens) + 1, 0, 0.01), (len(lens) + 2, len(lens) - 1, 0, 0.1), (len(lens) - 1, len(lens) + 2, 1, 0.1)]
+    for k in (5, 11, 32):
+        _check(ctx, seqs, pairs, k)
