@@ -1815,24 +1815,26 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 lds_pad = std::min(lds_pad, lim > 1 ? lim : 0);
             }
             ACHK(c, hipEventRecord(evs[evi++], s));
-            if (prof && packed)
-                hipLaunchKernelGGL(k_align_fwd16, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
-                                   static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
-                                   static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
-                                   static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
-                                   static_cast<int4*>(c->a_ends2.p));
-            else if (prof)
-                hipLaunchKernelGGL(k_align_fwd<true>, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
-                                   static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
-                                   static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
-                                   static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
-                                   static_cast<int4*>(c->a_ends2.p));
-            else
-                hipLaunchKernelGGL(k_align_fwd<false>, dim3(n_wg), dim3(wg_waves * 64), lds_pad, s,
-                                   static_cast<const AlnPairDev*>(c->a_pairs.p), ord, sl.second, waves, n_main, wpp_tail,
-                                   static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<int2*>(c->a_ck.p),
-                                   static_cast<const AlnCk*>(c->a_cko.p), static_cast<int2*>(c->a_lrow.p), lrow_stride,
-                                   static_cast<int4*>(c->a_ends2.p));
+            auto launch_fwd = [&](const uint32_t* o, uint32_t cnt, uint32_t wv, uint32_t wgw, uint32_t nwg, uint32_t nmain,
+                                  uint32_t wtail, size_t lds, int2* lr) {
+                const AlnPairDev* dpairs = static_cast<const AlnPairDev*>(c->a_pairs.p);
+                const uint8_t* dpool = static_cast<const uint8_t*>(c->a_pool.p);
+                int2* dck = static_cast<int2*>(c->a_ck.p);
+                const AlnCk* dcko = static_cast<const AlnCk*>(c->a_cko.p);
+                int4* dends = static_cast<int4*>(c->a_ends2.p);
+                if (prof && packed)
+                    hipLaunchKernelGGL(k_align_fwd16, dim3(nwg), dim3(wgw * 64), lds, s, dpairs, o, cnt, wv, nmain, wtail, dpool, P, dck,
+                                       dcko, lr, lrow_stride, dends);
+                else if (prof)
+                    hipLaunchKernelGGL(k_align_fwd<true>, dim3(nwg), dim3(wgw * 64), lds, s, dpairs, o, cnt, wv, nmain, wtail, dpool, P,
+                                       dck, dcko, lr, lrow_stride, dends);
+                else
+                    hipLaunchKernelGGL(k_align_fwd<false>, dim3(nwg), dim3(wgw * 64), lds, s, dpairs, o, cnt, wv, nmain, wtail, dpool, P,
+                                       dck, dcko, lr, lrow_stride, dends);
+            };
+            // (A launch of its own for the tail generation with 8 bands per pair was tried: an 8-wave workgroup
+            // lands on ONE CU, two waves per SIMD, and the tail took 30 ms instead of 18.)
+            launch_fwd(ord, sl.second, waves, wg_waves, n_wg, n_main, wpp_tail, lds_pad, static_cast<int2*>(c->a_lrow.p));
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(evs[evi++], s));
             hipLaunchKernelGGL(k_align_trace, dim3(sl.second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
