@@ -1322,6 +1322,19 @@ struct WinStat {
         ++pushed;
         if (pushed > k && int(__popc(wb)) >= il) ++cnt;
     }
+    // m <= 64 pushes at once, bit x of `bits` = the x-th character pushed; every lane gets the same arguments
+    // and lane x evaluates the window as it stands after push x
+    __device__ __forceinline__ void push_run(unsigned long long bits, uint32_t m, uint32_t kmask, uint32_t k, int il, uint32_t lane)
+    {
+        // the characters up to push `lane`, the latest in bit 0 (as the window keeps them)
+        const unsigned long long upto = __brevll(bits << (63u - lane));
+        const unsigned long long old = lane + 1u < 64u ? (unsigned long long)wb << (lane + 1u) : 0ull;
+        const uint32_t win = uint32_t(old | upto) & kmask;
+        const bool hit = lane < m && pushed + lane + 1u > k && int(__popc(win)) >= il;
+        cnt += uint32_t(__popcll(__ballot(hit)));
+        wb = uint32_t(__builtin_amdgcn_readlane(int(win), int(m - 1u)));
+        pushed += m;
+    }
     __device__ void blanks(uint32_t g, uint32_t kmask, uint32_t k, int il)
     {
         const uint32_t t = g < k ? g : k;
@@ -1368,6 +1381,10 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     WinStat ws;
     ws.blanks((m - j) + (n - i), kmask, k, il);  // trailing end gaps are the tail of the string
 
+#ifdef TR_PROF
+    unsigned long long tp_load = 0, tp_comp = 0, tp_walk = 0, tp_t = __builtin_readcyclecounter();
+    uint32_t tp_tiles = 0;
+#endif
     while (i > 0 && j > 0) {
         const uint32_t r0 = ((i - 1) / TILE) * TILE, c0 = ((j - 1) / TILE) * TILE;
         const uint32_t rows = i - r0, cols = j - c0;
@@ -1430,6 +1447,9 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             if (jb > 0 && jb <= m) dg = roh[jb - 1] + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);  // H(r0, jb); column 0 holds 0
         }
         __syncthreads();
+#ifdef TR_PROF
+        { const unsigned long long t = __builtin_readcyclecounter(); tp_load += t - tp_t; tp_t = t; ++tp_tiles; }
+#endif
         const uint32_t nact = (cols + TR_C - 1) / TR_C;
         const uint32_t nsteps = rows + nact - 1;
         int out_h = 0, out_e = ALN_NEG;
@@ -1450,24 +1470,20 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 uint32_t bits = 0;
 #pragma unroll
                 for (int c = 0; c < TR_C; ++c) {
-                    // the host aligner's cell, verbatim (ioc_align.cpp)
+                    // the host aligner's cell (ioc_align.cpp): H = diagonal, replaced by E if E > H, then by F if
+                    // F > H — written so that the chain to the next cell is sub, max, max3 and the provenance
+                    // compares hang off it (a dependent VALU op costs 8 cycles and this wave has its SIMD alone)
                     const int eo = hl - go, ee = el - P.gap_extend;
                     const bool ex = ee > eo;
-                    const int E = ex ? ee : eo;
+                    const int E = max(ee, eo);
                     const int fo = Hp[c] - go, fe = F[c] - P.gap_extend;
                     const bool fx = fe > fo;
-                    const int Fn = fx ? fe : fo;
+                    const int Fn = max(fe, fo);
                     const bool mt = qc == ((rpk[0] >> (8 * c)) & 0xFFu);
-                    int h = dg + (mt ? P.match : P.mismatch);
-                    uint32_t from = mt ? 0u : 3u;
-                    if (E > h) {
-                        h = E;
-                        from = 1u;
-                    }
-                    if (Fn > h) {
-                        h = Fn;
-                        from = 2u;
-                    }
+                    const int hd = dg + (mt ? P.match : P.mismatch);
+                    const int hde = max(hd, E);
+                    const int h = max(hde, Fn);
+                    const uint32_t from = Fn > hde ? 2u : (E > hd ? 1u : (mt ? 0u : 3u));
                     bits |= (from | (ex ? 4u : 0u) | (fx ? 8u : 0u)) << (4 * c);
                     dg = Hp[c];
                     Hp[c] = h;
@@ -1486,6 +1502,9 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             out_q = qc;
         }
         __syncthreads();
+#ifdef TR_PROF
+        { const unsigned long long t = __builtin_readcyclecounter(); tp_comp += t - tp_t; tp_t = t; }
+#endif
         // the host aligner's traceback loop inside this tile (identical in every lane)
         while (i > r0 && j > c0) {
             const uint32_t cj = j - c0 - 1;
@@ -1493,15 +1512,25 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             const uint32_t t = TR_C == 4 ? (uint32_t(dirs[ri][cj / TR_C]) >> (4 * (cj % TR_C))) & 0xFu
                                          : (uint32_t(dirs[ri >> 1][cj / TR_C]) >> (8 * (ri & 1) + 4 * (cj % TR_C))) & 0xFu;
             if (state == 0) {
-                const uint32_t from = t & 3u;
-                if (from == 1u) {
-                    state = 1;
-                } else if (from == 2u) {
-                    state = 2;
+                // look ahead along the diagonal: lane l reads the cell l steps up-left; the run of diagonal moves
+                // from here on goes into the window counter at once
+                const bool inr = i - r0 > lane && j - c0 > lane;
+                uint32_t tl = 1u;
+                if (inr) {
+                    const uint32_t rl = ri - lane, cl = cj - lane;
+                    tl = (TR_C == 4 ? (uint32_t(dirs[rl][cl / TR_C]) >> (4 * (cl % TR_C)))
+                                    : (uint32_t(dirs[rl >> 1][cl / TR_C]) >> (8 * (rl & 1) + 4 * (cl % TR_C)))) & 3u;
+                }
+                const bool dgl = inr && (tl == 0u || tl == 3u);
+                const unsigned long long dm = __ballot(dgl);
+                const uint32_t run = ~dm ? uint32_t(__builtin_ctzll(~dm)) : 64u;
+                if (run > 0) {
+                    const unsigned long long mb = __ballot(dgl && tl == 0u) & (run == 64u ? ~0ull : ((1ull << run) - 1ull));
+                    ws.push_run(mb, run, kmask, k, il, lane);
+                    i -= run;
+                    j -= run;
                 } else {
-                    ws.push(from == 0u ? 1u : 0u, kmask, k, il);
-                    --i;
-                    --j;
+                    state = (t & 3u) == 1u ? 1 : 2;
                 }
             } else if (state == 1) {
                 ws.push(0u, kmask, k, il);
@@ -1514,11 +1543,17 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             }
         }
         __syncthreads();
+#ifdef TR_PROF
+        { const unsigned long long t = __builtin_readcyclecounter(); tp_walk += t - tp_t; tp_t = t; }
+#endif
     }
     ws.blanks(i + j, kmask, k, il);  // leading end gaps
     if (lane == 0) {
         out_score[pid] = en.x;
         out_count[pid] = ws.cnt;
+#ifdef TR_PROF
+        if (pid == order[0]) printf("trace profile (cycles of the 100 MHz counter x tiles %u): load %llu, recompute %llu, walk %llu\n", tp_tiles, tp_load, tp_comp, tp_walk);
+#endif
     }
 }
 
