@@ -140,8 +140,10 @@ int ioc_clear_forced(ioc_ctx* ctx);
  * supplied speculatively for many queries at once.  target == NULL switches verdicts off. */
 int ioc_set_aln_verdicts(ioc_ctx* ctx, const int32_t* target, const int8_t* strand);
 /* With verdicts set, ioc_resolve also reports per query the candidates tied at the top Size among the
- * current clusters — the ones getBestClusterAln tries (cluster.cpp:481-489): count[n] and up to 4 keys
- * per query (keys[4 * q + i] = target << 1 | (strand == -1), unordered); more than 4: ioc_query_candidates. */
+ * current clusters — the ones getBestClusterAln tries (cluster.cpp:481-489): count[n] and up to
+ * IOC_TIE_SLOTS keys per query (keys[IOC_TIE_SLOTS * q + i] = target << 1 | (strand == -1), unordered);
+ * more than that: ioc_query_candidates. */
+#define IOC_TIE_SLOTS 16
 int ioc_get_ties(ioc_ctx* ctx, uint32_t* count, uint32_t* keys);
 
 /* Full candidate table of one query against the targets that are clusters under the current

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -102,7 +103,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -738,67 +739,91 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
     const uint32_t L = uint32_t(c->L);
     const uint32_t T = L + uint32_t(q);
     if (T == 0) return 0;
-    DevBuf hist, first;
-    int rc = dev_reserve(c, hist, size_t(2) * T * 4);
-    if (rc != IOC_OK) return rc;
-    rc = dev_reserve(c, first, size_t(2) * T * 4);
-    if (rc != IOC_OK) {
-        dev_free(hist);
-        return rc;
-    }
-    auto cleanup = [&]() {
-        dev_free(hist);
-        dev_free(first);
-    };
+    // (called once per tied / order-dependent query of a round, thousands of times on a large batch: scratch
+    // buffers are kept in the context and everything comes back with one synchronisation — the candidate list
+    // is copied at its capacity, its fill count arrives with it)
+    const auto tq0 = std::chrono::steady_clock::now();
+    RESERVE(c, c->b_qhist, size_t(2) * T * 4);
+    RESERVE(c, c->b_qfirst, size_t(2) * T * 4);
     const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
-    std::vector<uint32_t> hh(size_t(2) * T), hf(size_t(2) * T);
+    // the table is compacted on the device: a query hits a few dozen of its 2 T possible (target, strand) cells
+    const uint32_t n2 = 2u * T, QC = std::min<uint32_t>(n2, 4096u);
+    RESERVE(c, c->b_qout, (size_t(1) + 3 * size_t(QC)) * 4);
+    std::vector<uint32_t> ho(size_t(1) + 3 * size_t(QC));
     uint32_t cc = 0;
-    hipError_t e = hipMemsetAsync(hist.p, 0, size_t(2) * T * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(first.p, 0xFF, size_t(2) * T * 4, s);
+    const uint64_t cbase = 2ull * L * uint64_t(q) + uint64_t(q) * uint64_t(q > 0 ? q - 1 : 0);
+    const size_t ccap = size_t(2) * T, cfirst = std::min<size_t>(ccap, 4096);  // this query's candidate list: capacity, first copy
+    std::vector<uint32_t> ck(cfirst), cm(cfirst);
+    hipError_t e = hipMemsetAsync(c->b_qhist.p, 0, size_t(n2) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->b_qfirst.p, 0xFF, size_t(n2) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->b_qout.p, 0, 4, s);
     if (e == hipSuccess)
         e = iock_query_table(s, q, L, c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap, hash_shift(c->cap),
-                             c->b_post.p, valid, P<uint32_t>(hist), P<uint32_t>(first), c->post16);
-    if (e == hipSuccess) e = hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), first.p, hf.size() * 4, hipMemcpyDeviceToHost, s);
+                             c->b_post.p, valid, P<uint32_t>(c->b_qhist), P<uint32_t>(c->b_qfirst), c->post16);
+    if (e == hipSuccess) e = iock_query_compact(s, P<uint32_t>(c->b_qhist), P<uint32_t>(c->b_qfirst), n2, QC, P<uint32_t>(c->b_qout));
+    if (e == hipSuccess) e = hipMemcpyAsync(ho.data(), c->b_qout.p, ho.size() * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&cc, P<uint32_t>(c->b_cand_count) + q, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ck.data(), P<uint32_t>(c->b_cand_key) + cbase, cfirst * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(cm.data(), P<uint32_t>(c->b_cand_mapped) + cbase, cfirst * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        cleanup();
-        return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
-    }
-    // cached totalMapped values of this query's candidate list
-    const uint64_t cbase = 2ull * L * uint64_t(q) + uint64_t(q) * uint64_t(q > 0 ? q - 1 : 0);
-    std::vector<uint32_t> ck(cc), cm(cc);
-    if (cc) {
-        e = hipMemcpyAsync(ck.data(), P<uint32_t>(c->b_cand_key) + cbase, size_t(cc) * 4, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
+    if (getenv("IOC_TRACE_Q"))
+        fprintf(stderr, "[ioc] candidate table of query %d: %.3f ms on the device path, %u cells, %u candidates\n", q,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count(), ho[0], cc);
+    if (cc > ccap) return ioc_fail(c, IOC_ERR_STATE, "candidate list longer than its capacity");
+    if (cc > cfirst) {  // (a very long candidate list: the rest of it)
+        ck.resize(cc);
+        cm.resize(cc);
+        e = hipMemcpyAsync(ck.data() + cfirst, P<uint32_t>(c->b_cand_key) + cbase + cfirst, (cc - cfirst) * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(cm.data(), P<uint32_t>(c->b_cand_mapped) + cbase, size_t(cc) * 4, hipMemcpyDeviceToHost, s);
+            e = hipMemcpyAsync(cm.data() + cfirst, P<uint32_t>(c->b_cand_mapped) + cbase + cfirst, (cc - cfirst) * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) {
-            cleanup();
-            return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
-        }
+        if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
     }
-    cleanup();
-    std::vector<uint32_t> mapped(size_t(2) * T, 0xFFFFFFFFu);
+    struct Hit {
+        uint32_t idx, size, first;
+    };
+    std::vector<Hit> hits;
+    if (ho[0] <= QC) {
+        hits.resize(ho[0]);
+        for (uint32_t i = 0; i < ho[0]; ++i) hits[i] = Hit{ho[1 + 3 * i], ho[2 + 3 * i], ho[3 + 3 * i]};
+        std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.idx < b.idx; });
+    } else {  // more hit cells than the compact buffer holds: the whole table
+        std::vector<uint32_t> hh(n2), hf(n2);
+        e = hipMemcpyAsync(hh.data(), c->b_qhist.p, hh.size() * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), c->b_qfirst.p, hf.size() * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, std::string("ioc_query_candidates: ") + hipGetErrorString(e));
+        for (uint32_t i = 0; i < n2; ++i)
+            if (hh[i]) hits.push_back(Hit{i, hh[i], hf[i]});
+    }
+    // cached totalMapped values of this query's candidate list, by table cell
+    std::vector<std::pair<uint32_t, uint32_t>> mapped;
+    mapped.reserve(cc);
     for (uint32_t i = 0; i < cc; ++i) {
-        uint32_t tg = ck[i] >> 1, sb = ck[i] & 1u;
-        if (tg < T) mapped[size_t(sb) * T + tg] = cm[i];
+        const uint32_t tg = ck[i] >> 1, sb = ck[i] & 1u;
+        if (tg < T) mapped.emplace_back(sb * T + tg, cm[i]);
     }
+    std::stable_sort(mapped.begin(), mapped.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
     int out = 0;
-    for (uint32_t sb = 0; sb < 2; ++sb)
-        for (uint32_t t = 0; t < T; ++t) {
-            uint32_t sz = hh[size_t(sb) * T + t];
-            if (!sz) continue;
-            if (out < cap) {
-                if (target) target[out] = int32_t(t);
-                if (strand) strand[out] = sb ? -1 : 1;
-                if (size) size[out] = sz;
-                if (first_index) first_index[out] = hf[size_t(sb) * T + t];
-                if (total_mapped) total_mapped[out] = mapped[size_t(sb) * T + t];
+    for (const Hit& h : hits) {  // ascending cell index = (strand +1 first, then -1), targets ascending
+        if (out < cap) {
+            const uint32_t sb = h.idx >= T ? 1u : 0u, t = h.idx - sb * T;
+            if (target) target[out] = int32_t(t);
+            if (strand) strand[out] = sb ? -1 : 1;
+            if (size) size[out] = h.size;
+            if (first_index) first_index[out] = h.first;
+            if (total_mapped) {
+                auto it = std::lower_bound(mapped.begin(), mapped.end(), std::make_pair(h.idx, 0u),
+                                           [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+                // (the last entry of a cell wins, as the dense table's overwrite did)
+                uint32_t mv = 0xFFFFFFFFu;
+                for (; it != mapped.end() && it->first == h.idx; ++it) mv = it->second;
+                total_mapped[out] = mv;
             }
-            out++;
         }
+        out++;
+    }
     if (out > cap) return ioc_fail(c, IOC_ERR_CAPACITY, "candidate buffer too small: need " + std::to_string(out));
     return out;
 }

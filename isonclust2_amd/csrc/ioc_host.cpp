@@ -11,6 +11,8 @@
 // All arithmetic of the hot path itself (hits, Sizes, mapped totals, candidate walk) runs on the
 // GPU; there is no CPU fallback: without a device every entry point fails.
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -76,14 +78,38 @@ bool by_size_desc(const std::unique_ptr<SortedHit>& a, const std::unique_ptr<Sor
 struct PhaseTrace {
     bool on = getenv("IOC_TRACE") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    int64_t calls = 0;  // what the phase did that often (the per-query candidate tables of a round)
     void mark(const char* what)
     {
         if (!on) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[ioc] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        if (calls)
+            fprintf(stderr, "[ioc] %-28s %9.3f ms (%lld candidate tables)\n", what, std::chrono::duration<double, std::milli>(now - t).count(),
+                    (long long)calls);
+        else
+            fprintf(stderr, "[ioc] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        calls = 0;
         t = now;
     }
 };
+
+// f(0) .. f(count - 1) on the host's cores
+template <typename F>
+static void parallel_for(size_t count, F f)
+{
+    const size_t nt = std::min<size_t>(count, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    if (nt <= 1) {
+        for (size_t x = 0; x < count; ++x) f(x);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            for (size_t x = next.fetch_add(1); x < count; x = next.fetch_add(1)) f(x);
+        });
+    for (auto& t : th) t.join();
+}
 
 struct Cand {
     int32_t cls;  // final cluster id
@@ -168,15 +194,39 @@ struct Ordered {
     uint32_t size, mapped;
 };
 
-static int build_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::vector<Ordered>& out)
+// the device's hit table of one query (ioc_query_candidates), kept so that the host part can run on a thread
+struct RawCands {
+    int q = 0, nc = 0;
+    std::vector<int32_t> tg;
+    std::vector<int8_t> st;
+    std::vector<uint32_t> sz, fi, tm;
+};
+
+static int fetch_cands(ioc_ctx* c, int q, RawCands& rc)
+{
+    const int T = c->L + q;
+    rc.q = q;
+    rc.tg.resize(size_t(2) * T + 1);
+    rc.st.resize(size_t(2) * T + 1);
+    rc.sz.resize(size_t(2) * T + 1);
+    rc.fi.resize(size_t(2) * T + 1);
+    rc.tm.resize(size_t(2) * T + 1);
+    rc.nc = ioc_query_candidates(c, q, 2 * T, rc.tg.data(), rc.st.data(), rc.sz.data(), rc.fi.data(), rc.tm.data());
+    if (rc.nc < 0) return rc.nc;
+    for (auto* v : {&rc.sz, &rc.fi, &rc.tm}) v->resize(size_t(rc.nc));
+    rc.tg.resize(size_t(rc.nc));
+    rc.st.resize(size_t(rc.nc));
+    return IOC_OK;
+}
+
+// pure host code (reads the context's host arrays only): safe on worker threads
+static void order_from(const ioc_ctx* c, const RawCands& rc, const std::vector<int32_t>& cid, std::vector<Ordered>& out)
 {
     out.clear();
-    const int T = c->L + q;
-    std::vector<int32_t> tg(size_t(2) * T + 1);
-    std::vector<int8_t> st(size_t(2) * T + 1);
-    std::vector<uint32_t> sz(size_t(2) * T + 1), fi(size_t(2) * T + 1), tm(size_t(2) * T + 1);
-    int nc = ioc_query_candidates(c, q, 2 * T, tg.data(), st.data(), sz.data(), fi.data(), tm.data());
-    if (nc < 0) return nc;
+    const int q = rc.q, nc = rc.nc;
+    const std::vector<int32_t>& tg = rc.tg;
+    const std::vector<int8_t>& st = rc.st;
+    const std::vector<uint32_t>&sz = rc.sz, &fi = rc.fi, &tm = rc.tm;
     std::vector<Cand> cs;
     cs.reserve(size_t(nc));
     for (int i = 0; i < nc; ++i) {
@@ -219,8 +269,17 @@ static int build_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::
         const Info& h = res.at(std::make_pair(int(o->Cls), o->Strand));
         out.push_back(Ordered{int32_t(o->Cls), h.Target, int8_t(o->Strand), o->Size, h.Mapped});
     }
+}
+
+static int build_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::vector<Ordered>& out)
+{
+    RawCands rc;
+    int r = fetch_cands(c, q, rc);
+    if (r != IOC_OK) return r;
+    order_from(c, rc, cid, out);
     return IOC_OK;
 }
+
 
 // first passing candidate in the reference's order (cluster.cpp:381-403) — used for the queries whose
 // winner is order-dependent
@@ -450,7 +509,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         v_ties.assign(size_t(n) + 1, std::vector<uint32_t>());
         order_dep.assign(size_t(n) + 1, 0);
         tcount.assign(size_t(n) + 1, 0);
-        tkeys.assign(size_t(n) * 4 + 4, 0);
+        tkeys.assign(size_t(n) * IOC_TIE_SLOTS + IOC_TIE_SLOTS, 0);
         if ((r = ioc_set_aln_verdicts(c, v_t.data(), v_s.data())) != IOC_OK) return r;
     }
     for (int round = 0;; ++round) {
@@ -472,8 +531,8 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
             if (gated[size_t(i)] || !(flg[size_t(i)] & 2)) continue;
             aln_invoked++;
             std::vector<uint32_t> ties;
-            if (tcount[size_t(i)] <= 4) {
-                ties.assign(tkeys.begin() + size_t(i) * 4, tkeys.begin() + size_t(i) * 4 + tcount[size_t(i)]);
+            if (tcount[size_t(i)] <= IOC_TIE_SLOTS) {
+                ties.assign(tkeys.begin() + size_t(i) * IOC_TIE_SLOTS, tkeys.begin() + size_t(i) * IOC_TIE_SLOTS + tcount[size_t(i)]);
                 std::sort(ties.begin(), ties.end());
             } else if ((r = fetch_ties(c, i, cid, ties)) != IOC_OK) {
                 return r;
@@ -490,12 +549,47 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         if ((r = ad.ensure(want)) != IOC_OK) return r;
         tr.mark("alignment batch");
         bool changed = false;
+        // several candidates of a query align: the first one in the reference's hitOrder wins (cluster.cpp:481-511).
+        // That order is a std::sort over the iteration order of an unordered_map of ALL the query's hits (thousands
+        // on a large batch): the hit tables are fetched from the device one after the other, the containers are
+        // rebuilt on the host's cores.
+        std::vector<std::vector<uint32_t>> passes(bad.size());
+        std::vector<size_t> multi;
+        for (size_t b = 0; b < bad.size(); ++b) {
+            for (uint32_t t : cur[b])
+                if (ad.cache[AlnDriver::key(bad[b], t)] >= c->params.aligned_threshold) passes[b].push_back(t);
+            if (passes[b].size() > 1) multi.push_back(b);
+        }
+        std::vector<RawCands> raws(multi.size());
+        for (size_t x = 0; x < multi.size(); ++x)
+            if ((r = fetch_cands(c, bad[multi[x]], raws[x])) != IOC_OK) return r;
+        tr.calls += int64_t(multi.size());
+        std::vector<int32_t> win_t(multi.size(), -1);
+        std::vector<int8_t> win_s(multi.size(), 0);
+        parallel_for(multi.size(), [&](size_t x) {
+            std::vector<Ordered> order;
+            order_from(c, raws[x], cid, order);
+            const std::vector<uint32_t>& pass = passes[multi[x]];
+            const unsigned top = order.empty() ? 0 : order[0].size;
+            for (auto& o : order) {
+                if (o.size < top) break;
+                const uint32_t k = (uint32_t(o.target) << 1) | (o.strand < 0 ? 1u : 0u);
+                if (std::find(pass.begin(), pass.end(), k) != pass.end()) {
+                    win_t[x] = o.target;
+                    win_s[x] = o.strand;
+                    break;
+                }
+            }
+            std::vector<int32_t>().swap(raws[x].tg);  // (the tables are large)
+            std::vector<uint32_t>().swap(raws[x].sz);
+            std::vector<uint32_t>().swap(raws[x].fi);
+            std::vector<uint32_t>().swap(raws[x].tm);
+        });
+        size_t mx = 0;
         for (size_t b = 0; b < bad.size(); ++b) {
             const int i = bad[b];
             const std::vector<uint32_t>& ties = cur[b];
-            std::vector<uint32_t> pass;
-            for (uint32_t t : ties)
-                if (ad.cache[AlnDriver::key(i, t)] >= c->params.aligned_threshold) pass.push_back(t);
+            const std::vector<uint32_t>& pass = passes[b];
             int32_t vt = -1;
             int8_t vs = 0;
             order_dep[size_t(i)] = pass.size() > 1;
@@ -503,19 +597,9 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
                 vt = int32_t(pass[0] >> 1);
                 vs = (pass[0] & 1u) ? -1 : 1;
             } else if (pass.size() > 1) {
-                // several candidates align: the first one in the reference's hitOrder wins (cluster.cpp:481-511)
-                std::vector<Ordered> order;
-                if ((r = build_order(c, i, cid, order)) != IOC_OK) return r;
-                const unsigned top = order.empty() ? 0 : order[0].size;
-                for (auto& o : order) {
-                    if (o.size < top) break;
-                    const uint32_t k = (uint32_t(o.target) << 1) | (o.strand < 0 ? 1u : 0u);
-                    if (std::find(pass.begin(), pass.end(), k) != pass.end()) {
-                        vt = o.target;
-                        vs = o.strand;
-                        break;
-                    }
-                }
+                vt = win_t[mx];
+                vs = win_s[mx];
+                ++mx;
                 if (vt < 0) return ioc_fail(c, IOC_ERR_STATE, "aligned candidate missing from the candidate order");
             }
             if (vt != v_t[size_t(i)] || vs != v_s[size_t(i)] || ties != v_ties[size_t(i)]) changed = true;

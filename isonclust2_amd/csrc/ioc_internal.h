@@ -89,6 +89,7 @@ struct ioc_ctx {
     std::vector<uint8_t> aln_other;  // per pool sequence: holds a byte other than A C G T
     std::vector<int64_t> aln_offs;
     DevBuf b_aln_t, b_aln_s, b_tie_count, b_tie_keys;
+    DevBuf b_qhist, b_qfirst, b_qout;  // ioc_query_candidates: the query's hit table (kept between calls)
     std::vector<int32_t> h_aln_t;
     std::vector<int8_t> h_aln_s;
     bool aln_verdicts = false, aln_dirty = false;

@@ -60,7 +60,9 @@ struct DecideArgs {
     uint32_t* tie_count;    // per query: number of top-Size candidates that are clusters
     uint32_t* tie_keys;     // per query: up to IOC_TIE_SLOTS of their keys (target << 1 | strand bit), any order
 };
-#define IOC_TIE_SLOTS 4
+#ifndef IOC_TIE_SLOTS
+#define IOC_TIE_SLOTS 16  // (include/isonclust2_hip.h)
+#endif
 
 extern "C" {
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
@@ -90,6 +92,7 @@ hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const
                             const uint32_t* top_all, uint8_t* valid);
 hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks, uint32_t* q_count2);
 hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout);
+hipError_t iock_query_compact(hipStream_t st, const uint32_t* hist, const uint32_t* first, uint32_t n2, uint32_t cap, uint32_t* out);
 hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post,
                             const uint8_t* valid, uint32_t* hist, uint32_t* first, int post16);

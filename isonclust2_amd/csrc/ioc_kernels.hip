@@ -1900,6 +1900,28 @@ hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin,
     return hipGetLastError();
 }
 
+// non-empty entries of a query's hit table, as (index, Size, first Index) triples in any order: out[0] = count
+__global__ void __launch_bounds__(256) k_query_compact(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ first,
+                                                        uint32_t n2, uint32_t cap, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const uint32_t sz = hist[i];
+    if (!sz) return;
+    const uint32_t pos = atomicAdd(&out[0], 1u);
+    if (pos < cap) {
+        out[1 + 3 * pos] = i;
+        out[2 + 3 * pos] = sz;
+        out[3 + 3 * pos] = first[i];
+    }
+}
+
+hipError_t iock_query_compact(hipStream_t st, const uint32_t* hist, const uint32_t* first, uint32_t n2, uint32_t cap, uint32_t* out)
+{
+    hipLaunchKernelGGL(k_query_compact, dim3((n2 + 255) / 256), dim3(256), 0, st, hist, first, n2, cap, out);
+    return hipGetLastError();
+}
+
 hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift, const void* post,
                             const uint8_t* valid, uint32_t* hist, uint32_t* first, int post16)
