@@ -117,4 +117,26 @@ struct ioc_ctx {
 
 int ioc_fail(ioc_ctx* c, int code, const std::string& msg);
 
+
+// f(0) .. f(count - 1) on the host's cores (independent items only)
+#include <atomic>
+#include <thread>
+template <typename F>
+static inline void ioc_parallel_for(size_t count, F f)
+{
+    const size_t hw = std::thread::hardware_concurrency();
+    const size_t nt = std::min<size_t>(count, std::max<size_t>(1, std::min<size_t>(16, hw)));
+    if (nt <= 1) {
+        for (size_t x = 0; x < count; ++x) f(x);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            for (size_t x = next.fetch_add(1); x < count; x = next.fetch_add(1)) f(x);
+        });
+    for (auto& t : th) t.join();
+}
+
 #endif

@@ -600,6 +600,7 @@ struct PGraph {
     void add_alignment(const std::vector<std::pair<int, int>>& aln, const char* s, int len, int64_t w)
     {
         if (len <= 0) return;
+        planned = false;
         std::vector<int> pos_of;
         for (auto& a : aln)
             if (a.second >= 0) pos_of.push_back(a.second);
@@ -652,6 +653,39 @@ struct PGraph {
     }
     // heaviest bundle: per node the heaviest in-edge (ties: the predecessor with the higher score), the best
     // end node, then forward along the heaviest out-edges to a sink
+    // rows = nodes in topological order (+1: row 0 is the virtual source); predecessor rows; which rows keep their
+    // H / F1 / F2 in memory: those a later row cannot find in its tile's LDS ring (it sits in a lower tile or more
+    // than POA_RING rows on).  On a chain that is one row in 64.
+    std::vector<int32_t> p_poff, p_pred, p_slot;
+    int32_t p_nkeep = 1;
+    bool planned = false;
+    void plan()
+    {
+        const int R = int(nodes.size());
+        std::vector<int> row_of(static_cast<size_t>(R), 0);
+        for (int i = 0; i < R; ++i) row_of[size_t(rank[size_t(i)])] = i + 1;
+        p_poff.assign(size_t(R) + 2, 0);
+        p_pred.clear();
+        std::vector<uint8_t> keep(size_t(R) + 1, 0);
+        keep[0] = 1;
+        for (int i = 0; i < R; ++i) {
+            const PNode& nd = nodes[size_t(rank[size_t(i)])];
+            const int q = i + 1;
+            p_poff[size_t(q)] = int32_t(p_pred.size());
+            if (nd.in.empty()) p_pred.push_back(0);
+            for (int e : nd.in) {
+                const int pr = row_of[size_t(edges[size_t(e)].from)];
+                p_pred.push_back(pr);
+                if ((pr - 1) / POA_RB != (q - 1) / POA_RB || q - pr > POA_RING) keep[size_t(pr)] = 1;
+            }
+        }
+        p_poff[size_t(R) + 1] = int32_t(p_pred.size());
+        p_slot.assign(size_t(R) + 1, -1);
+        p_nkeep = 0;
+        for (int r = 0; r <= R; ++r)
+            if (keep[size_t(r)]) p_slot[size_t(r)] = p_nkeep++;
+        planned = true;
+    }
     std::string consensus() const
     {
         const size_t n = nodes.size();
@@ -721,8 +755,14 @@ int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes)
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
-    const size_t want = bytes + bytes / 8 + 4096;
+    // (batches grow as the graphs do: at least half as much again, or every round re-allocates gigabytes)
+    size_t want = std::max(bytes + bytes / 8 + 4096, b.cap + b.cap / 2);
     if (hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes + 4096;
+        b.p = nullptr;
+    }
+    if (!b.p && hipMalloc(&b.p, want) != hipSuccess) {
         b.p = nullptr;
         (void)hipGetLastError();
         return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: hipMalloc of the DP matrices failed");
@@ -742,41 +782,10 @@ struct HostJob {
     const PoaPending* item = nullptr;
     std::vector<std::pair<int, int>> aln;  // out: forward order, NODE IDS
     int32_t score = 0;
-    // rows = nodes in topological order (+1: row 0 is the virtual source); predecessor rows; which rows keep their
-    // H / F1 / F2 in memory: those a later row cannot find in its tile's LDS ring (it sits in a lower tile or more
-    // than POA_RING rows on).  On a chain that is one row in 64.
-    std::vector<int32_t> poff, pred, slot;
-    int32_t nkeep = 1;
-    void plan()
-    {
-        const int R = int(G->nodes.size());
-        std::vector<int> row_of(static_cast<size_t>(R), 0);
-        for (int i = 0; i < R; ++i) row_of[size_t(G->rank[size_t(i)])] = i + 1;
-        poff.assign(size_t(R) + 2, 0);
-        pred.clear();
-        std::vector<uint8_t> keep(size_t(R) + 1, 0);
-        keep[0] = 1;
-        for (int i = 0; i < R; ++i) {
-            const PNode& nd = G->nodes[size_t(G->rank[size_t(i)])];
-            const int q = i + 1;
-            poff[size_t(q)] = int32_t(pred.size());
-            if (nd.in.empty()) pred.push_back(0);
-            for (int e : nd.in) {
-                const int pr = row_of[size_t(G->edges[size_t(e)].from)];
-                pred.push_back(pr);
-                if ((pr - 1) / POA_RB != (q - 1) / POA_RB || q - pr > POA_RING) keep[size_t(pr)] = 1;
-            }
-        }
-        poff[size_t(R) + 1] = int32_t(pred.size());
-        slot.assign(size_t(R) + 1, -1);
-        nkeep = 0;
-        for (int r = 0; r <= R; ++r)
-            if (keep[size_t(r)]) slot[size_t(r)] = nkeep++;
-    }
     size_t bytes() const  // device memory of the alignment: direction word + E byte per cell, 3 planes of kept rows
     {
         const size_t W = item->seq.size() + 1, R1 = G->nodes.size() + 1;
-        return R1 * W * 5 + size_t(nkeep) * W * 12 + (W / POA_CB + 1) * R1 * sizeof(int4) + (size_t(1) << 20);
+        return R1 * W * 5 + size_t(G->p_nkeep) * W * 12 + (W / POA_CB + 1) * R1 * sizeof(int4) + (size_t(1) << 20);
     }
 };
 
@@ -813,7 +822,7 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         l.o_cells = tot_cells;
         tot_cells += (l.cells + 63) & ~size_t(63);
         l.o_plane = tot_plane;
-        tot_plane += (size_t(jobs[x].nkeep) * size_t(l.L + 1) + 63) & ~size_t(63);
+        tot_plane += (size_t(jobs[x].G->p_nkeep) * size_t(l.L + 1) + 63) & ~size_t(63);
         l.o_carry = tot_carry;
         tot_carry += size_t(l.ncb) * size_t(l.R + 1);
         l.o_tbest = tot_tbest;
@@ -840,12 +849,13 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
             if (nd.in.size() > size_t(POA_MAX_PREDS)) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
         }
         const HostJob& hj = jobs[x];
-        std::vector<int32_t> pslot(hj.pred.size());
-        for (size_t y = 0; y < hj.pred.size(); ++y) pslot[y] = hj.slot[size_t(hj.pred[y])];
-        l.o_poff = put32(hj.poff);
-        l.o_pred = put32(hj.pred);
+        const PGraph& hg = *hj.G;
+        std::vector<int32_t> pslot(hg.p_pred.size());
+        for (size_t y = 0; y < hg.p_pred.size(); ++y) pslot[y] = hg.p_slot[size_t(hg.p_pred[y])];
+        l.o_poff = put32(hg.p_poff);
+        l.o_pred = put32(hg.p_pred);
         l.o_pslot = put32(pslot);
-        l.o_slot = put32(hj.slot);
+        l.o_slot = put32(hg.p_slot);
         l.o_seq = small.size();
         small.insert(small.end(), seq.begin(), seq.end());
         align16();
@@ -943,8 +953,8 @@ int poa_flush(ioc_poa* p)
         // (device allocations of 100 GB take seconds: more, smaller batches cost less than that)
         size_t budget = std::min((free_b + have) / 2, size_t(48) << 30);
         if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
-        std::vector<HostJob> jobs;
-        std::vector<std::pair<int, int>> who;
+        std::vector<HostJob> jobs, cand;
+        std::vector<std::pair<int, int>> who, who_c;
         size_t used = 0;
         for (int side = 0; side < 2; ++side)
             for (auto& kv : p->pending[side]) {
@@ -952,21 +962,30 @@ int poa_flush(ioc_poa* p)
                 auto it = p->g[side].find(kv.first);
                 if (it == p->g[side].end()) return ioc_fail(p->ctx, IOC_ERR_STATE, "POA: addition to a graph that does not exist");
                 HostJob j;
-                it->second.ensure();
                 j.G = &it->second;
                 j.item = &kv.second.front();
-                if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
-                    jobs.push_back(j);
-                    who.emplace_back(side, kv.first);
-                    continue;
-                }
-                j.plan();
-                const size_t need = j.bytes();
-                if (!jobs.empty() && (used + need > budget || jobs.size() >= 256)) continue;  // next round
-                used += need;
-                jobs.push_back(std::move(j));
-                who.emplace_back(side, kv.first);
+                cand.push_back(j);
+                who_c.emplace_back(side, kv.first);
             }
+        // seeded graphs are built, and the row plans of graphs that changed are renewed, on the host's cores
+        ioc_parallel_for(cand.size(), [&](size_t x) {
+            PGraph& G = *cand[x].G;
+            G.ensure();
+            if (!G.planned && !G.nodes.empty()) G.plan();
+        });
+        for (size_t x = 0; x < cand.size(); ++x) {
+            HostJob& j = cand[x];
+            if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
+                jobs.push_back(j);
+                who.push_back(who_c[x]);
+                continue;
+            }
+            const size_t need = j.bytes();
+            if (!jobs.empty() && (used + need > budget || jobs.size() >= 2048)) continue;  // next round
+            used += need;
+            jobs.push_back(j);
+            who.push_back(who_c[x]);
+        }
         if (jobs.empty()) return IOC_OK;
         std::vector<HostJob> run;
         std::vector<size_t> run_ix;
@@ -982,16 +1001,23 @@ int poa_flush(ioc_poa* p)
             jobs[run_ix[y]].score = run[y].score;
         }
         const auto tg0 = std::chrono::steady_clock::now();
+        // (the graphs of a round are different graphs: their updates — AddAlignment + topological sort — run on
+        // the host's cores)
+        ioc_parallel_for(jobs.size(), [&](size_t x) {
+            HostJob& j = jobs[x];
+            j.G->add_alignment(j.aln, j.item->seq.data(), int(j.item->seq.size()), j.item->weight);
+        });
         for (size_t x = 0; x < jobs.size(); ++x) {
             HostJob& j = jobs[x];
-            p->last_node.clear();
-            p->last_pos.clear();
-            for (auto& a : j.aln) {
-                p->last_node.push_back(a.first);
-                p->last_pos.push_back(a.second);
+            if (x + 1 == jobs.size()) {  // what ioc_poa_last_alignment reports
+                p->last_node.clear();
+                p->last_pos.clear();
+                for (auto& a : j.aln) {
+                    p->last_node.push_back(a.first);
+                    p->last_pos.push_back(a.second);
+                }
+                p->last_score = j.score;
             }
-            p->last_score = j.score;
-            j.G->add_alignment(j.aln, j.item->seq.data(), int(j.item->seq.size()), j.item->weight);
             auto& q = p->pending[who[x].first][who[x].second];
             q.erase(q.begin());
         }
