@@ -129,6 +129,10 @@ int ioc_resolve(ioc_ctx* ctx, int32_t* n_iter);
  * (>= 2 passing candidates at the winning Size: host replays the libstdc++ order), bit1 = no
  * mapping hit but top >= MinShared (sahlin/furious: host alignment fallback, cluster.cpp:553-566). */
 int ioc_get_decisions(ioc_ctx* ctx, int32_t* target, int8_t* strand, uint8_t* flags);
+/* Per query, the Size below which the mapping walk never looks at a candidate: int(top * MinFraction) with
+ * top = the largest Size among the current clusters (cluster.cpp:381-403), or INT32_MAX when the query has no
+ * walk at all (top < MinShared, or a forced decision).  Valid after ioc_resolve. */
+int ioc_get_cuts(ioc_ctx* ctx, int32_t* cut);
 /* Host override of one query's decision (tie replay / alignment fallback); takes effect in the
  * next ioc_resolve. target -1 = new cluster. */
 int ioc_force_decision(ioc_ctx* ctx, int32_t query, int32_t target, int32_t strand);

@@ -100,7 +100,7 @@ class Timings(C.Structure):
 SYMBOLS = [
     "ioc_ctx_create", "ioc_ctx_destroy", "ioc_last_error", "ioc_set_stream", "ioc_synchronize",
     "ioc_set_params", "ioc_queries_upload", "ioc_queries_bind_device", "ioc_left_load",
-    "ioc_index_build", "ioc_score", "ioc_resolve", "ioc_get_decisions", "ioc_force_decision",
+    "ioc_index_build", "ioc_score", "ioc_resolve", "ioc_get_decisions", "ioc_get_cuts", "ioc_force_decision",
     "ioc_clear_forced", "ioc_query_candidates", "ioc_index_export", "ioc_qual_scores",
     "ioc_extract_minimizers", "ioc_extracted_download", "ioc_extracted_hpc_download", "ioc_queries_from_extracted",
     "ioc_get_timings", "ioc_count_reference_postings", "ioc_host_gap_limits", "ioc_host_err_cell", "ioc_host_min_total",
@@ -150,6 +150,7 @@ def load():
     L.ioc_score.argtypes = [vp]
     L.ioc_resolve.argtypes = [vp, pi32]
     L.ioc_get_decisions.argtypes = [vp, pi32, pi8, pu8]
+    L.ioc_get_cuts.argtypes = [vp, pi32]
     L.ioc_force_decision.argtypes = [vp, i32, i32, i32]
     L.ioc_clear_forced.argtypes = [vp]
     L.ioc_query_candidates.argtypes = [vp, i32, i32, pi32, pi8, pu32, pu32, pu32]

@@ -728,6 +728,18 @@ int ioc_get_decisions(ioc_ctx* c, int32_t* target, int8_t* strand, uint8_t* flag
     return IOC_OK;
 }
 
+int ioc_get_cuts(ioc_ctx* c, int32_t* cut)
+{
+    if (!c || !cut) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    const size_t n = size_t(c->n);
+    if (n == 0) return IOC_OK;
+    HIPCHK(c, hipMemcpyAsync(cut, c->b_cut.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IOC_OK;
+}
+
 int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, int8_t* strand, uint32_t* size,
                          uint32_t* first_index, uint32_t* total_mapped)
 {

@@ -14,6 +14,7 @@
 // operations the reference performs on them (ioc_consensus_ops), the way parasail can stay behind
 // ioc_get_ties / ioc_set_aln_verdicts.  Nothing here links the oracle; without a device every call fails.
 #include <algorithm>
+#include <iterator>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -43,6 +44,58 @@ void sorted_unique(std::vector<uint32_t>& v)
 }
 
 }  // namespace
+
+// Values of the clusters whose representative changed during the current pass (old and new minimizer sets):
+// a later entry of the pass keeps the decision the device made iff it shares fewer than
+// int(MinShared * MinFraction) values with each of them — then none of them was, or becomes, a candidate that
+// GetBestCluster looks at (cluster.cpp:324-406 walks candidates down to int(top * MinFraction), top >= MinShared).
+struct DirtyIndex {
+    static constexpr uint32_t CAP = 1u << 18, MASK = CAP - 1, EMPTY = 0xFFFFu;
+    static constexpr int MAX_SLOTS = 32;
+    std::vector<uint32_t> key = std::vector<uint32_t>(CAP, 0);
+    std::vector<uint16_t> val = std::vector<uint16_t>(CAP, uint16_t(EMPTY));
+    std::vector<uint32_t> touched;
+    int nslots = 0;
+    static uint32_t hash(uint32_t v) { return (v * 2654435761u) >> 14; }
+    void reset()
+    {
+        for (uint32_t h : touched) val[h] = uint16_t(EMPTY);
+        touched.clear();
+        nslots = 0;
+    }
+    bool full() const { return nslots >= MAX_SLOTS || touched.size() > CAP / 4; }
+    void add_cluster(const std::vector<uint32_t>& a, const std::vector<uint32_t>& b)  // sorted, unique
+    {
+        std::vector<uint32_t> u;
+        std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(u));
+        for (uint32_t v : u) {
+            uint32_t h = hash(v) & MASK;
+            while (val[h] != EMPTY) h = (h + 1) & MASK;
+            key[h] = v;
+            val[h] = uint16_t(nslots);
+            touched.push_back(h);
+        }
+        ++nslots;
+    }
+    // does the entry with these minimizer values (both strands' lists) reach `thr` shared values with any of them?
+    bool touches(const uint32_t* v1, int64_t n1, const uint32_t* v2, int64_t n2, int thr) const
+    {
+        if (nslots == 0) return false;
+        int cnt[MAX_SLOTS] = {0};
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t* v = pass ? v2 : v1;
+            const int64_t nv = pass ? n2 : n1;
+            for (int64_t x = 0; x < nv; ++x) {
+                uint32_t h = hash(v[x]) & MASK;
+                while (val[h] != EMPTY) {
+                    if (key[h] == v[x] && ++cnt[val[h]] >= thr) return true;
+                    h = (h + 1) & MASK;
+                }
+            }
+        }
+        return false;
+    }
+};
 
 extern "C" {
 
@@ -114,15 +167,26 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     std::vector<double> herr, rerr;
     std::string lseq;
     std::vector<int64_t> loff;
-    std::vector<int32_t> sub_cls;
+    std::vector<int32_t> sub_cls, sub_cut;
     std::vector<int8_t> sub_strand;
     const int k = p->k, w = p->w;
     int pos = 0;
     // phase clock for IOC_TRACE: [0] left view, [1] device pass, [2] graph hooks, [3] new representative
     double ph[4] = {0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // A pass decides a WINDOW of entries, not all that remain: a decision depends on earlier entries only, so a
+    // prefix of the batch gives the same decisions, and everything behind the next consensus event would be thrown
+    // away anyway.  The window follows the distance between events (fast mode: thousands of entries, sahlin mode
+    // with small clusters: a handful).
+    DirtyIndex dirty;
+    const int dirty_thr = std::max(1, int(double(p->min_shared) * p->min_fraction));
+    const bool one_event_per_pass = getenv("IOC_CONS_RESTART_ALWAYS") != nullptr;  // (the first version of this driver)
+    int window = n;
+    if (const char* e = getenv("IOC_CONS_WINDOW")) window = std::max(1, atoi(e));
+    const bool fixed_window = getenv("IOC_CONS_WINDOW") != nullptr;
+    std::vector<uint32_t> wval, wpos;
     while (pos < n) {
-        const int m = n - pos;
+        const int m = std::min(n - pos, window);
         double t0 = now();
         // ---- left view of the current state ----
         const int32_t Lc = int32_t(cl.size());
@@ -165,23 +229,34 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             lv.rep_off = loff.data();
             lv.cls_raw_err = rerr.data();
         }
-        // ---- the remaining entries [pos, n) as a batch view ----
-        const int64_t base = rb->off_fwd[pos];
+        // ---- the entries [pos, pos + m) as a batch view: their forward lists, then their reverse lists ----
+        const int64_t fb = rb->off_fwd[pos], fe = rb->off_fwd[pos + m], vb = rb->off_rev[pos], ve = rb->off_rev[pos + m];
+        const int64_t nf = fe - fb, nr = ve - vb;
+        wval.resize(size_t(nf + nr) + 1);
+        wpos.resize(size_t(nf + nr) + 1);
+        if (nf) {
+            memcpy(wval.data(), rb->min_val + fb, size_t(nf) * 4);
+            memcpy(wpos.data(), rb->min_pos + fb, size_t(nf) * 4);
+        }
+        if (nr) {
+            memcpy(wval.data() + nf, rb->min_val + vb, size_t(nr) * 4);
+            memcpy(wpos.data() + nf, rb->min_pos + vb, size_t(nr) * 4);
+        }
         of.resize(size_t(m) + 1);
         orv.resize(size_t(m) + 1);
         roff.resize(size_t(m) + 1);
         for (int i = 0; i <= m; ++i) {
-            of[size_t(i)] = rb->off_fwd[pos + i] - base;
-            orv[size_t(i)] = rb->off_rev[pos + i] - base;
+            of[size_t(i)] = rb->off_fwd[pos + i] - fb;
+            orv[size_t(i)] = nf + (rb->off_rev[pos + i] - vb);
             roff[size_t(i)] = rb->raw_off[pos + i] - rb->raw_off[pos];
         }
         ioc_batch_view sv = *rb;
         sv.n = m;
         sv.off_fwd = of.data();
         sv.off_rev = orv.data();
-        sv.min_val = rb->min_val + base;
-        sv.min_pos = rb->min_pos + base;
-        sv.total = rb->off_rev[n] - base;
+        sv.min_val = wval.data();
+        sv.min_pos = wpos.data();
+        sv.total = nf + nr;
         sv.raw_len = rb->raw_len + pos;
         sv.hpc_len = rb->hpc_len + pos;
         sv.score = rb->score + pos;
@@ -198,6 +273,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         t0 = now();
         int r = ioc_cluster_merge(c, p, table_path, Lc > 0 ? &lv : nullptr, &sv, sub_cls.data(), sub_strand.data(), &st);
         if (r != IOC_OK) return r;
+        sub_cut.assign(size_t(m) + 1, INT32_MAX);
+        if (m > 0 && (r = ioc_get_cuts(c, sub_cut.data())) != IOC_OK) return r;
         ph[1] += now() - t0;
         total.resolve_iters += st.resolve_iters;
         total.n_tie_replays += st.n_tie_replays;
@@ -207,15 +284,29 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         if (getenv("IOC_TRACE")) fprintf(stderr, "[ioc] consensus pass from entry %d (%d left clusters)\n", pos, Lc);
 
         // ---- walk the decisions in the reference's order until a representative changes ----
+        const int pass_from = pos;
         bool restarted = false;
+        dirty.reset();
         for (int x = 0; x < m; ++x) {
             const int i = pos + x;
             const int32_t dc = sub_cls[size_t(x)];
-            if (dc < 0) {
+            if (dc < 0) {  // (gated by its quality: no cluster has a say)
                 out_cls[i] = -1;
                 out_strand[i] = 0;
                 total.n_gated++;
                 continue;
+            }
+            // Representatives changed earlier in this pass: the device's decision for this entry stands only if
+            // the entry cannot see any of them — it shares fewer values with each than the Size its mapping walk
+            // stops at (int(top * MinFraction), ioc_get_cuts; without a walk: what would start one).
+            if (dirty.nslots) {
+                const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
+                if (dirty.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
+                                  rb->off_rev[i + 1] - rb->off_rev[i], thr)) {
+                    pos = i;
+                    restarted = true;
+                    break;
+                }
             }
             const char* rseq = rb->raw_seq + rb->raw_off[i];
             const int rlen = int(rb->raw_off[i + 1] - rb->raw_off[i]);
@@ -311,6 +402,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     std::sort(lst.begin(), lst.end());
                 }
             }
+            dirty.add_cluster(b.vals, nv);
             b.vals.swap(nv);
             b.raw_err = raw_err;
             b.hpc_err = hpc_err;  // consensus.cpp:121 — also when the 0.9999 branch (:112-117) fired
@@ -343,12 +435,21 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: purge failed");
             }
             ph[3] += now() - t0;
-            // everything after entry i has to see the new representative
-            pos = i + 1;
-            restarted = true;
-            break;
+            // every later entry that can see this cluster has to see the new representative: the walk goes on
+            // until it meets one (the check at the top), or restarts here when too many clusters have changed
+            if (one_event_per_pass || dirty.full()) {
+                pos = i + 1;
+                restarted = true;
+                break;
+            }
         }
-        if (!restarted) break;
+        if (restarted) {
+            // the next event is probably as far away as this one was
+            if (!fixed_window) window = std::max(64, 4 * std::max(1, pos - pass_from));
+        } else {
+            pos += m;  // the whole window stands
+            if (!fixed_window) window = std::min(n, std::max(64, 2 * window));
+        }
     }
     if (getenv("IOC_TRACE"))
         fprintf(stderr, "[ioc] consensus phases: left view %.1f ms, device passes %.1f ms, graph hooks %.1f ms, new representatives %.1f ms\n",
