@@ -93,23 +93,6 @@ struct PhaseTrace {
     }
 };
 
-// f(0) .. f(count - 1) on the host's cores
-template <typename F>
-static void parallel_for(size_t count, F f)
-{
-    const size_t nt = std::min<size_t>(count, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
-    if (nt <= 1) {
-        for (size_t x = 0; x < count; ++x) f(x);
-        return;
-    }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t)
-        th.emplace_back([&]() {
-            for (size_t x = next.fetch_add(1); x < count; x = next.fetch_add(1)) f(x);
-        });
-    for (auto& t : th) t.join();
-}
 
 struct Cand {
     int32_t cls;  // final cluster id
@@ -566,7 +549,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         tr.calls += int64_t(multi.size());
         std::vector<int32_t> win_t(multi.size(), -1);
         std::vector<int8_t> win_s(multi.size(), 0);
-        parallel_for(multi.size(), [&](size_t x) {
+        ioc_parallel_for(multi.size(), [&](size_t x) {
             std::vector<Ordered> order;
             order_from(c, raws[x], cid, order);
             const std::vector<uint32_t>& pass = passes[multi[x]];
