@@ -10,8 +10,19 @@ from isonclust2_amd import _lib, api, synth  # noqa: E402
 from tests.helpers import ToyGraphs  # noqa: E402
 from tests.test_consensus import _oracle_run  # noqa: E402
 
+import ctypes as C  # noqa: E402
+
+from oracle import pyoracle as po  # noqa: E402
+
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+mode = sys.argv[3] if len(sys.argv) > 3 else "fast"   # "sahlin": the oracle's aligner hook calls the product's host aligner
+hook = None
+if mode != "fast":
+    L = _lib.load()
+    CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
+    hook = CB(lambda read, nread, rep, nrep, go, ge, out, cap:
+              L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None))
 ctx = api.Context(0)
 bad = 0
 t0 = time.time()
@@ -23,10 +34,17 @@ for case in range(n_cases):
     cmin = int(rng.choice([2, 3, 5, 20]))
     period = int(rng.choice([5, 25, 500]))
     seed = int(rng.integers(0, 1 << 30))
+    if mode != "fast":
+        n, ln = min(n, 120), min(ln, 800)
     rs = synth.generate(n, g, ln, 11, 22, seed=seed, dup_every=int(rng.choice([0, 0, 2])))
     tag = f"case {case}: n={n} g={g} L={ln} cons=({cmin},{cmax},{period}) seed={seed}"
     try:
-        B, view, ost, og = _oracle_run(rs, cmax, cmin, period)
+        if hook is not None:
+            po.lib().orc_set_aligner(C.cast(hook, C.c_void_p))
+        try:
+            B, view, ost, og = _oracle_run(rs, cmax, cmin, period, mode=mode)
+        finally:
+            po.lib().orc_set_aligner(None)
         acl, ast = B.assignments(rs.n)
         ocl, ostr = acl[view["orig"]], ast[view["orig"]]
         seqs = [rs.read(int(i))[0] for i in view["orig"]]
@@ -36,7 +54,7 @@ for case in range(n_cases):
         v.update(raw_seq=b"".join(seqs), raw_off=off)
         pg = ToyGraphs()
         cargs = _lib.ConsensusArgs(cons_min_size=cmin, cons_max_size=cmax, cons_period=period, left_depth=-1, left_sizes=None)
-        cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, "fast"), None, v, cargs, pg.ops)
+        cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, mode), None, v, cargs, pg.ops)
         keys, offs, post = ctx.index_export()
         okeys, ooffs, opost = B.index()
         ok = (np.array_equal(cls, ocl) and np.array_equal(strand, ostr) and pg.log == og.log and
