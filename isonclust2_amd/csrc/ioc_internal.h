@@ -121,11 +121,12 @@ int ioc_fail(ioc_ctx* c, int code, const std::string& msg);
 // f(0) .. f(count - 1) on the host's cores (independent items only)
 #include <atomic>
 #include <thread>
+// (threads are started per call: `serial_below` items or fewer are not worth it)
 template <typename F>
-static inline void ioc_parallel_for(size_t count, F f)
+static inline void ioc_parallel_for(size_t count, F f, size_t serial_below = 4)
 {
     const size_t hw = std::thread::hardware_concurrency();
-    const size_t nt = std::min<size_t>(count, std::max<size_t>(1, std::min<size_t>(16, hw)));
+    const size_t nt = count < serial_below ? 1 : std::min<size_t>(count, std::max<size_t>(1, std::min<size_t>(16, hw)));
     if (nt <= 1) {
         for (size_t x = 0; x < count; ++x) f(x);
         return;

@@ -946,9 +946,17 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
 // work off every queue: one addition per graph and round, as many graphs per batch as the memory budget allows
 int poa_flush(ioc_poa* p)
 {
+    bool any = false;
+    for (int side = 0; side < 2 && !any; ++side)
+        for (auto& kv : p->pending[side])
+            if (!kv.second.empty()) {
+                any = true;
+                break;
+            }
+    if (!any) return IOC_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
     for (;;) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
         const size_t have = p->d_int.cap + p->d_dirs.cap + p->d_eb.cap;
         // (device allocations of 100 GB take seconds: more, smaller batches cost less than that)
         size_t budget = std::min((free_b + have) / 2, size_t(48) << 30);
@@ -972,7 +980,7 @@ int poa_flush(ioc_poa* p)
             PGraph& G = *cand[x].G;
             G.ensure();
             if (!G.planned && !G.nodes.empty()) G.plan();
-        });
+        }, 48);
         for (size_t x = 0; x < cand.size(); ++x) {
             HostJob& j = cand[x];
             if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
@@ -1006,7 +1014,7 @@ int poa_flush(ioc_poa* p)
         ioc_parallel_for(jobs.size(), [&](size_t x) {
             HostJob& j = jobs[x];
             j.G->add_alignment(j.aln, j.item->seq.data(), int(j.item->seq.size()), j.item->weight);
-        });
+        }, 16);
         for (size_t x = 0; x < jobs.size(); ++x) {
             HostJob& j = jobs[x];
             if (x + 1 == jobs.size()) {  // what ioc_poa_last_alignment reports
