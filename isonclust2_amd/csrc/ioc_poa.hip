@@ -200,7 +200,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
         if (t >= 0 && t < nrows) {  // (uniform in the wave)
             const int r = r_lo + t;
             const int4 cin = s_carry[wave][t];
-            const int pe_n = __builtin_amdgcn_readfirstlane(s_poff[t + 2]);
+            const int pe_nv = s_poff[t + 2];  // (made uniform at the end of the step: no wait for it up here)
             const int bs_n = s_base[t + 1];
             const int slot_n = s_slot[t + 1];
             const int pr0_n = s_pred[min(pe - pb0, pred_lds - 1)];
@@ -347,7 +347,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 }
             }
             pb = pe;
-            pe = pe_n;
+            pe = __builtin_amdgcn_readfirstlane(pe_nv);
             bs = bs_n;
             pr0 = pr0_n;
             my_slot = slot_n;
