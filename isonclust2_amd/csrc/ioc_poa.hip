@@ -195,6 +195,12 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     // what the wave's next row starts with, fetched one step ahead: list bounds, base, first predecessor
     int pb = __builtin_amdgcn_readfirstlane(s_poff[0]), pe = __builtin_amdgcn_readfirstlane(s_poff[1]), bs = s_base[0], pr0 = s_pred[0];
     int my_slot = s_slot[0];
+#ifdef POA_PROF
+    unsigned long long tp[4] = {0, 0, 0, 0}, tp_t = __builtin_readcyclecounter();
+#define POA_TICK(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tp[k] += t_ - tp_t; tp_t = t_; }
+#else
+#define POA_TICK(k)
+#endif
     for (int s = 0; s < nrows + POA_WAVES - 1; ++s) {
         const int t = s - wave;
         if (t >= 0 && t < nrows) {  // (uniform in the wave)
@@ -210,6 +216,29 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
                 int dg = POA_NEG;
                 const int sc = (bs == my_base) ? S.m : S.n;
+                const int pr0u = __builtin_amdgcn_readfirstlane(pr0);
+                if (pe - pb == 1 && t > 0 && pr0u == r - 1) {
+                    // the common row: ONE predecessor, the row above, in this tile — straight-line code (the general
+                    // loop below spends more time in its branches than in its arithmetic); same values bit for bit
+                    const int slp = (r - 1) & (POA_RING - 1);
+                    const int hu = sH[slp][tid], u1 = sF1[slp][tid], u2 = sF2[slp][tid];
+                    const int edge = s_carry[wave][t - 1].w;
+                    const int hl = __builtin_amdgcn_update_dpp(edge, hu, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    if (j > 0) {
+                        const int hd = hl + sc;
+                        if (hd > dg) dg = hd;
+                    }
+                    const int o1 = hu + S.g, x1 = u1 + S.e, v1 = max(o1, x1);
+                    if (v1 > f1) {
+                        f1 = v1;
+                        f1x = x1 > o1 ? 1u : 0u;
+                    }
+                    const int o2 = hu + S.q, x2 = u2 + S.c, v2 = max(o2, x2);
+                    if (v2 > f2) {
+                        f2 = v2;
+                        f2x = x2 > o2 ? 1u : 0u;
+                    }
+                } else {
                 // plane row of predecessor entry x (only the memory paths ask: a row read from memory is a kept one)
                 auto pslot_of = [&](int x) {
                     int v = s_pslot[min(x - pb0, pred_lds - 1)];
@@ -280,6 +309,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                         f2x = x2 > o2 ? 1u : 0u;
                     }
                 }
+                }
                 if (dg > hn) {
                     hn = dg;
                     d = SRC_DIAG;
@@ -294,6 +324,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 }
                 d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
             }
+            POA_TICK(0)
             // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
             const int vx = max(wave_prefix_max(active ? hn - S.e * j : POA_NEG), cin.x);
             const int vy = max(wave_prefix_max(active ? hn - S.c * j : POA_NEG), cin.y);
@@ -317,6 +348,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 }
                 eb |= (e1x << 3) | (e2x << 4);
             }
+            POA_TICK(1)
             const int sl = r & (POA_RING - 1);
             sH[sl][tid] = h;
             sF1[sl][tid] = f1;
@@ -351,9 +383,15 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             bs = bs_n;
             pr0 = pr0_n;
             my_slot = slot_n;
+            POA_TICK(2)
         }
         lds_barrier();  // the carries of this step's rows are in LDS before the waves on the right start them
+        POA_TICK(3)
     }
+#ifdef POA_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && diag == 10)
+        printf("tile profile (wave 0, %d rows): predecessors %llu, scan + E %llu, stores %llu, barrier %llu cycles\n", nrows, tp[0], tp[1], tp[2], tp[3]);
+#endif
     // ---- the tile's best cell: maximum score, ties to the smallest row, then the smallest column ----
     auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
         return s1 > s2 || (s1 == s2 && (r1 < r2 || (r1 == r2 && c1 < c2)));
