@@ -499,6 +499,7 @@ int ioc_force_decision(ioc_ctx* c, int32_t q, int32_t target, int32_t strand)
     c->h_forced_t[size_t(q)] = target < 0 ? (target == -2 ? -2 : -1) : target;  // -2: excluded (gated) entry
     c->h_forced_s[size_t(q)] = int8_t(target < 0 ? 0 : strand);
     c->forced_dirty = true;
+    c->warm_first = -1;
     return IOC_OK;
 }
 
@@ -508,6 +509,7 @@ int ioc_clear_forced(ioc_ctx* c)
     std::fill(c->h_forced_t.begin(), c->h_forced_t.end(), INT32_MIN);
     std::fill(c->h_forced_s.begin(), c->h_forced_s.end(), 0);
     c->forced_dirty = true;
+    c->warm_first = -1;
     return IOC_OK;
 }
 
@@ -518,6 +520,7 @@ int ioc_set_aln_verdicts(ioc_ctx* c, const int32_t* target, const int8_t* strand
     if (!c) return IOC_ERR_ARG;
     if (!target) {
         c->aln_verdicts = false;
+        c->warm_first = -1;
         return IOC_OK;
     }
     if (!strand) return IOC_ERR_ARG;
@@ -526,6 +529,13 @@ int ioc_set_aln_verdicts(ioc_ctx* c, const int32_t* target, const int8_t* strand
         if (target[i] != INT32_MIN && target[i] >= c->L + int32_t(i))
             return ioc_fail(c, IOC_ERR_ARG, "alignment verdict is not an earlier target");
         if (target[i] >= 0 && strand[i] != 1 && strand[i] != -1) return ioc_fail(c, IOC_ERR_ARG, "strand must be +1/-1");
+    }
+    if (c->resolved && c->aln_verdicts && c->warm_first >= 0 && c->h_aln_t.size() == n && c->h_aln_s.size() == n) {
+        size_t fd = 0;
+        while (fd < n && c->h_aln_t[fd] == target[fd] && c->h_aln_s[fd] == strand[fd]) ++fd;
+        c->warm_first = std::min<int32_t>(c->warm_first, int32_t(fd));
+    } else {
+        c->warm_first = -1;
     }
     c->h_aln_t.assign(target, target + n);
     c->h_aln_s.assign(strand, strand + n);
@@ -581,17 +591,21 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         }
     }
     HIPCHK(c, hipEventRecord(c->ev[4], s));
+    // Warm start: the previous call's fixed point is still in the buffers and only alignment verdicts changed
+    // since, the first of them at query warm_first: the decisions before it stand (a decision depends on earlier
+    // queries only), the exact sweeps go on from there on the previous `valid`.
+    const bool warm = c->resolved && c->warm_first >= 0 && c->warm_first <= n && c->aln_verdicts && env_u32("IOC_RESOLVE_WARM", 1) == 1;
     // initial guess (any guess converges to the same fixed point): "every query opens a cluster".
     // A guess from the all-pairs top Size (IOC_RESOLVE_GUESS=1) was measured SLOWER on config 2
     // (4 sweeps / 3.5 ms vs 3 sweeps / 2.0 ms): many entries with a large top still fail the mapped-ratio
     // test and do open clusters, and that side of the error cascades.
-    if (n > 0) {
+    if (n > 0 && !warm) {
         if (c->have_guess && env_u32("IOC_RESOLVE_GUESS", 0) == 1)
             HIPCHK(c, iock_guess_valid(s, n, c->d_off_fwd, c->d_off_rev, P<uint32_t>(c->b_top_all), P<uint8_t>(c->b_valid0)));
         else
             HIPCHK(c, hipMemsetAsync(c->b_valid0.p, 1, size_t(n), s));
     }
-    c->cur_valid = 0;
+    if (!warm) c->cur_valid = 0;
     uint32_t* d_first_changed = P<uint32_t>(c->b_misc) + 8;
     unsigned long long* d_evals = reinterpret_cast<unsigned long long*>(P<uint8_t>(c->b_misc) + 128);
     HIPCHK(c, hipMemsetAsync(d_evals, 0, 8, s));
@@ -656,6 +670,10 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     // against actual clusters only.  The result is the fixed point of the exact sweeps either way.
     int first = 0, iters = 0, sweeps = 0;
     a.lazy = env_u32("IOC_RESOLVE_LAZY", 1) == 1 ? 1 : 0;
+    if (warm) {
+        a.lazy = 0;
+        first = c->warm_first;
+    }
     while (n > 0) {
         if (first >= n) {
             // every query up to the last one is final for THIS stage: a lazy stage that ends on a change of the
@@ -709,6 +727,7 @@ fprintf(stderr, "[ioc eval diag] evals %llu: total %.0f cyc/eval = clear %.0f + 
     c->tm.resolve_iters = iters;
     if (n_iter) *n_iter = iters;
     c->resolved = true;
+    c->warm_first = n;  // nothing has changed since this fixed point
     c->exp_valid = false;
     return IOC_OK;
 }

@@ -330,6 +330,7 @@ struct AlnDriver {
         std::vector<int64_t> off(size_t(n) + size_t(L) + 1, 0);
         for (int i = 0; i < n; ++i) off[size_t(i) + 1] = off[size_t(i)] + (sa->r_off[i + 1] - sa->r_off[i]);
         for (int t = 0; t < L; ++t) off[size_t(n + t) + 1] = off[size_t(n + t)] + (sa->l_off[t + 1] - sa->l_off[t]);
+        if (L == 0) return ioc_align_set_pool(c, n, sa->r_seq + sa->r_off[0], off.data());  // (no copy: the batch's own buffer)
         std::vector<char> pool(size_t(off.back()) + 1);
         if (n > 0) memcpy(pool.data(), sa->r_seq + sa->r_off[0], size_t(off[size_t(n)]));
         if (L > 0) memcpy(pool.data() + off[size_t(n)], sa->l_seq + sa->l_off[0], size_t(off.back() - off[size_t(n)]));

@@ -89,7 +89,10 @@ struct ioc_ctx {
     std::vector<uint8_t> aln_other;  // per pool sequence: holds a byte other than A C G T
     std::vector<int64_t> aln_offs;
     DevBuf b_aln_t, b_aln_s, b_tie_count, b_tie_keys;
-    DevBuf b_qhist, b_qfirst, b_qout;  // ioc_query_candidates: the query's hit table (kept between calls)
+    DevBuf b_qhist, b_qfirst, b_qout;
+    // ioc_resolve warm start: first query whose alignment verdict changed since the last resolve (n: none; -1: no
+    // resolved state to start from).  Everything before it keeps its decision (it depends on earlier queries only).
+    int32_t warm_first = -1;  // ioc_query_candidates: the query's hit table (kept between calls)
     std::vector<int32_t> h_aln_t;
     std::vector<int8_t> h_aln_s;
     bool aln_verdicts = false, aln_dirty = false;
