@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Runs the isONclust2-hip CLI end to end on a slice of BASELINE config 4's shape: NB batches of 31 250 reads x
+2 kb (sort -> cluster each batch -> fold the merges left to right -> dump), sahlin mode; prints wall times."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, ".")
+from isonclust2_amd import synth  # noqa: E402
+
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+per = int(sys.argv[2]) if len(sys.argv) > 2 else 31250
+mode = sys.argv[3] if len(sys.argv) > 3 else "sahlin"
+CLI = os.path.join("isonclust2_amd", "bin", "isONclust2-hip")
+rs = synth.generate(nb * per, 1500, 2000, 10, 21, seed=11)
+d = tempfile.mkdtemp(prefix="ioc_cli4_")
+fq = os.path.join(d, "reads.fq")
+with open(fq, "wb") as f:
+    for i in range(rs.n):
+        s, q = rs.read(i)
+        f.write(b"@r%d\n" % i + s + b"\n+\n" + q + b"\n")
+env = dict(os.environ, ISONCLUST2_STATS_JSON="1")
+
+
+def run(args):
+    t = time.time()
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, (args, r.stderr[-2000:])
+    return time.time() - t
+
+
+out = {"workload": f"{nb} x {per} reads of 2 kb, {mode}", "fastq_MB": os.path.getsize(fq) / 1e6}
+out["sort_s"] = run(["sort", "-B", str(per), "-M", str(per), "-o", os.path.join(d, "sorted"), fq])
+batches = sorted((x for x in os.listdir(os.path.join(d, "sorted", "batches")) if x.endswith(".cer")),
+                 key=lambda x: int(x.split("_")[1].split(".")[0]))
+out["n_batches"] = len(batches)
+cl = []
+for i, b in enumerate(batches):
+    o = os.path.join(d, f"c{i}.cer")
+    cl.append(run(["cluster", "-l", os.path.join(d, "sorted", "batches", b), "-o", o, "-x", mode]))
+out["cluster_s"] = cl
+mg = []
+acc = os.path.join(d, "c0.cer")
+for i in range(1, len(batches)):
+    o = os.path.join(d, f"m{i}.cer")
+    mg.append(run(["cluster", "-l", acc, "-r", os.path.join(d, f"c{i}.cer"), "-o", o, "-x", mode]))
+    acc = o
+out["merge_s"] = mg
+out["dump_s"] = run(["dump", "-i", os.path.join(d, "sorted", "sorted_reads_idx.cer"), "-o", os.path.join(d, "dump"), acc])
+tsv = os.path.join(d, "dump", "clusters.tsv")
+if os.path.exists(tsv):
+    ids = set()
+    n = 0
+    for line in open(tsv).read().splitlines()[1:]:
+        ids.add(line.split("\t")[0])
+        n += 1
+    out["clusters"], out["reads_assigned"] = len(ids), n
+out["total_s"] = out["sort_s"] + sum(cl) + sum(mg) + out["dump_s"]
+print(json.dumps(out))
+subprocess.call(["rm", "-rf", d])
