@@ -14,6 +14,7 @@ from isonclust2_amd import synth  # noqa: E402
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 31250
 mode = sys.argv[3] if len(sys.argv) > 3 else "sahlin"
+cons = sys.argv[4].split(",") if len(sys.argv) > 4 else None   # ConsMinSize,ConsMaxSize,ConsPeriod: consensus mode
 CLI = os.path.join("isonclust2_amd", "bin", "isONclust2-hip")
 rs = synth.generate(nb * per, 1500, 2000, 10, 21, seed=11)
 d = tempfile.mkdtemp(prefix="ioc_cli4_")
@@ -33,7 +34,11 @@ def run(args):
 
 
 out = {"workload": f"{nb} x {per} reads of 2 kb, {mode}", "fastq_MB": os.path.getsize(fq) / 1e6}
-out["sort_s"] = run(["sort", "-B", str(per), "-M", str(per), "-o", os.path.join(d, "sorted"), fq])
+sort_args = ["sort", "-B", "1000000", "-M", str(per)]
+if cons:
+    sort_args += ["-g", cons[0], "-c", cons[1], "-P", cons[2]]
+    out["consensus"] = cons
+out["sort_s"] = run(sort_args + ["-o", os.path.join(d, "sorted"), fq])
 batches = sorted((x for x in os.listdir(os.path.join(d, "sorted", "batches")) if x.endswith(".cer")),
                  key=lambda x: int(x.split("_")[1].split(".")[0]))
 out["n_batches"] = len(batches)
