@@ -438,6 +438,15 @@ __device__ __forceinline__ uint32_t ref_byte(const uint8_t* __restrict__ r, uint
 //     E*(i, j) = max(E*(i, j-1), Hq(i, j-1))          F*(i, j) = max(F*(i-1, j), Hq(i-1, j))
 //     H*(i, j) = max3(Hq(i-1, j-1) + (s + 2 ge + go - ge), E*, F*)
 // 7 VALU per cell instead of 10; true values (checkpoints, end cell) are X* - ge * (i + j).
+// tail launch of the forward pass: a pair split over `groups` workgroups (see k_align_fwd)
+struct AlnCross {
+    uint32_t groups = 1;       // workgroups per pair (1: the usual launch)
+    uint32_t flag_stride = 0;  // flags per pair
+    uint32_t* flags = nullptr; // [pair][band][strip]: the band's checkpoints of the strip are out
+    int2* best = nullptr;      // [pair][band]: best cell of the band's part of the last column
+    uint32_t* err = nullptr;   // a wait ran out
+};
+
 struct FwdConst {
     int gd;      // go - ge
     int cm, cx;  // match / mismatch + 2 ge + gd
@@ -500,7 +509,7 @@ template <bool PROF>
 __global__ void __launch_bounds__(64 * ALN_MAXW) __attribute__((amdgpu_waves_per_eu(IOC_FWD_WAVES_PER_EU, 8)))
 k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, uint32_t count, uint32_t wpp_main,
             uint32_t n_main, uint32_t wpp_tail, const uint8_t* __restrict__ pool, AlnParams P, int2* ck, const AlnCk* __restrict__ cko, int2* lrow,
-            uint64_t lrow_stride, int4* __restrict__ ends)
+            uint64_t lrow_stride, int4* __restrict__ ends, AlnCross X)
 {
     // A workgroup is 4 (or 8) waves = one per SIMD of its CU, however the dispatcher places workgroups; it
     // carries (waves / wpp) pairs, each split over wpp waves ("bands").  (Workgroups of 2 waves were seen
@@ -517,9 +526,14 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     // generation, which runs on a half-empty chip, is over sooner.
     const bool tail = blockIdx.x >= n_main;
     const uint32_t wpp = tail ? wpp_tail : wpp_main, wg_waves = blockDim.x >> 6;
-    const uint32_t slot = wv / wpp, wave = wv % wpp, nwaves = wpp;
-    const uint32_t pslot = tail ? n_main * (wg_waves / wpp_main) + (blockIdx.x - n_main) * (wg_waves / wpp_tail) + slot
-                                : blockIdx.x * (wg_waves / wpp_main) + slot;  // pair of this wave, in `order`
+    // X.groups > 1 (the tail launch): a pair is split over X.groups WORKGROUPS of 4 waves, band = 4 * group + wave;
+    // the band below another workgroup's last band takes its top edges when that band's flag says they are there
+    const bool cross = X.groups > 1;
+    const uint32_t grp = cross ? blockIdx.x % X.groups : 0u;
+    const uint32_t slot = cross ? 0u : wv / wpp, wave = cross ? grp * wg_waves + wv : wv % wpp, nwaves = cross ? X.groups * wg_waves : wpp;
+    const uint32_t pslot = cross ? blockIdx.x / X.groups
+                         : tail  ? n_main * (wg_waves / wpp_main) + (blockIdx.x - n_main) * (wg_waves / wpp_tail) + slot
+                                 : blockIdx.x * (wg_waves / wpp_main) + slot;  // pair of this wave, in `order`
     const bool live = pslot < count;
     if (threadIdx.x == 0) s_rounds = 0;
     __syncthreads();
@@ -556,6 +570,8 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     uint32_t bc_i = 0;
 
     // the pairs of a workgroup may need different numbers of rounds: everybody stays for the barriers
+    uint32_t* xflag = cross ? X.flags + uint64_t(live ? pslot : 0) * X.flag_stride : nullptr;  // [band][strip]
+    bool xbad = false;
     if (live && lane == 0) atomicMax(&s_rounds, nstrips + nwaves - 1u);
     __syncthreads();
     const uint32_t rounds = s_rounds;
@@ -563,6 +579,21 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
         const int ps = int(round) - int(wave);
         if (live && ps >= 0 && uint32_t(ps) < nstrips && nblocks > 0) {
             const uint32_t p = uint32_t(ps);
+            if (cross && wv == 0 && wave > 0) {
+                // the band above lives in another workgroup: wait for its row checkpoint of this strip (bounded:
+                // the launch keeps all its workgroups resident, but a wait without an end could take the GPU down)
+                uint32_t seen = 0;
+                if (lane == 0) {
+                    for (uint32_t it = 0; it < (1u << 22); ++it) {
+                        seen = __hip_atomic_load(&xflag[uint64_t(wave - 1u) * nstrips + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                seen = uint32_t(__builtin_amdgcn_readfirstlane(int(seen)));
+                if (!seen) xbad = true;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
             const uint32_t jb = p * strip_cols + lane * FW_C;  // columns to the left of this lane's block
             uint32_t rpk[FW_C / 4];
 #pragma unroll
@@ -773,15 +804,39 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             if (lastc >= 0) {
                 s_best[wv][0] = bc;
                 s_best[wv][1] = int(bc_i);
+                if (cross) X.best[uint64_t(pslot) * nwaves + wave] = int2{bc, int(bc_i)};
+            }
+            if (cross) {  // this band's checkpoints of the strip are out: tell the band below (and the final reduction)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(&xflag[uint64_t(wave) * nstrips + p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (rounds > 1 || wpp > 1) __syncthreads();  // orders this round's checkpoints before the next round reads them
+        if (rounds > 1 || nwaves > 1) __syncthreads();  // orders this round's checkpoints before the next round reads them
     }
     __syncthreads();
 
     // end cell: best of the last column (rows ascending), replaced only by a strictly larger cell of the
     // last row (columns ascending from 0) — the host aligner's scan order (ioc_align.cpp)
-    if (live && wave == 0) {
+    if (xbad && lane == 0) atomicOr(X.err, 1u);
+    const bool reducer = cross ? (grp + 1u == X.groups && wv == 0) : wave == 0;
+    if (live && reducer) {
+        if (cross) {  // every band that has rows has finished its last strip?
+            uint32_t okf = 1;
+            if (lane == 0) {
+                for (uint32_t b2 = 0; b2 < nwaves && okf; ++b2) {
+                    if (min(n, b2 * tpb * TILE) >= n) break;
+                    uint32_t seen = 0;
+                    for (uint32_t it = 0; it < (1u << 22); ++it) {
+                        seen = __hip_atomic_load(&xflag[uint64_t(b2) * nstrips + (nstrips - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (!seen) okf = 0;
+                }
+                if (!okf) atomicOr(X.err, 1u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         int br = 0;  // H(n, 0)
         uint32_t bj = 0;
         for (uint32_t e = lane; e < nstrips * 64u; e += 64) {
@@ -805,9 +860,10 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             uint32_t bi = 0, bjj = m;
             for (uint32_t b2 = 0; b2 < nwaves; ++b2) {  // bands top to bottom: the first row wins ties
                 if (min(n, b2 * tpb * TILE) >= n) break;
-                if (s_best[slot * wpp + b2][0] > fin) {
-                    fin = s_best[slot * wpp + b2][0];
-                    bi = uint32_t(s_best[slot * wpp + b2][1]);
+                const int2 bb = cross ? X.best[uint64_t(pslot) * nwaves + b2] : int2{s_best[slot * wpp + b2][0], s_best[slot * wpp + b2][1]};
+                if (bb.x > fin) {
+                    fin = bb.x;
+                    bi = uint32_t(bb.y);
                 }
             }
             if (br > fin) {
@@ -1851,7 +1907,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             }
             ACHK(c, hipEventRecord(evs[evi++], s));
             auto launch_fwd = [&](const uint32_t* o, uint32_t cnt, uint32_t wv, uint32_t wgw, uint32_t nwg, uint32_t nmain,
-                                  uint32_t wtail, size_t lds, int2* lr) {
+                                  uint32_t wtail, size_t lds, int2* lr, const AlnCross& X) {
                 const AlnPairDev* dpairs = static_cast<const AlnPairDev*>(c->a_pairs.p);
                 const uint8_t* dpool = static_cast<const uint8_t*>(c->a_pool.p);
                 int2* dck = static_cast<int2*>(c->a_ck.p);
@@ -1862,14 +1918,85 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                                        dcko, lr, lrow_stride, dends);
                 else if (prof)
                     hipLaunchKernelGGL(k_align_fwd<true>, dim3(nwg), dim3(wgw * 64), lds, s, dpairs, o, cnt, wv, nmain, wtail, dpool, P,
-                                       dck, dcko, lr, lrow_stride, dends);
+                                       dck, dcko, lr, lrow_stride, dends, X);
                 else
                     hipLaunchKernelGGL(k_align_fwd<false>, dim3(nwg), dim3(wgw * 64), lds, s, dpairs, o, cnt, wv, nmain, wtail, dpool, P,
-                                       dck, dcko, lr, lrow_stride, dends);
+                                       dck, dcko, lr, lrow_stride, dends, X);
             };
-            // (A launch of its own for the tail generation with 8 bands per pair was tried: an 8-wave workgroup
-            // lands on ONE CU, two waves per SIMD, and the tail took 30 ms instead of 18.)
-            launch_fwd(ord, sl.second, waves, wg_waves, n_wg, n_main, wpp_tail, lds_pad, static_cast<int2*>(c->a_lrow.p));
+            // The tail generation runs on a mostly empty chip: its pairs are split over SEVERAL workgroups each
+            // (4 x 4 = 16 bands on 4 CUs; an 8-wave workgroup lands on one CU, two waves per SIMD, and was slower),
+            // the first band of a workgroup waiting on a flag for the row checkpoints of the band above.  Its own
+            // launch: all its workgroups are resident together, and the waits are bounded anyway (then the pairs
+            // are simply done again the usual way).
+            uint32_t groups = 1;
+            const bool force_cross = getenv("IOC_ALIGN_FORCE_CROSS") != nullptr;  // (tests: the whole slice the tail's way)
+            if (force_cross && !packed && wg_waves == 4) {
+                n_main = 0;
+                n_wg = 1;
+            }
+            // (Opt-in, IOC_ALIGN_CROSS_TAIL=1: measured on config 3 the tail itself gets shorter, but as a launch of
+            // its own it can no longer start on the CUs whose main workgroups finish early, and the step ends up 5 ms
+            // longer: 112 ms against 105.)
+            if (n_main < n_wg && !packed && wg_waves == 4 && (force_cross || getenv("IOC_ALIGN_CROSS_TAIL"))) {
+                const AlnPairDev& big = dp[order[sl.first]];
+                const uint32_t strips = (big.m + 64 * FW_C - 1) / (64 * FW_C), tiles = (big.n + TILE - 1) / TILE;
+                groups = 4;
+                while (groups > 1 && (strips < 4 * groups || tiles < 8 * groups)) groups >>= 1;  // bands = 4 * groups
+                const uint32_t rest = sl.second - n_main * ppw;
+                // one workgroup per CU (two on a CU run at half speed and hold up the whole chain of their pair), all
+                // resident together
+                while (groups > 1 && uint64_t(rest) * groups > uint64_t(n_cu)) groups >>= 1;
+            }
+            if (groups > 1) {
+                const uint32_t first_cnt = n_main * ppw, rest = sl.second - first_cnt, nb = 4 * groups;
+                const AlnPairDev& big = dp[order[sl.first]];
+                const uint32_t strips = (big.m + 64 * FW_C - 1) / (64 * FW_C);
+                AlnCross X;
+                X.groups = groups;
+                X.flag_stride = nb * strips;
+                const size_t fbytes = size_t(rest) * X.flag_stride * 4, bbytes = size_t(rest) * nb * sizeof(int2);
+                if ((r = reserve(c, c->a_xflags, fbytes + bbytes + 64)) != IOC_OK) return r;
+                X.err = static_cast<uint32_t*>(c->a_xflags.p);
+                X.flags = X.err + 16;
+                X.best = reinterpret_cast<int2*>(reinterpret_cast<uint8_t*>(c->a_xflags.p) + 64 + fbytes);
+                ACHK(c, hipMemsetAsync(c->a_xflags.p, 0, 64 + fbytes, s));
+                if (first_cnt) launch_fwd(ord, first_cnt, waves, wg_waves, n_main, n_main, waves, lds_pad, static_cast<int2*>(c->a_lrow.p), AlnCross{});
+                ACHK(c, hipGetLastError());
+                size_t xlds = 0;  // more than half a CU's LDS: the dispatcher cannot stack two of them
+                {
+                    hipFuncAttributes fa{};
+                    size_t stat = 52 * 1024;
+                    if (hipFuncGetAttributes(&fa, kfn) == hipSuccess) stat = fa.sharedSizeBytes;
+                    size_t& lim = prof ? c->aln_lds_max : c->aln_lds_max2;
+                    if (lim == 0) {
+                        int mx = 0;
+                        (void)hipDeviceGetAttribute(&mx, hipDeviceAttributeMaxSharedMemoryPerBlock, c->device);
+                        lim = 64 * 1024 > stat ? 64 * 1024 - stat : 1;
+                        if (mx > 72 * 1024 && hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, mx - int(stat)) == hipSuccess)
+                            lim = size_t(mx) - stat;
+                        (void)hipGetLastError();
+                    }
+                    const size_t want = 84 * 1024;
+                    if (want > stat && want - stat <= lim) xlds = (want - stat) & ~size_t(255);
+                }
+                launch_fwd(ord + first_cnt, rest, 4, 4, rest * groups, rest * groups, 4, xlds,
+                           static_cast<int2*>(c->a_lrow.p) + uint64_t(first_cnt) * lrow_stride, X);
+                ACHK(c, hipGetLastError());
+                uint32_t xerr = 0;
+                ACHK(c, hipMemcpyAsync(&xerr, X.err, 4, hipMemcpyDeviceToHost, s));
+                ACHK(c, hipStreamSynchronize(s));
+                if (xerr) {  // a wait ran out (the workgroups were not all resident): the tail again, the usual way
+                    launch_fwd(ord + first_cnt, rest, 4, 4, rest, rest, 4, 0,
+                               static_cast<int2*>(c->a_lrow.p) + uint64_t(first_cnt) * lrow_stride, AlnCross{});
+                    c->tm.n_align_refused += rest;
+                }
+            } else {
+                if (force_cross && n_main == 0) {  // (the forced split did not fit this slice)
+                    n_wg = (sl.second + ppw - 1) / ppw;
+                    n_main = n_wg;
+                }
+                launch_fwd(ord, sl.second, waves, wg_waves, n_wg, n_main, wpp_tail, lds_pad, static_cast<int2*>(c->a_lrow.p), AlnCross{});
+            }
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(evs[evi++], s));
             hipLaunchKernelGGL(k_align_trace, dim3(sl.second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,

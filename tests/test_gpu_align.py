@@ -215,3 +215,20 @@ def test_packed_forward_pass(ctx, monkeypatch, waves):
     pairs += [(len(lens), len(lens) + 1, 0, 0.01), (len(lens) + 2, len(lens) - 1, 0, 0.1), (len(lens) - 1, len(lens) + 2, 1, 0.1)]
     for k in (5, 11, 32):
         _check(ctx, seqs, pairs, k)
+
+
+def test_pairs_split_over_workgroups(ctx, monkeypatch):
+    """IOC_ALIGN_FORCE_CROSS=1: every pair the way the tail generation of a big launch is done — split over 2 or 4
+    workgroups (8 / 16 row bands), the first band of a workgroup waiting on a flag for the checkpoints of the band
+    above.  Lengths around the band boundaries; bands without rows; against the host aligner."""
+    monkeypatch.setenv("IOC_ALIGN_FORCE_CROSS", "1")
+    rng = random.Random(31)
+    base = bytes(rng.choice(b"ACGT") for _ in range(9000))
+    lens = [2048, 2049, 2300, 3000, 4096, 4097, 4500, 5000, 6100, 8192, 8200, 9000]
+    seqs = [_mutate(rng, base, 0.1)[:ln] for ln in lens]
+    pairs = []
+    for a in range(len(lens)):
+        for b in (a, (a + 3) % len(lens), (a + 7) % len(lens)):
+            pairs.append((a, b, (a + b) % 2, rng.choice([0.05, 0.2])))
+    _check(ctx, seqs, pairs, 11)
+    assert ctx.timings()["n_align_refused"] == 0      # no wait ran out
