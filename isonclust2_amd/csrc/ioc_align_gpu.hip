@@ -441,6 +441,8 @@ __device__ __forceinline__ uint32_t ref_byte(const uint8_t* __restrict__ r, uint
 // tail launch of the forward pass: a pair split over `groups` workgroups (see k_align_fwd)
 struct AlnCross {
     uint32_t groups = 1;       // workgroups per pair (1: the usual launch)
+    uint32_t first_wg = 0;     // first workgroup of the launch that belongs to a split pair
+    uint32_t first_pair = 0;   // ... and the pair (position in `order`) it starts with
     uint32_t flag_stride = 0;  // flags per pair
     uint32_t* flags = nullptr; // [pair][band][strip]: the band's checkpoints of the strip are out
     int2* best = nullptr;      // [pair][band]: best cell of the band's part of the last column
@@ -528,10 +530,13 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     const uint32_t wpp = tail ? wpp_tail : wpp_main, wg_waves = blockDim.x >> 6;
     // X.groups > 1 (the tail launch): a pair is split over X.groups WORKGROUPS of 4 waves, band = 4 * group + wave;
     // the band below another workgroup's last band takes its top edges when that band's flag says they are there
-    const bool cross = X.groups > 1;
-    const uint32_t grp = cross ? blockIdx.x % X.groups : 0u;
+    // (X.first_wg: the workgroups before it are ordinary ones of the same launch — the split pairs then start on
+    // whatever CU frees up first; a workgroup only ever waits for one with a smaller index, dispatched before it)
+    const bool cross = X.groups > 1 && blockIdx.x >= X.first_wg;
+    const uint32_t xb = cross ? blockIdx.x - X.first_wg : 0u;
+    const uint32_t grp = cross ? xb % X.groups : 0u;
     const uint32_t slot = cross ? 0u : wv / wpp, wave = cross ? grp * wg_waves + wv : wv % wpp, nwaves = cross ? X.groups * wg_waves : wpp;
-    const uint32_t pslot = cross ? blockIdx.x / X.groups
+    const uint32_t pslot = cross ? X.first_pair + xb / X.groups
                          : tail  ? n_main * (wg_waves / wpp_main) + (blockIdx.x - n_main) * (wg_waves / wpp_tail) + slot
                                  : blockIdx.x * (wg_waves / wpp_main) + slot;  // pair of this wave, in `order`
     const bool live = pslot < count;
@@ -570,7 +575,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     uint32_t bc_i = 0;
 
     // the pairs of a workgroup may need different numbers of rounds: everybody stays for the barriers
-    uint32_t* xflag = cross ? X.flags + uint64_t(live ? pslot : 0) * X.flag_stride : nullptr;  // [band][strip]
+    uint32_t* xflag = cross ? X.flags + uint64_t(live ? pslot - X.first_pair : 0) * X.flag_stride : nullptr;  // [band][strip]
     bool xbad = false;
     if (live && lane == 0) atomicMax(&s_rounds, nstrips + nwaves - 1u);
     __syncthreads();
@@ -583,12 +588,14 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 // the band above lives in another workgroup: wait for its row checkpoint of this strip (bounded:
                 // the launch keeps all its workgroups resident, but a wait without an end could take the GPU down)
                 uint32_t seen = 0;
-                if (lane == 0) {
+                if (lane == 0 && !xbad) {
                     for (uint32_t it = 0; it < (1u << 22); ++it) {
                         seen = __hip_atomic_load(&xflag[uint64_t(wave - 1u) * nstrips + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (seen) break;
+                        if ((it & 1023u) == 1023u && __hip_atomic_load(X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // somebody gave up
                         __builtin_amdgcn_s_sleep(8);
                     }
+                    if (!seen) atomicOr(X.err, 1u);
                 }
                 seen = uint32_t(__builtin_amdgcn_readfirstlane(int(seen)));
                 if (!seen) xbad = true;
@@ -804,7 +811,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             if (lastc >= 0) {
                 s_best[wv][0] = bc;
                 s_best[wv][1] = int(bc_i);
-                if (cross) X.best[uint64_t(pslot) * nwaves + wave] = int2{bc, int(bc_i)};
+                if (cross) X.best[uint64_t(pslot - X.first_pair) * nwaves + wave] = int2{bc, int(bc_i)};
             }
             if (cross) {  // this band's checkpoints of the strip are out: tell the band below (and the final reduction)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -860,7 +867,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             uint32_t bi = 0, bjj = m;
             for (uint32_t b2 = 0; b2 < nwaves; ++b2) {  // bands top to bottom: the first row wins ties
                 if (min(n, b2 * tpb * TILE) >= n) break;
-                const int2 bb = cross ? X.best[uint64_t(pslot) * nwaves + b2] : int2{s_best[slot * wpp + b2][0], s_best[slot * wpp + b2][1]};
+                const int2 bb = cross ? X.best[uint64_t(pslot - X.first_pair) * nwaves + b2] : int2{s_best[slot * wpp + b2][0], s_best[slot * wpp + b2][1]};
                 if (bb.x > fin) {
                     fin = bb.x;
                     bi = uint32_t(bb.y);
@@ -1934,13 +1941,19 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 n_main = 0;
                 n_wg = 1;
             }
-            // (Opt-in, IOC_ALIGN_CROSS_TAIL=1: measured on config 3 the tail itself gets shorter, but as a launch of
-            // its own it can no longer start on the CUs whose main workgroups finish early, and the step ends up 5 ms
-            // longer: 112 ms against 105.)
-            if (n_main < n_wg && !packed && wg_waves == 4 && (force_cross || getenv("IOC_ALIGN_CROSS_TAIL"))) {
+            // Default: in the SAME launch, behind the ordinary workgroups, so that a split pair starts on whatever CU
+            // frees up first (config 3: 105.2 -> 96.0 ms).  IOC_ALIGN_CROSS_TAIL=separate makes it a launch of its own
+            // (one workgroup per CU by an LDS reservation; measured slower: it cannot backfill, 112 ms),
+            // IOC_ALIGN_NO_CROSS_TAIL=1 keeps the tail pairs whole with twice the waves (the first version).
+            // Workgroups of a launch are handed out in index order and a workgroup only waits for a smaller index;
+            // the split ones are at most a third of the chip's slots, so they can never fill an XCD with waiters.
+            const char* ct0 = getenv("IOC_ALIGN_CROSS_TAIL");
+            const bool inl = !(ct0 && strcmp(ct0, "separate") == 0) && !force_cross;
+            if (n_main < n_wg && !packed && wg_waves == 4 && !getenv("IOC_ALIGN_NO_CROSS_TAIL")) {
                 const AlnPairDev& big = dp[order[sl.first]];
                 const uint32_t strips = (big.m + 64 * FW_C - 1) / (64 * FW_C), tiles = (big.n + TILE - 1) / TILE;
-                groups = 4;
+                groups = 2;  // (4 was measured slower: 99 ms)
+                if (const char* eg = getenv("IOC_ALIGN_CROSS_GROUPS")) groups = uint32_t(std::max(1, std::min(4, atoi(eg))));
                 while (groups > 1 && (strips < 4 * groups || tiles < 8 * groups)) groups >>= 1;  // bands = 4 * groups
                 const uint32_t rest = sl.second - n_main * ppw;
                 // one workgroup per CU (two on a CU run at half speed and hold up the whole chain of their pair), all
@@ -1960,6 +1973,21 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 X.flags = X.err + 16;
                 X.best = reinterpret_cast<int2*>(reinterpret_cast<uint8_t*>(c->a_xflags.p) + 64 + fbytes);
                 ACHK(c, hipMemsetAsync(c->a_xflags.p, 0, 64 + fbytes, s));
+                if (inl && first_cnt) {
+                    // one launch: ordinary workgroups, then the split pairs behind them
+                    X.first_wg = n_main;
+                    X.first_pair = first_cnt;
+                    launch_fwd(ord, sl.second, waves, wg_waves, n_main + rest * groups, n_main + rest * groups, waves, lds_pad,
+                               static_cast<int2*>(c->a_lrow.p), X);
+                    ACHK(c, hipGetLastError());
+                    uint32_t xe = 0;
+                    ACHK(c, hipMemcpyAsync(&xe, X.err, 4, hipMemcpyDeviceToHost, s));
+                    ACHK(c, hipStreamSynchronize(s));
+                    if (xe) {
+                        launch_fwd(ord + first_cnt, rest, 4, 4, rest, rest, 4, 0, static_cast<int2*>(c->a_lrow.p) + uint64_t(first_cnt) * lrow_stride, AlnCross{});
+                        c->tm.n_align_refused += rest;
+                    }
+                } else {
                 if (first_cnt) launch_fwd(ord, first_cnt, waves, wg_waves, n_main, n_main, waves, lds_pad, static_cast<int2*>(c->a_lrow.p), AlnCross{});
                 ACHK(c, hipGetLastError());
                 size_t xlds = 0;  // more than half a CU's LDS: the dispatcher cannot stack two of them
@@ -1989,6 +2017,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                     launch_fwd(ord + first_cnt, rest, 4, 4, rest, rest, 4, 0,
                                static_cast<int2*>(c->a_lrow.p) + uint64_t(first_cnt) * lrow_stride, AlnCross{});
                     c->tm.n_align_refused += rest;
+                }
                 }
             } else {
                 if (force_cross && n_main == 0) {  // (the forced split did not fit this slice)

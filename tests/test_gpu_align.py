@@ -186,6 +186,15 @@ def test_full_length_pairs_two_device_formulations_agree(ctx, monkeypatch):
     s4, w4, _ = ctx.align_pairs(pairs, 11)
     assert ctx.timings()["n_align_refused"] == 0          # every pair stayed inside the 16-bit window
     monkeypatch.delenv("IOC_ALIGN_PACKED")
+    monkeypatch.setenv("IOC_ALIGN_FORCE_CROSS", "1")      # every pair split over 2, then 4 workgroups
+    s5, w5, _ = ctx.align_pairs(pairs, 11)
+    monkeypatch.setenv("IOC_ALIGN_CROSS_GROUPS", "4")
+    s6, w6, _ = ctx.align_pairs(pairs[:60], 11)
+    assert ctx.timings()["n_align_refused"] == 0
+    monkeypatch.delenv("IOC_ALIGN_FORCE_CROSS")
+    monkeypatch.delenv("IOC_ALIGN_CROSS_GROUPS")
+    assert np.array_equal(s1, s5) and np.array_equal(w1, w5)
+    assert np.array_equal(s1[:60], s6) and np.array_equal(w1[:60], w6)
     assert np.array_equal(s1, s2) and np.array_equal(w1, w2)
     assert np.array_equal(s1, s3) and np.array_equal(w1, w3)
     assert np.array_equal(s1, s4) and np.array_equal(w1, w4)
@@ -232,3 +241,22 @@ def test_pairs_split_over_workgroups(ctx, monkeypatch):
             pairs.append((a, b, (a + b) % 2, rng.choice([0.05, 0.2])))
     _check(ctx, seqs, pairs, 11)
     assert ctx.timings()["n_align_refused"] == 0      # no wait ran out
+
+
+def test_tail_generation_split_in_launch(ctx, monkeypatch):
+    """More pairs than one resident generation of workgroups (config 3's 1622 pairs of 16.7 kb): the pairs of the
+    tail generation are split over two workgroups each, in the same launch behind the ordinary ones.  Same results
+    as with whole tail pairs (IOC_ALIGN_NO_CROSS_TAIL), and no wait ran out."""
+    from isonclust2_amd import synth
+    rs = synth.generate_config("config2", seed=1)
+    rng = random.Random(43)
+    ids = rng.sample(range(rs.n), 200)
+    seqs = [bytes(rs.read(i)[0]) for i in ids]
+    pairs = [(rng.randrange(200), rng.randrange(200), rng.random() < 0.5, 0.05 + 0.2 * rng.random()) for _ in range(1622)]
+    ctx.align_set_pool(seqs)
+    s1, w1, _ = ctx.align_pairs(pairs, 11)
+    assert ctx.timings()["n_align_refused"] == 0
+    monkeypatch.setenv("IOC_ALIGN_NO_CROSS_TAIL", "1")
+    s2, w2, _ = ctx.align_pairs(pairs, 11)
+    assert np.array_equal(s1, s2) and np.array_equal(w1, w2)
+    assert len(set(int(x) for x in w1)) > 50
