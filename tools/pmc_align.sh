@@ -7,7 +7,7 @@ OUT=gpurun_out/pmc_align
 mkdir -p "$OUT"
 CMD="python3 bench.py --mode sahlin --steps 1 --warmup 0 --no-cpu-baseline"
 for v in packed plain; do
-  if [ $v = plain ]; then export IOC_ALIGN_NO_PACKED=1; else unset IOC_ALIGN_NO_PACKED; fi
+  if [ $v = packed ]; then export IOC_ALIGN_PACKED=1; else unset IOC_ALIGN_PACKED; fi
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU --kernel-trace --output-format csv -d "$OUT/$v" -- $CMD > "$OUT/$v.log" 2>&1
   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_MISC --kernel-trace --output-format csv -d "$OUT/${v}2" -- $CMD > "$OUT/${v}2.log" 2>&1
 done
