@@ -1794,6 +1794,9 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         }
     }
     if (packed && waves > uint32_t(P16_MAXW)) waves = P16_MAXW;
+    // a handful of long pairs (the later alignment rounds of a batch): 4-wave workgroups, several per pair (below)
+    const bool few_pairs = !carry && !packed && !getenv("IOC_ALIGN_WAVES") && np <= 64 && waves >= 4 && !getenv("IOC_ALIGN_NO_CROSS_TAIL");
+    if (few_pairs) waves = 4;
     const uint32_t NT = waves * 64;
     int r;
     if ((r = reserve(c, c->a_pairs, size_t(np) * sizeof(AlnPairDev))) != IOC_OK) return r;
@@ -1936,7 +1939,8 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             // launch: all its workgroups are resident together, and the waits are bounded anyway (then the pairs
             // are simply done again the usual way).
             uint32_t groups = 1;
-            const bool force_cross = getenv("IOC_ALIGN_FORCE_CROSS") != nullptr;  // (tests: the whole slice the tail's way)
+            // the whole slice the tail's way: forced (tests), or a handful of pairs on an otherwise idle chip
+            const bool force_cross = getenv("IOC_ALIGN_FORCE_CROSS") != nullptr || (few_pairs && waves == 4);
             if (force_cross && !packed && wg_waves == 4) {
                 n_main = 0;
                 n_wg = 1;
@@ -1952,7 +1956,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             if (n_main < n_wg && !packed && wg_waves == 4 && !getenv("IOC_ALIGN_NO_CROSS_TAIL")) {
                 const AlnPairDev& big = dp[order[sl.first]];
                 const uint32_t strips = (big.m + 64 * FW_C - 1) / (64 * FW_C), tiles = (big.n + TILE - 1) / TILE;
-                groups = 2;  // (4 was measured slower: 99 ms)
+                groups = force_cross ? 4 : 2;  // (behind a full generation 4 was measured slower: 99 ms)
                 if (const char* eg = getenv("IOC_ALIGN_CROSS_GROUPS")) groups = uint32_t(std::max(1, std::min(4, atoi(eg))));
                 while (groups > 1 && (strips < 4 * groups || tiles < 8 * groups)) groups >>= 1;  // bands = 4 * groups
                 const uint32_t rest = sl.second - n_main * ppw;
