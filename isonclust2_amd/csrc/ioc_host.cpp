@@ -308,8 +308,8 @@ static void revcomp_inplace(std::string& s)
 
 // ---- alignment fallback (getBestClusterAln, cluster.cpp:461-515) --------------------------------------
 // The alignment of (query, candidate, strand) is a pure function of the two sequences, so results are
-// cached and the pairs of many queries are aligned in one GPU batch (ioc_align_pairs).  IOC_ALIGN_HOST=1
-// (or k > 32) routes the same pairs through the host aligner instead.
+// cached and the pairs of many queries are aligned in one GPU batch (ioc_align_pairs).  IOC_ALIGN_HOST=1 (tests
+// only) routes the same pairs through the host aligner instead.
 struct AlnDriver {
     ioc_ctx* c = nullptr;
     const SeqAccess* sa = nullptr;
@@ -321,7 +321,11 @@ struct AlnDriver {
 
     int init()
     {
-        host_only = getenv("IOC_ALIGN_HOST") != nullptr || c->params.k > 32;
+        // IOC_ALIGN_HOST=1 is a TEST knob (the host aligner is the definition the GPU kernels are checked against):
+        // nothing routes to it by itself — a window length the GPU aligner does not take is an error
+        host_only = getenv("IOC_ALIGN_HOST") != nullptr;
+        if (!host_only && c->params.k > 32)
+            return ioc_fail(c, IOC_ERR_CAPACITY, "alignment fallback: window length k above 32 is not supported by the GPU aligner");
         if (host_only) return IOC_OK;
         // resident queries: the pool was uploaded once by ioc_resident_set_sequences
         if (c->res_pool_ready && c->L == 0 && sa->r_seq == c->res_seq.data()) return IOC_OK;
