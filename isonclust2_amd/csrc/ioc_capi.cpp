@@ -103,7 +103,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -778,7 +778,7 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
     RESERVE(c, c->b_qfirst, size_t(2) * T * 4);
     const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
     // the table is compacted on the device: a query hits a few dozen of its 2 T possible (target, strand) cells
-    const uint32_t n2 = 2u * T, QC = std::min<uint32_t>(n2, 4096u);
+    const uint32_t n2 = 2u * T, QC = std::min<uint32_t>(n2, 32768u);  // (a query of a 30 k-read batch hits ~20 k cells)
     RESERVE(c, c->b_qout, (size_t(1) + 3 * size_t(QC)) * 4);
     std::vector<uint32_t> ho(size_t(1) + 3 * size_t(QC));
     uint32_t cc = 0;
@@ -858,6 +858,158 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
     if (out > cap) return ioc_fail(c, IOC_ERR_CAPACITY, "candidate buffer too small: need " + std::to_string(out));
     return out;
 }
+
+}  // extern "C"
+
+int ioc_query_candidates_many(ioc_ctx* c, const std::vector<int>& qs, std::vector<IocCandTable>& out)
+{
+    out.clear();
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
+    for (int q : qs)
+        if (q < 0 || q >= c->n) return ioc_fail(c, IOC_ERR_ARG, "bad query index");
+    out.resize(qs.size());
+    if (qs.empty()) return IOC_OK;
+    hipStream_t s = c->stream;
+    const uint32_t L = uint32_t(c->L);
+    const size_t n = size_t(c->n);
+    // the candidate lists' fill counts, once
+    std::vector<uint32_t> ccount(n);
+    HIPCHK(c, hipMemcpyAsync(ccount.data(), c->b_cand_count.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
+    size_t done = 0;
+    while (done < qs.size()) {
+        // a chunk: tables of `stride` words per query (the largest 2 T of the chunk), at most 256 MB each
+        uint32_t maxT = 1;
+        size_t cnt = 0;
+        while (done + cnt < qs.size() && cnt < 512) {
+            const uint32_t T = L + uint32_t(qs[done + cnt]);
+            const uint32_t mt = std::max(maxT, T);
+            if (cnt > 0 && uint64_t(cnt + 1) * 2ull * mt * 4ull > (256ull << 20)) break;
+            maxT = mt;
+            ++cnt;
+        }
+        const uint64_t stride = 2ull * maxT;
+        const uint32_t QC = uint32_t(stride);  // (every cell could be hit; only the filled part of a slice is copied back)
+        const size_t out_words = size_t(1) + 3 * size_t(QC);
+        RESERVE(c, c->b_qhist, size_t(cnt) * stride * 4);
+        RESERVE(c, c->b_qfirst, size_t(cnt) * stride * 4);
+        RESERVE(c, c->b_qout, size_t(cnt) * out_words * 4);
+        RESERVE(c, c->b_qlist, size_t(cnt) * 4);
+        std::vector<int32_t> ql(qs.begin() + done, qs.begin() + done + cnt);
+        const bool trq = getenv("IOC_TRACE") != nullptr;
+        auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tq0 = tnow();
+        HIPCHK(c, hipMemcpyAsync(c->b_qlist.p, ql.data(), cnt * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemsetAsync(c->b_qhist.p, 0, size_t(cnt) * stride * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_qfirst.p, 0xFF, size_t(cnt) * stride * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_qout.p, 0, size_t(cnt) * out_words * 4, s));
+        HIPCHK(c, iock_query_table_many(s, int(cnt), P<int32_t>(c->b_qlist), stride, L, c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p,
+                                        c->cap, hash_shift(c->cap), c->b_post.p, valid, P<uint32_t>(c->b_qhist), P<uint32_t>(c->b_qfirst),
+                                        c->post16, QC, P<uint32_t>(c->b_qout)));
+        if (trq) HIPCHK(c, hipStreamSynchronize(s));
+        const double tq1 = tnow();
+        // the fill counts first (one strided copy), then the filled part of every slice
+        std::vector<uint32_t> hcnt(cnt);
+        HIPCHK(c, hipMemcpy2DAsync(hcnt.data(), 4, c->b_qout.p, out_words * 4, 4, cnt, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        std::vector<size_t> hoff(cnt + 1, 0);
+        for (size_t x = 0; x < cnt; ++x) hoff[x + 1] = hoff[x] + 1 + 3 * size_t(std::min<uint32_t>(hcnt[x], QC));
+        std::vector<uint32_t> ho(hoff[cnt]);
+        for (size_t x = 0; x < cnt; ++x)
+            HIPCHK(c, hipMemcpyAsync(ho.data() + hoff[x], P<uint32_t>(c->b_qout) + x * out_words, (hoff[x + 1] - hoff[x]) * 4, hipMemcpyDeviceToHost, s));
+        if (trq) HIPCHK(c, hipStreamSynchronize(s));
+        const double tq2 = tnow();
+        // the queries' candidate lists (cached totalMapped values)
+        std::vector<std::vector<uint32_t>> ck(cnt), cm(cnt);
+        for (size_t x = 0; x < cnt; ++x) {
+            const int q = ql[x];
+            const uint32_t cc = ccount[size_t(q)];
+            const uint64_t cbase = 2ull * L * uint64_t(q) + uint64_t(q) * uint64_t(q > 0 ? q - 1 : 0);
+            if (cc > 2u * (L + uint32_t(q))) return ioc_fail(c, IOC_ERR_STATE, "candidate list longer than its capacity");
+            ck[x].resize(cc);
+            cm[x].resize(cc);
+            if (cc) {
+                HIPCHK(c, hipMemcpyAsync(ck[x].data(), P<uint32_t>(c->b_cand_key) + cbase, size_t(cc) * 4, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipMemcpyAsync(cm[x].data(), P<uint32_t>(c->b_cand_mapped) + cbase, size_t(cc) * 4, hipMemcpyDeviceToHost, s));
+            }
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (trq)
+            fprintf(stderr, "[ioc]   %zu candidate tables: kernels %.1f ms, compact lists back %.1f ms, candidate lists back %.1f ms\n", cnt, tq1 - tq0,
+                    tq2 - tq1, tnow() - tq2);
+        std::vector<int> overflow(cnt, 0);
+        const double tq3 = tnow();
+        ioc_parallel_for(cnt, [&](size_t x) {
+            const int q = ql[x];
+            const uint32_t T = L + uint32_t(q);
+            const uint32_t* o = ho.data() + hoff[x];
+            if (o[0] > QC) {
+                overflow[x] = 1;
+                return;
+            }
+            struct Hit {
+                uint32_t idx, size, first;
+            };
+            std::vector<Hit> hits(o[0]);
+            for (uint32_t i = 0; i < o[0]; ++i) hits[i] = Hit{o[1 + 3 * i], o[2 + 3 * i], o[3 + 3 * i]};
+            std::sort(hits.begin(), hits.end(), [](const Hit& a, const Hit& b) { return a.idx < b.idx; });
+            std::vector<std::pair<uint32_t, uint32_t>> mapped;
+            mapped.reserve(ck[x].size());
+            for (size_t i = 0; i < ck[x].size(); ++i) {
+                const uint32_t tg = ck[x][i] >> 1, sb = ck[x][i] & 1u;
+                if (tg < T) mapped.emplace_back(sb * T + tg, cm[x][i]);
+            }
+            auto by_cell = [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; };
+            std::stable_sort(mapped.begin(), mapped.end(), by_cell);
+            IocCandTable& t = out[done + x];
+            t.q = q;
+            t.tg.resize(hits.size());
+            t.st.resize(hits.size());
+            t.sz.resize(hits.size());
+            t.fi.resize(hits.size());
+            t.tm.resize(hits.size());
+            for (size_t i = 0; i < hits.size(); ++i) {
+                const uint32_t sb = hits[i].idx >= T ? 1u : 0u;
+                t.tg[i] = int32_t(hits[i].idx - sb * T);
+                t.st[i] = sb ? -1 : 1;
+                t.sz[i] = hits[i].size;
+                t.fi[i] = hits[i].first;
+                auto it = std::lower_bound(mapped.begin(), mapped.end(), std::make_pair(hits[i].idx, 0u), by_cell);
+                uint32_t mv = 0xFFFFFFFFu;
+                for (; it != mapped.end() && it->first == hits[i].idx; ++it) mv = it->second;
+                t.tm[i] = mv;
+            }
+        });
+        if (trq) fprintf(stderr, "[ioc]   ... lists sorted on the host's cores in %.1f ms\n", tnow() - tq3);
+        // (a table with more cells than the compact buffer holds: the one-query path copies it whole)
+        for (size_t x = 0; x < cnt; ++x)
+            if (overflow[x]) {
+                const int q = ql[x];
+                const size_t cap = size_t(2) * (L + uint32_t(q)) + 1;
+                IocCandTable& t = out[done + x];
+                t.q = q;
+                t.tg.resize(cap);
+                t.st.resize(cap);
+                t.sz.resize(cap);
+                t.fi.resize(cap);
+                t.tm.resize(cap);
+                const int nc = ioc_query_candidates(c, q, int32_t(cap - 1), t.tg.data(), t.st.data(), t.sz.data(), t.fi.data(), t.tm.data());
+                if (nc < 0) return nc;
+                t.tg.resize(size_t(nc));
+                t.st.resize(size_t(nc));
+                t.sz.resize(size_t(nc));
+                t.fi.resize(size_t(nc));
+                t.tm.resize(size_t(nc));
+            }
+        done += cnt;
+    }
+    return IOC_OK;
+}
+
+extern "C" {
 
 // The export (device -> host copy of the combined index, renumbering, sort by key) is computed once per
 // resolve and kept: callers size with a first call (keys == NULL) and fetch with a second one.

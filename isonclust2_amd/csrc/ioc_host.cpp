@@ -177,28 +177,15 @@ struct Ordered {
     uint32_t size, mapped;
 };
 
-// the device's hit table of one query (ioc_query_candidates), kept so that the host part can run on a thread
-struct RawCands {
-    int q = 0, nc = 0;
-    std::vector<int32_t> tg;
-    std::vector<int8_t> st;
-    std::vector<uint32_t> sz, fi, tm;
-};
+// the device's hit table of one query (IocCandTable, ioc_internal.h), kept so that the host part can run on a thread
+using RawCands = IocCandTable;
 
 static int fetch_cands(ioc_ctx* c, int q, RawCands& rc)
 {
-    const int T = c->L + q;
-    rc.q = q;
-    rc.tg.resize(size_t(2) * T + 1);
-    rc.st.resize(size_t(2) * T + 1);
-    rc.sz.resize(size_t(2) * T + 1);
-    rc.fi.resize(size_t(2) * T + 1);
-    rc.tm.resize(size_t(2) * T + 1);
-    rc.nc = ioc_query_candidates(c, q, 2 * T, rc.tg.data(), rc.st.data(), rc.sz.data(), rc.fi.data(), rc.tm.data());
-    if (rc.nc < 0) return rc.nc;
-    for (auto* v : {&rc.sz, &rc.fi, &rc.tm}) v->resize(size_t(rc.nc));
-    rc.tg.resize(size_t(rc.nc));
-    rc.st.resize(size_t(rc.nc));
+    std::vector<RawCands> one;
+    int r = ioc_query_candidates_many(c, std::vector<int>{q}, one);
+    if (r != IOC_OK) return r;
+    rc = std::move(one[0]);
     return IOC_OK;
 }
 
@@ -206,7 +193,7 @@ static int fetch_cands(ioc_ctx* c, int q, RawCands& rc)
 static void order_from(const ioc_ctx* c, const RawCands& rc, const std::vector<int32_t>& cid, std::vector<Ordered>& out)
 {
     out.clear();
-    const int q = rc.q, nc = rc.nc;
+    const int q = rc.q, nc = int(rc.tg.size());
     const std::vector<int32_t>& tg = rc.tg;
     const std::vector<int8_t>& st = rc.st;
     const std::vector<uint32_t>&sz = rc.sz, &fi = rc.fi, &tm = rc.tm;
@@ -548,9 +535,14 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
                 if (ad.cache[AlnDriver::key(bad[b], t)] >= c->params.aligned_threshold) passes[b].push_back(t);
             if (passes[b].size() > 1) multi.push_back(b);
         }
-        std::vector<RawCands> raws(multi.size());
-        for (size_t x = 0; x < multi.size(); ++x)
-            if ((r = fetch_cands(c, bad[multi[x]], raws[x])) != IOC_OK) return r;
+        std::vector<RawCands> raws;
+        {
+            std::vector<int> mq(multi.size());
+            for (size_t x = 0; x < multi.size(); ++x) mq[x] = bad[multi[x]];
+            if ((r = ioc_query_candidates_many(c, mq, raws)) != IOC_OK) return r;  // one launch per chunk of queries
+        }
+        tr.calls += int64_t(multi.size());
+        if (!multi.empty()) tr.mark("  candidate tables fetched");
         tr.calls += int64_t(multi.size());
         std::vector<int32_t> win_t(multi.size(), -1);
         std::vector<int8_t> win_s(multi.size(), 0);

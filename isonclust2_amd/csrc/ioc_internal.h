@@ -89,7 +89,7 @@ struct ioc_ctx {
     std::vector<uint8_t> aln_other;  // per pool sequence: holds a byte other than A C G T
     std::vector<int64_t> aln_offs;
     DevBuf b_aln_t, b_aln_s, b_tie_count, b_tie_keys;
-    DevBuf b_qhist, b_qfirst, b_qout;
+    DevBuf b_qhist, b_qfirst, b_qout, b_qlist;
     // ioc_resolve warm start: first query whose alignment verdict changed since the last resolve (n: none; -1: no
     // resolved state to start from).  Everything before it keeps its decision (it depends on earlier queries only).
     int32_t warm_first = -1;  // ioc_query_candidates: the query's hit table (kept between calls)
@@ -120,6 +120,18 @@ struct ioc_ctx {
 
 int ioc_fail(ioc_ctx* c, int code, const std::string& msg);
 
+
+
+// ioc_query_candidates for many queries at once (one launch per chunk, one synchronisation): per query the same
+// lists — target, strand (+1 / -1), Size, first hitting Index, cached totalMapped (0xFFFFFFFF: not evaluated) —
+// in ascending (strand +1 first, target) order.  Internal: used by the hitOrder replay of the sahlin driver.
+struct IocCandTable {
+    int q = 0;
+    std::vector<int32_t> tg;
+    std::vector<int8_t> st;
+    std::vector<uint32_t> sz, fi, tm;
+};
+int ioc_query_candidates_many(ioc_ctx* c, const std::vector<int>& qs, std::vector<IocCandTable>& out);
 
 // f(0) .. f(count - 1) on the host's cores (independent items only)
 #include <atomic>

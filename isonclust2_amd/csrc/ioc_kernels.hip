@@ -1679,6 +1679,67 @@ k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int6
     }
 }
 
+template <typename PT>
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_query_table_many(const int32_t* __restrict__ qlist, uint64_t stride, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
+              const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
+              const PT* __restrict__ post, const uint8_t* __restrict__ valid, uint32_t* __restrict__ hist_base,
+              uint32_t* __restrict__ first_base)
+{
+    // blockIdx.y = position in the query list; every query has a slice of `stride` words in the two tables
+    const int j = qlist[blockIdx.y];
+    uint32_t* __restrict__ hist = hist_base + uint64_t(blockIdx.y) * stride;
+    uint32_t* __restrict__ first = first_base + uint64_t(blockIdx.y) * stride;
+    const uint32_t T = L + uint32_t(j);
+    const int lane = lane_id();
+    const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6;
+    const uint32_t nw = (gridDim.x * IOC_BLOCK) >> 6;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t b = s == 0 ? off_fwd[j] : off_rev[j];
+        const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
+        for (int64_t c0 = b + int64_t(gw) * 64; c0 < e; c0 += int64_t(nw) * 64) {
+            int64_t t = c0 + lane;
+            uint32_t o = 0, c = 0, qi_ = 0;
+            if (t < e) index_lookup(rows, cap, shift, mins[t], o, c, qi_);
+            unsigned long long mask = __ballot(c != 0);
+            while (mask) {
+                int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                uint32_t lo = __builtin_amdgcn_readlane(o, l);
+                uint32_t lc = __builtin_amdgcn_readlane(c, l);
+                uint32_t idx = uint32_t(c0 + l - b);
+                for (uint32_t p = lane; p < lc; p += 64) {
+                    uint32_t tg = post[lo + p];
+                    if (tg < T && (tg < L || valid[tg - L])) {
+                        atomicAdd(&hist[uint32_t(s) * T + tg], 1u);
+                        atomicMin(&first[uint32_t(s) * T + tg], idx);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the non-empty cells of every query's table: out slice = [count][idx, Size, first] * cap
+__global__ void __launch_bounds__(256) k_query_compact_many(const int32_t* __restrict__ qlist, uint64_t stride, uint32_t L,
+                                                             const uint32_t* __restrict__ hist_base, const uint32_t* __restrict__ first_base,
+                                                             uint32_t cap, uint32_t* __restrict__ out_base)
+{
+    const uint32_t n2 = 2u * (L + uint32_t(qlist[blockIdx.y]));
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const uint32_t* hist = hist_base + uint64_t(blockIdx.y) * stride;
+    const uint32_t sz = hist[i];
+    if (!sz) return;
+    uint32_t* out = out_base + uint64_t(blockIdx.y) * (1u + 3u * uint64_t(cap));
+    const uint32_t pos = atomicAdd(&out[0], 1u);
+    if (pos < cap) {
+        out[1 + 3 * pos] = i;
+        out[2 + 3 * pos] = sz;
+        out[3 + 3 * pos] = first_base[uint64_t(blockIdx.y) * stride + i];
+    }
+}
+
 // =====================================================================================================
 // launchers
 // =====================================================================================================
@@ -1919,6 +1980,24 @@ __global__ void __launch_bounds__(256) k_query_compact(const uint32_t* __restric
 hipError_t iock_query_compact(hipStream_t st, const uint32_t* hist, const uint32_t* first, uint32_t n2, uint32_t cap, uint32_t* out)
 {
     hipLaunchKernelGGL(k_query_compact, dim3((n2 + 255) / 256), dim3(256), 0, st, hist, first, n2, cap, out);
+    return hipGetLastError();
+}
+
+hipError_t iock_query_table_many(hipStream_t st, int nq, const int32_t* qlist, uint64_t stride, uint32_t L, const int64_t* off_fwd,
+                                 const int64_t* off_rev, const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift,
+                                 const void* post, const uint8_t* valid, uint32_t* hist, uint32_t* first, int post16, uint32_t ccap,
+                                 uint32_t* out)
+{
+    if (post16)
+        hipLaunchKernelGGL(k_query_table_many<uint16_t>, dim3(16, unsigned(nq)), dim3(IOC_BLOCK), 0, st, qlist, stride, L, off_fwd, off_rev,
+                           mins, (const uint4*)rows, cap, shift, (const uint16_t*)post, valid, hist, first);
+    else
+        hipLaunchKernelGGL(k_query_table_many<uint32_t>, dim3(16, unsigned(nq)), dim3(IOC_BLOCK), 0, st, qlist, stride, L, off_fwd, off_rev,
+                           mins, (const uint4*)rows, cap, shift, (const uint32_t*)post, valid, hist, first);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_query_compact_many, dim3(unsigned((stride + 255) / 256), unsigned(nq)), dim3(256), 0, st, qlist, stride, L, hist, first,
+                       ccap, out);
     return hipGetLastError();
 }
 

@@ -26,10 +26,17 @@ with open(fq, "wb") as f:
 env = dict(os.environ, ISONCLUST2_STATS_JSON="1")
 
 
+stats = []
+
+
 def run(args):
     t = time.time()
     r = subprocess.run([CLI] + args, capture_output=True, text=True, env=env)
     assert r.returncode == 0, (args, r.stderr[-2000:])
+    if args[0] == "cluster":
+        js = [l for l in r.stderr.splitlines() if l.startswith("{")]
+        if js:
+            stats.append(json.loads(js[-1]))
     return time.time() - t
 
 
@@ -64,5 +71,26 @@ if os.path.exists(tsv):
         n += 1
     out["clusters"], out["reads_assigned"] = len(ids), n
 out["total_s"] = out["sort_s"] + sum(cl) + sum(mg) + out["dump_s"]
+out["cluster_stats"] = stats
+if os.environ.get("IOC_CLI4_TRACE"):   # phase trace of the slowest batch, aggregated
+    worst = max(range(len(cl)), key=lambda i: cl[i])
+    r = subprocess.run([CLI, "cluster", "-l", os.path.join(d, "sorted", "batches", batches[worst]), "-o", os.path.join(d, "x.cer"), "-x", mode],
+                       capture_output=True, text=True, env=dict(env, IOC_TRACE="1"))
+    agg = {}
+    for line in r.stderr.splitlines():
+        if line.startswith("[ioc] ") and line.rstrip().endswith("ms") is False and " ms" in line:
+            pass
+        if line.startswith("[ioc] "):
+            parts = line[6:].rsplit(None, 2)
+            try:
+                ms = float(parts[-2]) if parts[-1] == "ms" else float(line.split(" ms")[0].split()[-1])
+            except Exception:  # noqa: BLE001
+                continue
+            name = line[6:34].strip()
+            a = agg.setdefault(name, [0, 0.0])
+            a[0] += 1
+            a[1] += ms
+    out["slowest_batch_trace"] = {k: [v[0], round(v[1], 1)] for k, v in agg.items()}
+    out["slowest_batch_verdict_lines"] = [l for l in r.stderr.splitlines() if "verdicts" in l or "alignment batch" in l or "candidate tables" in l or "candidate lists" in l or "lists sorted" in l]
 print(json.dumps(out))
 subprocess.call(["rm", "-rf", d])
