@@ -91,6 +91,7 @@ if os.environ.get("IOC_CLI4_TRACE"):   # phase trace of the slowest batch, aggre
             a[0] += 1
             a[1] += ms
     out["slowest_batch_trace"] = {k: [v[0], round(v[1], 1)] for k, v in agg.items()}
+    out["slowest_batch_all_lines"] = [l for l in r.stderr.splitlines() if l.startswith("[ioc]") or l.startswith("{")][:60]
     out["slowest_batch_verdict_lines"] = [l for l in r.stderr.splitlines() if "verdicts" in l or "alignment batch" in l or "candidate tables" in l or "candidate lists" in l or "lists sorted" in l]
 print(json.dumps(out))
 subprocess.call(["rm", "-rf", d])
