@@ -1950,7 +1950,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             // (one workgroup per CU by an LDS reservation; measured slower: it cannot backfill, 112 ms),
             // IOC_ALIGN_NO_CROSS_TAIL=1 keeps the tail pairs whole with twice the waves (the first version).
             // Workgroups of a launch are handed out in index order and a workgroup only waits for a smaller index;
-            // the split ones are at most a third of the chip's slots, so they can never fill an XCD with waiters.
+            // the split ones are at most two thirds of an XCD's slots, so they can never fill an XCD with waiters.
             const char* ct0 = getenv("IOC_ALIGN_CROSS_TAIL");
             const bool inl = !(ct0 && strcmp(ct0, "separate") == 0) && !force_cross;
             if (n_main < n_wg && !packed && wg_waves == 4 && !getenv("IOC_ALIGN_NO_CROSS_TAIL")) {
@@ -1962,7 +1962,9 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                 const uint32_t rest = sl.second - n_main * ppw;
                 // one workgroup per CU (two on a CU run at half speed and hold up the whole chain of their pair), all
                 // resident together
-                while (groups > 1 && uint64_t(rest) * groups > uint64_t(n_cu)) groups >>= 1;
+                // (in-launch: at most 2 split workgroups per CU's worth, i.e. 64 of an XCD's 96 slots — waiters cannot
+                // fill an XCD; a launch of its own: one per CU)
+                while (groups > 1 && uint64_t(rest) * groups > uint64_t(inl ? 2 : 1) * uint64_t(n_cu)) groups >>= 1;
             }
             if (groups > 1) {
                 const uint32_t first_cnt = n_main * ppw, rest = sl.second - first_cnt, nb = 4 * groups;
