@@ -9,8 +9,11 @@ issue roofline of the forward DP kernel that dominates a sahlin step.
 
 One "step" = one pass of the hot path (ioc_cluster_resident) over one sorted batch whose minimizer SoA and raw
 sequences are already resident in HBM.  Batches shard one per GPU with no data-path collective (weak
-scaling); ranks only meet at the timing barrier.  Inputs are synthetic (isonclust2_amd/synth.py, seed = 1 +
-rank) and are prepared by the product's own GPU sort stage (ioc_qual_scores / ioc_extract_minimizers), never
+scaling); ranks only meet at the timing barrier.  Inputs are synthetic (isonclust2_amd/synth.py): every rank
+generates and prepares its OWN copy of the same batch (seed 1) — weak scaling with the per-GPU work fixed, so that
+the max over ranks measures the system and not the spread between batches (other seeds of the same shape take
+115-149 ms: some need a second alignment round); --rank-seeds gives rank r the batch of seed 1 + r instead.
+Inputs are prepared by the product's own GPU sort stage (ioc_qual_scores / ioc_extract_minimizers), never
 by the oracle.  The oracle appears only in the cpu_baseline legs (rank 0, N=1): timed on one host core — the
 full batch in fast mode (doubling as a full-size parity check), a bounded sample in sahlin mode.
 
@@ -181,6 +184,7 @@ def main():
                          "result (configs[1]) of the same batch beside it; fast / sahlin = that mode only")
     ap.add_argument("--cpu-sample", type=int, default=30, help="sahlin: reads in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rank-seeds", action="store_true", help="rank r clusters the batch of seed 1 + r (default: every rank the batch of seed 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--merge", action="store_true",
                     help="after the timed region: all-gather the clustered batches and left-fold merge them on rank 0")
@@ -211,7 +215,7 @@ def main():
     ctx = api.Context(dev_index)
     want_fast = a.mode in ("both", "fast")
     want_sahlin = a.mode in ("both", "sahlin")
-    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + rank, k, w,
+    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + (rank if a.rank_seeds else 0), k, w,
                                               "sahlin" if want_sahlin else "fast")
     if dist is not None:
         nreads = torch.tensor([rs.n], dtype=torch.int64, device=dev)
@@ -313,7 +317,8 @@ def main():
             "config": {"workload": f"{a.config} = BASELINE.json configs[{2 if head_mode == 'sahlin' else 1}]: {rs.tag}; one sorted "
                                    "3000-read / 50 Mb batch per GPU, minimizer SoA and sequences resident in HBM",
                        "mode": head_mode, "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
-                       "parallelism": f"batch-shard x{world}, no data-path collective"},
+                       "parallelism": f"batch-shard x{world}, no data-path collective",
+                       "rank_batches": "seed 1 + rank" if a.rank_seeds else "every rank its own copy of the seed-1 batch"},
             "phase_ms": head["phase_ms"],
             "roofline": roof if roof is not None else roof_aln,
             "cpu_baseline": head.get("cpu_baseline"), "parity": head.get("parity"),
