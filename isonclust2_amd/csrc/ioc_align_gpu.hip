@@ -1968,8 +1968,12 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             }
             if (groups > 1) {
                 const uint32_t first_cnt = n_main * ppw, rest = sl.second - first_cnt, nb = 4 * groups;
-                const AlnPairDev& big = dp[order[sl.first]];
-                const uint32_t strips = (big.m + 64 * FW_C - 1) / (64 * FW_C);
+                // flags are indexed [band][strip] with every pair's OWN strip count: a pair with fewer cells than the
+                // slice's first one may still have the longer reference, so the slot holds the largest count of the
+                // pairs that are actually split
+                uint32_t strips = 1;
+                for (uint32_t x = first_cnt; x < sl.second; ++x)
+                    strips = std::max(strips, (dp[order[sl.first + x]].m + 64 * FW_C - 1) / (64 * FW_C));
                 AlnCross X;
                 X.groups = groups;
                 X.flag_stride = nb * strips;

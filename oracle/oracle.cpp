@@ -13,10 +13,14 @@
  * known answers (test/isONclust2_test.cpp) and against oracle/_ref (the reference TUs that
  * compile stand-alone: kmer_index.cpp, util.cpp, p_emp_prob.cpp).
  *
- * Not restated (host-side third-party arithmetic absent from /root/reference): parasail
- * alignment (src/cluster.cpp:408-515) and spoa consensus (src/consensus.cpp).  Mode sahlin /
- * furious therefore return -2 from orc_cluster when an alignment would be needed, unless
- * built with an aligner hook (see orc_set_aligner).
+ * Third-party arithmetic absent from /root/reference: parasail (jeffdaily/parasail, .gitmodules:4-6, pinned
+ * version unrecoverable) and spoa (src/consensus.cpp).  For the alignment fallback (src/cluster.cpp:408-515)
+ * the oracle carries its OWN scalar statement of the call the reference makes — parasail_sg_trace_scan +
+ * parasail_result_get_traceback, published semantics: semi-global, all four ends free, a gap of length n costs
+ * open + (n-1)*extend, the comparison string spans the whole alignment incl. the end gaps (`sg_trace` below;
+ * tie-breaking PARITY UNPINNED beyond the reference's AlnRatioTest vector).  It is independent of the product's
+ * aligners: nothing under isonclust2_amd/ is called.  orc_set_aligner can still put another aligner behind
+ * the same seam (tests use it to cross-check the product's host aligner against this one).
  */
 #include "oracle.h"
 
@@ -406,9 +410,31 @@ SortedHits sort_hits(const HitMap& hits)
     return s;
 }
 
+// ---- tracing (test instrumentation, no counterpart in the reference) ----------------------------------------------------------
+// SURVEY §8(c) golden item (3): the candidate table of chosen loop indices exactly as the reference's containers hold it
+// when the loop reaches that entry — every (cls, strand) of the hit map with Size, the Index of its first hit, its
+// position in the SortMinimizerHits order — and every getMappedRatio call (arguments -> totalMapped, length, ratio).
+struct TraceRow {
+    int entry, cls, strand;
+    unsigned size, first_index, total_mapped;  // total_mapped: computed for EVERY candidate of a traced entry
+    int order_pos;                             // position in the reference's SortedHits order
+    int walked;                                // 1: the reference's walk really called getMappedRatio on it
+};
+struct MappedCall {
+    int entry, cls, strand;
+    unsigned total, hpc_len;
+    double ratio, p_error;
+};
+std::set<int> g_trace_entries;
+std::vector<TraceRow> g_trace_rows;
+bool g_trace_mapped = false;
+std::vector<MappedCall> g_mapped_calls;
+thread_local int g_cur_entry = -1;
+bool g_builtin_aligner = true;
+
 // ---- src/cluster.cpp:324-353 -----------------------------------------------------------------------------------------------------
 double mapped_ratio(const Seq& hpcSeq, const Seq& clHpc, const MzVec& mins, const HitVec& hits,
-                    const PTab& tab, double minProbNoHits, bool& ok, double* pErrOut = nullptr)
+                    const PTab& tab, double minProbNoHits, bool& ok, double* pErrOut = nullptr, double* totalOut = nullptr)
 {
     double pError = 1.0 - pmin_lookup(tab, clHpc.err, hpcSeq.err, ok);
     if (pErrOut) *pErrOut = pError;
@@ -423,6 +449,7 @@ double mapped_ratio(const Seq& hpcSeq, const Seq& clHpc, const MzVec& mins, cons
     auto& h = hits[hits.size() - 1];
     if (pow(pError, double(mins.size() - (h.Index + 1))) >= minProbNoHits)
         total += hpcSeq.seq.length() - h.Pos;
+    if (totalOut) *totalOut = total;
     return total / double(hpcSeq.seq.length());
 }
 
@@ -458,9 +485,14 @@ SCl best_mapping(const ProcSeq& read, const Batch& left, const HitMap& hits, con
         if (st) st->mapped_calls++;
         float mr;
         const MzVec& mm = (c->Strand == 1) ? read.Mins : read.RevMins;
-        mr = float(mapped_ratio(*read.Hpc, *(left.Cls.at(c->Cls)->at(0)->Hpc), mm, hits.at(scl), tab,
-                                args.min_prob_no_hits, ok));
+        double pe = 0, tot = 0;
+        const double mrd = mapped_ratio(*read.Hpc, *(left.Cls.at(c->Cls)->at(0)->Hpc), mm, hits.at(scl), tab,
+                                        args.min_prob_no_hits, ok, &pe, &tot);
+        mr = float(mrd);
         if (!ok) return NEG;
+        if (g_trace_mapped)
+            g_mapped_calls.push_back(MappedCall{g_cur_entry, int(c->Cls), int(c->Strand), unsigned(tot),
+                                                unsigned(read.Hpc->seq.length()), mrd, pe});
         if (mr >= args.mapped_threshold) {
             found = scl;
             foundSize = c->Size;
@@ -501,11 +533,116 @@ double aln_ratio(const std::string& comp, double e, unsigned slen, unsigned k)
     return aligned / slen;
 }
 
+// ---- the call of src/cluster.cpp:408-423 + :498-503 (ParasailAlign + parasail_result_get_traceback) ----------------------------
+// The oracle's own statement of parasail's semi-global alignment with traceback, from the library's published
+// semantics (the source is not in /root/reference): rows = read, columns = representative; H(i,0) = H(0,j) = 0
+// (leading end gaps free); E(i,j) = max(H(i,j-1) - open, E(i,j-1) - extend) is a gap in the read (a move along
+// the representative), F(i,j) = max(H(i-1,j) - open, F(i-1,j) - extend) a gap in the representative;
+// H = max(diagonal, E, F); the alignment ends at the best cell of the last column or last row (trailing end gaps
+// free).  Where the published semantics leave a choice, this statement fixes it and the product has to follow:
+// a tie between opening and extending a gap is an OPENING; H prefers the diagonal, then E, then F; the end cell is
+// the first maximum met walking down the last column, then along the last row (strictly greater replaces).
+// `comp` gets the bar character (0x7C) where two identical bases are paired and a blank everywhere else, end-gap columns
+// included, like parasail_result_get_traceback(..., 0x7C, ' ', ' ').  Whole-matrix, one byte per cell: test-sized
+// and baseline use only.
+int sg_trace(const std::string& read, const std::string& rep, int match, int mismatch, int open, int extend,
+             std::string& comp, int* score)
+{
+    const size_t n = read.size(), m = rep.size();
+    const int NEGI = -(1 << 29);
+    // per cell: bits 0-1 where H came from (0 diagonal, 1 E, 2 F), bit 2 E extended, bit 3 F extended
+    std::vector<unsigned char> dir((n + 1) * (m + 1), 0);
+    std::vector<int> hrow(m + 1, 0), frow(m + 1, NEGI);
+    int bestv = NEGI;
+    size_t bi = n, bj = m;
+    for (size_t i = 1; i <= n; i++) {
+        int diag = hrow[0];  // H(i-1, 0)
+        hrow[0] = 0;
+        int e = NEGI;
+        unsigned char* d = &dir[i * (m + 1)];
+        const char rc = read[i - 1];
+        for (size_t j = 1; j <= m; j++) {
+            unsigned char bits = 0;
+            const int eo = hrow[j - 1] - open, ee = e - extend;  // hrow[j-1] already holds H(i, j-1)
+            if (ee > eo) {
+                e = ee;
+                bits |= 4;
+            } else
+                e = eo;
+            const int up = hrow[j];  // H(i-1, j)
+            const int fo = up - open, fe = frow[j] - extend;
+            int f;
+            if (fe > fo) {
+                f = fe;
+                bits |= 8;
+            } else
+                f = fo;
+            frow[j] = f;
+            int h = diag + (rc == rep[j - 1] ? match : mismatch);
+            if (e > h) {
+                h = e;
+                bits = (unsigned char)((bits & 12) | 1);
+            }
+            if (f > h) {
+                h = f;
+                bits = (unsigned char)((bits & 12) | 2);
+            }
+            diag = up;
+            hrow[j] = h;
+            d[j] = bits;
+        }
+        if (hrow[m] > bestv) {
+            bestv = hrow[m];
+            bi = i;
+            bj = m;
+        }
+    }
+    for (size_t j = 0; j <= m; j++) {
+        const int v = n == 0 ? 0 : hrow[j];
+        if (v > bestv) {
+            bestv = v;
+            bi = n;
+            bj = j;
+        }
+    }
+    if (score) *score = bestv;
+    std::string back;
+    back.reserve(n + m);
+    back.append(m - bj, ' ');
+    back.append(n - bi, ' ');
+    size_t i = bi, j = bj;
+    int in = 0;  // 0: in H, 1: inside an E gap, 2: inside an F gap
+    while (i > 0 && j > 0) {
+        const unsigned char b = dir[i * (m + 1) + j];
+        if (in == 0) {
+            const int from = b & 3;
+            if (from == 0) {
+                back.push_back(read[i - 1] == rep[j - 1] ? '|' : ' ');
+                i--;
+                j--;
+            } else
+                in = from;
+        } else if (in == 1) {
+            back.push_back(' ');
+            if (!(b & 4)) in = 0;
+            j--;
+        } else {
+            back.push_back(' ');
+            if (!(b & 8)) in = 0;
+            i--;
+        }
+    }
+    back.append(j, ' ');
+    back.append(i, ' ');
+    comp.assign(back.rbegin(), back.rend());
+    return int(comp.size());
+}
+
 // ---- src/cluster.cpp:461-515 -----------------------------------------------------------------------------------------------------
 SCl best_aln(const ProcSeq& read, const SortedHits& order, const Batch& left, int& status)
 {
     if (order.size() == 0) return NEG;
-    if (!g_aligner) {
+    if (!g_aligner && !g_builtin_aligner) {
         status = -2;
         return NEG;
     }
@@ -521,15 +658,20 @@ SCl best_aln(const ProcSeq& read, const SortedHits& order, const Batch& left, in
             repSeq = t;
         }
         double e = read.Raw->err + rep->err;
-        std::vector<char> comp(rs.size() + repSeq.size() + 2);
-        int n = g_aligner(rs.c_str(), int(rs.size()), repSeq.c_str(), int(repSeq.size()), gap_open_for(e),
-                          1, comp.data(), int(comp.size()));
-        if (n < 0) {
-            status = -3;
-            return NEG;
+        std::string compStr;
+        if (g_aligner) {
+            std::vector<char> comp(rs.size() + repSeq.size() + 2);
+            int n = g_aligner(rs.c_str(), int(rs.size()), repSeq.c_str(), int(repSeq.size()), gap_open_for(e),
+                              1, comp.data(), int(comp.size()));
+            if (n < 0) {
+                status = -3;
+                return NEG;
+            }
+            compStr.assign(comp.data(), size_t(n));
+        } else {
+            sg_trace(rs, repSeq, 2, -2, gap_open_for(e), 1, compStr, nullptr);  // match 2, mismatch -2, extend 1: cluster.cpp:474-476
         }
-        double r = aln_ratio(std::string(comp.data(), size_t(n)), e, unsigned(rs.size()),
-                             unsigned(left.Args.k));
+        double r = aln_ratio(compStr, e, unsigned(rs.size()), unsigned(left.Args.k));
         if (r >= left.Args.aligned_threshold) return std::make_pair(int(c->Cls), c->Strand);
     }
     return NEG;
@@ -543,6 +685,34 @@ SCl best_cluster(unsigned rightId, Batch& left, Batch& right, const PTab& tab, o
     auto hits = minimizer_hits(read->Mins, read->RevMins, left.Db, st);
     auto order = sort_hits(hits);
     if (st) st->queries++;
+    g_cur_entry = int(rightId);
+    std::vector<size_t> traceAt;
+    if (g_trace_entries.count(int(rightId))) {
+        for (size_t pos = 0; pos < order.size(); pos++) {
+            auto& c = order[pos];
+            SCl scl(int(c->Cls), int(c->Strand));
+            const HitVec& hv = hits.at(scl);
+            bool ok2 = true;
+            double tot = 0;
+            const MzVec& mm = (c->Strand == 1) ? read->Mins : read->RevMins;
+            mapped_ratio(*read->Hpc, *(left.Cls.at(c->Cls)->at(0)->Hpc), mm, hv, tab, left.Args.min_prob_no_hits, ok2, nullptr, &tot);
+            traceAt.push_back(g_trace_rows.size());
+            g_trace_rows.push_back(TraceRow{int(rightId), int(c->Cls), int(c->Strand), c->Size, hv[0].Index, unsigned(tot), int(pos), 0});
+        }
+    }
+    const size_t callsBefore = g_mapped_calls.size();
+    struct MarkWalked {  // on every way out: mark the traced rows the walk really evaluated
+        const std::vector<size_t>& at;
+        size_t before;
+        bool on;
+        ~MarkWalked()
+        {
+            if (!on) return;
+            for (size_t x = before; x < g_mapped_calls.size(); x++)
+                for (size_t r : at)
+                    if (g_trace_rows[r].cls == g_mapped_calls[x].cls && g_trace_rows[r].strand == g_mapped_calls[x].strand) g_trace_rows[r].walked = 1;
+        }
+    } markWalked{traceAt, callsBefore, !traceAt.empty() && g_trace_mapped};
     if (order.size() == 0) return NEG;
     if (mode == 0 || mode == 1) {
         bool ok = true;
@@ -764,6 +934,63 @@ int cluster_sorted_reads(Batch& left, Batch& right, const char* binpath, orc_sta
 extern "C" {
 
 void orc_set_aligner(void* fn) { g_aligner = reinterpret_cast<aligner_fn>(fn); }
+void orc_use_builtin_aligner(int on) { g_builtin_aligner = on != 0; }
+
+int orc_align(const char* read, int nread, const char* rep, int nrep, int match, int mismatch, int gap_open, int gap_extend,
+              char* comp, int comp_cap, int* score)
+{
+    std::string c;
+    const int n = sg_trace(std::string(read, size_t(nread)), std::string(rep, size_t(nrep)), match, mismatch, gap_open, gap_extend, c, score);
+    if (comp) {
+        if (n + 1 > comp_cap) return -1;
+        memcpy(comp, c.data(), size_t(n));
+        comp[n] = 0;
+    }
+    return n;
+}
+int orc_gap_open(double e) { return gap_open_for(e); }
+double orc_aln_ratio(const char* comp, int n, double e, unsigned slen, unsigned k) { return aln_ratio(std::string(comp, size_t(n)), e, slen, k); }
+
+void orc_trace_set(const int32_t* entries, int n, int mapped_calls)
+{
+    g_trace_entries.clear();
+    for (int i = 0; i < n; i++) g_trace_entries.insert(entries[i]);
+    g_trace_mapped = mapped_calls != 0 || n > 0;
+    g_trace_rows.clear();
+    g_mapped_calls.clear();
+}
+int64_t orc_trace_rows(int32_t* entry, int32_t* cls, int32_t* strand, uint32_t* size, uint32_t* first_index, uint32_t* total_mapped,
+                       int32_t* order_pos, uint8_t* walked)
+{
+    if (entry)
+        for (size_t i = 0; i < g_trace_rows.size(); i++) {
+            const TraceRow& r = g_trace_rows[i];
+            entry[i] = r.entry;
+            cls[i] = r.cls;
+            strand[i] = r.strand;
+            size[i] = r.size;
+            first_index[i] = r.first_index;
+            total_mapped[i] = r.total_mapped;
+            order_pos[i] = r.order_pos;
+            walked[i] = uint8_t(r.walked);
+        }
+    return int64_t(g_trace_rows.size());
+}
+int64_t orc_trace_mapped_calls(int32_t* entry, int32_t* cls, int32_t* strand, uint32_t* total, uint32_t* hpc_len, double* ratio, double* p_error)
+{
+    if (entry)
+        for (size_t i = 0; i < g_mapped_calls.size(); i++) {
+            const MappedCall& r = g_mapped_calls[i];
+            entry[i] = r.entry;
+            cls[i] = r.cls;
+            strand[i] = r.strand;
+            total[i] = r.total;
+            hpc_len[i] = r.hpc_len;
+            ratio[i] = r.ratio;
+            p_error[i] = r.p_error;
+        }
+    return int64_t(g_mapped_calls.size());
+}
 
 void orc_set_consensus(const orc_cons_ops* ops, int cons_min_size, int cons_period)
 {
@@ -939,6 +1166,12 @@ void orc_reads_score_sort(void* h, int k, int /*w*/)
     r->orig.swap(no);
 }
 int orc_reads_n(void* h) { return int(static_cast<Reads*>(h)->v.size()); }
+// test plumbing: shift the original-read ids of a read set (several independently sorted read sets folded into one
+// clustering keep distinct ids)
+void orc_reads_shift_orig(void* h, int base)
+{
+    for (auto& o : static_cast<Reads*>(h)->orig) o += base;
+}
 void orc_reads_order(void* h, int32_t* orig, double* score, double* err)
 {
     auto r = static_cast<Reads*>(h);

@@ -60,6 +60,31 @@ typedef struct {
 /* ops == NULL switches the hook off; cons_min_size / cons_period = CmdArgs::ConsMinSize / ConsPeriod */
 void orc_set_consensus(const orc_cons_ops* ops, int cons_min_size, int cons_period);
 
+/* ---- alignment fallback (src/cluster.cpp:408-515) --------------------------------------------------
+ * The oracle's own scalar semi-global aligner with traceback (parasail itself is absent from the reference tree:
+ * tie-breaking parity unpinned beyond AlnRatioTest).  It is what sahlin / furious mode use unless another aligner
+ * is put behind the seam with orc_set_aligner (signature: int fn(read, nread, rep, nrep, gap_open, gap_extend,
+ * comp_out, comp_cap) -> length of comp or < 0).  orc_use_builtin_aligner(0) restores "status -2 without a hook". */
+void orc_set_aligner(void* fn);
+void orc_use_builtin_aligner(int on);
+int orc_align(const char* read, int nread, const char* rep, int nrep, int match, int mismatch, int gap_open, int gap_extend,
+              char* comp, int comp_cap, int* score);
+int orc_gap_open(double e);                                                              /* setGapOpen, cluster.cpp:425-440 */
+double orc_aln_ratio(const char* comp, int n, double e, unsigned slen, unsigned k);      /* getAlnRatio, cluster.cpp:442-459 */
+
+/* ---- tracing of the intermediate tables (SURVEY §8(c) golden item 3) ----------------------------------
+ * orc_trace_set: the right-batch entries whose candidate table is recorded when the greedy loop reaches them
+ * (n = 0: none); mapped_calls != 0 also logs every getMappedRatio call of the run.  Both logs are cleared here and
+ * filled by the next orc_cluster.  orc_trace_rows: one row per (cls, strand) of the traced entries' hit maps
+ * (minimizer.cpp:44-76): Size, Index of the first hit, totalMapped of getMappedRatio (computed for every candidate
+ * of a traced entry), position in the SortMinimizerHits order (cluster.cpp:622-636), walked = the reference's walk
+ * called getMappedRatio on it.  Call with NULLs to size. */
+void orc_trace_set(const int32_t* entries, int n, int mapped_calls);
+int64_t orc_trace_rows(int32_t* entry, int32_t* cls, int32_t* strand, uint32_t* size, uint32_t* first_index, uint32_t* total_mapped,
+                       int32_t* order_pos, uint8_t* walked);
+int64_t orc_trace_mapped_calls(int32_t* entry, int32_t* cls, int32_t* strand, uint32_t* total, uint32_t* hpc_len, double* ratio,
+                               double* p_error);
+
 /* ---- primitives ---------------------------------------------------------------- */
 int orc_hpc(const char* seq, const char* qual, int n, char* oseq, char* oqual);
 int orc_revcomp(const char* seq, int n, char* out);
@@ -87,6 +112,7 @@ void* orc_reads_new(const char* seqs, const char* quals, const int64_t* offs, in
 void orc_reads_free(void* h);
 void orc_reads_score_sort(void* h, int k, int w);
 int orc_reads_n(void* h);
+void orc_reads_shift_orig(void* h, int base); /* test plumbing: original-read ids += base */
 void orc_reads_order(void* h, int32_t* orig_index, double* score, double* err);
 
 /* ---- batch: PrepareSortedBatch + ClusterSortedReads ------------------------------ */

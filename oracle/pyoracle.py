@@ -82,6 +82,8 @@ def lib():
     L.orc_reads_free.argtypes = [vp]
     L.orc_reads_score_sort.argtypes = [vp, i32, i32]
     L.orc_reads_n.argtypes = [vp]
+    L.orc_reads_shift_orig.argtypes = [vp, i32]
+    L.orc_reads_shift_orig.restype = None
     L.orc_reads_order.argtypes = [vp, i32p, dp, dp]
     L.orc_batch_prepare.argtypes = [vp, i32, i32, C.POINTER(Params), i32]
     L.orc_batch_prepare.restype = vp
@@ -97,6 +99,18 @@ def lib():
     L.orc_batch_index.argtypes = [vp, u32p, i64p, u32p, i64p]
     L.orc_batch_index.restype = C.c_int64
     L.orc_set_aligner.argtypes = [vp]
+    L.orc_use_builtin_aligner.argtypes = [i32]
+    L.orc_align.argtypes = [cp, i32, cp, i32, i32, i32, i32, i32, cp, i32, i32p]
+    L.orc_gap_open.argtypes = [C.c_double]
+    L.orc_aln_ratio.argtypes = [cp, i32, C.c_double, C.c_uint, C.c_uint]
+    L.orc_aln_ratio.restype = C.c_double
+    u8p = C.POINTER(C.c_uint8)
+    L.orc_trace_set.argtypes = [i32p, i32, i32]
+    L.orc_trace_set.restype = None
+    L.orc_trace_rows.argtypes = [i32p, i32p, i32p, u32p, u32p, u32p, i32p, u8p]
+    L.orc_trace_rows.restype = C.c_int64
+    L.orc_trace_mapped_calls.argtypes = [i32p, i32p, i32p, u32p, u32p, dp, dp]
+    L.orc_trace_mapped_calls.restype = C.c_int64
     L.orc_batch_update_mindb.argtypes = [vp, C.c_int, u32p, C.c_int64, u32p, C.c_int64, C.c_int]
     L.orc_set_consensus.argtypes = [vp, C.c_int, C.c_int]
     L.orc_set_consensus.restype = None
@@ -162,6 +176,48 @@ def pmin_lookup(tab, e1, e2):
     return r
 
 
+def align(read: bytes, rep: bytes, e: float, k: int, match=2, mismatch=-2, gap_extend=1):
+    """The oracle's own semi-global aligner + getAlnRatio (src/cluster.cpp:408-459): (score, comp, ratio)."""
+    cap = len(read) + len(rep) + 2
+    comp = C.create_string_buffer(cap)
+    sc = C.c_int32()
+    n = lib().orc_align(read, len(read), rep, len(rep), match, mismatch, lib().orc_gap_open(e), gap_extend, comp, cap, C.byref(sc))
+    if n < 0:
+        raise RuntimeError("orc_align failed")
+    return sc.value, comp.raw[:n], lib().orc_aln_ratio(comp, n, e, len(read), k)
+
+
+def trace_set(entries=(), mapped_calls=False):
+    """Candidate tables of these right-batch entries (+ optionally every getMappedRatio call) are recorded by the
+    next Batch.cluster; trace_rows() / trace_mapped_calls() read them."""
+    a = np.ascontiguousarray(list(entries), np.int32)
+    lib().orc_trace_set(_p(a, C.c_int32) if len(a) else None, len(a), 1 if mapped_calls else 0)
+
+
+def trace_rows():
+    n = lib().orc_trace_rows(None, None, None, None, None, None, None, None)
+    d = dict(entry=np.zeros(n, np.int32), cls=np.zeros(n, np.int32), strand=np.zeros(n, np.int32),
+             size=np.zeros(n, np.uint32), first_index=np.zeros(n, np.uint32), total_mapped=np.zeros(n, np.uint32),
+             order_pos=np.zeros(n, np.int32), walked=np.zeros(n, np.uint8))
+    if n:
+        lib().orc_trace_rows(_p(d["entry"], C.c_int32), _p(d["cls"], C.c_int32), _p(d["strand"], C.c_int32),
+                             _p(d["size"], C.c_uint32), _p(d["first_index"], C.c_uint32), _p(d["total_mapped"], C.c_uint32),
+                             _p(d["order_pos"], C.c_int32), _p(d["walked"], C.c_uint8))
+    return d
+
+
+def trace_mapped_calls():
+    n = lib().orc_trace_mapped_calls(None, None, None, None, None, None, None)
+    d = dict(entry=np.zeros(n, np.int32), cls=np.zeros(n, np.int32), strand=np.zeros(n, np.int32),
+             total=np.zeros(n, np.uint32), hpc_len=np.zeros(n, np.uint32), ratio=np.zeros(n, np.float64),
+             p_error=np.zeros(n, np.float64))
+    if n:
+        lib().orc_trace_mapped_calls(_p(d["entry"], C.c_int32), _p(d["cls"], C.c_int32), _p(d["strand"], C.c_int32),
+                                     _p(d["total"], C.c_uint32), _p(d["hpc_len"], C.c_uint32), _p(d["ratio"], C.c_double),
+                                     _p(d["p_error"], C.c_double))
+    return d
+
+
 class ReadSet:
     """FillQualScores + SortByQualScores over a list of (seq, qual) byte strings."""
 
@@ -182,6 +238,9 @@ class ReadSet:
 
     def score_sort(self, k, w):
         lib().orc_reads_score_sort(self.h, k, w)
+
+    def shift_orig(self, base):
+        lib().orc_reads_shift_orig(self.h, int(base))
 
     def order(self):
         n = lib().orc_reads_n(self.h)

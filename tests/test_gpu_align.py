@@ -243,6 +243,23 @@ def test_pairs_split_over_workgroups(ctx, monkeypatch):
     assert ctx.timings()["n_align_refused"] == 0      # no wait ran out
 
 
+@pytest.mark.parametrize("force", [True, False])
+def test_split_pair_with_longer_reference_than_the_first(ctx, monkeypatch, force):
+    """The cross-workgroup flags are indexed with every pair's own strip count: a split pair with FEWER cells but a
+    LONGER reference than the slice's first pair (16000 x 8000 = 8 strips, then 3000 x 16000 = 16 strips) must not
+    run over its flag slot (round-1 advisor finding).  Both routes that split pairs: forced, and the default route
+    for a handful of pairs on an idle chip."""
+    if force:
+        monkeypatch.setenv("IOC_ALIGN_FORCE_CROSS", "1")
+    rng = random.Random(77)
+    base = bytes(rng.choice(b"ACGT") for _ in range(16500))
+    seqs = [_mutate(rng, base, 0.08)[:16000], _mutate(rng, base, 0.08)[:8000], _mutate(rng, base, 0.08)[:3000],
+            _mutate(rng, base, 0.08)[:16000], _mutate(rng, base[5000:], 0.08)[:9000]]
+    pairs = [(0, 1, 0, 0.1), (2, 3, 0, 0.1), (2, 0, 0, 0.2), (4, 3, 0, 0.05), (2, 3, 1, 0.1), (1, 0, 0, 0.1)]
+    _check(ctx, seqs, pairs, 11)
+    assert ctx.timings()["n_align_refused"] == 0
+
+
 def test_tail_generation_split_in_launch(ctx, monkeypatch):
     """More pairs than one resident generation of workgroups (config 3's 1622 pairs of 16.7 kb): the pairs of the
     tail generation are split over two workgroups each, in the same launch behind the ordinary ones.  Same results
