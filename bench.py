@@ -3,26 +3,36 @@
 
 Headline (`value`) = sahlin mode, the mode BASELINE.json's metric names (configs[2]): index build +
 shared-minimizer scoring + mapped-ratio resolve + the alignment fallback (GPU, batched) + decisions back on
-the host.  The fast-mode result of the SAME resident batch (configs[1]: no alignment) rides along in
-`fast_mode`, with the HBM roofline of the scoring kernels in `roofline`; `roofline_align` is the integer-VALU
-issue roofline of the forward DP kernel that dominates a sahlin step.
+the host, over ONE sorted batch whose minimizer SoA and raw sequences are ALREADY RESIDENT IN HBM when the timed
+region starts (`value_region: "resident"`, the driver's contract).  The fast-mode result of the same resident batch
+(configs[1]) rides along in `fast_mode`.  Beside it, the two regions SURVEY.md §8(d) defines:
 
-One "step" = one pass of the hot path (ioc_cluster_resident) over one sorted batch whose minimizer SoA and raw
-sequences are already resident in HBM.  Batches shard one per GPU with no data-path collective (weak
-scaling); ranks only meet at the timing barrier.  Inputs are synthetic (isonclust2_amd/synth.py): every rank
-generates and prepares its OWN copy of the same batch (seed 1) — weak scaling with the per-GPU work fixed, so that
-the max over ranks measures the system and not the spread between batches (other seeds of the same shape take
-115-149 ms: some need a second alignment round); --rank-seeds gives rank r the batch of seed 1 + r instead.
-Inputs are prepared by the product's own GPU sort stage (ioc_qual_scores / ioc_extract_minimizers), never
-by the oracle.  The oracle appears only in the cpu_baseline legs (rank 0, N=1): timed on one host core — the
-full batch in fast mode (doubling as a full-size parity check), a bounded sample in sahlin mode.
+  core   host arrays (the parsed batch in host RAM) -> assignments + MinDB back in host RAM; H2D of the 191 MB
+         minimizer SoA (+ 50 MB of sequences in sahlin mode) and every D2H included (ioc_cluster_merge +
+         ioc_index_export).  The >= 20x target is judged on this region.
+  cli    the whole `isONclust2-hip cluster` process on the batch's .cer file (load, core, bookkeeping, save).
+
+`roofline` = HBM roofline of the shared-minimizer scoring kernels (the kernel north_star asks the HBM fraction
+of); `roofline_align` = the integer-VALU issue roofline of the forward DP kernel that dominates a sahlin step
+(peak from the issue-rate microbenchmark tools/micro/valu_rate.hip, profiles/r02_valu_rate.txt).
+
+N > 1: one process per GPU; rank r clusters ITS OWN batch (seed 1 + r: BASELINE.json configs[3] = 8 different
+batches), no data-path collective, ranks meet at the timing barrier (weak scaling; `--same-seed` gives every rank
+the seed-1 batch instead).  After the timed region the batches are MERGED (the one exchange step of the path):
+representative records all-gathered, folded left to right; reported in `merge` with its own time.
+
+CPU baseline (rank 0, N = 1): the oracle (CPU restatement, `-O3 -DNDEBUG -msse3`, libstdc++) on ONE pinned core:
+fast mode = the full batch (doubling as a full-size parity check), sahlin mode = a bounded sample with the oracle's
+own SCALAR aligner (not parasail's striped SIMD scan).  min over the runs that fit the time budget (<= 3).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,116 +41,66 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# int32 VALU issue peak: MEASURED with tools/micro/valu_rate.hip (profiles/r02_valu_rate.txt), not assumed; the
+# file's JSON line overrides this default when present
+VALU_PEAK_TOPS_DEFAULT = 256 * 4 * 16 * 2.4e9 / 1e12
+ALIGN_VALU_PER_CELL = 5  # fwd_cells: add with byte select, max3, sub, max, max (ioc_align_gpu.hip)
 
 
-def prepare_resident_batch(ctx, api, synth, config, seed, k, w, mode="fast"):
-    """raw reads -> GPU quality scores -> stable sort -> GPU HPC/minimizers -> resident queries."""
-    rs = synth.generate_config(config, seed=seed)
-    score, err = ctx.qual_scores(rs.offs, rs.qual, k)                       # FillQualScores
-    order = np.argsort(-score, kind="stable")                               # SortByQualScores
-    lens = np.diff(rs.offs)[order]
-    so = np.zeros(rs.n + 1, np.int64)
-    so[1:] = np.cumsum(lens)
-    starts = rs.offs[:-1][order]
-    idx = np.repeat(starts - so[:-1], lens) + np.arange(so[-1])
-    ex = ctx.extract_minimizers(so, rs.seq[idx], rs.qual[idx], k, w)        # PrepareSortedBatch
-    p = api.default_params(k, w, mode)
-    ctx.set_params(p)
-    # gates of the clustering loop (src/cluster.cpp:116-160); MinQual default 7.0
-    keep = (ex["status"] == 0) & (score[order] >= 0) & (-10 * np.log10(err[order]) > 7.0)
-    cell = np.array([api.host_err_cell(e) if kp else 1 for e, kp in zip(ex["hpc_err"], keep)], np.uint8)
-    need = np.array([api.host_min_total(h, p.mapped_threshold) if kp else 0xFFFFFFFE
-                     for h, kp in zip(ex["hpc_len"], keep)], np.uint32)
-    ctx.queries_from_extracted(keep, cell, need)
-    ctx.left_load(0, None, None, None, None)
-    if mode == "sahlin":   # BASELINE.json configs[2]: the alignment fallback needs the raw sequences
-        ctx.resident_set_sequences(rs.seq[idx], so, err[order])
-    ex.update(score=score[order], raw_err=err[order])
-    ctx._last_extract = ex
-    return rs, order, int(ex["off_rev"][-1])
-
-
-def resident_to_clustered(ctx, api, pipeline, rs, order, cls, strand, rank):
-    """ClusteredBatch (representative records + membership + MinDB) of the batch just clustered."""
-    import numpy as np
-    n_min = ctx.timings()["n_minimizers"]
-    mn, ps = ctx.extracted_download(int(n_min))
-    ex = ctx._last_extract
-    view = dict(off_fwd=ex["off_fwd"], off_rev=ex["off_rev"], min_val=mn, min_pos=ps,
-                raw_len=np.diff(rs.offs)[order].astype(np.uint32), hpc_len=ex["hpc_len"],
-                score=ex["score"], raw_err=ex["raw_err"], hpc_err=ex["hpc_err"],
-                state=np.zeros(rs.n, np.uint8), min_qual=7.0)
-    keys, offs, post = ctx.index_export()
-    ok = cls >= 0
-    ncl = int(cls.max()) + 1 if ok.any() else 0
-    rep_entry = np.full(ncl, -1, np.int64)
-    for i in np.nonzero(ok)[0][::-1]:
-        rep_entry[cls[i]] = i            # first entry of each cluster = its creator
-    base = rank * 10_000_000
-    return pipeline.ClusteredBatch(rep_view=pipeline.gather_records(view, rep_entry),
-                                   member_cls=cls[ok].astype(np.int32),
-                                   member_read=(base + order[ok]).astype(np.int64),
-                                   member_strand=strand[ok].astype(np.int32), mindb=(keys, offs, post),
-                                   depth=0, batch_start=base, batch_end=base + rs.n - 1)
-
-
-def cpu_baseline_sahlin_sample(rs, order, cls, strand, k, w, sample):
-    """Sahlin mode on one host core is dominated by 16.7 kb x 16.7 kb alignments (~1 s each): the oracle
-    runs on the first `sample` reads of the sorted batch only (its aligner hook calls the product's host
-    aligner, parasail being absent); the GPU result on the same sub-batch is the parity check."""
-    import ctypes as C
-    from oracle import pyoracle as po
-    from isonclust2_amd import _lib, api
-    from tests.helpers import oracle_sorted_batch
-    sub = rs.subset(order[:sample]) if hasattr(rs, "subset") else None
-    if sub is None:
-        return None
-    B, view = oracle_sorted_batch(sub, k, w)
-    L = _lib.load()
-    CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
-    fn = CB(lambda read, nread, rep, nrep, go, ge, out, cap:
-            L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None))
-    po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
+def valu_peak():
+    """(peak T lane-op/s, source): the best rate any plain int32 VALU instruction reached in the microbenchmark."""
+    p = os.path.join(ROOT, "profiles", "r02_valu_rate.txt")
     try:
-        t0 = time.perf_counter()
-        st = B.cluster(mode="sahlin", stats=True)
-        dt = time.perf_counter() - t0
-    finally:
-        po.lib().orc_set_aligner(None)
-    acl, ast = B.assignments(sub.n)
-    ocl, ost = acl[view["orig"]], ast[view["orig"]]
-    # the same sub-batch through the product (own context: the benchmark's resident batch stays untouched)
-    seqs = [sub.read(int(i))[0] for i in view["orig"]]
-    off = np.zeros(len(seqs) + 1, np.int64)
-    off[1:] = np.cumsum([len(x) for x in seqs])
-    v = dict(view)
-    v.update(raw_seq=b"".join(seqs), raw_off=off)
-    c2 = api.Context(0)
-    gcl, gst, _ = c2.cluster_batch(api.default_params(k, w, "sahlin"), v)
-    c2.close()
-    mism = int(np.count_nonzero((ocl != gcl) | (ost != gst)))
-    return dt, st, mism, sub.n
+        for line in open(p):
+            if line.startswith("JSON "):
+                d = json.loads(line[5:])
+                best = max(d[k] for k in ("v_add_u32", "v_max_i32", "v_max3_i32") if k in d)
+                return best, "measured: profiles/r02_valu_rate.txt (best of v_add_u32 / v_max_i32 / v_max3_i32 over 1-8 waves per SIMD)"
+    except Exception:
+        pass
+    return VALU_PEAK_TOPS_DEFAULT, "assumed 4 cycles per wave64 instruction per SIMD (no measurement file)"
 
 
-def cpu_baseline_and_parity(rs, order, cls, strand, k, w):
-    """Oracle (CPU restatement, 1 core) on the SAME batch: timing of the ClusterSortedReads region,
-    exact M/H/C_s counts for the roofline, and a full-size parity check of the GPU result."""
-    from oracle import pyoracle as po
-    from tests.helpers import oracle_sorted_batch
-    B, view = oracle_sorted_batch(rs, k, w)
-    assert np.array_equal(view["orig"], order), "sort order differs from the oracle's"
-    t0 = time.perf_counter()
-    st = B.cluster(mode="fast", stats=True)
-    dt = time.perf_counter() - t0
-    acl, ast = B.assignments(rs.n)
-    ocl, ost = acl[view["orig"]], ast[view["orig"]]
-    mism = int(np.count_nonzero((ocl != cls) | (ost != strand)))
-    return dt, st, mism
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 39.3 T int32 lane-ops/s: 1024 SIMDs x 16 lanes x 2.4 GHz (one
-                                               # wave64 int32 VALU instruction = 4 cycles of its SIMD)
-ALIGN_VALU_PER_CELL = 5                        # fwd_cells (query-profile kernel): add with byte select, max3, sub, max, max (ioc_align_gpu.hip)
+class pinned:
+    """taskset for the calling thread: one core for the duration of a CPU-baseline run."""
+
+    def __enter__(self):
+        self.old = os.sched_getaffinity(0)
+        self.core = max(self.old)
+        os.sched_setaffinity(0, {self.core})
+        return self
+
+    def __exit__(self, *a):
+        os.sched_setaffinity(0, self.old)
+
+
+def prepare(ctx, api, pipeline, synth, config, seed, k, w, rank):
+    """raw reads -> GPU quality scores -> stable sort -> GPU HPC/minimizers: the sorted batch as host arrays
+    (core / cli / merge regions) AND as resident queries (the headline's timed region)."""
+    rs = synth.generate_config(config, seed=seed)
+    sb, order = pipeline.sort_stage(ctx, rs, k, w, read_id_base=rs.n * rank, batch_nr=rank)
+    v = sb.view
+    p = api.default_params(k, w, "sahlin")
+    ctx.set_params(p)
+    # gates of the clustering loop (src/cluster.cpp:116-160)
+    keep = (v["state"] == 0) & (v["score"] >= 0) & (v["raw_len"] >= 2 * k) & (v["hpc_len"] >= 2 * k)
+    cell = np.array([api.host_err_cell(e) if kp else 1 for e, kp in zip(v["hpc_err"], keep)], np.uint8)
+    need = np.array([api.host_min_total(h, p.mapped_threshold) if kp else 0xFFFFFFFE
+                     for h, kp in zip(v["hpc_len"], keep)], np.uint32)
+    ctx.queries_from_extracted(keep, cell, need)     # the extractor's output stays where it is: in HBM
+    ctx.left_load(0, None, None, None, None)
+    ctx.resident_set_sequences(v["raw_seq"], v["raw_off"], v["raw_err"])
+    return rs, sb, order
 
 
 def timed_steps(ctx, torch, dist, dev, steps, warmup):
@@ -173,6 +133,106 @@ def timed_steps(ctx, torch, dist, dev, steps, warmup):
     return cls, strand, st, tm, elapsed, acc
 
 
+def core_region(ctx, api, pipeline, sb, k, w, mode, runs):
+    """SURVEY §8(d) *core*: the parsed batch in host RAM -> assignments + updated MinDB in host RAM, through
+    ioc_cluster_merge + ioc_index_export; PCIe both ways inside the timed region."""
+    p = api.default_params(k, w, mode)
+    view = sb.view if mode != "fast" else {kk: vv for kk, vv in sb.view.items() if kk not in ("raw_seq", "raw_off")}
+    ms, cb = [], None
+    for _ in range(runs + 1):                      # first run untimed (allocations)
+        t0 = time.perf_counter()
+        cb = pipeline.cluster_single(ctx, p, pipeline.SortedBatch(view=view, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
+                                                                  batch_start=sb.batch_start, batch_end=sb.batch_end))
+        ms.append((time.perf_counter() - t0) * 1e3)
+    ms = ms[1:]
+    h2d = sum(np.asarray(view[x]).nbytes for x in ("min_val", "min_pos", "off_fwd", "off_rev", "hpc_len")) + (len(view.get("raw_seq", b"")))
+    return {"ms_min": min(ms), "ms_mean": sum(ms) / len(ms), "runs": len(ms), "h2d_bytes": int(h2d),
+            "d2h_bytes": int(sum(a.nbytes for a in cb.mindb) + 5 * len(sb.read_ids))}, cb
+
+
+def cli_region(rs, mode, runs=3):
+    """SURVEY §8(d) *cli*: the whole `isONclust2-hip cluster -l batch.cer -o out.cer -x mode` process."""
+    cli = os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
+    if not os.path.exists(cli):
+        return None
+    d = tempfile.mkdtemp(prefix="ioc_bench_")
+    try:
+        fq = os.path.join(d, "reads.fq")
+        with open(fq, "wb") as f:
+            for i in range(rs.n):
+                s, q = rs.read(i)
+                f.write(b"@r%d\n" % i + s + b"\n+\n" + q + b"\n")
+        t = time.perf_counter()
+        subprocess.check_call([cli, "sort", "-B", "60000", "-M", str(rs.n), "-o", os.path.join(d, "sorted"), fq],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_sort = time.perf_counter() - t
+        batch = os.path.join(d, "sorted", "batches", "isONbatch_0.cer")
+        res = []
+        for _ in range(runs):
+            t = time.perf_counter()
+            r = subprocess.run([cli, "cluster", "-l", batch, "-o", os.path.join(d, "out.cer"), "-x", mode], capture_output=True,
+                               text=True, env=dict(os.environ, ISONCLUST2_STATS_JSON="1"))
+            wall = (time.perf_counter() - t) * 1e3
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            j = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+            j["process_wall_ms"] = wall
+            res.append(j)
+        best = min(res, key=lambda j: j["process_wall_ms"])
+        return {"process_wall_ms_min": best["process_wall_ms"], "phases_of_that_run": best, "runs": runs,
+                "sort_process_s": t_sort, "batch_cer_MB": os.path.getsize(batch) / 1e6}
+    finally:
+        subprocess.call(["rm", "-rf", d])
+
+
+def cpu_baseline_fast(rs, order, cls, strand, k, w, max_runs, budget_s):
+    """Oracle (CPU restatement) on the SAME batch, one pinned core: timing of the ClusterSortedReads region (min over
+    the runs), exact M/H/C_s counts for the roofline, and a full-size parity check of the GPU result."""
+    from tests.helpers import oracle_sorted_batch
+    times, st, mism = [], None, None
+    t_all = time.perf_counter()
+    with pinned() as pin:
+        for _ in range(max_runs):
+            B, view = oracle_sorted_batch(rs, k, w)
+            assert np.array_equal(view["orig"], order), "sort order differs from the oracle's"
+            t0 = time.perf_counter()
+            st = B.cluster(mode="fast", stats=True)
+            times.append(time.perf_counter() - t0)
+            acl, ast = B.assignments(rs.n)
+            ocl, ost = acl[view["orig"]], ast[view["orig"]]
+            mism = int(np.count_nonzero((ocl != cls) | (ost != strand)))
+            if time.perf_counter() - t_all + times[-1] > budget_s:
+                break
+    return min(times), times, st, mism, pin.core
+
+
+def cpu_baseline_sahlin(ctx_factory, api, pipeline, rs, order, k, w, sample, max_runs, budget_s):
+    """Sahlin mode on one host core is dominated by 16.7 kb x 16.7 kb alignments: the oracle (with its OWN scalar
+    aligner — not parasail's SIMD scan, not the product's) runs on the first `sample` reads of the sorted batch; the
+    product clusters the same sub-batch on the GPU for the parity check."""
+    from tests.helpers import oracle_sorted_batch
+    sub = rs.subset(order[:sample])
+    times, st = [], None
+    t_all = time.perf_counter()
+    with pinned() as pin:
+        for _ in range(max_runs):
+            B, view = oracle_sorted_batch(sub, k, w)
+            t0 = time.perf_counter()
+            st = B.cluster(mode="sahlin", stats=True)
+            times.append(time.perf_counter() - t0)
+            acl, ast = B.assignments(sub.n)
+            ocl, ost = acl[view["orig"]], ast[view["orig"]]
+            if time.perf_counter() - t_all + times[-1] > budget_s:
+                break
+    c2 = ctx_factory()
+    sb, o2 = pipeline.sort_stage(c2, sub, k, w)
+    assert np.array_equal(o2, view["orig"])
+    gcl, gst, _ = c2.cluster_batch(api.default_params(k, w, "sahlin"), sb.view)
+    c2.close()
+    mism = int(np.count_nonzero((ocl != gcl) | (ost != gst)))
+    return min(times), times, st, mism, sub.n, pin.core
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,12 +242,17 @@ def main():
     ap.add_argument("--mode", default="both", choices=["both", "fast", "sahlin"],
                     help="both (default): headline = sahlin mode (BASELINE.json's metric, configs[2]) with the fast-mode "
                          "result (configs[1]) of the same batch beside it; fast / sahlin = that mode only")
-    ap.add_argument("--cpu-sample", type=int, default=30, help="sahlin: reads in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=200, help="sahlin: reads in the CPU-baseline sample")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="CPU baseline: at most this many runs (min is reported)")
+    ap.add_argument("--cpu-budget", type=float, default=75.0, help="CPU baseline: seconds per leg after which no further run starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rank-seeds", action="store_true", help="rank r clusters the batch of seed 1 + r (default: every rank the batch of seed 1)")
+    ap.add_argument("--no-core", action="store_true", help="skip the core region (host arrays -> host results)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the cli region (whole `cluster` process on a .cer file)")
+    ap.add_argument("--same-seed", action="store_true", help="every rank clusters its own copy of the seed-1 batch (default: rank r the batch of seed 1 + r)")
+    ap.add_argument("--rank-seeds", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--merge", action="store_true",
-                    help="after the timed region: all-gather the clustered batches and left-fold merge them on rank 0")
+    ap.add_argument("--no-merge", action="store_true", help="N > 1: skip the merge of the ranks' batches after the timed region")
+    ap.add_argument("--merge", action="store_true", help="(default since round 2; kept for old command lines)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -196,7 +261,7 @@ def main():
     k, w = 11, 15
 
     import torch
-    from isonclust2_amd import api, synth
+    from isonclust2_amd import api, pipeline, synth
 
     dist = None
     ndev = max(1, torch.cuda.device_count())
@@ -215,8 +280,9 @@ def main():
     ctx = api.Context(dev_index)
     want_fast = a.mode in ("both", "fast")
     want_sahlin = a.mode in ("both", "sahlin")
-    rs, order, n_min = prepare_resident_batch(ctx, api, synth, a.config, 1 + (rank if a.rank_seeds else 0), k, w,
-                                              "sahlin" if want_sahlin else "fast")
+    seed = 1 if a.same_seed else 1 + rank
+    rs, sb, order = prepare(ctx, api, pipeline, synth, a.config, seed, k, w, rank)
+    n_min = int(sb.view["off_rev"][-1])
     if dist is not None:
         nreads = torch.tensor([rs.n], dtype=torch.int64, device=dev)
         dist.all_reduce(nreads, op=dist.ReduceOp.SUM)
@@ -248,24 +314,50 @@ def main():
                              "refused_by_packed_kernel": tm.get("n_align_refused", 0)}}
         sah_res = (cls, strand, st, tm, acc)
 
+    # ---- roofline inputs that need the resident fast-mode clustering (rank 0) ----
+    roof = roof_aln = None
+    fcls = fstrand = None
+    if rank == 0 and fast is not None:
+        ctx.set_params(api.default_params(k, w, "fast"))
+        fcls, fstrand, fst = ctx.cluster_resident()     # untimed: leaves the fast-mode clustering on the device
+        M = fast_res[3]["n_minimizers"]
+        # H = postings the reference's GetMinimizerHits traverses on this batch, counted on the device
+        # from the final clustering (instrumentation launch, untimed); C_s = survivor candidates
+        H = ctx.count_reference_postings()
+        Cs = fast_res[3]["n_mapped_evals"]
+        roof_counts = (M, H, Cs, fst)
+
+    # ---- core region (every rank: its ClusteredBatch is also what the merge exchanges) ----
+    core = {}
+    cb_merge = None
+    if not a.no_core or (world > 1 and not a.no_merge):
+        if want_fast:
+            core["fast"], cb = core_region(ctx, api, pipeline, sb, k, w, "fast", 1 if a.no_core else 3)
+            cb_merge = cb
+        if want_sahlin:
+            core["sahlin"], cb = core_region(ctx, api, pipeline, sb, k, w, "sahlin", 1 if a.no_core else 3)
+            cb_merge = cb
+        for m in core:
+            core[m]["reads_per_s"] = rs.n / (core[m]["ms_min"] * 1e-3)
+
+    # ---- merge of the ranks' batches (configs[3]): the one exchange step of the path ----
+    merge = None
+    if world > 1 and not a.no_merge:
+        from isonclust2_amd import dist as idist
+        mode = "sahlin" if want_sahlin else "fast"
+        merge = idist.timed_merge(ctx, api.default_params(k, w, mode), cb_merge, dist, torch, dev)
+
     if rank == 0:
-        out_extra = {}
         # ---- fast mode (configs[1]): HBM roofline of the scoring kernels + full-batch CPU baseline / parity ----
-        roof = None
         if fast is not None:
-            ctx.set_params(api.default_params(k, w, "fast"))
-            fcls, fstrand, fst = ctx.cluster_resident()     # untimed: leaves the fast-mode clustering on the device
-            M = fast_res[3]["n_minimizers"]
-            # H = postings the reference's GetMinimizerHits traverses on this batch, counted on the device
-            # from the final clustering (instrumentation launch, untimed); C_s = survivor candidates
-            H = ctx.count_reference_postings()
-            Cs = fast_res[3]["n_mapped_evals"]
+            M, H, Cs, fst = roof_counts
             h_source = "device count (ioc_count_reference_postings)"
             if single:
-                dt, ost, mism = cpu_baseline_and_parity(rs, order, fcls, fstrand, k, w)
-                fast["cpu_baseline"] = {"value": rs.n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                tmin, times, ost, mism, core_id = cpu_baseline_fast(rs, order, fcls, fstrand, k, w, a.cpu_runs, a.cpu_budget)
+                fast["cpu_baseline"] = {"value": rs.n / tmin, "unit": "reads/s", "cores": 1, "kind": "port",
+                                        "cpu_model": cpu_model(), "pinned_core": core_id, "runs_s": [round(t, 2) for t in times],
                                         "sample": f"the full {a.config} batch ({rs.n} reads), fast mode, ClusterSortedReads "
-                                                  "region, oracle -O3 -msse3, 1 run"}
+                                                  f"region, oracle -O3 -DNDEBUG -msse3, min of {len(times)} run(s), 1 pinned core"}
                 fast["parity"] = {"entries": rs.n, "mismatches": mism, "clusters": fst["n_clusters"],
                                   "tie_replays": fst["n_tie_replays"], "oracle_postings": ost["postings"],
                                   "device_postings": H}
@@ -289,39 +381,51 @@ def main():
                         pass
         # ---- sahlin mode (configs[2]): the step is dominated by the alignment fallback's forward DP, an
         # integer-VALU kernel (no HBM traffic to speak of, no MFMA): its issue-rate roofline beside the HBM one ----
-        roof_aln = None
         if sah is not None:
             cells = sah_res[3]["n_align_cells"]
             ms_fwd = sah_res[4]["ms_align_fwd"]
             if cells and ms_fwd > 0:
+                peak, src = valu_peak()
                 ach = cells * ALIGN_VALU_PER_CELL / (ms_fwd * 1e-3) / 1e12
-                roof_aln = {"bound": "valu-int32", "kernel": "k_align_fwd", "achieved": ach, "peak": VALU_PEAK_TOPS,
-                            "unit": "T lane-op/s", "frac": ach / VALU_PEAK_TOPS, "kernel_ms": ms_fwd,
+                roof_aln = {"bound": "valu-int32", "kernel": "k_align_fwd", "achieved": ach, "peak": peak, "peak_source": src,
+                            "unit": "T lane-op/s", "frac": ach / peak, "kernel_ms": ms_fwd,
                             "cells": cells, "valu_per_cell": ALIGN_VALU_PER_CELL,
                             "gcells_per_s": cells / (ms_fwd * 1e-3) / 1e9}
             if single:
-                res = cpu_baseline_sahlin_sample(rs, order, sah_res[0], sah_res[1], k, w, a.cpu_sample)
-                if res is not None:
-                    dt, ost, mism, ns = res
-                    sah["cpu_baseline"] = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-                                           "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 "
-                                                     "-msse3 with the product's host aligner behind its aligner hook "
-                                                     "(parasail absent), 1 run"}
-                    sah["parity"] = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
+                tmin, times, ost, mism, ns, core_id = cpu_baseline_sahlin(lambda: api.Context(dev_index), api, pipeline, rs, order, k, w,
+                                                                         a.cpu_sample, a.cpu_runs, a.cpu_budget)
+                sah["cpu_baseline"] = {"value": ns / tmin, "unit": "reads/s", "cores": 1, "kind": "port",
+                                       "cpu_model": cpu_model(), "pinned_core": core_id, "runs_s": [round(t, 2) for t in times],
+                                       "aligner": "the oracle's own SCALAR semi-global aligner with full traceback (oracle.cpp sg_trace) — "
+                                                  "not parasail's striped SIMD scan (absent from the reference tree)",
+                                       "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 -DNDEBUG "
+                                                 f"-msse3, min of {len(times)} run(s), 1 pinned core; {ost['aln_invoked']} reads reach the fallback"}
+                sah["parity"] = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
+        cli = None
+        if world == 1 and not a.no_cli:
+            cli = {}
+            if want_sahlin:
+                cli["sahlin"] = cli_region(rs, "sahlin")
+            if want_fast:
+                cli["fast"] = cli_region(rs, "fast")
         head, head_mode = (sah, "sahlin") if sah is not None else (fast, "fast")
         out = {
             "metric": f"reads/s clustered ({head_mode} mode, k=11 w=15)",
             "value": head["value"], "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "value_region": "resident: one pass of the hot path (ioc_cluster_resident) over a sorted batch already in HBM; "
+                            "`core` = host arrays -> host results incl. PCIe, `cli` = whole cluster process incl. .cer I/O",
             "config": {"workload": f"{a.config} = BASELINE.json configs[{2 if head_mode == 'sahlin' else 1}]: {rs.tag}; one sorted "
                                    "3000-read / 50 Mb batch per GPU, minimizer SoA and sequences resident in HBM",
                        "mode": head_mode, "k": k, "w": w, "reads_per_gpu": rs.n, "minimizers_per_gpu": int(n_min),
-                       "parallelism": f"batch-shard x{world}, no data-path collective",
-                       "rank_batches": "seed 1 + rank" if a.rank_seeds else "every rank its own copy of the seed-1 batch"},
+                       "parallelism": f"batch-shard x{world}, no data-path collective in the timed region",
+                       "rank_batches": "every rank its own copy of the seed-1 batch" if a.same_seed else "rank r: the batch of seed 1 + r (different batches)",
+                       "identical_batches": bool(a.same_seed) and world > 1},
             "phase_ms": head["phase_ms"],
             "roofline": roof if roof is not None else roof_aln,
             "cpu_baseline": head.get("cpu_baseline"), "parity": head.get("parity"),
+            "core": core or None, "cli": cli, "merge": merge,
         }
         if head_mode == "sahlin":
             out["alignment"] = sah["alignment"]
@@ -329,23 +433,6 @@ def main():
             if fast is not None:
                 out["fast_mode"] = fast       # BASELINE.json configs[1] on the same batch
         print(json.dumps(out), flush=True)
-    if a.merge:
-        # config 4: RCCL all-gather of every rank's clustered batch, then the reference's left fold
-        # ((b0 + b1) + b2) ... with ioc_cluster_merge on rank 0 (untimed extra, reported on stderr)
-        from isonclust2_amd import dist as idist
-        from isonclust2_amd import pipeline
-        ctx.set_params(api.default_params(k, w, "fast"))
-        cls, strand, st = ctx.cluster_resident()
-        cb = resident_to_clustered(ctx, api, pipeline, rs, order, cls, strand, rank)
-        t1 = time.perf_counter()
-        allb = idist.allgather_clustered(cb, dist)
-        t2 = time.perf_counter()
-        if rank == 0:
-            merged = idist.fold_merge(ctx, api.default_params(k, w, "fast"), allb)
-            t3 = time.perf_counter()
-            print(json.dumps({"merge": {"batches": len(allb), "clusters_in": [b.n_clusters for b in allb],
-                                        "clusters_out": merged.n_clusters, "allgather_ms": (t2 - t1) * 1e3,
-                                        "fold_ms": (t3 - t2) * 1e3}}), file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

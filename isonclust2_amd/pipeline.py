@@ -35,6 +35,8 @@ class ClusteredBatch:
     batch_start: int = 0
     batch_end: int = 0
     stats: dict = field(default_factory=dict)
+    rep_seq: bytes = None    # raw sequences of the representatives, concatenated (sahlin / furious merges align them)
+    rep_off: np.ndarray = None
 
     @property
     def n_clusters(self):
@@ -46,6 +48,45 @@ class ClusteredBatch:
         cls[self.member_read] = self.member_cls
         strand[self.member_read] = self.member_strand
         return cls, strand
+
+
+def gather_seqs(seq, off, idx):
+    """Sequences idx out of a concatenated byte string with offsets -> (bytes, offsets)."""
+    if seq is None:
+        return None, None
+    a = np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else np.asarray(seq, np.uint8)
+    off = np.asarray(off, np.int64)
+    idx = np.asarray(idx, np.int64)
+    lens = (off[1:] - off[:-1])[idx]
+    o = np.zeros(len(idx) + 1, np.int64)
+    o[1:] = np.cumsum(lens)
+    sel = np.repeat(off[:-1][idx] - o[:-1], lens) + np.arange(o[-1])
+    return a[sel].tobytes(), o
+
+
+def sort_stage(ctx, rs, k, w, read_id_base=0, batch_nr=0, min_qual=7.0):
+    """`isONclust2 sort` on one read set that becomes ONE batch (src/main.cpp:105-199): FillQualScores ->
+    SortByQualScores -> PrepareSortedBatch, the two compute steps on the GPU through the C ABI
+    (ioc_qual_scores, ioc_extract_minimizers).  Returns (SortedBatch, order): the batch as host arrays in the
+    layout of ioc_batch_view (raw sequences included), order[i] = index in `rs` of entry i."""
+    score, err = ctx.qual_scores(rs.offs, rs.qual, k)                       # FillQualScores
+    order = np.argsort(-score, kind="stable")                               # SortByQualScores (stable, descending)
+    lens = np.diff(rs.offs)[order]
+    so = np.zeros(rs.n + 1, np.int64)
+    so[1:] = np.cumsum(lens)
+    idx = np.repeat(rs.offs[:-1][order] - so[:-1], lens) + np.arange(so[-1])
+    seq = rs.seq[idx]
+    ex = ctx.extract_minimizers(so, seq, rs.qual[idx], k, w)                # PrepareSortedBatch
+    mn, ps = ctx.extracted_download(int(ex["off_rev"][-1]))
+    # qualscore.cpp:56-73: placeholder entries (state 1) for reads the sort stage gates
+    gated = (ex["status"] != 0) | (-10 * np.log10(err[order]) <= min_qual)
+    view = dict(off_fwd=ex["off_fwd"], off_rev=ex["off_rev"], min_val=mn, min_pos=ps,
+                raw_len=lens.astype(np.uint32), hpc_len=ex["hpc_len"], score=np.where(ex["status"] != 0, -1.0, score[order]),
+                raw_err=err[order], hpc_err=ex["hpc_err"], state=gated.astype(np.uint8), min_qual=min_qual,
+                raw_seq=seq.tobytes(), raw_off=so)
+    sb = SortedBatch(view=view, read_ids=read_id_base + order.astype(np.int64), batch_nr=batch_nr,
+                     batch_start=read_id_base, batch_end=read_id_base + rs.n - 1)
+    return sb, order
 
 
 def gather_records(view, idx):
@@ -111,7 +152,8 @@ def cluster_single(ctx, params, sb: SortedBatch) -> ClusteredBatch:
             seen[c] = True
             rep_entry[c] = i
     rep_view = gather_records(sb.view, rep_entry)
-    return ClusteredBatch(rep_view=rep_view, member_cls=cls[ok].astype(np.int32),
+    rep_seq, rep_off = gather_seqs(sb.view.get("raw_seq"), sb.view.get("raw_off"), rep_entry)
+    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off, member_cls=cls[ok].astype(np.int32),
                           member_read=np.asarray(sb.read_ids)[ok].astype(np.int64),
                           member_strand=strand[ok].astype(np.int32), mindb=(keys, offs, post),
                           depth=sb.depth + 1 if sb.depth < 0 else sb.depth + 1,
@@ -132,6 +174,9 @@ def cluster_merge(ctx, params, left: ClusteredBatch, right: ClusteredBatch, min_
     rv.update(n_members=counts, depth=right.depth, min_cls_size=min_cls_size)
     lv = dict(cls_hpc_err=left.rep_view["hpc_err"], keys=left.mindb[0], offs=left.mindb[1],
               postings=left.mindb[2])
+    if left.rep_seq is not None and right.rep_seq is not None:   # sahlin / furious: getBestClusterAln aligns representatives
+        lv.update(rep_seq=left.rep_seq, rep_off=left.rep_off, cls_raw_err=left.rep_view["raw_err"])
+        rv.update(raw_seq=right.rep_seq, raw_off=right.rep_off)
     cls, strand, st = ctx.cluster_merge(params, lv, rv)
     keys, offs, post = ctx.index_export()
     L = left.n_clusters
@@ -145,12 +190,17 @@ def cluster_merge(ctx, params, left: ClusteredBatch, right: ClusteredBatch, min_
             seen.add(int(cls[i]))
             created.append(i)
     rep_view = left.rep_view
+    rep_seq, rep_off = left.rep_seq, left.rep_off
     if created:
         rep_view = concat_records(left.rep_view, gather_records(right.rep_view, np.array(created)))
+        if left.rep_seq is not None and right.rep_seq is not None:
+            add, ao = gather_seqs(right.rep_seq, right.rep_off, np.array(created))
+            rep_seq = left.rep_seq + add
+            rep_off = np.concatenate([left.rep_off, ao[1:] + left.rep_off[-1]])
     mcl = cls[right.member_cls]
     mst = strand[right.member_cls].astype(np.int32) * right.member_strand
     keep = mcl >= 0
-    return ClusteredBatch(rep_view=rep_view,
+    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off,
                           member_cls=np.concatenate([left.member_cls, mcl[keep].astype(np.int32)]),
                           member_read=np.concatenate([left.member_read, right.member_read[keep]]),
                           member_strand=np.concatenate([left.member_strand, mst[keep]]),

@@ -29,13 +29,7 @@ def oracle_entry_assignments(B, view, mode="fast"):
     return acl[view["orig"]], ast[view["orig"]], st
 
 
-def fnv1a(cls, strand):
-    h = 0xcbf29ce484222325
-    for c, s in zip(cls.tolist(), strand.tolist()):
-        for b in (c & 0xFFFFFFFF).to_bytes(4, "little") + (s & 0xFF).to_bytes(1, "little"):
-            h ^= b
-            h = (h * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
-    return h
+from isonclust2_amd.digest import fnv1a  # noqa: E402,F401  (one definition for tests, goldens and bench)
 
 
 class ToyGraphs:

@@ -54,12 +54,17 @@ def _worker(rank, world, port, q):
     elapsed = 0.5 + 0.25 * rank
     tmax = d.max_over_ranks(elapsed, dist)
     total = d.sum_over_ranks(n, dist)
-    got = d.allgather_clustered(cb, dist)
+    got, nbytes = d.allgather_clustered(cb, dist)
+    assert len(nbytes) == world and nbytes[0] > nbytes[1] // 2
     ok = len(got) == world
     for rr, g in enumerate(got):
         exp, _ = _oracle_clustered(seed=1 + rr)
         ok &= np.array_equal(g.member_cls, exp.member_cls) and np.array_equal(g.member_read, exp.member_read)
-        ok &= np.array_equal(g.mindb[2], exp.mindb[2]) and np.array_equal(g.rep_view["min_val"], exp.rep_view["min_val"])
+        if rr == 0:   # only the leftmost batch's MinDB travels
+            ok &= np.array_equal(g.mindb[2], exp.mindb[2]) and np.array_equal(g.mindb[0], exp.mindb[0])
+        else:
+            ok &= len(g.mindb[2]) == 0
+        ok &= np.array_equal(g.rep_view["min_val"], exp.rep_view["min_val"]) and np.array_equal(g.rep_view["hpc_err"], exp.rep_view["hpc_err"])
         ok &= np.array_equal(g.rep_view["off_rev"], exp.rep_view["off_rev"]) and g.batch_end == exp.batch_end
     q.put((rank, tmax, total, bool(ok)))
     dist.barrier()

@@ -1,0 +1,97 @@
+"""BASELINE.json configs[1..3] at FULL size on the GPU against committed oracle goldens
+(tests/golden/oracle_assignments.json, generated in the build container by tools/gen_golden.py --full /
+--full-sahlin: FNV-1a digests of the oracle's assignments, cluster counts, alignment-fallback counts).
+
+  configs[1]  3000 reads / 50 Mb, k=11 w=15, fast mode               test_config2_fast_full
+  configs[2]  the same batch, sahlin mode (GPU alignment fallback)   test_config2_sahlin_full
+  configs[3]  8 batches x 3000 reads (seeds 1..8), each clustered on its own, folded left to right
+              (README.md:105-117; src/cluster.cpp:67-322 with two batches)   test_config4_fold_*
+
+Everything runs through the C ABI from host arrays (the *core* region of SURVEY §8(d)): GPU sort stage ->
+ioc_cluster_merge -> assignments + ioc_index_export.  The oracle is not run here (minutes per batch on a core; in
+sahlin mode a quarter of an hour): the goldens stand for it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import api, pipeline, synth
+from tests.helpers import fnv1a
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_assignments.json")))
+K, W = 11, 15
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def batches(ctx):
+    """The sorted batches of seeds 1..8, prepared once by the product's own GPU sort stage."""
+    cache = {}
+
+    def get(seed):
+        if seed not in cache:
+            rs = synth.generate_config("config2", seed=seed)
+            sb, order = pipeline.sort_stage(ctx, rs, K, W, read_id_base=rs.n * (seed - 1), batch_nr=seed - 1)
+            cache[seed] = (sb, rs.n)
+        return cache[seed]
+    return get
+
+
+def _single(ctx, batches, seed, mode):
+    sb, n = batches(seed)
+    cb = pipeline.cluster_single(ctx, api.default_params(K, W, mode), sb)
+    acl, ast = cb.assignments(sb.batch_start + n)
+    cls_e, strand_e = acl[sb.read_ids], ast[sb.read_ids]   # per entry of the sorted batch
+    return cb, cls_e, strand_e
+
+
+def test_config2_fast_full(ctx, batches):
+    g = GOLD["config2:1"]
+    cb, cls, strand = _single(ctx, batches, 1, "fast")
+    assert cb.n_clusters == g["clusters"]
+    assert f"{fnv1a(cls, strand):016x}" == g["fnv1a"]
+    # the exported MinDB holds exactly the postings AddMinimizers appended (src/minimizer.cpp:31-42)
+    assert len(cb.mindb[2]) == g["stats"]["index_appends"]
+    # the raw hits GetMinimizerHits emits on this batch (src/minimizer.cpp:44-76), recounted on the device
+    assert ctx.count_reference_postings() == g["stats"]["postings"]
+
+
+def test_config2_sahlin_full(ctx, batches):
+    g = GOLD["config2:1:sahlin"]
+    cb, cls, strand = _single(ctx, batches, 1, "sahlin")
+    assert cb.n_clusters == g["clusters"]
+    assert cb.stats["n_aln_invoked"] == g["stats"]["aln_invoked"]      # reads reaching getBestClusterAln (cluster.cpp:563)
+    assert f"{fnv1a(cls, strand):016x}" == g["fnv1a"]
+    assert len(cb.mindb[2]) == g["stats"]["index_appends"]
+
+
+@pytest.mark.parametrize("mode", ["fast", "sahlin"])
+def test_config4_fold(ctx, batches, mode):
+    """configs[3] on one GPU: every batch clustered on its own (checked against its golden), then
+    ((b1 + b2) + b3) ... with the merge path; cluster counts after every merge and the digest over all 24 000 reads."""
+    g = GOLD[f"config4:{mode}"]
+    cbs = []
+    for seed in g["seeds"]:
+        cb, cls, strand = _single(ctx, batches, seed, mode)
+        gs = GOLD[f"config2:{seed}" + ("" if mode == "fast" else ":sahlin")]
+        assert cb.n_clusters == gs["clusters"], seed
+        assert f"{fnv1a(cls, strand):016x}" == gs["fnv1a"], seed
+        cbs.append(cb)
+    p = api.default_params(K, W, mode)
+    left = cbs[0]
+    for step, cb in zip(g["steps"], cbs[1:]):
+        left = pipeline.cluster_merge(ctx, p, left, cb)
+        assert left.n_clusters == step["clusters_after"], step["right_seed"]
+        if mode == "sahlin":
+            assert left.stats["n_aln_invoked"] == step["stats"]["aln_invoked"], step["right_seed"]
+    acl, ast = left.assignments(g["n"])
+    assert int(np.count_nonzero(acl >= 0)) == g["assigned"]
+    assert f"{fnv1a(acl, ast):016x}" == g["fnv1a"]

@@ -75,3 +75,42 @@ def test_left_fold_merge_equals_oracle(ctx, cfg, seed, nb):
         assert len(bad) == 0, (b, len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
         assert left.n_clusters == left_o.n_clusters()
         _same_index(left, left_o)
+
+
+@pytest.mark.parametrize("cfg,seed,nb,mode", [("config1", 1, 4, "fast"), ("short_dup", 1, 3, "fast"), ("config1", 2, 3, "sahlin"),
+                                              ("short_dup", 2, 4, "sahlin")])
+def test_one_pass_merge_of_all_batches_equals_the_oracle_fold(ctx, cfg, seed, nb, mode):
+    """dist.merge_all: ((b0 + b1) + b2) ... computed as ONE pass of the merge path over the concatenated right
+    representatives — against the oracle folding the batches one merge at a time (cluster.cpp:67-322), on batches
+    that share transcripts (joins across batches, strand flips, ties; sahlin: representatives aligned against
+    representatives)."""
+    from isonclust2_amd import dist as idist
+    rs = synth.generate_config(cfg, seed=seed)
+    obs, sbs = _batches(rs, nb)
+    for sb, B in zip(sbs, obs):   # raw sequences for the alignment fallback
+        info = B.entry_info()
+        seqs = [rs.read(int(i))[0] for i in info["orig"]]
+        off = np.zeros(len(seqs) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in seqs])
+        sb.view.update(raw_seq=b"".join(seqs), raw_off=off)
+    p = api.default_params(11, 15, mode)
+    for B in obs:
+        B.cluster(mode=mode)
+    cbs = [pipeline.cluster_single(ctx, p, sb) for sb in sbs]
+    left_o = obs[0]
+    aln = 0
+    for b in range(1, nb):
+        st = left_o.cluster(right=obs[b], mode=mode)
+        aln += st["aln_invoked"]
+    merged = idist.merge_all(ctx, p, cbs)
+    ocl, ost = left_o.assignments(rs.n)
+    cls, strand = merged.assignments(rs.n)
+    bad = np.nonzero((cls != ocl) | (strand != ost))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
+    assert merged.n_clusters == left_o.n_clusters()
+    _same_index(merged, left_o)
+    assert merged.stats["n_aln_invoked"] == aln
+    # and the packed record round-trips (what the all-gather ships)
+    g = idist.unpack_clustered(idist.pack_clustered(cbs[1]))
+    assert np.array_equal(g.rep_view["min_val"], cbs[1].rep_view["min_val"]) and g.rep_seq == cbs[1].rep_seq
+    assert np.array_equal(g.rep_off, cbs[1].rep_off) and np.array_equal(g.member_read, cbs[1].member_read)

@@ -1,0 +1,127 @@
+// Issue rate of the integer / float VALU instructions the aligner's forward pass is made of, on gfx950, at 1 / 2 / 4 / 8
+// waves per SIMD (developer microbenchmark; its output is kept under profiles/ and sets bench.py's VALU peak).
+// Every wave runs 16 independent dependency chains of the instruction under test; a workgroup is 256 threads = one wave
+// per SIMD, an LDS reservation caps the workgroups per CU at the wanted number and the grid is exactly CUs x that number,
+// so every SIMD holds exactly `wps` waves for the whole launch.  Cycles come from s_memtime (shader clock) next to the
+// wall time, so the real clock under load is printed too.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rate tools/micro/valu_rate.hip && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+enum { FMA_F32, ADD_U32, MAX_I32, MAX3_I32, ADD_SDWA, PK_MAX_I16, PK_ADD_I16, MOV_DPP, MIX_ALIGN, N_MODES };
+static const char* NAMES[N_MODES] = {"v_fma_f32", "v_add_u32", "v_max_i32", "v_max3_i32", "v_add_u32_sdwa (byte sel)",
+                                     "v_pk_max_i16", "v_pk_add_i16", "v_mov_b32_dpp wave_shr:1",
+                                     "aligner cell mix (add_sdwa, max3, sub, max, max)"};
+static const int OPS[N_MODES] = {1, 1, 1, 1, 1, 1, 1, 1, 5};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters, uint32_t seed)
+{
+    extern __shared__ uint32_t pad[];
+    uint32_t a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = seed + threadIdx.x * 17 + i;
+    uint32_t b = seed * 3 + 1, c = seed ^ 0x1234;
+    float fb = 1.0001f, fc = 0.5f;
+    const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (MODE == FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(fb), "v"(fc));
+            if (MODE == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (MODE == MAX_I32) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (MODE == MAX3_I32) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (MODE == ADD_SDWA) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[i]) : "v"(b));
+            if (MODE == PK_MAX_I16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (MODE == PK_ADD_I16) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (MODE == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
+            if (MODE == MIX_ALIGN) {
+                uint32_t x, e, f;
+                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(x) : "v"(a[i]), "v"(b));
+                asm volatile("v_max_i32 %0, %1, %2" : "=v"(e) : "v"(a[(i + 1) & 15]), "v"(c));
+                asm volatile("v_max_i32 %0, %1, %2" : "=v"(f) : "v"(a[(i + 2) & 15]), "v"(b));
+                asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(e), "v"(f));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(c));
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + pad[0] * 0;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+void run(int n_cu, int wps, double* out_rate)
+{
+    const int grid = n_cu * wps, iters = 4000;
+    uint32_t* d;
+    uint64_t* dc;
+    hipMalloc(&d, size_t(grid) * 256 * 4);
+    hipMalloc(&dc, size_t(grid) * 8);
+    // at most `wps` workgroups per CU: each takes just over 160 KB / (wps + 1) of LDS (64 KB is the default cap per block)
+    size_t lds = wps >= 8 ? 0 : (size_t(160) * 1024 / (wps + 1) + 1024) & ~size_t(255);
+    if (lds > 64 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, 10, 1u);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, iters, 1u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    uint64_t* hc = new uint64_t[grid];
+    hipMemcpy(hc, dc, size_t(grid) * 8, hipMemcpyDeviceToHost);
+    double cavg = 0;
+    for (int i = 0; i < grid; ++i) cavg += double(hc[i]);
+    cavg /= grid;
+    delete[] hc;
+    const double winstr = double(iters) * 16 * OPS[MODE];           // wave-instructions per wave
+    const double lane_ops = winstr * 64 * 4 * double(grid);         // lane-operations of the launch
+    const double rate = lane_ops / (ms * 1e-3) / 1e12;
+    // cycles of a SIMD per wave-instruction it issued: the wave's own cycles / its instructions / waves sharing the SIMD
+    printf("  %-48s wps %d: %8.3f ms  %6.2f T lane-op/s  %5.2f cyc per wave-instr per SIMD  (shader clock %.2f GHz)\n", NAMES[MODE], wps, ms,
+           rate, cavg / winstr / wps, cavg / (ms * 1e-3) / 1e9);
+    if (out_rate) *out_rate = rate;
+    hipFree(d);
+    hipFree(dc);
+}
+
+template <int MODE>
+void sweep(int n_cu, double* best)
+{
+    for (int wps : {1, 2, 4, 8}) {
+        double r = 0;
+        run<MODE>(n_cu, wps, &r);
+        if (r > best[MODE]) best[MODE] = r;
+    }
+}
+
+int main()
+{
+    int n_cu = 256, clk = 0;
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0);
+    hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0);
+    printf("device: %d CUs, nominal clock %.2f GHz; SIMDs %d\n", n_cu, clk / 1e6, n_cu * 4);
+    double best[N_MODES] = {0};
+    sweep<FMA_F32>(n_cu, best);
+    sweep<ADD_U32>(n_cu, best);
+    sweep<MAX_I32>(n_cu, best);
+    sweep<MAX3_I32>(n_cu, best);
+    sweep<ADD_SDWA>(n_cu, best);
+    sweep<PK_MAX_I16>(n_cu, best);
+    sweep<PK_ADD_I16>(n_cu, best);
+    sweep<MOV_DPP>(n_cu, best);
+    sweep<MIX_ALIGN>(n_cu, best);
+    printf("JSON {");
+    for (int m = 0; m < N_MODES; ++m) printf("%s\"%s\": %.3f", m ? ", " : "", NAMES[m], best[m]);
+    printf("}\n");
+    return 0;
+}
