@@ -373,7 +373,7 @@ int ioc_index_build(ioc_ctx* c)
         RESERVE(c, c->b_cnt, size_t(nslots + 1) * 4);
         RESERVE(c, c->b_off, size_t(nslots + 1) * 4);
         RESERVE(c, c->b_rows, size_t(nslots) * 16);
-        RESERVE(c, c->b_qinfo, size_t(nslots) * 4);
+        RESERVE(c, c->b_qinfo, size_t(nslots) * 8);  // two words per slot: length + epoch cuts (ioc_kernels.hip, index_lookup)
         RESERVE(c, c->b_scan, (size_t(nslots) / 1024 + 4) * 4);
         HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(nslots) * 4, s));
         HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(nslots + 1) * 4, s));

@@ -25,6 +25,12 @@
 #define IOC_EMPTY 0xFFFFFFFFu
 #define IOC_FLAT_UNROLL 8
 #define IOC_SHORT_LIST 192
+#ifndef IOC_SCORE_ABL
+#define IOC_SCORE_ABL 0
+#endif
+#ifndef IOC_SCORE_OLD_TRAVERSE
+#define IOC_SCORE_OLD_TRAVERSE 0  // 1: round 1's per-posting code in k_score_part (ablation builds)
+#endif
 
 namespace {
 
@@ -36,15 +42,43 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t v, uint32_t shift)
     return (v * 0x9E3779B1u) >> shift;
 }
 
-// Lookup in the packed rows (key, off, cnt, -) — one 16-byte load per probe step.
+// Rows of the index: {key, list offset, w2, w3}.  A list of >= IOC_EPOCH_LONG entries has w3 = 0x80000000 and w2 = its
+// length.  A shorter one packs, next to its length (10 bits), where it can be CUT for a query that sees only the targets
+// below T: f_i = ceil(#entries below the epoch boundary e_i / 8), 7 bits each, for the 7 boundaries e_1 < ... < e_7 that cut
+// the target ids into 8 equal ranges — w2 = len | f1 << 10 | f2 << 17 | f3 << 24, w3 = f4 | f5 << 7 | f6 << 14 | f7 << 21.
+// (Round 1 had 3 boundaries: a query then walked, on average, an eighth of every list beyond its window; now a sixteenth.)
+#define IOC_EPOCHS 7
+#define IOC_EPOCH_LONG 1016u
+struct Epochs {
+    uint32_t e[IOC_EPOCHS];
+};
+// which field holds the cut of a query with window T: (word 0 = w2 / 1 = w3, shift); word 2 = no cut (T beyond e_7)
+__device__ __forceinline__ void epoch_field(const Epochs& E, uint32_t T, uint32_t& word, uint32_t& shift)
+{
+    int f = IOC_EPOCHS;
+#pragma unroll
+    for (int i = IOC_EPOCHS - 1; i >= 0; --i)
+        if (T <= E.e[i]) f = i;
+    word = f < 3 ? 0u : f < IOC_EPOCHS ? 1u : 2u;
+    shift = f < 3 ? 10u + 7u * uint32_t(f) : 7u * uint32_t(f - 3);
+}
+// visible length of a short list (info = {w2, w3}, len already decoded) under (word, shift) of epoch_field
+__device__ __forceinline__ uint32_t epoch_cut(uint2 info, uint32_t len, uint32_t word, uint32_t shift)
+{
+    if (word == 2u) return len;
+    const uint32_t f = ((word ? info.y : info.x) >> shift) & 127u;
+    return min(len, f * 8u);
+}
+
+// Lookup in the packed rows — one 16-byte load per probe step.  cnt = the list's length, info = {w2, w3}.
 __device__ __forceinline__ bool index_lookup(const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
-                                             uint32_t v, uint32_t& off, uint32_t& cnt, uint32_t& info)
+                                             uint32_t v, uint32_t& off, uint32_t& cnt, uint2& info)
 {
     if (v == IOC_EMPTY) {
         uint4 r = rows[cap];
         off = r.y;
-        cnt = r.z;
-        info = r.w;
+        cnt = (r.w & 0x80000000u) ? r.z : (r.z & 1023u);
+        info = make_uint2(r.z, r.w);
         return cnt != 0;
     }
     uint32_t h = hash_slot(v, shift);
@@ -52,8 +86,8 @@ __device__ __forceinline__ bool index_lookup(const uint4* __restrict__ rows, uin
         uint4 r = rows[h];
         if (r.x == v) {
             off = r.y;
-            cnt = r.z;
-            info = r.w;
+            cnt = (r.w & 0x80000000u) ? r.z : (r.z & 1023u);
+            info = make_uint2(r.z, r.w);
             return true;
         }
         if (r.x == IOC_EMPTY) return false;
@@ -62,14 +96,19 @@ __device__ __forceinline__ bool index_lookup(const uint4* __restrict__ rows, uin
     return false;
 }
 
+// inclusive prefix sum over the 64 lanes: 4 DPP row shifts inside the rows of 16 lanes, then the two row broadcasts
+// (lane 15 of a row to the next row, lane 31 to the upper half) — 6 data-parallel adds, no LDS crossbar (the
+// __shfl_up form cost 5 VALU + 1 ds_bpermute per step)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
+#define IOC_DPP_ADD(ctrl, rmask) v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), ctrl, rmask, 0xF, false))
+    IOC_DPP_ADD(0x111, 0xF);  // row_shr:1
+    IOC_DPP_ADD(0x112, 0xF);  // row_shr:2
+    IOC_DPP_ADD(0x114, 0xF);  // row_shr:4
+    IOC_DPP_ADD(0x118, 0xF);  // row_shr:8
+    IOC_DPP_ADD(0x142, 0xA);  // row_bcast:15 into rows 1 and 3
+    IOC_DPP_ADD(0x143, 0xC);  // row_bcast:31 into rows 2 and 3
+#undef IOC_DPP_ADD
     return v;
 }
 
@@ -342,8 +381,7 @@ k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32
 template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-             PT* __restrict__ post, uint32_t L, uint32_t words_per_wave, uint32_t e1, uint32_t e2,
-             uint32_t e3, uint32_t* __restrict__ qinfo)
+             PT* __restrict__ post, uint32_t L, uint32_t words_per_wave, Epochs E, uint2* __restrict__ qinfo)
 {
     extern __shared__ uint32_t sbits[];  // IOC_WAVES * words_per_wave
     const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6;  // global wave id
@@ -352,25 +390,27 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
     uint32_t* bits = sbits + size_t(wave_id()) * words_per_wave;
     for (uint32_t slot = gw; slot < nslots; slot += nw) {
         const uint32_t c = cnt[slot];
-        // epoch boundaries: number of entries below the target ids e1 < e2 < e3, 10 bits each
-        // (lists of >= 1024 entries get 0x80000000: k_score falls back to a binary search)
+        // epoch cuts (see index_lookup): per boundary the number of entries below it, in units of 8 postings
+        // (the counts do not depend on the order of the list, which is only sorted below)
         {
-            uint32_t info = 0x80000000u;
-            if (c < 1024) {
+            uint2 info = make_uint2(c, 0x80000000u);
+            if (c < IOC_EPOCH_LONG) {
                 const uint32_t o0 = off[slot];
-                uint32_t b1 = 0, b2 = 0, b3 = 0;
+                uint32_t b[IOC_EPOCHS];
+#pragma unroll
+                for (int i = 0; i < IOC_EPOCHS; ++i) b[i] = 0;
                 for (uint32_t t = lane; t < c; t += 64) {
                     const uint32_t v = post[o0 + t];
-                    b1 += v < e1;
-                    b2 += v < e2;
-                    b3 += v < e3;
+#pragma unroll
+                    for (int i = 0; i < IOC_EPOCHS; ++i) b[i] += v < E.e[i];
                 }
-                for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                    b1 += __shfl_down(b1, o2);
-                    b2 += __shfl_down(b2, o2);
-                    b3 += __shfl_down(b3, o2);
+#pragma unroll
+                for (int i = 0; i < IOC_EPOCHS; ++i) {
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) b[i] += __shfl_down(b[i], o2);
+                    b[i] = (b[i] + 7u) >> 3;
                 }
-                info = b1 | (b2 << 10) | (b3 << 20);
+                info.x = c | (b[0] << 10) | (b[1] << 17) | (b[2] << 24);
+                info.y = b[3] | (b[4] << 7) | (b[5] << 14) | (b[6] << 21);
             }
             if (lane == 0) qinfo[slot] = info;
         }
@@ -422,11 +462,12 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
 
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_pack_rows(uint32_t nslots, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ off,
-            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ qinfo, uint4* __restrict__ rows)
+            const uint32_t* __restrict__ cnt, const uint2* __restrict__ qinfo, uint4* __restrict__ rows)
 {
     uint32_t s = blockIdx.x * IOC_BLOCK + threadIdx.x;
     if (s >= nslots) return;
-    rows[s] = make_uint4(keys[s], off[s], cnt[s], qinfo[s]);
+    const uint2 q = qinfo[s];  // {length | cuts, cuts} or {length, long-list flag}: see index_lookup
+    rows[s] = make_uint4(keys[s], off[s], q.x, q.y);
 }
 
 // =====================================================================================================
@@ -591,13 +632,114 @@ __device__ __forceinline__ void flat_traverse(const PT* __restrict__ post, uint3
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- u16 postings, single pass: the per-posting work of flat_traverse cut to 2 VALU ----------------------------------------
+// rocprof on round 1's kernel: VALU-issue (68 % busy, 9 VALU per posting slot) and LDS (63 % busy) bound together.  Per
+// posting the compiler emitted extract (and / shift) + compare + shift-add + the exec save / restore around the atomic.
+// Here the window test runs on the raw 16-bit half of the loaded word (v_cmp_lt_u32_sdwa), the counter's LDS address
+// is half * 4 + base in one v_mad_u32_u16 (op_sel picks the half), and the atomic is issued under the compare's mask:
+// 2 VALU + 1 ds_add_u32 per posting; padding (0xFFFF) and the entries of the epoch slack fail the test as before.
+__device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t hbase, uint32_t one)
+{
+    uint32_t a;
+    unsigned long long sv;
+#if IOC_SCORE_ABL == 1   // ablation build: no LDS atomics
+    asm volatile("v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\tv_mad_u32_u16 %0, %2, 4, %4 op_sel:[0,0,0,0]\n\t"
+                 "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n\tv_mad_u32_u16 %0, %2, 4, %4 op_sel:[1,0,0,0]"
+                 : "=&v"(a), "=&s"(sv) : "v"(w), "v"(T), "v"(hbase), "v"(one) : "vcc", "memory");
+    return;
+#elif IOC_SCORE_ABL == 2  // ablation build: conflict-free atomics (every lane its own bank)
+    hbase += (threadIdx.x & 31u) * 4u;
+    w = 0;
+    T = T ? 1u : 0u;
+#endif
+    asm volatile(
+        "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_mad_u32_u16 %0, %2, 4, %4 op_sel:[0,0,0,0]\n\t"
+        "ds_add_u32 %0, %5\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_mad_u32_u16 %0, %2, 4, %4 op_sel:[1,0,0,0]\n\t"
+        "ds_add_u32 %0, %5\n\t"
+        "s_mov_b64 exec, %1"
+        : "=&v"(a), "=&s"(sv)
+        : "v"(w), "v"(T), "v"(hbase), "v"(one)
+        : "vcc", "memory");
+}
+
+__device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ post, uint32_t o, uint32_t len,
+                                                  uint32_t* __restrict__ wb, unsigned long long* __restrict__ bm,
+                                                  uint32_t* __restrict__ h, uint32_t T, unsigned long long& trav, uint32_t& abl)
+{
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long le_mask = lt_mask | (1ull << lane);
+    const uint32_t lenU = (len + 7u) >> 3;
+    const unsigned long long nz = __ballot(lenU != 0);
+    if (nz == 0ull) return;
+    const uint32_t incl = wave_incl_scan(lenU);
+    const uint32_t total = __shfl(incl, 63);
+    const uint32_t excl = incl - lenU;
+    const uint32_t nwords = (total + 63) >> 6;
+    if (nwords > IOC_BM_WORDS) {  // a very long chunk: the general path (6-step search)
+        flat_traverse<0, uint16_t>(post, o, len, wb, bm, h, 0u, T, trav, abl);
+        return;
+    }
+    const uint4* __restrict__ post4 = reinterpret_cast<const uint4*>(post);
+    trav += 8ull * total;
+    for (uint32_t w = lane; w < nwords + IOC_FLAT_UNROLL; w += 64) bm[w] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lenU) {
+        wb[__popcll(nz & lt_mask)] = (o >> 3) - excl;  // unit address = wb[list] + p
+        atomicOr(&bm[excl >> 6], 1ull << (excl & 63u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t hbase = uint32_t(reinterpret_cast<uintptr_t>(h));  // LDS byte address of the strand's histogram
+    const uint32_t one = 1u;
+    uint32_t c0 = 0;
+    for (uint32_t w0 = 0; w0 < nwords; w0 += IOC_FLAT_UNROLL) {
+        unsigned long long B[IOC_FLAT_UNROLL];
+        uint32_t r[IOC_FLAT_UNROLL], base[IOC_FLAT_UNROLL];
+        uint4 tg[IOC_FLAT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) B[u] = bm[w0 + u];
+#pragma unroll
+        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+            const uint32_t rr = c0 + uint32_t(__popcll(B[u] & le_mask)) - 1u;
+            r[u] = rr < 64u ? rr : 63u;
+            c0 += uint32_t(__popcll(B[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) base[u] = wb[r[u]];
+#pragma unroll
+        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+            const uint32_t p = (w0 + u) * 64u + uint32_t(lane);
+            tg[u] = post4[p < total ? base[u] + p : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+            // (a lane past the end of the concatenation loaded unit 0: a window of 0 targets rejects all of it)
+            const uint32_t Tl = (w0 + u) * 64u + uint32_t(lane) < total ? T : 0u;
+            count_word_u16(tg[u].x, Tl, hbase, one);
+            count_word_u16(tg[u].y, Tl, hbase, one);
+            count_word_u16(tg[u].z, Tl, hbase, one);
+            count_word_u16(tg[u].w, Tl, hbase, one);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the atomics above are invisible to the compiler's counters)
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int V, typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
         const uint32_t* __restrict__ mins, const uint4* __restrict__ rows, uint32_t cap, uint32_t shift,
         const PT* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
-        unsigned long long* __restrict__ traversed, uint32_t e1, uint32_t e2, uint32_t e3,
+        unsigned long long* __restrict__ traversed, Epochs E,
         const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum)
 {
     extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
@@ -607,8 +749,9 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
     const int j = n - 1 - int(blockIdx.x);
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);  // visible targets: [0, T)
-    // first epoch boundary >= T: its position field in the row info (30 = none: whole list)
-    const uint32_t eshift = T <= e1 ? 0u : T <= e2 ? 10u : T <= e3 ? 20u : 30u;
+    // first epoch boundary >= T: the field of the row info that holds its cut
+    uint32_t eword, eshift;
+    epoch_field(E, T, eword, eshift);
     const int lane = lane_id(), wave = wave_id();
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     uint32_t written = 0;
@@ -629,7 +772,8 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
             uint32_t* h = hist + uint32_t(s) * Tr;
             // software pipelining: the hash probe of the next chunk is issued before this chunk's
             // postings are traversed
-            uint32_t o_nx = 0, c_nx = 0, q_nx = 0;
+            uint32_t o_nx = 0, c_nx = 0;
+            uint2 q_nx = make_uint2(0u, 0u);
             {
                 const int64_t t = b + wave * 64 + lane;
                 if (t < e) index_lookup(rows, cap, shift, mins[t], o_nx, c_nx, q_nx);
@@ -637,12 +781,12 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
             if (V == 5) continue;  // ablation: no probes, no traversal
             for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
                 uint32_t o = o_nx, len = c_nx;
-                const uint32_t qi = q_nx;
+                const uint2 qi = q_nx;
                 {
                     const int64_t t = c0 + IOC_WAVES * 64 + lane;
                     o_nx = 0;
                     c_nx = 0;
-                    q_nx = 0;
+                    q_nx = make_uint2(0u, 0u);
                     if (t < e) index_lookup(rows, cap, shift, mins[t], o_nx, c_nx, q_nx);
                 }
                 // Visible part of the ascending list.  Single pass (the common case): the row carries
@@ -650,8 +794,8 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
                 // boundary >= T without touching it; the few entries in [T, boundary) are rejected by
                 // the window test below.  Long lists and range passes pay a binary search.
                 if (len) {
-                    if (rbase == 0 && hi == T && !(qi & 0x80000000u)) {
-                        if (eshift < 30) len = (qi >> eshift) & 1023u;
+                    if (rbase == 0 && hi == T && !(qi.y & 0x80000000u)) {
+                        len = epoch_cut(qi, len, eword, eshift);
                     } else {
                         const PT* pl = post + o;
                         // (start rounded down to a 16-byte unit; entries < rbase are rejected below)
@@ -781,8 +925,8 @@ template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
-             uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, uint32_t e1,
-             uint32_t e2, uint32_t e3, unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len)
+             uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, Epochs E,
+             unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t s_wb[IOC_WAVES][64];
@@ -792,7 +936,8 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);
     if (T == 0) return;
-    const uint32_t eshift = T <= e1 ? 0u : T <= e2 ? 10u : T <= e3 ? 20u : 30u;
+    uint32_t eword, eshift;
+    epoch_field(E, T, eword, eshift);
     const int lane = lane_id(), wave = wave_id();
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
     uint32_t* const wb_ = s_wb[wave];
@@ -808,16 +953,19 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
         uint32_t* h = hist + uint32_t(s) * T;
         for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
             const int64_t t = c0 + lane;
-            uint32_t o = 0, len = 0, qi = 0;
+            uint32_t o = 0, len = 0;
+            uint2 qi = make_uint2(0u, 0u);
             if (t < e) index_lookup(rows, cap, shift, pmins[t], o, len, qi);
             if (len) {
-                if (!(qi & 0x80000000u)) {
-                    if (eshift < 30) len = (qi >> eshift) & 1023u;
-                } else {
+                if (!(qi.y & 0x80000000u))
+                    len = epoch_cut(qi, len, eword, eshift);
+                else
                     len = list_lower_bound(post + o, len, T);
-                }
             }
-            flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
+            if (sizeof(PT) == 2 && !IOC_SCORE_OLD_TRAVERSE)
+                flat_traverse_u16(reinterpret_cast<const uint16_t*>(post), o, len, wb_, bm_, h, T, trav, abl);
+            else
+                flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
         }
     }
     __syncthreads();
@@ -1658,7 +1806,8 @@ k_query_table(int j, uint32_t L, const int64_t* __restrict__ off_fwd, const int6
         const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
         for (int64_t c0 = b + int64_t(gw) * 64; c0 < e; c0 += int64_t(nw) * 64) {
             int64_t t = c0 + lane;
-            uint32_t o = 0, c = 0, qi_ = 0;
+            uint32_t o = 0, c = 0;
+            uint2 qi_ = make_uint2(0u, 0u);
             if (t < e) index_lookup(rows, cap, shift, mins[t], o, c, qi_);
             unsigned long long mask = __ballot(c != 0);
             while (mask) {
@@ -1699,7 +1848,8 @@ k_query_table_many(const int32_t* __restrict__ qlist, uint64_t stride, uint32_t 
         const int64_t e = s == 0 ? off_fwd[j + 1] : off_rev[j + 1];
         for (int64_t c0 = b + int64_t(gw) * 64; c0 < e; c0 += int64_t(nw) * 64) {
             int64_t t = c0 + lane;
-            uint32_t o = 0, c = 0, qi_ = 0;
+            uint32_t o = 0, c = 0;
+            uint2 qi_ = make_uint2(0u, 0u);
             if (t < e) index_lookup(rows, cap, shift, mins[t], o, c, qi_);
             unsigned long long mask = __ballot(c != 0);
             while (mask) {
@@ -1827,18 +1977,17 @@ hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* d
     return hipGetLastError();
 }
 
-static void epoch_bounds(uint32_t L, uint32_t n, uint32_t& e1, uint32_t& e2, uint32_t& e3)
+static Epochs epoch_bounds(uint32_t L, uint32_t n)
 {
-    e1 = L + (n + 3) / 4;
-    e2 = L + (n + 1) / 2;
-    e3 = L + uint32_t((3ull * n + 3) / 4);
+    Epochs E;
+    for (int i = 0; i < IOC_EPOCHS; ++i) E.e[i] = L + uint32_t((uint64_t(n) * uint64_t(i + 1) + IOC_EPOCHS) / (IOC_EPOCHS + 1));
+    return E;
 }
 
 hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, void* post,
                            uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16)
 {
-    uint32_t e1, e2, e3;
-    epoch_bounds(L, n, e1, e2, e3);
+    const Epochs E = epoch_bounds(L, n);
     uint32_t words = (n + 31) / 32;
     if (words == 0) words = 1;
     size_t lds = size_t(IOC_WAVES) * words * 4;
@@ -1846,12 +1995,12 @@ hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off,
         if (lds > 48 * 1024)
             CK(hipFuncSetAttribute((const void*)k_sort_lists<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(k_sort_lists<uint16_t>, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt,
-                           (uint16_t*)post, L, words, e1, e2, e3, qinfo);
+                           (uint16_t*)post, L, words, E, (uint2*)qinfo);
     } else {
         if (lds > 48 * 1024)
             CK(hipFuncSetAttribute((const void*)k_sort_lists<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(k_sort_lists<uint32_t>, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt,
-                           (uint32_t*)post, L, words, e1, e2, e3, qinfo);
+                           (uint32_t*)post, L, words, E, (uint2*)qinfo);
     }
     return hipGetLastError();
 }
@@ -1860,7 +2009,7 @@ hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys,
                           const uint32_t* cnt, const uint32_t* qinfo, void* rows)
 {
     hipLaunchKernelGGL(k_pack_rows, dim3((nslots + IOC_BLOCK - 1) / IOC_BLOCK), dim3(IOC_BLOCK), 0, st, nslots, keys,
-                       off, cnt, qinfo, (uint4*)rows);
+                       off, cnt, (const uint2*)qinfo, (uint4*)rows);
     return hipGetLastError();
 }
 
@@ -1877,8 +2026,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
     size_t lds = size_t(2) * r * 4;
     if (part && pmins && pbnd && tmax <= range && cap >= 1024) {
-        uint32_t e1, e2, e3;
-        epoch_bounds(L, uint32_t(n), e1, e2, e3);
+        const Epochs E = epoch_bounds(L, uint32_t(n));
         if (lds > 40 * 1024) {
             CK(hipFuncSetAttribute((const void*)k_score_part<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
             CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -1890,25 +2038,24 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
                            max_len);
         if (post16)
             hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
-                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, e1, e2, e3,
+                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, E,
                                traversed, max_len);
         else
             hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
-                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, e1, e2, e3,
+                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, E,
                                traversed, max_len);
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
                            cand_count, audit_valid, audit_sum, top_all, max_len);
         return hipGetLastError();
     }
-    uint32_t e1, e2, e3;
-    epoch_bounds(L, uint32_t(n), e1, e2, e3);
+    const Epochs E = epoch_bounds(L, uint32_t(n));
 #define LAUNCH_SCORE(V, PT, PP)                                                                                      \
     do {                                                                                                             \
         if (lds > 48 * 1024)                                                                                         \
             CK(hipFuncSetAttribute((const void*)k_score_t<V, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); \
         hipLaunchKernelGGL((k_score_t<V, PT>), dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,      \
                            (const uint4*)rows, cap, shift, PP, range, keep, cand_key, cand_size, cand_count,         \
-                           traversed, e1, e2, e3, audit_valid, audit_sum);                                           \
+                           traversed, E, audit_valid, audit_sum);                                           \
     } while (0)
     if (post16) {
         LAUNCH_SCORE(0, uint16_t, post_h);

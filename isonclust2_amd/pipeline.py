@@ -135,10 +135,16 @@ def concat_records(a, b):
     return out
 
 
-def cluster_single(ctx, params, sb: SortedBatch) -> ClusteredBatch:
-    """`cluster -l batch.cer`: initial clustering of one sorted batch (src/main.cpp:262-275)."""
+def cluster_single(ctx, params, sb: SortedBatch, timing=None) -> ClusteredBatch:
+    """`cluster -l batch.cer`: initial clustering of one sorted batch (src/main.cpp:262-275).
+    timing (optional dict): receives "abi_ms", the wall time of the two C-ABI calls that make up the *core* region of
+    SURVEY §8(d) — host arrays in, assignments + MinDB in host arrays out — without this function's bookkeeping."""
+    import time
+    t0 = time.perf_counter()
     cls, strand, st = ctx.cluster_batch(params, sb.view)
     keys, offs, post = ctx.index_export()
+    if timing is not None:
+        timing["abi_ms"] = (time.perf_counter() - t0) * 1e3
     ok = cls >= 0
     # the entry that opened cluster c is its representative (cluster.cpp:178-206)
     n_cls = int(st["n_clusters"])

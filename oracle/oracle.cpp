@@ -552,44 +552,40 @@ int sg_trace(const std::string& read, const std::string& rep, int match, int mis
     const int NEGI = -(1 << 29);
     // per cell: bits 0-1 where H came from (0 diagonal, 1 E, 2 F), bit 2 E extended, bit 3 F extended
     std::vector<unsigned char> dir((n + 1) * (m + 1), 0);
-    std::vector<int> hrow(m + 1, 0), frow(m + 1, NEGI);
+    // Two sweeps per row.  Sweep A has no dependence along the row (the compiler vectorizes it): F and the diagonal
+    // candidate of every cell from the previous row.  Sweep B carries E and H along the row.
+    std::vector<int> hrow(m + 1, 0), frow(m + 1, NEGI), dg(m + 1, 0), fb(m + 1, 0), repi(m + 1, 0);
+    for (size_t j = 0; j < m; j++) repi[j] = (unsigned char)rep[j];
     int bestv = NEGI;
     size_t bi = n, bj = m;
     for (size_t i = 1; i <= n; i++) {
-        int diag = hrow[0];  // H(i-1, 0)
-        hrow[0] = 0;
-        int e = NEGI;
-        unsigned char* d = &dir[i * (m + 1)];
-        const char rc = read[i - 1];
+        const int rc = (unsigned char)read[i - 1];
+        int* __restrict h = hrow.data();
+        int* __restrict f = frow.data();
+        int* __restrict d = dg.data();
+        int* __restrict fbit = fb.data();
+        const int* __restrict rp = repi.data();
+        const int mm = int(m);
+        for (int j = 1; j <= mm; j++) {  // (h is only read here: it still holds the previous row)
+            const int fo = h[j] - open, fe = f[j] - extend;
+            fbit[j] = fe > fo ? 8 : 0;
+            f[j] = fe > fo ? fe : fo;
+            d[j] = h[j - 1] + (rc == rp[j - 1] ? match : mismatch);
+        }
+        h[0] = 0;
+        int e = NEGI, hl = 0;  // hl = H(i, j-1)
+        unsigned char* __restrict out = &dir[i * (m + 1)];
         for (size_t j = 1; j <= m; j++) {
-            unsigned char bits = 0;
-            const int eo = hrow[j - 1] - open, ee = e - extend;  // hrow[j-1] already holds H(i, j-1)
-            if (ee > eo) {
-                e = ee;
-                bits |= 4;
-            } else
-                e = eo;
-            const int up = hrow[j];  // H(i-1, j)
-            const int fo = up - open, fe = frow[j] - extend;
-            int f;
-            if (fe > fo) {
-                f = fe;
-                bits |= 8;
-            } else
-                f = fo;
-            frow[j] = f;
-            int h = diag + (rc == rep[j - 1] ? match : mismatch);
-            if (e > h) {
-                h = e;
-                bits = (unsigned char)((bits & 12) | 1);
-            }
-            if (f > h) {
-                h = f;
-                bits = (unsigned char)((bits & 12) | 2);
-            }
-            diag = up;
-            hrow[j] = h;
-            d[j] = bits;
+            const int eo = hl - open, ee = e - extend;
+            const unsigned char ebit = (unsigned char)(ee > eo ? 4 : 0);
+            e = ee > eo ? ee : eo;
+            const int dj = d[j], fj = f[j];
+            const int mde = e > dj ? e : dj;  // (off the carried chain: only `from` needs it)
+            const unsigned char from = (unsigned char)(fj > mde ? 2 : (e > dj ? 1 : 0));
+            const int tdf = fj > dj ? fj : dj;
+            hl = e > tdf ? e : tdf;           // carried chain: hl -> hl - open -> e -> hl
+            h[j] = hl;
+            out[j] = (unsigned char)(from | ebit | fbit[j]);
         }
         if (hrow[m] > bestv) {
             bestv = hrow[m];

@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 OUT=gpurun_out/profile_$1
 mkdir -p "$OUT"
 # default bench = sahlin headline + fast-mode leg: the trace covers every kernel of both
-CMD="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
-FAST="python3 bench.py --mode fast --steps 5 --warmup 1 --no-cpu-baseline"
+CMD="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-cli --no-core"
+FAST="python3 bench.py --mode fast --steps 5 --warmup 1 --no-cpu-baseline --no-cli --no-core"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $FAST > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $FAST > "$OUT/write.log" 2>&1

@@ -2,8 +2,9 @@
 // waves per SIMD (developer microbenchmark; its output is kept under profiles/ and sets bench.py's VALU peak).
 // Every wave runs 16 independent dependency chains of the instruction under test; a workgroup is 256 threads = one wave
 // per SIMD, an LDS reservation caps the workgroups per CU at the wanted number and the grid is exactly CUs x that number,
-// so every SIMD holds exactly `wps` waves for the whole launch.  Cycles come from s_memtime (shader clock) next to the
-// wall time, so the real clock under load is printed too.
+// so every SIMD holds exactly `wps` waves for the whole launch.  Launches run >= 10 ms after a burn-in (the clock under an
+// all-VALU load settles well below the 2.4 GHz nominal); the shader clock during the launch is read as
+// s_memtime ticks per s_memrealtime tick (100 MHz) by one wave per workgroup.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_rate tools/micro/valu_rate.hip && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -24,7 +25,7 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters
     for (int i = 0; i < 16; ++i) a[i] = seed + threadIdx.x * 17 + i;
     uint32_t b = seed * 3 + 1, c = seed ^ 0x1234;
     float fb = 1.0001f, fc = 0.5f;
-    const uint64_t t0 = __builtin_readcyclecounter();
+    const uint64_t t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -46,22 +47,25 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters
             }
         }
     }
-    const uint64_t t1 = __builtin_readcyclecounter();
+    const uint64_t t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s ^= a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + pad[0] * 0;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) {
+        cyc[2 * blockIdx.x] = t1 - t0;
+        cyc[2 * blockIdx.x + 1] = w1 - w0;
+    }
 }
 
 template <int MODE>
 void run(int n_cu, int wps, double* out_rate)
 {
-    const int grid = n_cu * wps, iters = 4000;
+    const int grid = n_cu * wps, iters = 60000 / wps;
     uint32_t* d;
     uint64_t* dc;
     hipMalloc(&d, size_t(grid) * 256 * 4);
-    hipMalloc(&dc, size_t(grid) * 8);
+    hipMalloc(&dc, size_t(grid) * 16);
     // at most `wps` workgroups per CU: each takes just over 160 KB / (wps + 1) of LDS (64 KB is the default cap per block)
     size_t lds = wps >= 8 ? 0 : (size_t(160) * 1024 / (wps + 1) + 1024) & ~size_t(255);
     if (lds > 64 * 1024) {
@@ -70,25 +74,30 @@ void run(int n_cu, int wps, double* out_rate)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, 10, 1u);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, iters / 4, 1u);  // burn-in
     hipEventRecord(e0);
     hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, iters, 1u);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    uint64_t* hc = new uint64_t[grid];
-    hipMemcpy(hc, dc, size_t(grid) * 8, hipMemcpyDeviceToHost);
-    double cavg = 0;
-    for (int i = 0; i < grid; ++i) cavg += double(hc[i]);
+    uint64_t* hc = new uint64_t[2 * grid];
+    hipMemcpy(hc, dc, size_t(grid) * 16, hipMemcpyDeviceToHost);
+    double cavg = 0, wavg = 0;
+    for (int i = 0; i < grid; ++i) {
+        cavg += double(hc[2 * i]);
+        wavg += double(hc[2 * i + 1]);
+    }
     cavg /= grid;
+    wavg /= grid;
     delete[] hc;
+    const double ghz = cavg / wavg * 0.1;  // s_memtime ticks per 10 ns
     const double winstr = double(iters) * 16 * OPS[MODE];           // wave-instructions per wave
     const double lane_ops = winstr * 64 * 4 * double(grid);         // lane-operations of the launch
     const double rate = lane_ops / (ms * 1e-3) / 1e12;
     // cycles of a SIMD per wave-instruction it issued: the wave's own cycles / its instructions / waves sharing the SIMD
-    printf("  %-48s wps %d: %8.3f ms  %6.2f T lane-op/s  %5.2f cyc per wave-instr per SIMD  (shader clock %.2f GHz)\n", NAMES[MODE], wps, ms,
-           rate, cavg / winstr / wps, cavg / (ms * 1e-3) / 1e9);
+    printf("  %-48s wps %d: %8.3f ms  %6.2f T lane-op/s  %5.2f s_memtime ticks per wave-instr per SIMD  (ticks at %.2f GHz; workgroups busy %.0f %% of the launch)\n",
+           NAMES[MODE], wps, ms, rate, cavg / winstr / wps, ghz, wavg * 1e-5 / ms * 100);
     if (out_rate) *out_rate = rate;
     hipFree(d);
     hipFree(dc);
