@@ -118,7 +118,7 @@ void put_mins(Writer& w, const std::vector<Minimizer>& m)
 void get_mins(Reader& r, std::vector<Minimizer>& m)
 {
     uint64_t n = r.pod<uint64_t>();
-    if (!r.ok || uint64_t(r.e - r.p) < n * sizeof(Minimizer)) {
+    if (!r.ok || n > uint64_t(r.e - r.p) / sizeof(Minimizer)) {  // (no multiplication: a crafted count must not wrap)
         r.ok = false;
         return;
     }
@@ -266,7 +266,7 @@ bool load_batch(Batch& b, const std::string& path, std::string& err)
     for (uint64_t i = 0; r.ok && i < nk; ++i) {
         uint32_t key = r.pod<uint32_t>();
         uint64_t m = r.pod<uint64_t>();
-        if (uint64_t(r.e - r.p) < m * 4) {
+        if (m > uint64_t(r.e - r.p) / 4) {  // (compared without multiplying: a crafted 64-bit count must not wrap)
             r.ok = false;
             break;
         }
@@ -323,6 +323,14 @@ bool load_batch(Batch& b, const std::string& path, std::string& err)
         if (!r.ok || uint64_t(r.e - r.p) < n) {
             r.ok = false;
             break;
+        }
+        // a non-null graph must be this build's blob: the reference writes spoa's own members here, without a length
+        // prefix (spoa's cereal layout is not in the reference tree) — such a file cannot be exchanged in consensus mode
+        if (n < 8 || memcmp(r.p, "IOCPOA1", 8) != 0) {
+            err = "Failed to load batch " + path + ": consensus graph " + std::to_string(i) +
+                  " is not in this build's format (spoa-serialized graphs of the reference are not readable here; "
+                  "files written with consensus off exchange fine)";
+            return false;
         }
         b.ConsGs.back().assign(r.p, r.p + n);
         r.p += n;

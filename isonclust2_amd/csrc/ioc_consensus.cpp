@@ -466,6 +466,9 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     c->exp_offs.push_back(int64_t(c->exp_post.size()));
     c->exp_valid = true;
     c->resolved = true;
+    // the device state belongs to this driver's LAST windowed pass: a later ioc_set_aln_verdicts + ioc_resolve on the
+    // context must not warm-start from it
+    c->warm_first = -1;
     total.n_clusters = int64_t(cl.size());
     if (stats) *stats = total;
     return IOC_OK;

@@ -396,19 +396,17 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
             uint2 info = make_uint2(c, 0x80000000u);
             if (c < IOC_EPOCH_LONG) {
                 const uint32_t o0 = off[slot];
-                uint32_t b[IOC_EPOCHS];
+                uint32_t b[IOC_EPOCHS];  // wave-uniform: one compare + ballot + scalar popcount per boundary and 64 entries
 #pragma unroll
                 for (int i = 0; i < IOC_EPOCHS; ++i) b[i] = 0;
-                for (uint32_t t = lane; t < c; t += 64) {
-                    const uint32_t v = post[o0 + t];
+                for (uint32_t t0 = 0; t0 < c; t0 += 64) {
+                    const uint32_t t = t0 + uint32_t(lane);
+                    const uint32_t v = t < c ? uint32_t(post[o0 + t]) : IOC_EMPTY;
 #pragma unroll
-                    for (int i = 0; i < IOC_EPOCHS; ++i) b[i] += v < E.e[i];
+                    for (int i = 0; i < IOC_EPOCHS; ++i) b[i] += uint32_t(__popcll(__ballot(v < E.e[i])));
                 }
 #pragma unroll
-                for (int i = 0; i < IOC_EPOCHS; ++i) {
-                    for (int o2 = 32; o2 > 0; o2 >>= 1) b[i] += __shfl_down(b[i], o2);
-                    b[i] = (b[i] + 7u) >> 3;
-                }
+                for (int i = 0; i < IOC_EPOCHS; ++i) b[i] = (b[i] + 7u) >> 3;
                 info.x = c | (b[0] << 10) | (b[1] << 17) | (b[2] << 24);
                 info.y = b[3] | (b[4] << 7) | (b[5] << 14) | (b[6] << 21);
             }

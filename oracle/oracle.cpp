@@ -1016,7 +1016,7 @@ int orc_revcomp(const char* seq, int n, char* out)
 int orc_kmer_encode(const char* seq, int n, int k, uint32_t* out)
 {
     auto v = kmer_encode(std::string(seq, size_t(n)), unsigned(k));
-    if (out) memcpy(out, v.data(), v.size() * 4);
+    if (out && !v.empty()) memcpy(out, v.data(), v.size() * 4);  // (an empty vector's data() may be null: memcpy(_, null, 0) is UB)
     return int(v.size());
 }
 

@@ -55,7 +55,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    L = C.CDLL(build())
+    # ORACLE_LIB: a sanitizer build of the oracle (tools/run_sanitizers.sh)
+    L = C.CDLL(os.environ.get("ORACLE_LIB") or build())
     vp, i32, i64p = C.c_void_p, C.c_int, C.POINTER(C.c_int64)
     u32p, i32p, dp, cp = C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_char_p
     L.orc_hpc.argtypes = [cp, cp, i32, cp, cp]

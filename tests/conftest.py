@@ -14,7 +14,7 @@ def pytest_sessionstart(session):
     them (hipcc cross-compiles gfx950 without a GPU).  Building is not a fallback: the tests still fail
     if the HIP library cannot be built or loaded."""
     lib = os.path.join(ROOT, "isonclust2_amd", "libisonclust2_hip.so")
-    cli = os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
+    cli = os.environ.get("IOC_CLI") or os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
     orc = os.path.join(ROOT, "oracle", "liboracle.so")
     if not (os.path.exists(lib) and os.path.exists(cli) and os.path.exists(orc)):
         import __graft_entry__ as g

@@ -10,7 +10,7 @@ import pytest
 from isonclust2_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
+CLI = os.environ.get("IOC_CLI") or os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
 
 
 def run(*args, **kw):
