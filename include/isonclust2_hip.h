@@ -256,6 +256,15 @@ int ioc_align_pairs(ioc_ctx* ctx, int32_t n_pairs, const ioc_aln_pair* pairs, in
                     int32_t mismatch, int32_t gap_extend, int32_t* out_score, int64_t* out_windows,
                     double* out_ratio);
 
+/* The minimizer lists of the entries `entries[0..n_idx)` of the context's CURRENT queries (ioc_queries_upload /
+ * ioc_queries_from_extracted / the batch of the last ioc_cluster_batch), gathered on the device into caller-owned
+ * DEVICE buffers in the compact layout of ioc_batch_view (all forward lists, then all reverse lists): what a rank
+ * contributes to the merge's all-gather — the representatives' records never leave HBM (src/cluster.cpp:537: a right
+ * cluster is matched through its representative's Mins / RevMins).  off_fwd / off_rev [n_idx + 1] (host) receive the
+ * offsets; cap = capacity of the two buffers in words.  Returns the number of words written or a negative status. */
+int64_t ioc_gather_records_device(ioc_ctx* ctx, int32_t n_idx, const int32_t* entries, uint32_t* d_out_min,
+                                  uint32_t* d_out_pos, int64_t cap, int64_t* off_fwd, int64_t* off_rev);
+
 /* ---- host driver: ClusterSortedReads on flat arrays (src/cluster.cpp:67-322, consensus off) ------ */
 typedef struct {
     /* right batch, one record per entry in loop order */
@@ -280,6 +289,15 @@ typedef struct {
     const int32_t* n_members;  /* reads[i]->size() - 1; NULL = fresh reads */
     int32_t depth;             /* right Batch::Depth; the MinClsSize filter applies when > 0 (:119-123) */
     int32_t min_cls_size;      /* left SortArgs.MinClsSize after the -A override (main.cpp:329-331) */
+    /* several clustered batches merged in ONE pass (the left fold ((b0 + b1) + b2) ... of freshly clustered batches makes
+     * the decisions of one loop over b0's, b1's, ... representatives in that order: cluster.cpp:178-217 only appends):
+     * entries with is_cluster[i] != 0 are the leftmost batch's clusters — they keep their cluster (ids in entry order)
+     * without being matched, exactly as if they had come in through ioc_left_view.  NULL: none. */
+    const uint8_t* is_cluster;
+    /* != 0: min_val / min_pos are DEVICE pointers (e.g. the output of ioc_gather_records_device after an RCCL
+     * all-gather); they are used in place and must stay valid until the context's queries are replaced.  Entries
+     * that the gates skip must then carry no minimizers. */
+    int32_t minimizers_on_device;
 } ioc_batch_view;
 
 /* Left batch of a merge (`cluster -l L -r R`): its clusters' representative HPC error rates and the

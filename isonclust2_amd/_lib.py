@@ -32,7 +32,8 @@ class BatchView(C.Structure):
                 ("raw_err", C.POINTER(C.c_double)), ("hpc_err", C.POINTER(C.c_double)),
                 ("state", C.POINTER(C.c_uint8)), ("min_qual", C.c_double),
                 ("raw_seq", C.c_char_p), ("raw_off", C.POINTER(C.c_int64)),
-                ("n_members", C.POINTER(C.c_int32)), ("depth", C.c_int32), ("min_cls_size", C.c_int32)]
+                ("n_members", C.POINTER(C.c_int32)), ("depth", C.c_int32), ("min_cls_size", C.c_int32),
+                ("is_cluster", C.POINTER(C.c_uint8)), ("minimizers_on_device", C.c_int32)]
 
 
 class LeftView(C.Structure):
@@ -108,7 +109,7 @@ SYMBOLS = [
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
     "ioc_index_update", "ioc_left_export", "ioc_cluster_consensus",
     "ioc_poa_create", "ioc_poa_destroy", "ioc_poa_bind", "ioc_poa_graph_export", "ioc_poa_last_alignment",
-    "ioc_poa_graph_save", "ioc_poa_graph_load",
+    "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_gather_records_device",
 ]
 
 _lib = None
@@ -143,6 +144,8 @@ def load():
     L.ioc_set_params.argtypes = [vp, C.POINTER(Params), pi32]
     L.ioc_queries_upload.argtypes = [vp, i32, pi64, pi64, pu32, pu32, i64, pu32, pu8, pu32]
     L.ioc_queries_bind_device.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, pi64, pi64]
+    L.ioc_gather_records_device.argtypes = [vp, i32, pi32, vp, vp, i64, pi64, pi64]
+    L.ioc_gather_records_device.restype = i64
     L.ioc_left_load.argtypes = [vp, i32, pu8, i64, pu32, pi64, pu32]
     L.ioc_index_update.argtypes = [vp, i32, pu32, i64, pu32, i64, C.c_uint8]
     L.ioc_left_export.argtypes = [vp, pi64, pi64, pu32, pi64, pu32]

@@ -52,6 +52,7 @@ class Context:
             raise IocError(rc, "ioc_ctx_create failed (no MI355X visible?)")
         self.h = h
         self._keep = []
+        self.serial = 0      # bumped whenever the context's queries are replaced
 
     def close(self):
         if getattr(self, "h", None):
@@ -221,6 +222,17 @@ class Context:
                                                     _p(min_total, C.c_uint32)))
         self.n = len(keep)
 
+    def gather_records_device(self, entries, d_min_ptr, d_pos_ptr, cap):
+        """ioc_gather_records_device: the minimizer lists of `entries` of the current queries, gathered on the device
+        into the caller's device buffers (addresses as ints, capacity in words).  Returns (words, off_fwd, off_rev)."""
+        entries = np.ascontiguousarray(entries, np.int32)
+        n = len(entries)
+        of, orv = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        w = self.L.ioc_gather_records_device(self.h, n, _p(entries, C.c_int32), C.c_void_p(int(d_min_ptr)), C.c_void_p(int(d_pos_ptr)),
+                                             int(cap), _p(of, C.c_int64), _p(orv, C.c_int64))
+        self._chk(w)
+        return int(w), of, orv
+
     def timings(self):
         t = Timings()
         self._chk(self.L.ioc_get_timings(self.h, C.byref(t)))
@@ -245,11 +257,12 @@ class Context:
         keys, offs, postings (the left clusters' representative error rates + MinDB as CSR).
         batch: the right batch (ioc_batch_view fields; for a clustered right batch one record per
         right cluster = its representative, plus n_members / depth / min_cls_size)."""
+        on_dev = bool(batch.get("minimizers_on_device"))   # min_val / min_pos: device addresses (ints), total = words
         arrs = {
             "off_fwd": np.ascontiguousarray(batch["off_fwd"], np.int64),
             "off_rev": np.ascontiguousarray(batch["off_rev"], np.int64),
-            "min_val": np.ascontiguousarray(batch["min_val"], np.uint32),
-            "min_pos": np.ascontiguousarray(batch["min_pos"], np.uint32),
+            "min_val": None if on_dev else np.ascontiguousarray(batch["min_val"], np.uint32),
+            "min_pos": None if on_dev else np.ascontiguousarray(batch["min_pos"], np.uint32),
             "raw_len": np.ascontiguousarray(batch["raw_len"], np.uint32),
             "hpc_len": np.ascontiguousarray(batch["hpc_len"], np.uint32),
             "score": np.ascontiguousarray(batch["score"], np.float64),
@@ -265,15 +278,25 @@ class Context:
         if batch.get("raw_seq") is not None:   # sahlin / furious: sequences for the host aligner
             rseq = batch["raw_seq"] if isinstance(batch["raw_seq"], bytes) else np.asarray(batch["raw_seq"], np.uint8).tobytes()
             roff = np.ascontiguousarray(batch["raw_off"], np.int64)
+        isc = None
+        if batch.get("is_cluster") is not None:
+            isc = np.ascontiguousarray(batch["is_cluster"], np.uint8)
+        if on_dev:
+            mvp = C.cast(C.c_void_p(int(batch["min_val"])), C.POINTER(C.c_uint32))
+            mpp = C.cast(C.c_void_p(int(batch["min_pos"])), C.POINTER(C.c_uint32))
+            total = int(batch["total"])
+        else:
+            mvp, mpp, total = _p(arrs["min_val"], C.c_uint32), _p(arrs["min_pos"], C.c_uint32), len(arrs["min_val"])
         v = BatchView(n=n, off_fwd=_p(arrs["off_fwd"], C.c_int64), off_rev=_p(arrs["off_rev"], C.c_int64),
-                      min_val=_p(arrs["min_val"], C.c_uint32), min_pos=_p(arrs["min_pos"], C.c_uint32),
-                      total=len(arrs["min_val"]), raw_len=_p(arrs["raw_len"], C.c_uint32),
+                      min_val=mvp, min_pos=mpp,
+                      total=total, raw_len=_p(arrs["raw_len"], C.c_uint32),
                       hpc_len=_p(arrs["hpc_len"], C.c_uint32), score=_p(arrs["score"], C.c_double),
                       raw_err=_p(arrs["raw_err"], C.c_double), hpc_err=_p(arrs["hpc_err"], C.c_double),
                       state=_p(arrs["state"], C.c_uint8), min_qual=float(batch.get("min_qual", 7.0)),
                       raw_seq=rseq, raw_off=_p(roff, C.c_int64) if roff is not None else None,
                       n_members=_p(nm, C.c_int32) if nm is not None else None,
-                      depth=int(batch.get("depth", -1)), min_cls_size=int(batch.get("min_cls_size", 3)))
+                      depth=int(batch.get("depth", -1)), min_cls_size=int(batch.get("min_cls_size", 3)),
+                      is_cluster=_p(isc, C.c_uint8) if isc is not None else None, minimizers_on_device=1 if on_dev else 0)
         lv = None
         if left is not None and left.get("resident"):
             # the left state already on the device (left_load + index_update) is used as it is
@@ -307,6 +330,8 @@ class Context:
                                                    C.byref(ops), _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
         self.n = n
         self.params = params
+        self.serial += 1
+        self._keep = [batch.get("_keepalive")]   # device tensors borrowed by the context (minimizers_on_device)
         return cls, strand, st.as_dict()
 
     def cluster_merge(self, params: Params, left, batch: dict, table=_lib.TABLE_PATH):

@@ -228,6 +228,85 @@ int ioc_queries_upload(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int6
     return IOC_OK;
 }
 
+// ioc_queries_upload with the two minimizer arrays already in HBM (borrowed, used in place)
+int ioc_queries_upload_devmins(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int64_t* off_rev, const uint32_t* d_min_val,
+                               const uint32_t* d_min_pos, int64_t total, const uint32_t* hpc_len, const uint8_t* err_cell,
+                               const uint32_t* min_total)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > 0 && (!hpc_len || !err_cell || !min_total || (total > 0 && (!d_min_val || !d_min_pos))))
+        return ioc_fail(c, IOC_ERR_ARG, "null query array");
+    for (int i = 0; i < n; ++i)
+        if (err_cell[i] < 1 || err_cell[i] > 15) return ioc_fail(c, IOC_ERR_ARG, "err_cell outside 1..15");
+    int r = queries_common(c, n, off_fwd, off_rev, total);
+    if (r != IOC_OK) return r;
+    RESERVE(c, c->b_off_fwd, size_t(n + 1) * 8);
+    RESERVE(c, c->b_off_rev, size_t(n + 1) * 8);
+    RESERVE(c, c->b_hpc_len, size_t(n) * 4);
+    RESERVE(c, c->b_err_cell, size_t(n));
+    RESERVE(c, c->b_min_total, size_t(n) * 4);
+    hipStream_t s = c->stream;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->b_off_fwd.p, off_fwd, size_t(n + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_off_rev.p, off_rev, size_t(n + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_hpc_len.p, hpc_len, size_t(n) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_err_cell.p, err_cell, size_t(n), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_min_total.p, min_total, size_t(n) * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->d_off_fwd = P<int64_t>(c->b_off_fwd);
+    c->d_off_rev = P<int64_t>(c->b_off_rev);
+    c->d_min = d_min_val;
+    c->d_pos = d_min_pos;
+    c->d_hpc_len = P<uint32_t>(c->b_hpc_len);
+    c->d_err_cell = P<uint8_t>(c->b_err_cell);
+    c->d_min_total = P<uint32_t>(c->b_min_total);
+    c->borrowed = true;
+    return IOC_OK;
+}
+
+int64_t ioc_gather_records_device(ioc_ctx* c, int32_t n_idx, const int32_t* entries, uint32_t* d_out_min, uint32_t* d_out_pos,
+                                  int64_t cap, int64_t* off_fwd, int64_t* off_rev)
+{
+    if (!c || n_idx < 0 || (n_idx > 0 && (!entries || !off_fwd || !off_rev))) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->h_off_fwd.size() != size_t(c->n) + 1 || !c->d_min || !c->d_pos) return ioc_fail(c, IOC_ERR_STATE, "no queries on the device");
+    std::vector<int64_t> src(size_t(2) * n_idx + 1), dst(size_t(2) * n_idx + 1);
+    std::vector<uint32_t> len(size_t(2) * n_idx + 1);
+    int64_t tot = 0;
+    for (int side = 0; side < 2; ++side) {
+        const std::vector<int64_t>& ho = side == 0 ? c->h_off_fwd : c->h_off_rev;
+        int64_t* oo = side == 0 ? off_fwd : off_rev;
+        for (int i = 0; i < n_idx; ++i) {
+            const int e = entries[i];
+            if (e < 0 || e >= c->n) return ioc_fail(c, IOC_ERR_ARG, "ioc_gather_records_device: entry out of range");
+            const size_t x = size_t(side) * n_idx + size_t(i);
+            src[x] = ho[size_t(e)];
+            dst[x] = tot;
+            len[x] = uint32_t(ho[size_t(e) + 1] - ho[size_t(e)]);
+            oo[i] = tot;
+            tot += int64_t(len[x]);
+        }
+        oo[n_idx] = tot;
+    }
+    if (tot > cap) return ioc_fail(c, IOC_ERR_CAPACITY, "ioc_gather_records_device: output buffers too small: need " + std::to_string(tot));
+    if (tot == 0) return 0;
+    if (!d_out_min || !d_out_pos) return ioc_fail(c, IOC_ERR_ARG, "null device buffer");
+    const size_t nl = size_t(2) * n_idx;
+    RESERVE(c, c->b_misc, nl * 20 + 256);
+    int64_t* d_src = reinterpret_cast<int64_t*>(P<uint8_t>(c->b_misc) + 256);
+    int64_t* d_dst = d_src + nl;
+    uint32_t* d_len = reinterpret_cast<uint32_t*>(d_dst + nl);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(d_src, src.data(), nl * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), nl * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_len, len.data(), nl * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, iock_gather_lists(s, uint32_t(nl), d_src, d_dst, d_len, c->d_min, c->d_pos, d_out_min, d_out_pos));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return tot;
+}
+
 int ioc_queries_bind_device(ioc_ctx* c, int32_t n, const int64_t* d_off_fwd, const int64_t* d_off_rev,
                             const uint32_t* d_min_val, const uint32_t* d_min_pos, int64_t total,
                             const uint32_t* d_hpc_len, const uint8_t* d_err_cell, const uint32_t* d_min_total,

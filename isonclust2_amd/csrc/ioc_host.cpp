@@ -436,7 +436,8 @@ static int fetch_ties(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::v
 }
 
 static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std::vector<uint32_t>& need,
-                        int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats, const SeqAccess* sa)
+                        int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats, const SeqAccess* sa,
+                        const std::vector<uint8_t>* keep_cluster = nullptr)
 {
     const int n = c->n;
     int r;
@@ -449,6 +450,10 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     // gated entries never become clusters: force them out of the target set
     for (int i = 0; i < n; ++i)
         if (gated[size_t(i)] && (r = ioc_force_decision(c, i, -2, 0)) != IOC_OK) return r;
+    // entries that ARE clusters already (the leftmost batch of a one-pass merge): decided, never matched
+    if (keep_cluster)
+        for (int i = 0; i < n; ++i)
+            if ((*keep_cluster)[size_t(i)] && (r = ioc_force_decision(c, i, -1, 0)) != IOC_OK) return r;
     const bool aln_mode = c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS;
     if (aln_mode && (!sa || !sa->r_seq || !sa->r_off || !sa->r_err || (c->L > 0 && (!sa->l_seq || !sa->l_off || !sa->l_err))))
         return ioc_fail(c, IOC_ERR_ARG, "sahlin/furious need the raw sequences for the alignment fallback (cluster.cpp:461-515)");
@@ -702,7 +707,11 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
         if (stats) *stats = ioc_cluster_stats{next, 0, ng, 0, 0, 0};
         return IOC_OK;
     }
-    if (!compact) {
+    if (rb->minimizers_on_device) {
+        if (compact) return ioc_fail(c, IOC_ERR_INPUT, "minimizers_on_device: entries skipped by the gates must carry no minimizers");
+        r = ioc_queries_upload_devmins(c, n, rb->off_fwd, rb->off_rev, rb->min_val, rb->min_pos, rb->total, rb->hpc_len, cell.data(),
+                                       need.data());
+    } else if (!compact) {
         r = ioc_queries_upload(c, n, rb->off_fwd, rb->off_rev, rb->min_val, rb->min_pos, rb->total, rb->hpc_len,
                                cell.data(), need.data());
     } else {
@@ -773,7 +782,14 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
             if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
         }
     }
-    return run_pipeline(c, gated, need, out_cls, out_strand, stats, &sa);
+    // one-pass merge: the leftmost batch's clusters are not matched, they are clusters (see ioc_batch_view::is_cluster)
+    std::vector<uint8_t> keep_cluster;
+    if (rb->is_cluster) {
+        keep_cluster.assign(rb->is_cluster, rb->is_cluster + n);
+        for (int i = 0; i < n; ++i)
+            if (keep_cluster[size_t(i)] && gated[size_t(i)]) return ioc_fail(c, IOC_ERR_INPUT, "is_cluster: a gated entry cannot be a cluster");
+    }
+    return run_pipeline(c, gated, need, out_cls, out_strand, stats, &sa, keep_cluster.empty() ? nullptr : &keep_cluster);
 }
 
 int ioc_resident_set_sequences(ioc_ctx* c, const char* raw_seq, const int64_t* raw_off, const double* raw_err)

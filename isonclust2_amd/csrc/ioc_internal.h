@@ -133,6 +133,12 @@ struct IocCandTable {
 };
 int ioc_query_candidates_many(ioc_ctx* c, const std::vector<int>& qs, std::vector<IocCandTable>& out);
 
+// ioc_capi.cpp: queries whose minimizer arrays are already in HBM (ioc_batch_view::minimizers_on_device)
+extern "C" int ioc_queries_upload_devmins(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int64_t* off_rev, const uint32_t* d_min_val,
+                                          const uint32_t* d_min_pos, int64_t total, const uint32_t* hpc_len, const uint8_t* err_cell,
+                                          const uint32_t* min_total);
+
+
 // f(0) .. f(count - 1) on the host's cores (independent items only)
 #include <atomic>
 #include <thread>

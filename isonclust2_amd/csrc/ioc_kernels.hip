@@ -2003,6 +2003,31 @@ hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off,
     return hipGetLastError();
 }
 
+// list e of the gather: words [src[e], src[e] + len[e]) of the source arrays to dst[e] of the destination arrays
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_gather_lists(uint32_t nlists, const int64_t* __restrict__ src, const int64_t* __restrict__ dst, const uint32_t* __restrict__ len,
+               const uint32_t* __restrict__ smin, const uint32_t* __restrict__ spos, uint32_t* __restrict__ dmin,
+               uint32_t* __restrict__ dpos)
+{
+    for (uint32_t e = blockIdx.x; e < nlists; e += gridDim.x) {
+        const int64_t a = src[e], b = dst[e];
+        const uint32_t n = len[e];
+        for (uint32_t t = threadIdx.x; t < n; t += IOC_BLOCK) {
+            dmin[b + t] = smin[a + t];
+            dpos[b + t] = spos[a + t];
+        }
+    }
+}
+
+hipError_t iock_gather_lists(hipStream_t st, uint32_t nlists, const int64_t* src, const int64_t* dst, const uint32_t* len,
+                             const uint32_t* smin, const uint32_t* spos, uint32_t* dmin, uint32_t* dpos)
+{
+    if (nlists == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_lists, dim3(nlists < 65535u ? nlists : 65535u), dim3(IOC_BLOCK), 0, st, nlists, src, dst, len, smin,
+                       spos, dmin, dpos);
+    return hipGetLastError();
+}
+
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
                           const uint32_t* cnt, const uint32_t* qinfo, void* rows)
 {

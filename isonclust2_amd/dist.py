@@ -4,18 +4,23 @@ Initial clustering shards batches one per GPU and needs no communication (the re
 runs them as separate processes, README.md:105-117).  The one exchange step of the path is the
 merge (`cluster -l L -r R`, src/cluster.cpp:67-322 with two batches):
 
-  1. every rank packs its clustered batch — one record per cluster representative (forward + reverse
-     minimizer lists, lengths, error rates, raw sequence for sahlin / furious), the membership of its reads
-     and, on rank 0 only, the MinDB of the leftmost batch — into ONE flat u32 buffer (`pack_clustered`);
-  2. ONE ragged all-gather of those buffers as device tensors (RCCL over xGMI; sizes first);
-  3. every rank replays the reference's left fold ((b0 + b1) + b2) ... on its own GPU (`merge_all`).
+  1. every rank gathers the minimizer lists of its cluster representatives ON THE DEVICE, out of the batch's
+     query arrays that are still in HBM, into two u32 device buffers (ioc_gather_records_device): the bulk of a
+     representative record (~64 KB each at 16.7 kb reads) never visits the host;
+  2. ragged all-gather of those two buffers as device tensors (RCCL over xGMI, HBM to HBM; sizes first), and of
+     one small packed u32 record per rank with what is left: lengths, error rates, membership of the reads,
+     raw sequences of the representatives in sahlin / furious mode (`pack_clustered(..., with_minimizers=False)`);
+  3. every rank replays the reference's left fold ((b0 + b1) + b2) ... on its own GPU with the gathered
+     buffers used in place (ioc_batch_view::minimizers_on_device) — `merge_all_device`.
+  (`merge_all` is the same merge from host arrays: the path of the tests that have no second GPU.)
 
 Step 3 is ONE pass of the merge path, not world-1 of them: with consensus off a merge only appends the right
 batch's unmatched clusters to the left and extends the MinDB by their minimizers (cluster.cpp:178-217), so
-folding b1, b2, ... one after the other makes exactly the decisions of one greedy loop over the concatenated
-right representatives of b1, b2, ... against the left state of b0 (same order of queries, same left state at every
-query, `right.Depth == 0` for freshly clustered batches so the MinClsSize gate of cluster.cpp:119-123 is off) —
-checked against the oracle's step-by-step fold in tests/test_gpu_fullsize.py and tests/test_dist_gloo.py.
+folding b1, b2, ... one after the other makes exactly the decisions of one greedy loop over the representatives
+of b0, b1, b2, ... in that order in which b0's are clusters from the start (ioc_batch_view::is_cluster; same order
+of queries, same left state at every query, `right.Depth == 0` for freshly clustered batches so the MinClsSize gate
+of cluster.cpp:119-123 is off; the left MinDB is what AddMinimizers makes of b0's representatives, so it need not
+travel) — checked against the oracle's step-by-step fold in tests/test_gpu_merge.py and tests/test_gpu_fullsize.py.
 All-pairs scoring + fixed-point resolve of that one pass run on every rank (replicated: the result is needed
 everywhere, and a rank's share of the candidate tables would be ~N^2 x 12 B to exchange — two orders of magnitude
 more than the representative records themselves).
@@ -25,7 +30,7 @@ import time
 
 import numpy as np
 
-from .pipeline import ClusteredBatch, cluster_merge, concat_records
+from .pipeline import VIEW_KEYS, ClusteredBatch, cluster_merge, concat_records, gather_records, gather_seqs
 
 _MAGIC = 0x494F4332  # "IOC2"
 _U32_FIELDS = ("raw_len", "hpc_len", "state")
@@ -85,22 +90,25 @@ def _words(a, dtype):
     return a.view(np.uint32).reshape(-1)
 
 
-def pack_clustered(cb: ClusteredBatch, with_mindb=True) -> np.ndarray:
-    """Flat u32 image: header | per-representative arrays | minimizer lists | membership | MinDB | sequences."""
+def pack_clustered(cb: ClusteredBatch, with_mindb=False, with_minimizers=True) -> np.ndarray:
+    """Flat u32 image: header | per-representative arrays | [minimizer lists] | membership | [MinDB] | sequences."""
     rv = cb.rep_view
     n = cb.n_clusters
     of, orv = np.asarray(rv["off_fwd"], np.int64), np.asarray(rv["off_rev"], np.int64)
     nf, nr = (of[1:] - of[:-1]).astype(np.uint32), (orv[1:] - orv[:-1]).astype(np.uint32)
     ftot, rtot = int(of[-1] - of[0]), int(orv[-1] - orv[0])
-    mv, mp = np.asarray(rv["min_val"], np.uint32), np.asarray(rv["min_pos"], np.uint32)
-    assert int(of[0]) == 0 and int(orv[0]) == ftot and len(mv) == ftot + rtot, "records must be compact, forward lists first"
+    if with_minimizers:
+        mv, mp = np.asarray(rv["min_val"], np.uint32), np.asarray(rv["min_pos"], np.uint32)
+        assert int(of[0]) == 0 and int(orv[0]) == ftot and len(mv) == ftot + rtot, "records must be compact, forward lists first"
+    else:
+        mv = mp = np.zeros(0, np.uint32)
     keys, offs, post = cb.mindb if with_mindb else (np.zeros(0, np.uint32), np.zeros(1, np.int64), np.zeros(0, np.uint32))
     seq = np.frombuffer(cb.rep_seq, np.uint8) if cb.rep_seq is not None else np.zeros(0, np.uint8)
     seq_pad = np.zeros((len(seq) + 3) // 4 * 4, np.uint8)
     seq_pad[:len(seq)] = seq
     nm = len(cb.member_cls)
     head = np.array([_MAGIC, n, ftot, rtot, nm, len(keys), len(post), len(seq), 1 if cb.rep_seq is not None else 0,
-                     cb.depth & 0xFFFFFFFF, 0, 0], np.uint32)
+                     cb.depth & 0xFFFFFFFF, 1 if with_minimizers else 0, 0], np.uint32)
     parts = [head, _words([cb.batch_start, cb.batch_end], np.int64), _words([rv.get("min_qual", 7.0)], np.float64), nf, nr]
     parts += [_words(rv[k], np.uint32) for k in _U32_FIELDS]
     parts += [_words(rv[k], np.float64) for k in _F64_FIELDS]
@@ -114,7 +122,7 @@ def pack_clustered(cb: ClusteredBatch, with_mindb=True) -> np.ndarray:
 
 def unpack_clustered(buf: np.ndarray) -> ClusteredBatch:
     buf = np.ascontiguousarray(buf, np.uint32)
-    magic, n, ftot, rtot, nm, nk, npost, nseq, has_seq, depth = (int(x) for x in buf[:10])
+    magic, n, ftot, rtot, nm, nk, npost, nseq, has_seq, depth, has_min = (int(x) for x in buf[:11])
     if magic != _MAGIC:
         raise ValueError("not a packed clustered batch")
     pos = [12]
@@ -131,7 +139,8 @@ def unpack_clustered(buf: np.ndarray) -> ClusteredBatch:
     rv = {k: take(n, np.uint32) for k in _U32_FIELDS}
     rv["state"] = rv["state"].astype(np.uint8)
     rv.update({k: take(n, np.float64) for k in _F64_FIELDS})
-    rv["min_val"], rv["min_pos"] = take(ftot + rtot, np.uint32), take(ftot + rtot, np.uint32)
+    nmin = ftot + rtot if has_min else 0
+    rv["min_val"], rv["min_pos"] = take(nmin, np.uint32), take(nmin, np.uint32)
     off_f = np.zeros(n + 1, np.int64)
     off_f[1:] = np.cumsum(nf)
     off_r = np.zeros(n + 1, np.int64)
@@ -148,82 +157,187 @@ def unpack_clustered(buf: np.ndarray) -> ClusteredBatch:
                           rep_seq=rep_seq, rep_off=rep_off)
 
 
+def _allgather_u32(buf_dev_or_np, dist, torch, dev):
+    """Ragged all-gather of one u32 buffer per rank: returns (gathered tensor / array of world * cap words, cap, sizes).
+    `buf_dev_or_np`: a torch int32 tensor on `dev` (used in place: RCCL moves HBM to HBM) or a numpy u32 array."""
+    world = dist.get_world_size()
+    is_t = torch.is_tensor(buf_dev_or_np)
+    n = int(buf_dev_or_np.numel()) if is_t else len(buf_dev_or_np)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=dev))
+    sz = [int(x) for x in sizes.cpu().numpy()]
+    cap = max(max(sz), 1)
+    if is_t:
+        t = buf_dev_or_np
+        if dev.type != t.device.type:      # (gloo in the CPU / one-GPU tests: the collective runs on host tensors)
+            t = t.to(dev)
+        send = t if n == cap else torch.cat([t, torch.zeros(cap - n, dtype=torch.int32, device=dev)])
+    else:
+        pad = np.zeros(cap, np.uint32)
+        pad[:n] = buf_dev_or_np
+        send = torch.from_numpy(pad.view(np.int32)).to(dev)
+    recv = torch.empty(world * cap, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    return recv, cap, sz
+
+
 def allgather_clustered(cb: ClusteredBatch, dist):
-    """ONE ragged all-gather of every rank's packed record as u32 tensors on the backend's device (RCCL: HBM to HBM
-    over xGMI; sizes first, then one padded payload).  Only rank 0's record carries a MinDB (the leftmost batch's)."""
+    """ONE ragged all-gather of every rank's packed record (minimizer lists included, from host arrays): the path
+    without device-resident records.  Returns (batches, bytes per rank)."""
     if dist is None:
         return [cb], [0]
     import torch
     dev = _device(dist)
-    world, rank = dist.get_world_size(), dist.get_rank()
-    buf = pack_clustered(cb, with_mindb=(rank == 0))
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, torch.tensor([len(buf)], dtype=torch.int64, device=dev))
-    cap = int(sizes.max().item())
-    send = torch.zeros(cap, dtype=torch.int32, device=dev)
-    send[:len(buf)] = torch.from_numpy(buf.view(np.int32)).to(dev)
-    recv = torch.empty(world * cap, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(recv, send)
+    recv, cap, sz = _allgather_u32(pack_clustered(cb), dist, torch, dev)
     out = recv.cpu().numpy().view(np.uint32)
-    sz = sizes.cpu().numpy()
-    return [unpack_clustered(out[r * cap:r * cap + int(sz[r])]) for r in range(world)], [int(4 * x) for x in sz]
+    return [unpack_clustered(out[r * cap:r * cap + sz[r]]) for r in range(len(sz))], [4 * x for x in sz]
 
 
-def concat_right(batches):
-    """The right batches b1, b2, ... as ONE right batch: representative records, membership (cluster ids shifted),
-    sequences."""
-    rv = batches[0].rep_view
-    for b in batches[1:]:
-        rv = concat_records(rv, b.rep_view)
+def _assemble(batches, cls, strand, st, rep_view=None, rep_seq=None, rep_off=None, mindb=None):
+    """Membership of the merged clustering from the per-representative decisions of the one-pass merge
+    (cluster.cpp:223-261: the members of a right cluster move with their strands flipped on a reverse-strand match)."""
     shift = np.cumsum([0] + [b.n_clusters for b in batches[:-1]])
-    have_seq = all(b.rep_seq is not None for b in batches)
-    rep_seq = rep_off = None
-    if have_seq:
-        rep_seq = b"".join(b.rep_seq for b in batches)
+    mcl = np.concatenate([cls[b.member_cls + s] for b, s in zip(batches, shift)]).astype(np.int32)
+    mst = np.concatenate([strand[b.member_cls + s].astype(np.int32) * b.member_strand for b, s in zip(batches, shift)]).astype(np.int32)
+    mrd = np.concatenate([b.member_read for b in batches])
+    keep = mcl >= 0
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int64), np.zeros(0, np.uint32))
+    if rep_view is None:   # only the counts of the merged clusters are known here
+        rep_view = dict(hpc_len=np.zeros(int(st["n_clusters"]), np.uint32))
+    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off, member_cls=mcl[keep], member_read=mrd[keep],
+                          member_strand=mst[keep], mindb=mindb if mindb is not None else empty, depth=batches[0].depth + len(batches) - 1,
+                          batch_start=batches[0].batch_start, batch_end=batches[-1].batch_end, stats=st)
+
+
+def _meta_view(batches):
+    """Per-representative host arrays of all batches in merge order + the is_cluster mask of the leftmost batch."""
+    v = {k: np.concatenate([np.asarray(b.rep_view[k]) for b in batches]) for k in VIEW_KEYS}
+    v["min_qual"] = batches[0].rep_view.get("min_qual", 7.0)
+    v["is_cluster"] = np.concatenate([np.full(b.n_clusters, 1 if i == 0 else 0, np.uint8) for i, b in enumerate(batches)])
+    v["depth"] = 0
+    if all(b.rep_seq is not None for b in batches):
+        v["raw_seq"] = b"".join(b.rep_seq for b in batches)
         offs, base = [np.zeros(1, np.int64)], 0
         for b in batches:
             offs.append(np.asarray(b.rep_off, np.int64)[1:] + base)
             base += int(b.rep_off[-1])
-        rep_off = np.concatenate(offs)
-    return ClusteredBatch(rep_view=rv, rep_seq=rep_seq, rep_off=rep_off,
-                          member_cls=np.concatenate([b.member_cls + s for b, s in zip(batches, shift)]).astype(np.int32),
-                          member_read=np.concatenate([b.member_read for b in batches]),
-                          member_strand=np.concatenate([b.member_strand for b in batches]),
-                          mindb=(np.zeros(0, np.uint32), np.zeros(1, np.int64), np.zeros(0, np.uint32)), depth=0,
-                          batch_start=batches[0].batch_start, batch_end=batches[-1].batch_end)
+        v["raw_off"] = np.concatenate(offs)
+    return v
 
 
-def merge_all(ctx, params, batches, min_cls_size=3):
-    """((b0 + b1) + b2) ... as ONE pass of the merge path (see the module docstring)."""
+def merge_all(ctx, params, batches, min_cls_size=3, export_mindb=True):
+    """((b0 + b1) + b2) ... as ONE pass of the merge path (see the module docstring), from host arrays."""
     if len(batches) == 1:
         return batches[0]
-    if any(b.depth != 0 for b in batches[1:]):
-        return fold_merge(ctx, params, batches, min_cls_size)     # merged right batches: the MinClsSize gate is per merge
-    return cluster_merge(ctx, params, batches[0], concat_right(batches[1:]), min_cls_size=min_cls_size)
+    if any(b.depth != 0 for b in batches):
+        return fold_merge(ctx, params, batches, min_cls_size)     # merged batches: the MinClsSize gate is per merge
+    rv = batches[0].rep_view
+    for b in batches[1:]:
+        rv = concat_records(rv, b.rep_view)
+    v = _meta_view(batches)
+    v.update(off_fwd=rv["off_fwd"], off_rev=rv["off_rev"], min_val=rv["min_val"], min_pos=rv["min_pos"], min_cls_size=min_cls_size)
+    cls, strand, st = ctx.cluster_merge(params, None, v)
+    # the merged clusters' records: the representatives that opened (or kept) a cluster, in cluster order
+    n = len(cls)
+    own = np.nonzero(cls >= 0)[0]
+    first = own[np.unique(cls[own], return_index=True)[1]]
+    assert np.array_equal(cls[first], np.arange(len(first)))
+    rep_view = gather_records(rv, first)
+    rep_seq, rep_off = gather_seqs(v.get("raw_seq"), v.get("raw_off"), first)
+    mindb = ctx.index_export() if export_mindb else None
+    return _assemble(batches, cls, strand, st, rep_view, rep_seq, rep_off, mindb)
 
 
 def fold_merge(ctx, params, batches, min_cls_size=3):
-    """The reference's left fold over clustered batches, one merge at a time."""
+    """The reference's left fold over clustered batches, one merge at a time (cross-check of the one-pass forms)."""
     left = batches[0]
     for b in batches[1:]:
         left = cluster_merge(ctx, params, left, b, min_cls_size=min_cls_size)
     return left
 
 
-def timed_merge(ctx, params, cb: ClusteredBatch, dist, torch=None, dev=None):
-    """bench.py's merge leg: pack + all-gather + one-pass merge on every rank, each phase timed (max over ranks)."""
+# ---- device-resident representative records -------------------------------------------------------------------------
+def gather_local(ctx, cb: ClusteredBatch, torch, dev):
+    """The minimizer lists of this rank's cluster representatives, gathered on the device out of the batch's query
+    arrays (still in HBM after the clustering call) into two torch int32 tensors."""
+    if cb.rep_entry is None or cb.ctx_serial != ctx.serial:
+        raise RuntimeError("gather_local: the context no longer holds the queries of this batch")
+    rv = cb.rep_view
+    words = int((rv["off_fwd"][-1] - rv["off_fwd"][0]) + (rv["off_rev"][-1] - rv["off_rev"][0]))
+    mins = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+    poss = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    w, _, _ = ctx.gather_records_device(cb.rep_entry, mins.data_ptr(), poss.data_ptr(), words)
+    assert w == words
+    return mins[:words], poss[:words]
+
+
+def merge_gathered(ctx, params, metas, recv_min, recv_pos, cap, min_cls_size=3, export_mindb=False):
+    """Step 3 of the module docstring: metas[r] = rank r's record without minimizers, recv_min / recv_pos = the
+    all-gathered device buffers (rank r's block at [r * cap, ...): its forward lists, then its reverse lists).
+    The blocks are re-laid on the device as [all forward lists][all reverse lists] (one HBM-to-HBM copy), which is
+    the CSR form ioc_batch_view takes, and used in place."""
+    import torch
+    ft = [int(np.asarray(b.rep_view["off_fwd"])[-1]) for b in metas]                           # forward words per rank
+    rt = [int(np.asarray(b.rep_view["off_rev"])[-1]) - f for b, f in zip(metas, ft)]           # reverse words per rank
+    parts_f = [slice(r * cap, r * cap + ft[r]) for r in range(len(metas))]
+    parts_r = [slice(r * cap + ft[r], r * cap + ft[r] + rt[r]) for r in range(len(metas))]
+    cmin = torch.cat([recv_min[x] for x in parts_f] + [recv_min[x] for x in parts_r])
+    cpos = torch.cat([recv_pos[x] for x in parts_f] + [recv_pos[x] for x in parts_r])
+    fbase = np.cumsum([0] + ft)
+    rbase = np.cumsum([0] + rt) + fbase[-1]
+    off_f = np.concatenate([np.asarray(b.rep_view["off_fwd"], np.int64)[:-1] + fbase[r] for r, b in enumerate(metas)] + [fbase[-1:]])
+    off_r = np.concatenate([np.asarray(b.rep_view["off_rev"], np.int64)[:-1] - ft[r] + rbase[r] for r, b in enumerate(metas)] + [rbase[-1:]])
+    v = _meta_view(metas)
+    v.update(off_fwd=off_f, off_rev=off_r, min_val=cmin.data_ptr(), min_pos=cpos.data_ptr(), total=int(cmin.numel()),
+             minimizers_on_device=True, min_cls_size=min_cls_size, _keepalive=(cmin, cpos))
+    torch.cuda.synchronize()        # torch's stream wrote the buffers, the context's stream reads them
+    cls, strand, st = ctx.cluster_merge(params, None, v)
+    mindb = ctx.index_export() if export_mindb else None
+    return _assemble(metas, cls, strand, st, mindb=mindb)
+
+
+def merge_all_device(ctx, params, cb: ClusteredBatch, dist, torch, min_cls_size=3, export_mindb=False, timing=None):
+    """The merge of all ranks' freshly clustered batches with device-resident representative records (module
+    docstring, steps 1-3).  Every rank returns the merged clustering (membership + counts; the merged clusters'
+    records stay in HBM)."""
+    import time
+    dev = torch.device("cuda", torch.cuda.current_device())
     t0 = time.perf_counter()
-    allb, nbytes = allgather_clustered(cb, dist)
-    if torch is not None and dev is not None and dev.type == "cuda":
-        torch.cuda.synchronize()
+    mins, poss = gather_local(ctx, cb, torch, dev)                       # step 1: HBM -> HBM
+    meta = pack_clustered(cb, with_minimizers=False)
     t1 = time.perf_counter()
-    merged = merge_all(ctx, params, allb)
+    if dist is None:
+        recv_min, recv_pos, cap, metas, nbytes = mins, poss, int(mins.numel()), [unpack_clustered(meta)], [0]
+    else:
+        cdev = _device(dist)                                             # nccl: the GPU; gloo (tests): host
+        recv_min, cap, sz = _allgather_u32(mins, dist, torch, cdev)      # step 2: RCCL all-gather of the device buffers
+        recv_pos, _, _ = _allgather_u32(poss, dist, torch, cdev)
+        rmeta, mcap, msz = _allgather_u32(meta, dist, torch, cdev)
+        mh = rmeta.cpu().numpy().view(np.uint32)
+        metas = [unpack_clustered(mh[r * mcap:r * mcap + msz[r]]) for r in range(len(msz))]
+        nbytes = [8 * a + 4 * b for a, b in zip(sz, msz)]
+        if cdev.type != "cuda":
+            recv_min, recv_pos = recv_min.to(dev), recv_pos.to(dev)
+        torch.cuda.synchronize()
     t2 = time.perf_counter()
-    n_reads = int(sum(len(b.member_read) for b in allb))
+    merged = merge_gathered(ctx, params, metas, recv_min, recv_pos, cap, min_cls_size, export_mindb)   # step 3
+    t3 = time.perf_counter()
+    if timing is not None:
+        timing.update(gather_ms=(t1 - t0) * 1e3, allgather_ms=(t2 - t1) * 1e3, merge_ms=(t3 - t2) * 1e3, payload_bytes_per_rank=nbytes,
+                      clusters_in=[m.n_clusters for m in metas])
+    return merged
+
+
+def timed_merge(ctx, params, cb: ClusteredBatch, dist, torch=None, dev=None):
+    """bench.py's merge leg: device gather + all-gather + one-pass merge on every rank, each phase timed (max over
+    ranks)."""
     from .digest import fnv1a_reads
-    return {"batches": len(allb), "clusters_in": [b.n_clusters for b in allb], "clusters_out": merged.n_clusters,
-            "reads_assigned": n_reads, "allgather_ms": max_over_ranks((t1 - t0) * 1e3, dist),
-            "merge_ms": max_over_ranks((t2 - t1) * 1e3, dist),
-            "payload_bytes_per_rank": nbytes,
-            "fnv1a": fnv1a_reads(merged), "merged_on": "every rank (replicated one-pass merge)",
+    tm = {}
+    merged = merge_all_device(ctx, params, cb, dist, torch, timing=tm)
+    return {"batches": len(tm["clusters_in"]), "clusters_in": tm["clusters_in"], "clusters_out": merged.n_clusters,
+            "reads_assigned": int(len(merged.member_read)), "gather_ms": max_over_ranks(tm["gather_ms"], dist),
+            "allgather_ms": max_over_ranks(tm["allgather_ms"], dist), "merge_ms": max_over_ranks(tm["merge_ms"], dist),
+            "payload_bytes_per_rank": tm["payload_bytes_per_rank"], "fnv1a": fnv1a_reads(merged),
+            "merged_on": "every rank (device-resident representative records, replicated one-pass merge)",
             "aln_invoked": merged.stats.get("n_aln_invoked")}

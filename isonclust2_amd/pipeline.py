@@ -37,6 +37,8 @@ class ClusteredBatch:
     stats: dict = field(default_factory=dict)
     rep_seq: bytes = None    # raw sequences of the representatives, concatenated (sahlin / furious merges align them)
     rep_off: np.ndarray = None
+    rep_entry: np.ndarray = None   # entry of the sorted batch each cluster's representative came from (fresh batches)
+    ctx_serial: int = -1           # Context.serial after the clustering call: the context still holds this batch's queries iff equal
 
     @property
     def n_clusters(self):
@@ -159,7 +161,8 @@ def cluster_single(ctx, params, sb: SortedBatch, timing=None) -> ClusteredBatch:
             rep_entry[c] = i
     rep_view = gather_records(sb.view, rep_entry)
     rep_seq, rep_off = gather_seqs(sb.view.get("raw_seq"), sb.view.get("raw_off"), rep_entry)
-    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off, member_cls=cls[ok].astype(np.int32),
+    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off, rep_entry=rep_entry.astype(np.int32),
+                          ctx_serial=getattr(ctx, "serial", -1), member_cls=cls[ok].astype(np.int32),
                           member_read=np.asarray(sb.read_ids)[ok].astype(np.int64),
                           member_strand=strand[ok].astype(np.int32), mindb=(keys, offs, post),
                           depth=sb.depth + 1 if sb.depth < 0 else sb.depth + 1,

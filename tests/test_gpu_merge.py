@@ -114,3 +114,51 @@ def test_one_pass_merge_of_all_batches_equals_the_oracle_fold(ctx, cfg, seed, nb
     g = idist.unpack_clustered(idist.pack_clustered(cbs[1]))
     assert np.array_equal(g.rep_view["min_val"], cbs[1].rep_view["min_val"]) and g.rep_seq == cbs[1].rep_seq
     assert np.array_equal(g.rep_off, cbs[1].rep_off) and np.array_equal(g.member_read, cbs[1].member_read)
+
+
+@pytest.mark.parametrize("cfg,seed,nb,mode", [("config1", 3, 4, "fast"), ("short_dup", 3, 3, "sahlin")])
+def test_device_resident_records_merge_equals_the_oracle_fold(ctx, cfg, seed, nb, mode):
+    """The merge as the ranks of a node run it (dist.merge_all_device), minus the collective: every batch's
+    representative records are gathered ON THE DEVICE out of the batch's query arrays (ioc_gather_records_device),
+    the buffers are laid side by side as an all-gather would leave them, and the one-pass merge uses them in place
+    (ioc_batch_view::minimizers_on_device, ::is_cluster) — against the oracle folding the batches one merge at a time."""
+    import torch
+    from isonclust2_amd import dist as idist
+    rs = synth.generate_config(cfg, seed=seed)
+    obs, sbs = _batches(rs, nb)
+    for sb, B in zip(sbs, obs):
+        info = B.entry_info()
+        seqs = [rs.read(int(i))[0] for i in info["orig"]]
+        off = np.zeros(len(seqs) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in seqs])
+        sb.view.update(raw_seq=b"".join(seqs), raw_off=off)
+    p = api.default_params(11, 15, mode)
+    dev = torch.device("cuda", 0)
+    parts, metas = [], []
+    for sb, B in zip(sbs, obs):
+        B.cluster(mode=mode)
+        cb = pipeline.cluster_single(ctx, p, sb)
+        mins, poss = idist.gather_local(ctx, cb, torch, dev)
+        # the gathered lists are the host records' lists, word for word
+        assert np.array_equal(mins.cpu().numpy().view(np.uint32), cb.rep_view["min_val"])
+        assert np.array_equal(poss.cpu().numpy().view(np.uint32), cb.rep_view["min_pos"])
+        parts.append((mins, poss))
+        metas.append(idist.unpack_clustered(idist.pack_clustered(cb, with_minimizers=False)))
+    first = pipeline.cluster_single(ctx, p, sbs[0])
+    pipeline.cluster_single(ctx, p, sbs[1])
+    with pytest.raises(RuntimeError):       # the context has moved on: an older batch can no longer be gathered
+        idist.gather_local(ctx, first, torch, dev)
+    cap = max(int(m.numel()) for m, _ in parts) + 5
+    pad = lambda t: torch.cat([t, torch.full((cap - int(t.numel()),), 0x7FFFFFFF, dtype=torch.int32, device=dev)])
+    recv_min = torch.cat([pad(m) for m, _ in parts])
+    recv_pos = torch.cat([pad(q) for _, q in parts])
+    merged = idist.merge_gathered(ctx, p, metas, recv_min, recv_pos, cap, export_mindb=True)
+    left_o = obs[0]
+    for b in range(1, nb):
+        left_o.cluster(right=obs[b], mode=mode)
+    ocl, ost = left_o.assignments(rs.n)
+    cls, strand = merged.assignments(rs.n)
+    bad = np.nonzero((cls != ocl) | (strand != ost))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
+    assert merged.n_clusters == left_o.n_clusters()
+    _same_index(merged, left_o)
