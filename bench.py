@@ -144,9 +144,11 @@ def core_region(ctx, api, pipeline, sb, k, w, mode, runs):
         cb = pipeline.cluster_single(ctx, p, pipeline.SortedBatch(view=view, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
                                                                   batch_start=sb.batch_start, batch_end=sb.batch_end), timing=tm)
         ms.append(tm["abi_ms"])                    # ioc_cluster_merge + ioc_index_export, nothing else
+        parts = (tm["cluster_ms"], tm["export_ms"])
     ms = ms[1:]
     h2d = sum(np.asarray(view[x]).nbytes for x in ("min_val", "min_pos", "off_fwd", "off_rev", "hpc_len")) + (len(view.get("raw_seq", b"")))
-    return {"ms_min": min(ms), "ms_mean": sum(ms) / len(ms), "runs": len(ms), "h2d_bytes": int(h2d),
+    return {"ms_min": min(ms), "ms_mean": sum(ms) / len(ms), "runs": len(ms), "last_run_ms": {"ioc_cluster_merge": parts[0], "ioc_index_export": parts[1]},
+            "h2d_bytes": int(h2d),
             "d2h_bytes": int(sum(a.nbytes for a in cb.mindb) + 5 * len(sb.read_ids))}, cb
 
 
@@ -314,6 +316,26 @@ def main():
                              "refused_by_packed_kernel": tm.get("n_align_refused", 0)}}
         sah_res = (cls, strand, st, tm, acc)
 
+    # ---- every rank's own result against the committed oracle digest of ITS batch (tests/golden, tools/gen_golden.py) ----
+    golden = {}
+    try:
+        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_assignments.json")))
+    except Exception:
+        pass
+    from isonclust2_amd.digest import fnv1a
+    rank_parity = {}
+    for mode_name, res in (("fast", fast_res if want_fast else None), ("sahlin", sah_res if want_sahlin else None)):
+        if res is None or a.config != "config2":
+            continue
+        g = golden.get(f"config2:{seed}" + ("" if mode_name == "fast" else ":sahlin"))
+        ok = -1 if g is None else int(f"{fnv1a(res[0], res[1]):016x}" == g["fnv1a"] and res[2]["n_clusters"] == g["clusters"])
+        if dist is not None:
+            t = torch.tensor([ok], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        rank_parity[mode_name] = {1: "every rank's assignments equal the oracle's digest of its batch", 0: "MISMATCH on at least one rank",
+                                  -1: "no golden for at least one rank's batch"}[ok]
+
     # ---- roofline inputs that need the resident fast-mode clustering (rank 0) ----
     roof = roof_aln = None
     fcls = fstrand = None
@@ -346,6 +368,15 @@ def main():
         from isonclust2_amd import dist as idist
         mode = "sahlin" if want_sahlin else "fast"
         merge = idist.timed_merge(ctx, api.default_params(k, w, mode), cb_merge, dist, torch, dev)
+        merge["mode"] = mode
+        g4 = golden.get(f"config4:{mode}")
+        if g4 is not None and not a.same_seed and a.config == "config2" and 2 <= world <= len(g4["seeds"]):
+            # the left fold of the first `world` batches is a prefix of the 8-batch fold: cluster counts after every step
+            # are in the golden; the digest only for all 8
+            merge["golden"] = {"clusters_out_expected": g4["steps"][world - 2]["clusters_after"],
+                               "clusters_match": merge["clusters_out"] == g4["steps"][world - 2]["clusters_after"]}
+            if world == len(g4["seeds"]):
+                merge["golden"]["digest_match"] = merge["fnv1a"] == g4["fnv1a"]
 
     if rank == 0:
         # ---- fast mode (configs[1]): HBM roofline of the scoring kernels + full-batch CPU baseline / parity ----
@@ -425,7 +456,7 @@ def main():
             "phase_ms": head["phase_ms"],
             "roofline": roof if roof is not None else roof_aln,
             "cpu_baseline": head.get("cpu_baseline"), "parity": head.get("parity"),
-            "core": core or None, "cli": cli, "merge": merge,
+            "core": core or None, "cli": cli, "merge": merge, "golden_parity": rank_parity or None,
         }
         if head_mode == "sahlin":
             out["alignment"] = sah["alignment"]

@@ -103,7 +103,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -1094,61 +1094,61 @@ extern "C" {
 // resolve and kept: callers size with a first call (keys == NULL) and fetch with a second one.
 static int index_export_compute(ioc_ctx* c)
 {
+    // The final MinDB = the index's posting lists restricted to the targets that are clusters, with final ids
+    // (AddMinimizers for every query that opened a cluster, minimizer.cpp:31-42).  Filtering and renumbering run on the
+    // device (k_export_count / k_export_fill: one wave per list); the host only orders the keys (the reference's
+    // unordered_map has no order of its own: the CSR is given in ascending key order) and takes the compact result.
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint32_t nslots = c->cap + 1;
-    const uint32_t psize = c->post16 ? 2u : 4u;
-    std::vector<uint32_t> hk(nslots), ho(size_t(nslots) + 1), hc(nslots), hp(size_t(c->n_post) + 1);
-    std::vector<uint16_t> hp16(c->post16 ? size_t(c->n_post) + 1 : 1);
     std::vector<uint8_t> valid(size_t(c->n) + 1);
-    HIPCHK(c, hipMemcpyAsync(hk.data(), c->b_keys.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(ho.data(), c->b_off.p, size_t(nslots + 1) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(hc.data(), c->b_cnt.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
-    if (c->n_post)
-        HIPCHK(c, hipMemcpyAsync(c->post16 ? (void*)hp16.data() : (void*)hp.data(), c->b_post.p,
-                                 size_t(c->n_post) * psize, hipMemcpyDeviceToHost, s));
     const void* v = c->cur_valid == 0 ? c->b_valid0.p : c->b_valid1.p;
     if (c->n) HIPCHK(c, hipMemcpyAsync(valid.data(), v, size_t(c->n), hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> hk(nslots);
+    HIPCHK(c, hipMemcpyAsync(hk.data(), c->b_keys.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (c->post16)
-        for (size_t i = 0; i < size_t(c->n_post); ++i) hp[i] = hp16[i];
     // final cluster id of query i that opened a cluster = L + rank among such queries (cluster.cpp:178)
     std::vector<int32_t> cid(size_t(c->n) + 1, -1);
     int32_t next = c->L;
     for (int i = 0; i < c->n; ++i)
         if (valid[size_t(i)]) cid[size_t(i)] = next++;
-    struct Row {
-        uint32_t key, slot;
-    };
-    std::vector<Row> rows;
-    for (uint32_t sl = 0; sl < nslots; ++sl) {
-        if (hc[sl] == 0) continue;
-        uint32_t key = (sl == c->cap) ? 0xFFFFFFFFu : hk[sl];
-        rows.push_back(Row{key, sl});
+    RESERVE(c, c->b_exp_cid, (size_t(c->n) + 1) * 4);
+    RESERVE(c, c->b_exp_cnt, size_t(nslots) * 4);
+    RESERVE(c, c->b_exp_off, size_t(nslots) * 8);
+    HIPCHK(c, hipMemcpyAsync(c->b_exp_cid.p, cid.data(), (size_t(c->n) + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, iock_export_count(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, c->post16, uint32_t(c->L),
+                                P<int32_t>(c->b_exp_cid), P<uint32_t>(c->b_exp_cnt)));
+    std::vector<uint32_t> hcnt(nslots);
+    HIPCHK(c, hipMemcpyAsync(hcnt.data(), c->b_exp_cnt.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // keys whose every contributor joined another cluster were never inserted by AddMinimizers: no entry (the reference
+    // keeps keys with emptied lists only through UpdateMinDB, i.e. in consensus mode)
+    std::vector<uint64_t> rows;  // key << 32 | slot
+    rows.reserve(nslots / 2);
+    for (uint32_t sl = 0; sl < nslots; ++sl)
+        if (hcnt[sl]) rows.push_back((uint64_t(sl == c->cap ? 0xFFFFFFFFu : hk[sl]) << 32) | sl);
+    std::sort(rows.begin(), rows.end());
+    std::vector<int64_t> hoff(nslots, 0);
+    c->exp_keys.resize(rows.size());
+    c->exp_offs.resize(rows.size() + 1);
+    int64_t tot = 0;
+    for (size_t i = 0; i < rows.size(); ++i) {
+        const uint32_t sl = uint32_t(rows[i] & 0xFFFFFFFFu);
+        c->exp_keys[i] = uint32_t(rows[i] >> 32);
+        c->exp_offs[i] = tot;
+        hoff[sl] = tot;
+        tot += int64_t(hcnt[sl]);
     }
-    std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.key < b.key; });
-    c->exp_keys.clear();
-    c->exp_offs.clear();
-    c->exp_post.clear();
-    c->exp_keys.reserve(rows.size());
-    c->exp_offs.reserve(rows.size() + 1);
-    c->exp_post.reserve(size_t(c->n_post));
-    const uint32_t L = uint32_t(c->L);
-    for (auto& r : rows) {
-        const size_t start = c->exp_post.size();
-        for (uint32_t p = 0; p < hc[r.slot]; ++p) {
-            uint32_t t = hp[size_t(ho[r.slot]) + p];
-            int32_t id = t < L ? int32_t(t) : cid[size_t(t - L)];
-            if (id < 0) continue;
-            c->exp_post.push_back(uint32_t(id));
-        }
-        // the reference keeps keys with emptied lists only through UpdateMinDB (consensus); a key
-        // whose every contributor joined another cluster was never inserted by AddMinimizers.
-        if (c->exp_post.size() == start) continue;
-        c->exp_keys.push_back(r.key);
-        c->exp_offs.push_back(int64_t(start));
+    c->exp_offs[rows.size()] = tot;
+    c->exp_post.resize(size_t(tot));
+    if (tot > 0) {
+        RESERVE(c, c->b_exp_out, size_t(tot) * 4);
+        HIPCHK(c, hipMemcpyAsync(c->b_exp_off.p, hoff.data(), size_t(nslots) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, iock_export_fill(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, c->post16, uint32_t(c->L),
+                                   P<int32_t>(c->b_exp_cid), P<uint32_t>(c->b_exp_cnt), P<int64_t>(c->b_exp_off), P<uint32_t>(c->b_exp_out)));
+        HIPCHK(c, hipMemcpyAsync(c->exp_post.data(), c->b_exp_out.p, size_t(tot) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
     }
-    c->exp_offs.push_back(int64_t(c->exp_post.size()));
     c->exp_valid = true;
     return IOC_OK;
 }

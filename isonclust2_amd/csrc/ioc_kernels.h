@@ -81,6 +81,10 @@ hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* d
                              const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, void* post, int post16);
 hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, void* post,
                            uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16);
+hipError_t iock_export_count(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
+                             uint32_t L, const int32_t* cid, uint32_t* out_cnt);
+hipError_t iock_export_fill(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
+                            uint32_t L, const int32_t* cid, const uint32_t* out_cnt, const int64_t* out_off, uint32_t* out);
 hipError_t iock_gather_lists(hipStream_t st, uint32_t nlists, const int64_t* src, const int64_t* dst, const uint32_t* len,
                              const uint32_t* smin, const uint32_t* spos, uint32_t* dmin, uint32_t* dpos);
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,

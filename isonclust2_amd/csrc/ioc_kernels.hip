@@ -1900,6 +1900,62 @@ __global__ void __launch_bounds__(256) k_query_compact_many(const int32_t* __res
 static int g_score_variant = 0;
 static int g_part32 = 0;
 
+namespace {
+// ---- MinDB export (ioc_index_export): the posting lists restricted to the targets that ARE clusters, with final ids ----
+// cid[t - L] = final cluster id of query t - L if it opened a cluster, -1 otherwise; left targets keep their ids.
+// One wave per slot; the order inside a list (ascending targets) is kept, and final ids ascend with the targets.
+template <typename PT>
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_export_count(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt, const PT* __restrict__ post,
+               uint32_t L, const int32_t* __restrict__ cid, uint32_t* __restrict__ out_cnt)
+{
+    const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6, nw = (gridDim.x * IOC_BLOCK) >> 6;
+    const int lane = lane_id();
+    for (uint32_t slot = gw; slot < nslots; slot += nw) {
+        const uint32_t c = cnt[slot], o = off[slot];
+        uint32_t k = 0;
+        for (uint32_t t0 = 0; t0 < c; t0 += 64) {
+            const uint32_t t = t0 + uint32_t(lane);
+            bool keep = false;
+            if (t < c) {
+                const uint32_t tg = post[o + t];
+                keep = tg < L || cid[tg - L] >= 0;
+            }
+            k += uint32_t(__popcll(__ballot(keep)));
+        }
+        if (lane == 0) out_cnt[slot] = k;
+    }
+}
+
+template <typename PT>
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_export_fill(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt, const PT* __restrict__ post,
+              uint32_t L, const int32_t* __restrict__ cid, const uint32_t* __restrict__ out_cnt, const int64_t* __restrict__ out_off,
+              uint32_t* __restrict__ out)
+{
+    const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6, nw = (gridDim.x * IOC_BLOCK) >> 6;
+    const int lane = lane_id();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t slot = gw; slot < nslots; slot += nw) {
+        if (out_cnt[slot] == 0) continue;
+        const uint32_t c = cnt[slot], o = off[slot];
+        int64_t w = out_off[slot];
+        for (uint32_t t0 = 0; t0 < c; t0 += 64) {
+            const uint32_t t = t0 + uint32_t(lane);
+            int32_t id = -1;
+            if (t < c) {
+                const uint32_t tg = post[o + t];
+                id = tg < L ? int32_t(tg) : cid[tg - L];
+            }
+            const unsigned long long m = __ballot(id >= 0);
+            if (id >= 0) out[w + __popcll(m & lt_mask)] = uint32_t(id);
+            w += __popcll(m);
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 void iock_set_score_variant(int v) { g_score_variant = v; }
@@ -2017,6 +2073,30 @@ k_gather_lists(uint32_t nlists, const int64_t* __restrict__ src, const int64_t* 
             dpos[b + t] = spos[a + t];
         }
     }
+}
+
+hipError_t iock_export_count(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
+                             uint32_t L, const int32_t* cid, uint32_t* out_cnt)
+{
+    const unsigned nb = 2048;
+    if (post16)
+        hipLaunchKernelGGL(k_export_count<uint16_t>, dim3(nb), dim3(IOC_BLOCK), 0, st, nslots, off, cnt, (const uint16_t*)post, L, cid, out_cnt);
+    else
+        hipLaunchKernelGGL(k_export_count<uint32_t>, dim3(nb), dim3(IOC_BLOCK), 0, st, nslots, off, cnt, (const uint32_t*)post, L, cid, out_cnt);
+    return hipGetLastError();
+}
+
+hipError_t iock_export_fill(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
+                            uint32_t L, const int32_t* cid, const uint32_t* out_cnt, const int64_t* out_off, uint32_t* out)
+{
+    const unsigned nb = 2048;
+    if (post16)
+        hipLaunchKernelGGL(k_export_fill<uint16_t>, dim3(nb), dim3(IOC_BLOCK), 0, st, nslots, off, cnt, (const uint16_t*)post, L, cid, out_cnt,
+                           out_off, out);
+    else
+        hipLaunchKernelGGL(k_export_fill<uint32_t>, dim3(nb), dim3(IOC_BLOCK), 0, st, nslots, off, cnt, (const uint32_t*)post, L, cid, out_cnt,
+                           out_off, out);
+    return hipGetLastError();
 }
 
 hipError_t iock_gather_lists(hipStream_t st, uint32_t nlists, const int64_t* src, const int64_t* dst, const uint32_t* len,

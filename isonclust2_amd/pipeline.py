@@ -144,9 +144,11 @@ def cluster_single(ctx, params, sb: SortedBatch, timing=None) -> ClusteredBatch:
     import time
     t0 = time.perf_counter()
     cls, strand, st = ctx.cluster_batch(params, sb.view)
+    t1 = time.perf_counter()
     keys, offs, post = ctx.index_export()
     if timing is not None:
-        timing["abi_ms"] = (time.perf_counter() - t0) * 1e3
+        t2 = time.perf_counter()
+        timing.update(abi_ms=(t2 - t0) * 1e3, cluster_ms=(t1 - t0) * 1e3, export_ms=(t2 - t1) * 1e3)
     ok = cls >= 0
     # the entry that opened cluster c is its representative (cluster.cpp:178-206)
     n_cls = int(st["n_clusters"])

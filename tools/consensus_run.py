@@ -8,8 +8,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
-from isonclust2_amd import _lib, api, synth  # noqa: E402
-from tests.helpers import oracle_sorted_batch  # noqa: E402
+from isonclust2_amd import _lib, api, pipeline, synth  # noqa: E402
 from tests.test_gpu_poa import Poa  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -20,13 +19,9 @@ a = ap.parse_args()
 n, g, ln = (int(x) for x in a.shape.split(","))
 cmin, cmax, per = (int(x) for x in a.cons.split(","))
 rs = synth.generate(n, g, ln, 10, 21, seed=1)
-B, view = oracle_sorted_batch(rs)     # (sort stage only: the oracle does not cluster here)
-seqs = [rs.read(int(i))[0] for i in view["orig"]]
-off = np.zeros(len(seqs) + 1, np.int64)
-off[1:] = np.cumsum([len(x) for x in seqs])
-v = dict(view)
-v.update(raw_seq=b"".join(seqs), raw_off=off)
 ctx = api.Context(0)
+sb, _ = pipeline.sort_stage(ctx, rs, 11, 15)     # the product's own GPU sort stage
+v = sb.view
 poa = Poa(ctx)
 cargs = _lib.ConsensusArgs(cons_min_size=cmin, cons_max_size=cmax, cons_period=per, left_depth=-1, left_sizes=None)
 t = time.time()
