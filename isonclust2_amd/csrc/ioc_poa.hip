@@ -37,7 +37,10 @@
 namespace {
 
 constexpr int POA_NEG = INT32_MIN / 4;
-constexpr int POA_THREADS = 256;
+#ifndef IOC_POA_THREADS
+#define IOC_POA_THREADS 256
+#endif
+constexpr int POA_THREADS = IOC_POA_THREADS;  // columns of a tile = threads of its workgroup (a multiple of 64)
 constexpr int POA_MAX_COLS = 1 << 20;
 constexpr int POA_MAX_PREDS = 127;
 

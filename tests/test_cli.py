@@ -68,18 +68,9 @@ def test_sort_cluster_merge_dump_matches_oracle(tmp_path, mode):
     order, score, _ = R.order()
     p = po.default_params(11, 15)
     A, B = po.Batch(R, 0, half - 1, p, 0), po.Batch(R, half, rs.n - 1, p, 1)
-    if mode == "sahlin":
-        import ctypes as C
-        from isonclust2_amd import _lib
-        L = _lib.load()
-        CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
-        fn = CB(lambda a, na, b, nb, go, ge, o, cap: L.ioc_host_align(a, na, b, nb, 2, -2, go, ge, C.cast(o, C.c_char_p), cap, None))
-        po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
-    A.cluster(mode=mode)
+    A.cluster(mode=mode)      # (sahlin: the oracle aligns with its own scalar aligner)
     B.cluster(mode=mode)
     A.cluster(right=B, mode=mode)
-    if mode == "sahlin":
-        po.lib().orc_set_aligner(None)
     ocl, ost = A.assignments(rs.n)
     # the dump sorts clusters by size (unstable std::sort, cluster.cpp:570-580): compare partitions + strands
     got = {}

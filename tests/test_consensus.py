@@ -64,17 +64,7 @@ def test_cons_period_stops_the_updates_of_large_clusters():
 def test_device_consensus_equals_oracle(mode, shape, seed, cmax, cmin, period):
     from isonclust2_amd import _lib, api
     rs = synth.generate(shape[0], shape[1], shape[2], 11 if mode == "sahlin" else 12, 21, seed=seed)
-    hook = None
-    if mode == "sahlin":   # the oracle's aligner hook calls the product's host aligner (parasail absent)
-        L = _lib.load()
-        CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
-        hook = CB(lambda read, nread, rep, nrep, go, ge, out, cap:
-                  L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None))
-        po.lib().orc_set_aligner(C.cast(hook, C.c_void_p))
-    try:
-        B, view, ost, og = _oracle_run(rs, cmax, cmin, period, mode=mode)
-    finally:
-        po.lib().orc_set_aligner(None)
+    B, view, ost, og = _oracle_run(rs, cmax, cmin, period, mode=mode)   # (sahlin: the oracle's own scalar aligner)
     assert ost["cons_invoked"] > 3
     acl, ast = B.assignments(rs.n)
     ocl, ostr = acl[view["orig"]], ast[view["orig"]]

@@ -77,15 +77,31 @@ def test_config2_sahlin_full(ctx, batches):
 def test_config4_fold(ctx, batches, mode):
     """configs[3] on one GPU: every batch clustered on its own (checked against its golden), then
     ((b1 + b2) + b3) ... with the merge path; cluster counts after every merge and the digest over all 24 000 reads."""
+    import torch
+    from isonclust2_amd import dist as idist
     g = GOLD[f"config4:{mode}"]
-    cbs = []
+    dev = torch.device("cuda", 0)
+    cbs, parts, metas = [], [], []
     for seed in g["seeds"]:
         cb, cls, strand = _single(ctx, batches, seed, mode)
         gs = GOLD[f"config2:{seed}" + ("" if mode == "fast" else ":sahlin")]
         assert cb.n_clusters == gs["clusters"], seed
         assert f"{fnv1a(cls, strand):016x}" == gs["fnv1a"], seed
         cbs.append(cb)
+        # what this batch's rank contributes to the merge's all-gather: its representatives' lists, gathered on the device
+        parts.append(idist.gather_local(ctx, cb, torch, dev))
+        metas.append(idist.unpack_clustered(idist.pack_clustered(cb, with_minimizers=False)))
     p = api.default_params(K, W, mode)
+    # the merge as the ranks run it (device-resident records, ONE pass): digest over all 24 000 reads
+    cap = max(int(m.numel()) for m, _ in parts)
+    pad = lambda t: torch.cat([t, torch.zeros(cap - int(t.numel()), dtype=torch.int32, device=dev)])
+    one = idist.merge_gathered(ctx, p, metas, torch.cat([pad(m) for m, _ in parts]), torch.cat([pad(q) for _, q in parts]), cap)
+    del parts
+    ocl, ost = one.assignments(g["n"])
+    assert one.n_clusters == g["clusters"] and f"{fnv1a(ocl, ost):016x}" == g["fnv1a"]
+    if mode == "sahlin":
+        assert one.stats["n_aln_invoked"] == sum(st["stats"]["aln_invoked"] for st in g["steps"])
+    # and the reference's own order of work: one merge after the other
     left = cbs[0]
     for step, cb in zip(g["steps"], cbs[1:]):
         left = pipeline.cluster_merge(ctx, p, left, cb)

@@ -1,9 +1,8 @@
 """GPU parity of sahlin / furious mode (minimizer mapping + alignment fallback, src/cluster.cpp:545-566)
-against the oracle.  parasail is absent from the reference tree, so the oracle aligns through its aligner
-hook with the product's host aligner, while the product aligns on the GPU (ioc_align_pairs, bit-identical
-to that host aligner: tests/test_gpu_align.py).  What is checked is the control flow — which reads reach
-the fallback, which candidates are aligned in which order, and how the batched, speculative verdicts feed
-back into the greedy loop."""
+against the oracle.  parasail is absent from the reference tree: the oracle aligns with its OWN scalar aligner
+(oracle.cpp sg_trace, pinned by the reference's AlnRatioTest vector), the product aligns on the GPU
+(ioc_align_pairs) — two independent implementations.  Checked: which reads reach the fallback, which candidates are
+aligned in which order, every verdict, and how the batched, speculative verdicts feed back into the greedy loop."""
 import ctypes as C
 
 import numpy as np
@@ -15,20 +14,13 @@ from tests.helpers import oracle_entry_assignments, oracle_sorted_batch
 
 pytestmark = pytest.mark.gpu
 
-_CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
-
-
 @pytest.fixture(scope="module")
 def hooked_oracle():
-    L = _lib.load()
-
-    def cb(read, nread, rep, nrep, go, ge, out, cap):
-        return L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None)
-
-    fn = _CB(cb)
-    po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
-    yield fn
+    """Since round 2 the oracle aligns with its OWN scalar aligner (oracle.cpp sg_trace): nothing of the product sits
+    behind the oracle in these tests (the name of the fixture is historical)."""
     po.lib().orc_set_aligner(None)
+    po.lib().orc_use_builtin_aligner(1)
+    yield None
 
 
 @pytest.fixture(scope="module")

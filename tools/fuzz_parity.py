@@ -16,13 +16,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 aln_mode = sys.argv[3] if len(sys.argv) > 3 else None     # "sahlin" / "furious": small batches through the alignment fallback
 rng = np.random.default_rng(seed0)
 ctx = api.Context(0)
-if aln_mode:
-    import ctypes as C
-    from isonclust2_amd import _lib
-    _L = _lib.load()
-    _CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
-    _hook = _CB(lambda a, na, b, nb, go, ge, o, cap: _L.ioc_host_align(a, na, b, nb, 2, -2, go, ge, C.cast(o, C.c_char_p), cap, None))
-    po.lib().orc_set_aligner(C.cast(_hook, C.c_void_p))
+# (sahlin / furious: the oracle aligns with its own scalar aligner, oracle.cpp sg_trace — nothing of the product behind it)
 bad = 0
 t0 = time.time()
 for case in range(n_cases):

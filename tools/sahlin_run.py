@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer driver for the alignment modes: cluster a synthetic batch in sahlin / furious mode on the
 GPU (mapping + batched GPU aligner), print time and stats; --check compares with the oracle (slow: the
-oracle aligns on one host core through the product's host aligner)."""
+oracle aligns on one host core with its own scalar aligner)."""
 import argparse
 import ctypes as C
 import sys
@@ -42,14 +42,7 @@ for r in range(a.reps):
     dt = time.time() - t
     print(f"rep {r}: {a.mode} {rs.tag}: {dt * 1e3:.1f} ms ({rs.n / dt:.0f} reads/s) {st}", flush=True)
 if a.check:
-    L = _lib.load()
-    CB = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char), C.c_int)
-
-    def cb(read, nread, rep, nrep, go, ge, out, cap):
-        return L.ioc_host_align(read, nread, rep, nrep, 2, -2, go, ge, C.cast(out, C.c_char_p), cap, None)
-
-    fn = CB(cb)
-    po.lib().orc_set_aligner(C.cast(fn, C.c_void_p))
+    # (the oracle aligns with its own scalar aligner: nothing of the product behind it)
     t = time.time()
     ocl, ost, ostat = oracle_entry_assignments(B, view, mode=a.mode)
     dt = time.time() - t
