@@ -373,7 +373,25 @@ typedef struct {
     int (*consensus)(void* user, int side, int idx, char* out, int cap);                    /* GenerateConsensus -> length, consensus.cpp:87 */
     int (*purge)(void* user, int side, int idx, const char* seq, int len, unsigned weight); /* ConsPurge, consensus.cpp:128-137 */
     void (*rep_changed)(void* user, int32_t cls, const ioc_rep_record* rec);                /* optional: the pointers die with the call */
+    /* OPTIONAL (NULL: every consensus is taken at once, as the reference does): a graph store that can DEFER consensus
+     * requests and undo tagged operations lets the driver collect the consensus events of many clusters of a pass and
+     * have their graph additions aligned in ONE batch (the reference's result is unchanged: the driver verifies, once
+     * the new representatives are known, that no entry it walked past them could see one, and rolls back otherwise). */
+    const struct ioc_consensus_spec_ops* spec;
 } ioc_consensus_ops;
+/* tag = the right-batch entry that caused the operation (ascending over a call of ioc_cluster_consensus) */
+typedef struct ioc_consensus_spec_ops {
+    int (*create_tagged)(void* user, int side, int idx, const char* seq, int len, int tag);
+    int (*add_tagged)(void* user, int side, int idx, const char* seq, int len, unsigned weight, int tag);
+    /* GenerateConsensus of graph (side, idx) as it is after the additions queued so far: computed by flush(), fetched
+     * by collect() (returns the length) */
+    int (*consensus_deferred)(void* user, int side, int idx, int tag);
+    int (*flush)(void* user);
+    int (*collect)(void* user, int side, int idx, int tag, char* out, int cap);
+    /* undo every operation tagged >= first_tag (graphs, queued additions, deferred results); commit: forget how to */
+    int (*rollback)(void* user, int first_tag);
+    int (*commit)(void* user);
+} ioc_consensus_spec_ops;
 typedef struct {
     int32_t cons_min_size;      /* CmdArgs::ConsMinSize */
     int32_t cons_max_size;      /* CmdArgs::ConsMaxSize; <= 0: no consensus (graphs are still created, as in the reference) */
@@ -397,7 +415,7 @@ int ioc_cluster_consensus(ioc_ctx* ctx, const ioc_params* p, const char* table_p
 typedef struct ioc_poa ioc_poa;
 int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int32_t q, int32_t c, ioc_poa** out);
 void ioc_poa_destroy(ioc_poa* poa);
-/* fills user + create / size / add / consensus / purge of *ops (rep_changed is left to the caller) */
+/* fills user + create / size / add / consensus / purge + spec of *ops (rep_changed is left to the caller) */
 void ioc_poa_bind(ioc_poa* poa, ioc_consensus_ops* ops);
 /* inspection: a graph's nodes (letter, topological order) and weighted edges; the alignment (node id or -1,
  * position or -1, forward order) and score of the last `add`.  Returns the number of pairs. */

@@ -71,7 +71,8 @@ CONS_REP_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(RepRecord)
 
 class ConsensusOps(C.Structure):  # ioc_consensus_ops (the oracle's orc_cons_ops is its first six members)
     _fields_ = [("user", C.c_void_p), ("create", CONS_CREATE), ("size", CONS_SIZE), ("add", CONS_ADD),
-                ("consensus", CONS_CONSENSUS), ("purge", CONS_PURGE), ("rep_changed", CONS_REP_CHANGED)]
+                ("consensus", CONS_CONSENSUS), ("purge", CONS_PURGE), ("rep_changed", CONS_REP_CHANGED),
+                ("spec", C.c_void_p)]   # ioc_consensus_spec_ops* (NULL: no deferred consensus; ioc_poa_bind sets it)
 
 
 class ConsensusArgs(C.Structure):  # ioc_consensus_args

@@ -50,13 +50,13 @@ void sorted_unique(std::vector<uint32_t>& v)
 // int(MinShared * MinFraction) values with each of them — then none of them was, or becomes, a candidate that
 // GetBestCluster looks at (cluster.cpp:324-406 walks candidates down to int(top * MinFraction), top >= MinShared).
 struct DirtyIndex {
-    static constexpr uint32_t CAP = 1u << 18, MASK = CAP - 1, EMPTY = 0xFFFFu;
-    static constexpr int MAX_SLOTS = 32;
+    static constexpr uint32_t CAP = 1u << 20, MASK = CAP - 1, EMPTY = 0xFFFFu;
+    static constexpr int MAX_SLOTS = 256;  // clusters whose representative changes in one pass (deferred consensus batches that many events)
     std::vector<uint32_t> key = std::vector<uint32_t>(CAP, 0);
     std::vector<uint16_t> val = std::vector<uint16_t>(CAP, uint16_t(EMPTY));
     std::vector<uint32_t> touched;
     int nslots = 0;
-    static uint32_t hash(uint32_t v) { return (v * 2654435761u) >> 14; }
+    static uint32_t hash(uint32_t v) { return (v * 2654435761u) >> 12; }
     void reset()
     {
         for (uint32_t h : touched) val[h] = uint16_t(EMPTY);
@@ -185,6 +185,34 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     if (const char* e = getenv("IOC_CONS_WINDOW")) window = std::max(1, atoi(e));
     const bool fixed_window = getenv("IOC_CONS_WINDOW") != nullptr;
     std::vector<uint32_t> wval, wpos;
+    // Deferred consensus (ioc_consensus_spec_ops; IOC_CONS_SPECULATE=0 switches it off): the walk does not wait for a
+    // consensus — it records the event, queues the request and goes on as long as the entries it meets cannot see the
+    // OLD representative of a cluster with a pending event.  At the end of the pass all requested consensus sequences
+    // come back from ONE flush of the graph store (their additions aligned together), the new representatives are
+    // re-minimized by ONE extractor launch, and the entries walked after each event are checked again, in order,
+    // against old AND new minimizer sets — the reference's result is a function of those sets only.  An entry that
+    // could see a new representative after all ends the pass there: host state is undone from the journal, the graph
+    // store rolls back the operations tagged with later entries.
+    const ioc_consensus_spec_ops* spec = ops->spec;
+    if (const char* e = getenv("IOC_CONS_SPECULATE"))
+        if (atoi(e) == 0) spec = nullptr;
+    if (one_event_per_pass) spec = nullptr;
+    struct PendingEvent {
+        int x, i;
+        int32_t dc;
+        double hpc_err, raw_err;
+    };
+    struct Undo {
+        int kind;  // 0 gated, 1 new cluster, 2 join
+        int x;
+        int32_t dc;
+        int64_t dsize;
+        std::vector<uint8_t> key_was_new;  // new cluster: per value, whether AddMinimizers opened the key
+    };
+    std::vector<PendingEvent> evs;
+    std::vector<Undo> journal;
+    DirtyIndex dirty_b;
+    int64_t n_spec_rollbacks = 0, n_spec_events = 0, n_spec_flushes = 0;
     while (pos < n) {
         const int m = std::min(n - pos, window);
         double t0 = now();
@@ -287,6 +315,9 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         const int pass_from = pos;
         bool restarted = false;
         dirty.reset();
+        evs.clear();
+        journal.clear();
+        int stop_x = m;  // (deferred mode) the walk stands up to here unless the verification says otherwise
         for (int x = 0; x < m; ++x) {
             const int i = pos + x;
             const int32_t dc = sub_cls[size_t(x)];
@@ -294,6 +325,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 out_cls[i] = -1;
                 out_strand[i] = 0;
                 total.n_gated++;
+                if (spec && !evs.empty()) journal.push_back(Undo{0, x, -1, 0, {}});
                 continue;
             }
             // Representatives changed earlier in this pass: the device's decision for this entry stands only if
@@ -303,6 +335,10 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
                 if (dirty.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
                                   rb->off_rev[i + 1] - rb->off_rev[i], thr)) {
+                    if (spec) {  // (it sees the OLD representative of a cluster with a pending event: the pass ends here)
+                        stop_x = x;
+                        break;
+                    }
                     pos = i;
                     restarted = true;
                     break;
@@ -323,8 +359,16 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 ns.raw.assign(rseq, size_t(rlen));
                 ns.have_raw = true;
                 // AddMinimizers (minimizer.cpp:31-42): the new id is larger than every id in the lists
+                if (spec && !evs.empty()) {
+                    Undo u{1, x, dc, 0, {}};
+                    u.key_was_new.reserve(ns.vals.size());
+                    for (uint32_t v : ns.vals) u.key_was_new.push_back(db.find(v) == db.end() ? 1 : 0);
+                    journal.push_back(std::move(u));
+                }
                 for (uint32_t v : ns.vals) db[v].push_back(uint32_t(dc));
-                if (ops->create(ops->user, 0, dc, rseq, rlen) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: create failed");
+                // (before the first event of a pass nothing is ever undone: no snapshot needed)
+                if ((spec && !evs.empty() ? spec->create_tagged(ops->user, 0, dc, rseq, rlen, i) : ops->create(ops->user, 0, dc, rseq, rlen)) < 0)
+                    return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: create failed");
                 cl.push_back(std::move(ns));
                 out_cls[i] = dc;
                 out_strand[i] = 1;
@@ -338,6 +382,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             out_strand[i] = sub_strand[size_t(x)];
             total.n_joined++;
             b.size += entry_size > 1 ? entry_size - 1 : 1;
+            if (spec && !evs.empty()) journal.push_back(Undo{2, x, dc, entry_size > 1 ? entry_size - 1 : 1, {}});
             if (ca->cons_max_size <= 0) continue;
             if (ca->left_depth == -1 && ca->cons_period > 0 && b.size > ca->cons_period) continue;   // :267-271
             const int cons_min = ca->left_depth != -1 ? 2 : ca->cons_min_size;                         // :284-288
@@ -351,10 +396,24 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             const double raw_err = (b.raw_err * double(left_size) + rb->raw_err[i] * double(right_size)) / double(left_size + right_size);
             // (the reference reverse-complements a copy and throws it away, consensus.cpp:47-49: the read goes in as it is)
             t0 = now();
-            if (ops->add(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u) < 0)
+            if ((spec ? spec->add_tagged(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u, i)
+                      : ops->add(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u)) < 0)
                 return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: add failed");
             ph[2] += now() - t0;
             if (ops->size(ops->user, 0, dc) < cons_min) continue;
+            if (spec) {
+                // ---- the consensus is requested, not awaited ----
+                if (spec->consensus_deferred(ops->user, 0, dc, i) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: deferred consensus failed");
+                if (evs.empty()) journal.clear();
+                evs.push_back(PendingEvent{x, i, dc, hpc_err, raw_err});
+                dirty.add_cluster(b.vals, std::vector<uint32_t>());  // what later entries must not see: the OLD set for now
+                n_spec_events++;
+                if (dirty.full()) {
+                    stop_x = x + 1;
+                    break;
+                }
+                continue;
+            }
             t0 = now();
             std::vector<char> buf(size_t(1) << 22);
             const int clen = ops->consensus(ops->user, 0, dc, buf.data(), int(buf.size()));
@@ -443,6 +502,171 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 break;
             }
         }
+        if (spec) {
+            // ---- deferred mode, second half of the pass: consensus sequences, new representatives, verification ----
+            const int pos0 = pass_from;
+            int end_x = stop_x;  // entries [0, end_x) of the window stand
+            if (!evs.empty()) {
+                double t1 = now();
+                n_spec_flushes++;
+                if (spec->flush(ops->user) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: flush failed");
+                const size_t ne = evs.size();
+                std::vector<std::string> cons(ne);
+                std::vector<char> buf(size_t(1) << 22);
+                for (size_t e = 0; e < ne; ++e) {
+                    const int clen = spec->collect(ops->user, 0, evs[e].dc, evs[e].i, buf.data(), int(buf.size()));
+                    if (clen < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: consensus failed");
+                    cons[e].assign(buf.data(), size_t(clen));
+                    if (!(cons[e].size() > size_t(2 * k) || cons[e].size() >= size_t(w)))
+                        return ioc_fail(c, IOC_ERR_INPUT, "consensus shorter than 2k and w (the reference re-minimizes an empty sequence here)");
+                }
+                ph[2] += now() - t1;
+                t1 = now();
+                // the new representatives: fixed quality character, HPC, minimizers — ONE extractor call for all of them
+                std::vector<int64_t> xoff(ne + 1, 0);
+                std::string xseq, xqual;
+                std::vector<char> qraw(ne);
+                for (size_t e = 0; e < ne; ++e) {
+                    qraw[e] = std::to_string(int(-10 * log10(evs[e].raw_err)) + 33)[0];  // :98-99: first CHARACTER of the number
+                    xseq += cons[e];
+                    xqual.append(cons[e].size(), qraw[e]);
+                    xoff[e + 1] = int64_t(xseq.size());
+                }
+                std::vector<uint32_t> hlen(ne);
+                std::vector<double> herr_k1(ne);
+                std::vector<int64_t> xf(ne + 1), xr(ne + 1);
+                std::vector<int32_t> xst(ne);
+                int r2 = ioc_extract_minimizers(c, int32_t(ne), xoff.data(), reinterpret_cast<const uint8_t*>(xseq.data()),
+                                                reinterpret_cast<const uint8_t*>(xqual.data()), k, w, hlen.data(), herr_k1.data(), xf.data(),
+                                                xr.data(), xst.data());
+                if (r2 != IOC_OK) return r2;
+                for (size_t e = 0; e < ne; ++e)
+                    if (xst[e] != 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus with a non-ACGT base or an HPC length below 2k / w");
+                const int64_t nmin = xr[ne];
+                std::vector<uint32_t> mv(size_t(nmin) + 1), mp(size_t(nmin) + 1);
+                if ((r2 = ioc_extracted_download(c, mv.data(), mp.data(), nmin)) != IOC_OK) return r2;
+                std::vector<char> hs(xseq.size() + 1), hq(xseq.size() + 1);
+                if ((r2 = ioc_extracted_hpc_download(c, hs.data(), hq.data(), int64_t(xseq.size()))) != IOC_OK) return r2;
+                ph[3] += now() - t1;
+                t1 = now();
+                // ---- in the reference's order: finalize event e, then look again at the entries walked after it ----
+                dirty_b.reset();
+                size_t e = 0;
+                int violation = -1;
+                for (int x = evs[0].x; x < stop_x && violation < 0; ++x) {
+                    const int i = pos0 + x;
+                    if (x > evs[0].x && sub_cls[size_t(x)] >= 0 && dirty_b.nslots) {
+                        // (an entry with an event of its own is looked at again like any other, before its event counts)
+                        const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
+                        if (dirty_b.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
+                                            rb->off_rev[i + 1] - rb->off_rev[i], thr)) {
+                            violation = x;  // it can see a NEW representative: everything from here on is decided again
+                            break;
+                        }
+                    }
+                    if (e < ne && evs[e].x == x) {
+                        const PendingEvent& ev = evs[e];
+                        ClState& b = cl[size_t(ev.dc)];
+                        std::vector<uint32_t> nv(mv.begin() + xf[e], mv.begin() + xf[e + 1]);
+                        sorted_unique(nv);
+                        {   // UpdateMinDB (minimizer.cpp:124-160) on the host MinDB
+                            std::vector<uint32_t> to_del, to_ins;
+                            std::set_difference(b.vals.begin(), b.vals.end(), nv.begin(), nv.end(), std::back_inserter(to_del));
+                            std::set_difference(nv.begin(), nv.end(), b.vals.begin(), b.vals.end(), std::back_inserter(to_ins));
+                            for (uint32_t v : to_del) {
+                                auto& lst = db[v];
+                                std::vector<uint32_t> t2(lst);
+                                sorted_unique(t2);
+                                t2.erase(std::remove(t2.begin(), t2.end(), uint32_t(ev.dc)), t2.end());
+                                lst.swap(t2);
+                            }
+                            for (uint32_t v : to_ins) {
+                                auto& lst = db[v];
+                                lst.push_back(uint32_t(ev.dc));
+                                std::sort(lst.begin(), lst.end());
+                            }
+                        }
+                        dirty_b.add_cluster(b.vals, nv);
+                        b.vals.swap(nv);
+                        b.raw_err = ev.raw_err;
+                        b.hpc_err = ev.hpc_err;  // consensus.cpp:121 — also when the 0.9999 branch (:112-117) fired
+                        b.raw = cons[e];
+                        b.have_raw = true;
+                        b.seq_id = next_seq_id++;
+                        total.n_cons_invoked++;
+                        if (ops->rep_changed) {
+                            ioc_rep_record rec{};
+                            rec.raw_seq = cons[e].data();
+                            rec.raw_len = int32_t(cons[e].size());
+                            rec.raw_qual = qraw[e];
+                            rec.raw_err = ev.raw_err;
+                            rec.raw_score = ev.raw_err * double(cons[e].size());
+                            rec.hpc_seq = hs.data() + xoff[e];
+                            rec.hpc_len = int32_t(hlen[e]);
+                            rec.hpc_err = ev.hpc_err;
+                            rec.fwd_min = mv.data() + xf[e];
+                            rec.fwd_pos = mp.data() + xf[e];
+                            rec.n_fwd = int32_t(xf[e + 1] - xf[e]);
+                            rec.rev_min = mv.data() + xr[e];
+                            rec.rev_pos = mp.data() + xr[e];
+                            rec.n_rev = int32_t(xr[e + 1] - xr[e]);
+                            rec.entry = ev.i;
+                            ops->rep_changed(ops->user, ev.dc, &rec);
+                        }
+                        const int gsz = ops->size(ops->user, 0, ev.dc);
+                        if (gsz > ca->cons_max_size) {  // ConsPurge, consensus.cpp:128-137
+                            if (ops->purge(ops->user, 0, ev.dc, cons[e].data(), int(cons[e].size()), unsigned(gsz)) < 0)
+                                return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: purge failed");
+                        }
+                        ++e;
+                        if (dirty_b.full() && x + 1 < stop_x) violation = x + 1;  // too many changed clusters to keep checking: the pass ends here
+                        continue;
+                    }
+                }
+                if (violation >= 0) {
+                    // ---- undo what the walk did for the entries [violation, stop_x), newest first ----
+                    n_spec_rollbacks++;
+                    for (size_t u = journal.size(); u-- > 0;) {
+                        const Undo& un = journal[u];
+                        if (un.x < violation) break;
+                        if (un.kind == 0) {
+                            total.n_gated--;
+                        } else if (un.kind == 1) {
+                            ClState& ns = cl.back();
+                            if (int32_t(cl.size()) - 1 != un.dc) return ioc_fail(c, IOC_ERR_STATE, "consensus rollback: cluster stack out of order");
+                            for (size_t y = ns.vals.size(); y-- > 0;) {
+                                auto it = db.find(ns.vals[y]);
+                                if (it == db.end() || it->second.empty() || it->second.back() != uint32_t(un.dc))
+                                    return ioc_fail(c, IOC_ERR_STATE, "consensus rollback: MinDB out of order");
+                                it->second.pop_back();
+                                if (un.key_was_new[y]) db.erase(it);
+                            }
+                            cl.pop_back();
+                        } else {
+                            cl[size_t(un.dc)].size -= un.dsize;
+                            total.n_joined--;
+                        }
+                    }
+                    if (spec->rollback(ops->user, pos0 + violation) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: rollback failed");
+                    end_x = violation;
+                } else {
+                    if (spec->commit(ops->user) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: commit failed");
+                }
+                ph[3] += now() - t1;
+            } else if (spec->commit(ops->user) < 0) {
+                return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: commit failed");
+            }
+            pos = pos0 + end_x;
+            restarted = end_x < m;
+            if (restarted) {
+                if (!fixed_window) window = std::max(64, 4 * std::max(1, pos - pass_from));
+            } else if (!fixed_window) {
+                window = std::min(n, std::max(64, 2 * window));
+            }
+            if (getenv("IOC_TRACE") && !evs.empty())
+                fprintf(stderr, "[ioc]   deferred: %zu events in the pass, entries [%d, %d) stand\n", evs.size(), pass_from, pos);
+            continue;
+        }
         if (restarted) {
             // the next event is probably as far away as this one was
             if (!fixed_window) window = std::max(64, 4 * std::max(1, pos - pass_from));
@@ -451,6 +675,9 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             if (!fixed_window) window = std::min(n, std::max(64, 2 * window));
         }
     }
+    if (getenv("IOC_TRACE") && spec)
+        fprintf(stderr, "[ioc] deferred consensus: %lld events in %lld flushes, %lld rollbacks\n", (long long)n_spec_events, (long long)n_spec_flushes,
+                (long long)n_spec_rollbacks);
     if (getenv("IOC_TRACE"))
         fprintf(stderr, "[ioc] consensus phases: left view %.1f ms, device passes %.1f ms, graph hooks %.1f ms, new representatives %.1f ms\n",
                 ph[0], ph[1], ph[2], ph[3]);

@@ -30,6 +30,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "ioc_internal.h"
@@ -768,6 +769,8 @@ struct PGraph {
 struct PoaPending {
     std::string seq;
     int64_t weight = 1;
+    int tag = -1;         // the driver's entry that caused the operation (ioc_consensus_spec_ops), -1: untagged
+    bool marker = false;  // not an addition: "take the consensus here" (consensus_deferred)
 };
 
 struct ioc_poa {
@@ -779,6 +782,20 @@ struct ioc_poa {
     // queues of all graphs are worked off together, one addition per graph and round, in batched launches
     std::map<int, std::vector<PoaPending>> pending[2];
     bool lazy = true;
+    // deferred consensus (ioc_consensus_spec_ops): results by (side, idx, tag); what a graph and its queue were before the
+    // first speculative operation was APPLIED to it (graphs that did not exist: existed = false)
+    std::map<std::tuple<int, int, int>, std::string> deferred;
+    struct Snap {
+        bool existed = false;
+        int max_tag = -1;  // the latest entry whose operation was applied to the graph since the snapshot
+        PGraph g;
+        std::vector<PoaPending> q;
+        // a graph (re)created by a tagged operation of the pass: the seed and every operation issued to it since are kept,
+        // so that a rollback to a point AFTER its creation can rebuild it (create_tag < first_tag)
+        int create_tag = -1;
+        std::string create_seq;
+    };
+    std::map<int, Snap> snap[2];
     DevBuf d_int, d_dirs, d_eb, d_carry, d_tbest, d_small, d_aln, d_jobs;
     // the alignment of the last addition worked off (tests / inspection): node ids, positions, score
     std::vector<int32_t> last_node, last_pos;
@@ -985,14 +1002,48 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
 }
 
 // work off every queue: one addition per graph and round, as many graphs per batch as the memory budget allows
-int poa_flush(ioc_poa* p)
+// a consensus marker at the head of a queue: the consensus of the graph as it is now
+void poa_take_markers(ioc_poa* p, int side, int idx, std::vector<PoaPending>& q)
 {
+    while (!q.empty() && q.front().marker) {
+        auto sn = p->snap[side].find(idx);
+        if (sn != p->snap[side].end()) sn->second.max_tag = std::max(sn->second.max_tag, q.front().tag);
+        auto it = p->g[side].find(idx);
+        if (it != p->g[side].end()) {
+            it->second.ensure();
+            p->deferred[std::make_tuple(side, idx, q.front().tag)] = it->second.consensus();
+        }
+        q.erase(q.begin());
+    }
+}
+void poa_snapshot(ioc_poa* p, int side, int idx)
+{
+    if (p->snap[side].count(idx)) return;
+    ioc_poa::Snap s;
+    auto it = p->g[side].find(idx);
+    s.existed = it != p->g[side].end();
+    if (s.existed) s.g = it->second;
+    auto pq = p->pending[side].find(idx);
+    if (pq != p->pending[side].end()) s.q = pq->second;
+    p->snap[side][idx] = std::move(s);
+}
+
+// only_marked: work off the queues of the graphs that hold a consensus marker (and snapshot those graphs first)
+int poa_flush(ioc_poa* p, bool only_marked = false)
+{
+    auto wanted = [&](const std::vector<PoaPending>& q) {
+        if (q.empty()) return false;
+        if (!only_marked) return true;
+        for (auto& it : q)
+            if (it.marker) return true;
+        return false;
+    };
     bool any = false;
-    for (int side = 0; side < 2 && !any; ++side)
+    for (int side = 0; side < 2; ++side)
         for (auto& kv : p->pending[side])
-            if (!kv.second.empty()) {
+            if (wanted(kv.second)) {
                 any = true;
-                break;
+                if (only_marked) poa_snapshot(p, side, kv.first);
             }
     if (!any) return IOC_OK;
     size_t free_b = 0, total_b = 0;
@@ -1007,6 +1058,8 @@ int poa_flush(ioc_poa* p)
         size_t used = 0;
         for (int side = 0; side < 2; ++side)
             for (auto& kv : p->pending[side]) {
+                if (!wanted(kv.second)) continue;
+                poa_take_markers(p, side, kv.first, kv.second);
                 if (kv.second.empty()) continue;
                 auto it = p->g[side].find(kv.first);
                 if (it == p->g[side].end()) return ioc_fail(p->ctx, IOC_ERR_STATE, "POA: addition to a graph that does not exist");
@@ -1068,7 +1121,12 @@ int poa_flush(ioc_poa* p)
                 p->last_score = j.score;
             }
             auto& q = p->pending[who[x].first][who[x].second];
+            {
+                auto sn = p->snap[who[x].first].find(who[x].second);
+                if (sn != p->snap[who[x].first].end()) sn->second.max_tag = std::max(sn->second.max_tag, q.front().tag);
+            }
             q.erase(q.begin());
+            poa_take_markers(p, who[x].first, who[x].second, q);
         }
         p->ms_graph += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
     }
@@ -1091,7 +1149,10 @@ int op_size(void* u, int side, int idx)
     auto it = p->g[side].find(idx);
     if (it == p->g[side].end()) return -1;
     auto pq = p->pending[side].find(idx);
-    return it->second.nseq + (pq == p->pending[side].end() ? 0 : int(pq->second.size()));  // queued additions count
+    int queued = 0;  // queued additions count (consensus markers do not)
+    if (pq != p->pending[side].end())
+        for (auto& x : pq->second) queued += !x.marker;
+    return it->second.nseq + queued;
 }
 int op_add(void* u, int side, int idx, const char* seq, int len, unsigned weight)
 {
@@ -1129,6 +1190,108 @@ int op_purge(void* u, int side, int idx, const char* seq, int len, unsigned weig
     p->pending[side].erase(idx);
     return 0;
 }
+
+// ---- ioc_consensus_spec_ops ------------------------------------------------------------------------------------
+int sp_create(void* u, int side, int idx, const char* seq, int len, int tag)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1) return -1;
+    poa_snapshot(p, side, idx);  // (a graph that did not exist: rollback erases it)
+    ioc_poa::Snap& sn = p->snap[side][idx];
+    sn.max_tag = std::max(sn.max_tag, tag);
+    sn.create_tag = tag;
+    sn.create_seq.assign(seq, size_t(len));
+    sn.q.clear();
+    return op_create(u, side, idx, seq, len);
+}
+int sp_add(void* u, int side, int idx, const char* seq, int len, unsigned weight, int tag)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1 || len < 0) return -1;
+    if (p->g[side].find(idx) == p->g[side].end()) return -1;
+    if (len == 0) return 0;
+    PoaPending it;
+    it.seq.assign(seq, size_t(len));
+    it.weight = int64_t(weight);
+    it.tag = tag;
+    {
+        auto sn = p->snap[side].find(idx);
+        if (sn != p->snap[side].end() && sn->second.create_tag >= 0) sn->second.q.push_back(it);  // (the log of a graph created in this pass)
+    }
+    p->pending[side][idx].push_back(std::move(it));
+    return 0;
+}
+int sp_consensus_deferred(void* u, int side, int idx, int tag)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    if (side < 0 || side > 1 || p->g[side].find(idx) == p->g[side].end()) return -1;
+    PoaPending it;
+    it.marker = true;
+    it.tag = tag;
+    {
+        auto sn = p->snap[side].find(idx);
+        if (sn != p->snap[side].end() && sn->second.create_tag >= 0) sn->second.q.push_back(it);
+    }
+    p->pending[side][idx].push_back(std::move(it));
+    return 0;
+}
+int sp_flush(void* u) { return poa_flush(static_cast<ioc_poa*>(u), true) == IOC_OK ? 0 : -1; }
+int sp_collect(void* u, int side, int idx, int tag, char* out, int cap)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    auto it = p->deferred.find(std::make_tuple(side, idx, tag));
+    if (it == p->deferred.end()) {
+        if (poa_flush(p, true) != IOC_OK) return -1;
+        it = p->deferred.find(std::make_tuple(side, idx, tag));
+        if (it == p->deferred.end()) return -1;
+    }
+    if (int(it->second.size()) > cap) return -1;
+    memcpy(out, it->second.data(), it->second.size());
+    return int(it->second.size());
+}
+int sp_rollback(void* u, int first_tag)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    for (int side = 0; side < 2; ++side) {
+        for (auto& kv : p->snap[side]) {
+            if (kv.second.max_tag < first_tag) continue;  // everything applied to it stands (e.g. a finalized event + purge)
+            if (kv.second.create_tag >= 0 && kv.second.create_tag < first_tag) {
+                // created earlier in the pass by an entry that stands: the seed again, with the operations issued since
+                PGraph G;
+                G.seed_with(kv.second.create_seq.data(), int(kv.second.create_seq.size()), 1);
+                p->g[side][kv.first] = std::move(G);
+                p->pending[side][kv.first] = std::move(kv.second.q);
+                continue;
+            }
+            if (kv.second.existed)
+                p->g[side][kv.first] = std::move(kv.second.g);
+            else
+                p->g[side].erase(kv.first);
+            if (kv.second.q.empty())
+                p->pending[side].erase(kv.first);
+            else
+                p->pending[side][kv.first] = std::move(kv.second.q);
+        }
+        p->snap[side].clear();
+        // what was only queued: drop the operations of the entries that are walked again
+        for (auto& kv : p->pending[side]) {
+            auto& q = kv.second;
+            q.erase(std::remove_if(q.begin(), q.end(), [&](const PoaPending& x) { return x.tag >= first_tag; }), q.end());
+        }
+    }
+    for (auto it = p->deferred.begin(); it != p->deferred.end();)
+        it = std::get<2>(it->first) >= first_tag ? p->deferred.erase(it) : std::next(it);
+    return 0;
+}
+int sp_commit(void* u)
+{
+    ioc_poa* p = static_cast<ioc_poa*>(u);
+    p->snap[0].clear();
+    p->snap[1].clear();
+    p->deferred.clear();
+    return 0;
+}
+const ioc_consensus_spec_ops g_spec_ops = {sp_create, sp_add, sp_consensus_deferred, sp_flush, sp_collect, sp_rollback, sp_commit};
 
 }  // namespace
 
@@ -1168,6 +1331,7 @@ void ioc_poa_bind(ioc_poa* p, ioc_consensus_ops* ops)
     ops->add = op_add;
     ops->consensus = op_consensus;
     ops->purge = op_purge;
+    ops->spec = getenv("IOC_CONS_SPECULATE") && atoi(getenv("IOC_CONS_SPECULATE")) == 0 ? nullptr : &g_spec_ops;
 }
 
 int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_t* n_edges, char* bases, int32_t* rank,

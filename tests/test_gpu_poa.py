@@ -298,3 +298,57 @@ def test_graph_dp_with_a_tiny_predecessor_staging_area(ctx, monkeypatch):
     poa.create(0, _mutate(rng, truth, 0.1))
     _check_adds(poa, 0, [_mutate(rng, truth, 0.15) for _ in range(5)] + [truth[:120] + truth[150:]])
     poa.close()
+
+
+def _run_consensus(ctx, rs, mode, cons, window=None, speculate=True, monkeypatch=None):
+    """ioc_cluster_consensus on the product's own sort stage with the POA engine; returns everything comparable."""
+    from isonclust2_amd import pipeline
+    sb, _ = pipeline.sort_stage(ctx, rs, 11, 15)
+    events = []
+
+    def rep_changed(user, cls, rec):
+        r = rec.contents
+        events.append((int(cls), int(r.entry), C.string_at(r.raw_seq, r.raw_len), int(r.hpc_len), int(r.n_fwd), int(r.n_rev)))
+
+    monkeypatch.setenv("IOC_CONS_SPECULATE", "1" if speculate else "0")
+    if window:
+        monkeypatch.setenv("IOC_CONS_WINDOW", str(window))
+    else:
+        monkeypatch.delenv("IOC_CONS_WINDOW", raising=False)
+    poa = Poa(ctx)
+    cb = _lib.CONS_REP_CHANGED(rep_changed)
+    poa.ops.rep_changed = cb
+    cargs = _lib.ConsensusArgs(cons_min_size=cons[0], cons_max_size=cons[1], cons_period=cons[2], left_depth=-1, left_sizes=None)
+    cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, mode), None, sb.view, cargs, poa.ops)
+    db = ctx.index_export()
+    graphs = {}
+    for c in range(int(st["n_clusters"])):
+        if poa.size(c) >= 0:
+            g = poa.graph(c)
+            graphs[c] = (g[0], tuple(g[1].tolist()), tuple(g[2].tolist()), tuple(g[3].tolist()), tuple(g[4].tolist()), poa.size(c))
+    poa.close()
+    return cls, strand, st, events, db, graphs
+
+
+@pytest.mark.parametrize("shape,mode,cons,window", [((300, 6, 600), "fast", (3, 12, 500), None), ((300, 6, 600), "fast", (3, 12, 500), 7),
+                                                    ((260, 10, 500), "sahlin", (2, 8, 40), None), ((400, 5, 400), "fast", (4, 1000, 500), 64),
+                                                    ((220, 3, 900), "sahlin", (3, 6, 500), 16)])
+def test_deferred_consensus_equals_immediate(ctx, monkeypatch, shape, mode, cons, window):
+    """The driver with deferred consensus requests (ioc_consensus_spec_ops: events of many clusters of a pass batched,
+    verification afterwards, rollback on a violation) against the same driver taking every consensus at once, as the
+    reference does: assignments, the sequence of representative replacements with their consensus sequences, the final
+    MinDB and every cluster's final graph must be the same."""
+    from isonclust2_amd import synth
+    rs = synth.generate(shape[0], shape[1], shape[2], 11, 21, seed=sum(shape) + len(mode), dup_every=2 if shape[1] > 8 else 0)
+    a = _run_consensus(ctx, rs, mode, cons, window, speculate=False, monkeypatch=monkeypatch)
+    b = _run_consensus(ctx, rs, mode, cons, window, speculate=True, monkeypatch=monkeypatch)
+    assert a[2]["n_cons_invoked"] > 5
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2]["n_cons_invoked"] == b[2]["n_cons_invoked"] and a[2]["n_clusters"] == b[2]["n_clusters"]
+    assert a[3] == b[3]                                    # every representative replacement, in order, with its consensus
+    for x, y in zip(a[4], b[4]):
+        assert np.array_equal(x, y)                        # MinDB
+    assert a[5].keys() == b[5].keys()
+    for c in a[5]:
+        assert a[5][c] == b[5][c], c                       # nodes, order, weighted edges, sequence count of every graph
+    assert b[2]["n_cons_restarts"] <= a[2]["n_cons_restarts"]

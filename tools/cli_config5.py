@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Runs the isONclust2-hip CLI end to end on a slice of BASELINE config 4's shape: NB batches of 31 250 reads x
-2 kb (sort -> cluster each batch -> fold the merges left to right -> dump), sahlin mode; prints wall times."""
+"""Runs the isONclust2-hip CLI end to end on a slice of BASELINE.json configs[4]'s shape ("config 5" in SURVEY.md §8(d):
+2 M reads / 4 Gb in 64 batches of 31 250 reads x 2 kb, sahlin mode, consensus on): NB batches — sort -> cluster each
+batch -> fold the merges left to right -> dump — through the files, one GPU; prints wall times and what the domain
+offers as size-independent checks (every read assigned exactly once, clusters = the generator's transcripts).
+    tools/cli_config5.py NB [reads per batch] [mode] [ConsMinSize,ConsMaxSize,ConsPeriod]"""
 import json
 import os
 import subprocess
@@ -33,6 +36,7 @@ def run(args):
     t = time.time()
     r = subprocess.run([CLI] + args, capture_output=True, text=True, env=env)
     assert r.returncode == 0, (args, r.stderr[-2000:])
+    print(f"[cli_config5] {args[0]} {os.path.basename(args[-1]) if args[0] != 'sort' else ''}: {time.time() - t:.1f} s", file=sys.stderr, flush=True)
     if args[0] == "cluster":
         js = [l for l in r.stderr.splitlines() if l.startswith("{")]
         if js:
@@ -70,6 +74,8 @@ if os.path.exists(tsv):
         ids.add(line.split("\t")[0])
         n += 1
     out["clusters"], out["reads_assigned"] = len(ids), n
+    out["every_read_assigned_once"] = n == rs.n and len(set(line.split("\t")[2] for line in open(tsv).read().splitlines()[1:])) == rs.n
+    out["transcripts_in_generator"] = 1500
 out["total_s"] = out["sort_s"] + sum(cl) + sum(mg) + out["dump_s"]
 out["cluster_stats"] = stats
 if os.environ.get("IOC_CLI4_TRACE"):   # phase trace of the slowest batch, aggregated
