@@ -386,7 +386,8 @@ typedef struct ioc_consensus_spec_ops {
     /* GenerateConsensus of graph (side, idx) as it is after the additions queued so far: computed by flush(), fetched
      * by collect() (returns the length) */
     int (*consensus_deferred)(void* user, int side, int idx, int tag);
-    int (*flush)(void* user);
+    /* safe_tag: operations tagged below it are never rolled back — the store may work them off in the same batches */
+    int (*flush)(void* user, int safe_tag);
     int (*collect)(void* user, int side, int idx, int tag, char* out, int cap);
     /* undo every operation tagged >= first_tag (graphs, queued additions, deferred results); commit: forget how to */
     int (*rollback)(void* user, int first_tag);

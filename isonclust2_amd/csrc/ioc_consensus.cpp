@@ -211,8 +211,13 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     };
     std::vector<PendingEvent> evs;
     std::vector<Undo> journal;
+    std::vector<uint32_t> upd_keys;  // keys UpdateMinDB went through in the pass's verification (db[v] opens a key, even an empty one)
     DirtyIndex dirty_b;
     int64_t n_spec_rollbacks = 0, n_spec_events = 0, n_spec_flushes = 0;
+    // IOC_CONS_FORCE_ROLLBACK=N (tests): every N-th entry looked at again is treated as if it could see a new
+    // representative — a rollback only repeats work, the result must not change
+    const int force_rb = getenv("IOC_CONS_FORCE_ROLLBACK") ? std::max(0, atoi(getenv("IOC_CONS_FORCE_ROLLBACK"))) : 0;
+    int64_t rb_counter = 0;
     while (pos < n) {
         const int m = std::min(n - pos, window);
         double t0 = now();
@@ -509,7 +514,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             if (!evs.empty()) {
                 double t1 = now();
                 n_spec_flushes++;
-                if (spec->flush(ops->user) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: flush failed");
+                if (spec->flush(ops->user, evs[0].i) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: flush failed");
                 const size_t ne = evs.size();
                 std::vector<std::string> cons(ne);
                 std::vector<char> buf(size_t(1) << 22);
@@ -551,10 +556,15 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 t1 = now();
                 // ---- in the reference's order: finalize event e, then look again at the entries walked after it ----
                 dirty_b.reset();
+                upd_keys.clear();
                 size_t e = 0;
                 int violation = -1;
                 for (int x = evs[0].x; x < stop_x && violation < 0; ++x) {
                     const int i = pos0 + x;
+                    if (force_rb && x > evs[0].x && (++rb_counter % force_rb) == 0) {
+                        violation = x;
+                        break;
+                    }
                     if (x > evs[0].x && sub_cls[size_t(x)] >= 0 && dirty_b.nslots) {
                         // (an entry with an event of its own is looked at again like any other, before its event counts)
                         const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
@@ -579,11 +589,13 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                                 sorted_unique(t2);
                                 t2.erase(std::remove(t2.begin(), t2.end(), uint32_t(ev.dc)), t2.end());
                                 lst.swap(t2);
+                                upd_keys.push_back(v);
                             }
                             for (uint32_t v : to_ins) {
                                 auto& lst = db[v];
                                 lst.push_back(uint32_t(ev.dc));
                                 std::sort(lst.begin(), lst.end());
+                                upd_keys.push_back(v);
                             }
                         }
                         dirty_b.add_cluster(b.vals, nv);
@@ -626,6 +638,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 if (violation >= 0) {
                     // ---- undo what the walk did for the entries [violation, stop_x), newest first ----
                     n_spec_rollbacks++;
+                    std::sort(upd_keys.begin(), upd_keys.end());
                     for (size_t u = journal.size(); u-- > 0;) {
                         const Undo& un = journal[u];
                         if (un.x < violation) break;
@@ -639,7 +652,10 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                                 if (it == db.end() || it->second.empty() || it->second.back() != uint32_t(un.dc))
                                     return ioc_fail(c, IOC_ERR_STATE, "consensus rollback: MinDB out of order");
                                 it->second.pop_back();
-                                if (un.key_was_new[y]) db.erase(it);
+                                // the key goes with the cluster that opened it — unless an event that stands went through it
+                                // since (in the reference's order UpdateMinDB's db[v] would have opened it, minimizer.cpp:143-152)
+                                if (un.key_was_new[y] && it->second.empty() && !std::binary_search(upd_keys.begin(), upd_keys.end(), ns.vals[y]))
+                                    db.erase(it);
                             }
                             cl.pop_back();
                         } else {

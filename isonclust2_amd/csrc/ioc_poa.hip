@@ -810,11 +810,13 @@ namespace {
 int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes)
 {
     if (b.cap >= bytes) return IOC_OK;
+    const size_t old_cap = b.cap;
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
-    // (batches grow as the graphs do: at least half as much again, or every round re-allocates gigabytes)
-    size_t want = std::max(bytes + bytes / 8 + 4096, b.cap + b.cap / 2);
+    // (batches grow as the graphs do and — with deferred consensus — as the passes do: below a gigabyte four times as much
+    // again, then half as much again, or every round re-allocates gigabytes: 1.8 s of hipMalloc in a 31 250-read batch)
+    size_t want = std::max(bytes + bytes / 8 + 4096, old_cap < (size_t(1) << 30) ? 4 * old_cap : old_cap + old_cap / 2);
     if (hipMalloc(&b.p, want) != hipSuccess) {
         (void)hipGetLastError();
         want = bytes + 4096;
@@ -1028,20 +1030,25 @@ void poa_snapshot(ioc_poa* p, int side, int idx)
     p->snap[side][idx] = std::move(s);
 }
 
-// only_marked: work off the queues of the graphs that hold a consensus marker (and snapshot those graphs first)
-int poa_flush(ioc_poa* p, bool only_marked = false)
+// only_marked: work off the queues of the graphs that hold a consensus marker (those graphs are snapshotted first) — as many
+// rounds as they need; the head of any other queue rides along in those rounds while it is tagged below safe_tag (such an
+// operation is never rolled back), so that plain additions do not pile up behind a graph's first consensus
+int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
 {
-    auto wanted = [&](const std::vector<PoaPending>& q) {
-        if (q.empty()) return false;
-        if (!only_marked) return true;
+    auto marked = [&](const std::vector<PoaPending>& q) {
         for (auto& it : q)
             if (it.marker) return true;
         return false;
     };
+    auto wanted = [&](const std::vector<PoaPending>& q) {
+        if (q.empty()) return false;
+        if (!only_marked) return true;
+        return marked(q) || (!q.front().marker && q.front().tag < safe_tag);
+    };
     bool any = false;
     for (int side = 0; side < 2; ++side)
         for (auto& kv : p->pending[side])
-            if (wanted(kv.second)) {
+            if (!kv.second.empty() && (!only_marked || marked(kv.second))) {
                 any = true;
                 if (only_marked) poa_snapshot(p, side, kv.first);
             }
@@ -1056,11 +1063,22 @@ int poa_flush(ioc_poa* p, bool only_marked = false)
         std::vector<HostJob> jobs, cand;
         std::vector<std::pair<int, int>> who, who_c;
         size_t used = 0;
+        if (only_marked) {  // rounds go on only while a graph with a consensus request has work left
+            bool more = false;
+            for (int side = 0; side < 2 && !more; ++side)
+                for (auto& kv : p->pending[side])
+                    if (marked(kv.second)) {
+                        more = true;
+                        break;
+                    }
+            if (!more) return IOC_OK;
+        }
         for (int side = 0; side < 2; ++side)
             for (auto& kv : p->pending[side]) {
                 if (!wanted(kv.second)) continue;
                 poa_take_markers(p, side, kv.first, kv.second);
                 if (kv.second.empty()) continue;
+                if (only_marked && !marked(kv.second) && !(kv.second.front().tag < safe_tag)) continue;
                 auto it = p->g[side].find(kv.first);
                 if (it == p->g[side].end()) return ioc_fail(p->ctx, IOC_ERR_STATE, "POA: addition to a graph that does not exist");
                 HostJob j;
@@ -1235,7 +1253,7 @@ int sp_consensus_deferred(void* u, int side, int idx, int tag)
     p->pending[side][idx].push_back(std::move(it));
     return 0;
 }
-int sp_flush(void* u) { return poa_flush(static_cast<ioc_poa*>(u), true) == IOC_OK ? 0 : -1; }
+int sp_flush(void* u, int safe_tag) { return poa_flush(static_cast<ioc_poa*>(u), true, safe_tag) == IOC_OK ? 0 : -1; }
 int sp_collect(void* u, int side, int idx, int tag, char* out, int cap)
 {
     ioc_poa* p = static_cast<ioc_poa*>(u);

@@ -352,3 +352,13 @@ def test_deferred_consensus_equals_immediate(ctx, monkeypatch, shape, mode, cons
     for c in a[5]:
         assert a[5][c] == b[5][c], c                       # nodes, order, weighted edges, sequence count of every graph
     assert b[2]["n_cons_restarts"] <= a[2]["n_cons_restarts"]
+    # rollbacks forced at every 5th / 2nd re-checked entry (graphs created, extended and purged inside rolled-back
+    # stretches): a rollback only repeats work
+    for every in ("5", "2"):
+        monkeypatch.setenv("IOC_CONS_FORCE_ROLLBACK", every)
+        c = _run_consensus(ctx, rs, mode, cons, window, speculate=True, monkeypatch=monkeypatch)
+        monkeypatch.delenv("IOC_CONS_FORCE_ROLLBACK")
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and a[3] == c[3]
+        for x, y in zip(a[4], c[4]):
+            assert np.array_equal(x, y)
+        assert a[5] == c[5]
