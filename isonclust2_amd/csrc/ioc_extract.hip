@@ -279,40 +279,62 @@ k_minimizers(int n, const int64_t* __restrict__ offs, const uint8_t* __restrict_
             const int64_t p = t0 - 1 + i;  // k-mer start
             uint32_t v = 0xFFFFFFFFu;
             if (p >= 0 && p < nk) {
-                v = 0;
-                for (int t = 0; t < kk; ++t) v = (v << 2) | code_at(packed, L, rev, uint32_t(p + skip + t));
+                // The kk bases of the k-mer are 2 kk consecutive bits of the 2-bit image (at most two of its words): one
+                // 64-bit funnel instead of a loop of kk LDS reads.  Forward strand: base t of the k-mer sits at bits
+                // 2 t of the field and has to become digit kk-1-t — reverse the ORDER of the 2-bit groups (bit reversal,
+                // then the two bits of every group swapped back).  Reverse strand: the k-mer at p reads the image
+                // downwards from L-1-p and complements, so the field that ENDS at L-1-(p+skip) already has its first base
+                // on top: complement it, no reversal.
+                const uint32_t s0 = rev ? uint32_t(L - uint32_t(p + skip) - uint32_t(kk)) : uint32_t(p + skip);
+                const uint32_t wd = s0 >> 4, sh = (s0 & 15u) * 2u;
+                const unsigned long long two = (unsigned long long)packed[wd] | ((unsigned long long)(sh + 2u * uint32_t(kk) > 32u ? packed[wd + 1] : 0u) << 32);
+                const uint32_t mask = kk == 16 ? 0xFFFFFFFFu : ((1u << (2 * kk)) - 1u);
+                const uint32_t x = uint32_t(two >> sh) & mask;
+                if (rev) {
+                    v = ~x & mask;
+                } else {
+                    const uint32_t b = __brev(x);
+                    v = (((b >> 1) & 0x55555555u) | ((b & 0x55555555u) << 1)) >> (32 - 2 * kk);
+                }
             }
             kv[i] = v;
         }
         __syncthreads();
         const int64_t j = t0 + threadIdx.x;  // window index
         uint32_t flag = 0, amin = 0, vmin = 0;
-        if (j < nw) {
-            // leftmost argmin of window j (kv index threadIdx.x + 1 ..) and of window j-1
-            uint32_t best = kv[threadIdx.x + 1];
+        // leftmost argmin of the window that starts at kv index q
+        auto argmin_at = [&](int q, uint32_t& best) {
+            best = kv[q];
             int bi = 0;
             for (int t = 1; t < W; ++t) {
-                const uint32_t v = kv[threadIdx.x + 1 + t];
+                const uint32_t v = kv[q + t];
                 if (v < best) {
                     best = v;
                     bi = t;
                 }
             }
-            amin = uint32_t(j + bi);
-            vmin = best;
-            if (j == 0) {
-                flag = 1;
-            } else {
-                uint32_t pb = kv[threadIdx.x];
-                int pi = 0;
-                for (int t = 1; t < W; ++t) {
-                    const uint32_t v = kv[threadIdx.x + t];
-                    if (v < pb) {
-                        pb = v;
-                        pi = t;
+            return bi;
+        };
+        int my_arg = -1;
+        if (j < nw) {
+            my_arg = argmin_at(int(threadIdx.x) + 1, vmin);
+            amin = uint32_t(j + my_arg);
+        }
+        // the argmin of window j - 1 is the left neighbour's (lane shift inside a wave; the first lane of a wave, whose
+        // neighbour sits in another wave or another tile, scans that window itself)
+        {
+            const int prev = __shfl_up(my_arg, 1);
+            if (j < nw) {
+                if (j == 0) {
+                    flag = 1;
+                } else {
+                    int pi = prev;
+                    if ((threadIdx.x & 63u) == 0) {
+                        uint32_t pb;
+                        pi = argmin_at(int(threadIdx.x), pb);
                     }
+                    flag = (uint32_t(j - 1 + pi) != amin);
                 }
-                flag = (uint32_t(j - 1 + pi) != amin);
             }
         }
         uint32_t tot;
