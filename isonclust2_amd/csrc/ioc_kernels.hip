@@ -926,7 +926,10 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
              uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, Epochs E,
              unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len)
 {
-    extern __shared__ uint32_t hist[];  // 2 * (L + j)
+    // ONE strand's histogram at a time (L + j counters): half the LDS of a both-strands histogram, twice the workgroups per
+    // CU (the kernel is bound by latency as much as by VALU issue and LDS conflicts: 17.6 waves per CU with 24 KB per
+    // workgroup); a strand's counts go out as soon as it is done
+    extern __shared__ uint32_t hist[];  // L + j
     __shared__ uint32_t s_wb[IOC_WAVES][64];
     __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];
     const int j = n - 1 - int(blockIdx.x / IOC_PARTS);
@@ -942,13 +945,14 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
     unsigned long long* const bm_ = s_bm[wave];
     unsigned long long trav = 0;
     uint32_t abl = 0;
-    for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) hist[i] = 0;
-    __syncthreads();
+    const bool narrow = *max_len < 65536u;  // two u16 counts per word (cbase and 2T are even)
     for (int s = 0; s < 2; ++s) {
+        for (uint32_t i = threadIdx.x; i < T; i += IOC_BLOCK) hist[i] = 0;
+        __syncthreads();
         const int64_t b0 = s == 0 ? off_fwd[j] : off_rev[j];
         const uint32_t* bnd = pbnd + (size_t(j) * 2 + s) * (IOC_PARTS + 1);
         const int64_t b = b0 + bnd[x], e = b0 + bnd[x + 1];  // this partition's bucket
-        uint32_t* h = hist + uint32_t(s) * T;
+        uint32_t* h = hist;
         for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
             const int64_t t = c0 + lane;
             uint32_t o = 0, len = 0;
@@ -965,14 +969,16 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
             else
                 flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
         }
-    }
-    __syncthreads();
-    if (*max_len < 65536u) {  // two u16 counts per word (cbase and 2T are even)
-        uint32_t* out = part + (IOC_PARTS * cbase) / 2 + size_t(x) * T;
-        for (uint32_t i = threadIdx.x; i < T; i += IOC_BLOCK) out[i] = hist[2 * i] | (hist[2 * i + 1] << 16);
-    } else {
-        uint32_t* out = part + IOC_PARTS * cbase + size_t(x) * 2 * T;
-        for (uint32_t i = threadIdx.x; i < 2 * T; i += IOC_BLOCK) out[i] = hist[i];
+        __syncthreads();
+        // the partial histogram of (query, partition) is [strand][target]: this strand's slice
+        if (narrow) {
+            uint16_t* out = reinterpret_cast<uint16_t*>(part + (IOC_PARTS * cbase) / 2 + size_t(x) * T) + size_t(s) * T;
+            for (uint32_t i = threadIdx.x; i < T; i += IOC_BLOCK) out[i] = uint16_t(hist[i]);
+        } else {
+            uint32_t* out = part + IOC_PARTS * cbase + size_t(x) * 2 * T + size_t(s) * T;
+            for (uint32_t i = threadIdx.x; i < T; i += IOC_BLOCK) out[i] = hist[i];
+        }
+        __syncthreads();
     }
     if (traversed && lane == 0) atomicAdd(traversed, trav);
 }
@@ -2140,11 +2146,11 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
         hipLaunchKernelGGL(k_partition_mins, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd,
                            max_len);
         if (post16)
-            hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
+            hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L,
                                off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, E,
                                traversed, max_len);
         else
-            hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds, st, n, L,
+            hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L,
                                off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, E,
                                traversed, max_len);
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
