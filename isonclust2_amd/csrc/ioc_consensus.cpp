@@ -28,6 +28,14 @@
 
 namespace {
 
+// a graph operation of the caller failed: keep what it left in the context's error text (the shipped POA engine reports
+// there), the caller of the ABI sees both
+int hook_fail(ioc_ctx* c, const char* what)
+{
+    const std::string inner = c->err;
+    return ioc_fail(c, IOC_ERR_INPUT, std::string("consensus hook: ") + what + " failed" + (inner.empty() ? "" : ": " + inner));
+}
+
 struct ClState {
     uint64_t seq_id = 0;             // identity of the representative's sequence (alignment results are kept by identity)
     double raw_err = 0, hpc_err = 0;
@@ -108,6 +116,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         return ioc_fail(c, IOC_ERR_ARG, "consensus needs all five graph operations");
     const int n = rb->n;
     if (n < 0) return ioc_fail(c, IOC_ERR_ARG, "negative batch size");
+    c->err.clear();
     if (!rb->raw_seq || !rb->raw_off)
         return ioc_fail(c, IOC_ERR_ARG, "consensus needs the raw sequences of the right batch (graph seeds and additions)");
     const bool aln_mode = p->mode == IOC_MODE_SAHLIN || p->mode == IOC_MODE_FURIOUS;
@@ -373,7 +382,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 for (uint32_t v : ns.vals) db[v].push_back(uint32_t(dc));
                 // (before the first event of a pass nothing is ever undone: no snapshot needed)
                 if ((spec && !evs.empty() ? spec->create_tagged(ops->user, 0, dc, rseq, rlen, i) : ops->create(ops->user, 0, dc, rseq, rlen)) < 0)
-                    return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: create failed");
+                    return hook_fail(c, "create");
                 cl.push_back(std::move(ns));
                 out_cls[i] = dc;
                 out_strand[i] = 1;
@@ -403,12 +412,12 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             t0 = now();
             if ((spec ? spec->add_tagged(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u, i)
                       : ops->add(ops->user, 0, dc, rseq, rlen, have_right ? unsigned(right_size) : 1u)) < 0)
-                return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: add failed");
+                return hook_fail(c, "add");
             ph[2] += now() - t0;
             if (ops->size(ops->user, 0, dc) < cons_min) continue;
             if (spec) {
                 // ---- the consensus is requested, not awaited ----
-                if (spec->consensus_deferred(ops->user, 0, dc, i) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: deferred consensus failed");
+                if (spec->consensus_deferred(ops->user, 0, dc, i) < 0) return hook_fail(c, "deferred consensus");
                 if (evs.empty()) journal.clear();
                 evs.push_back(PendingEvent{x, i, dc, hpc_err, raw_err});
                 dirty.add_cluster(b.vals, std::vector<uint32_t>());  // what later entries must not see: the OLD set for now
@@ -422,7 +431,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             t0 = now();
             std::vector<char> buf(size_t(1) << 22);
             const int clen = ops->consensus(ops->user, 0, dc, buf.data(), int(buf.size()));
-            if (clen < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: consensus failed");
+            if (clen < 0) return hook_fail(c, "consensus");
             ph[2] += now() - t0;
             t0 = now();
             std::string cons(buf.data(), size_t(clen));
@@ -496,7 +505,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             const int gsz = ops->size(ops->user, 0, dc);
             if (gsz > ca->cons_max_size) {  // ConsPurge, consensus.cpp:128-137
                 if (ops->purge(ops->user, 0, dc, cons.data(), int(cons.size()), unsigned(gsz)) < 0)
-                    return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: purge failed");
+                    return hook_fail(c, "purge");
             }
             ph[3] += now() - t0;
             // every later entry that can see this cluster has to see the new representative: the walk goes on
@@ -514,13 +523,13 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             if (!evs.empty()) {
                 double t1 = now();
                 n_spec_flushes++;
-                if (spec->flush(ops->user, evs[0].i) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: flush failed");
+                if (spec->flush(ops->user, evs[0].i) < 0) return hook_fail(c, "flush");
                 const size_t ne = evs.size();
                 std::vector<std::string> cons(ne);
                 std::vector<char> buf(size_t(1) << 22);
                 for (size_t e = 0; e < ne; ++e) {
                     const int clen = spec->collect(ops->user, 0, evs[e].dc, evs[e].i, buf.data(), int(buf.size()));
-                    if (clen < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: consensus failed");
+                    if (clen < 0) return hook_fail(c, "consensus");
                     cons[e].assign(buf.data(), size_t(clen));
                     if (!(cons[e].size() > size_t(2 * k) || cons[e].size() >= size_t(w)))
                         return ioc_fail(c, IOC_ERR_INPUT, "consensus shorter than 2k and w (the reference re-minimizes an empty sequence here)");
@@ -628,7 +637,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                         const int gsz = ops->size(ops->user, 0, ev.dc);
                         if (gsz > ca->cons_max_size) {  // ConsPurge, consensus.cpp:128-137
                             if (ops->purge(ops->user, 0, ev.dc, cons[e].data(), int(cons[e].size()), unsigned(gsz)) < 0)
-                                return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: purge failed");
+                                return hook_fail(c, "purge");
                         }
                         ++e;
                         if (dirty_b.full() && x + 1 < stop_x) violation = x + 1;  // too many changed clusters to keep checking: the pass ends here
@@ -663,14 +672,14 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                             total.n_joined--;
                         }
                     }
-                    if (spec->rollback(ops->user, pos0 + violation) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: rollback failed");
+                    if (spec->rollback(ops->user, pos0 + violation) < 0) return hook_fail(c, "rollback");
                     end_x = violation;
                 } else {
-                    if (spec->commit(ops->user) < 0) return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: commit failed");
+                    if (spec->commit(ops->user) < 0) return hook_fail(c, "commit");
                 }
                 ph[3] += now() - t1;
             } else if (spec->commit(ops->user) < 0) {
-                return ioc_fail(c, IOC_ERR_INPUT, "consensus hook: commit failed");
+                return hook_fail(c, "commit");
             }
             pos = pos0 + end_x;
             restarted = end_x < m;

@@ -803,20 +803,27 @@ struct ioc_poa {
     int64_t n_batches = 0, n_aligned = 0;
     double ms_layout = 0, ms_alloc = 0, ms_gpu = 0, ms_graph = 0;  // IOC_TRACE: host layout of the batches, launches + copies, AddAlignment
     std::string err;
+    size_t reserve_hint = 0;  // the memory budget of a batch (poa_flush): what a large buffer is sized for at once
 };
 
 namespace {
 
-int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes)
+int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes, size_t hint = 0)
 {
     if (b.cap >= bytes) return IOC_OK;
     const size_t old_cap = b.cap;
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
-    // (batches grow as the graphs do and — with deferred consensus — as the passes do: below a gigabyte four times as much
-    // again, then twice as much, or every round re-allocates gigabytes: hipMalloc costs ~0.1 ms per MB, 2.2 s in a 31 250-read batch)
-    size_t want = std::max(bytes + bytes / 8 + 4096, old_cap < (size_t(1) << 30) ? 4 * old_cap : 2 * old_cap);
+    // hipMalloc costs ~0.1 ms per MB (3.4 s of a 31 250-read batch's 17 s went there while buffers grew by factors towards a
+    // 48 GB budget).  Batches grow as the graphs do and — with deferred consensus — as the passes do, up to the budget of
+    // poa_flush: small buffers double; past a gigabyte the next size is `hint`, the buffer's share of that budget (one more
+    // allocation, the last), or half as much again.
+    size_t want = bytes + bytes / 8 + 4096;
+    if (want < (size_t(1) << 30))
+        want = std::max(want, std::min(2 * old_cap, size_t(1) << 30));
+    else
+        want = std::max(want, hint ? hint : old_cap + old_cap / 2);
     if (hipMalloc(&b.p, want) != hipSuccess) {
         (void)hipGetLastError();
         want = bytes + 4096;
@@ -825,7 +832,7 @@ int poa_reserve(ioc_poa* p, DevBuf& b, size_t bytes)
     if (!b.p && hipMalloc(&b.p, want) != hipSuccess) {
         b.p = nullptr;
         (void)hipGetLastError();
-        return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: hipMalloc of the DP matrices failed");
+        return ioc_fail(p->ctx, IOC_ERR_CAPACITY, "POA: hipMalloc of the DP matrices failed (" + std::to_string(want >> 20) + " MB)");
     }
     b.cap = want;
     return IOC_OK;
@@ -927,8 +934,8 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     int r;
     const double t_res = now();
     if ((r = poa_reserve(p, p->d_int, tot_plane * 12)) != IOC_OK) return r;   // H, F1, F2 planes of the kept rows
-    if ((r = poa_reserve(p, p->d_dirs, tot_cells * 4)) != IOC_OK) return r;
-    if ((r = poa_reserve(p, p->d_eb, tot_cells)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_dirs, tot_cells * 4, p->reserve_hint / 5 * 4)) != IOC_OK) return r;
+    if ((r = poa_reserve(p, p->d_eb, tot_cells, p->reserve_hint / 5)) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_carry, tot_carry * sizeof(int4))) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_tbest, tot_tbest * sizeof(int4))) != IOC_OK) return r;
     if ((r = poa_reserve(p, p->d_small, small.size())) != IOC_OK) return r;
@@ -1057,9 +1064,11 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
     for (;;) {
         const size_t have = p->d_int.cap + p->d_dirs.cap + p->d_eb.cap;
-        // (device allocations of 100 GB take seconds: more, smaller batches cost less than that)
-        size_t budget = std::min((free_b + have) / 2, size_t(48) << 30);
+        // (device allocations cost ~0.1 ms per MB: more, smaller batches cost less than a budget of tens of GB —
+        // 10 GB hold ~400 additions of a 2 kb read to a 2.5 k-node graph, more than the chip runs at a time)
+        size_t budget = std::min((free_b + have) / 2, size_t(10) << 30);
         if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
+        p->reserve_hint = budget + budget / 16;  // (the cells' direction words are 4/5 of it, their E bytes 1/5)
         std::vector<HostJob> jobs, cand;
         std::vector<std::pair<int, int>> who, who_c;
         size_t used = 0;

@@ -54,16 +54,19 @@ CONFIGS = {
 
 
 def generate(n_reads, n_transcripts, length, q_lo=10.0, q_hi=21.0, seed=1, dup_every=0,
-             len_jitter=0.0):
-    """dup_every=2 duplicates every second transcript (paralog-like, forces candidate ties)."""
+             len_jitter=0.0, tr_seed=None):
+    """dup_every=2 duplicates every second transcript (paralog-like, forces candidate ties).
+    tr_seed: draw the transcripts from a generator of their own, so that chunks of one read set made with different
+    `seed`s (in parallel processes) sample the same transcriptome."""
     rng = np.random.default_rng(seed)
+    trng = rng if tr_seed is None else np.random.default_rng(tr_seed)
     tr = []
     for t in range(n_transcripts):
-        L = length if len_jitter == 0 else max(64, int(length * (1 + len_jitter * (rng.random() * 2 - 1))))
+        L = length if len_jitter == 0 else max(64, int(length * (1 + len_jitter * (trng.random() * 2 - 1))))
         if dup_every and t % dup_every == 1:
             tr.append(tr[-1].copy())
         else:
-            tr.append(_ACGT[rng.integers(0, 4, L)])
+            tr.append(_ACGT[trng.integers(0, 4, L)])
     seqs, quals = [], []
     which = rng.integers(0, n_transcripts, n_reads).astype(np.int32)
     strand = np.where(rng.random(n_reads) < 0.5, -1, 1).astype(np.int8)
@@ -98,6 +101,8 @@ def generate(n_reads, n_transcripts, length, q_lo=10.0, q_hi=21.0, seed=1, dup_e
     offs = np.zeros(n_reads + 1, np.int64)
     offs[1:] = np.cumsum([len(s) for s in seqs])
     tag = f"synth(n={n_reads},G={n_transcripts},L={length},Q=[{q_lo:g},{q_hi:g}],seed={seed},dup={dup_every})"
+    if tr_seed is not None:
+        tag = tag[:-1] + f",tr_seed={tr_seed})"
     return ReadSet(np.concatenate(seqs), np.concatenate(quals), offs, which, strand, tag)
 
 
