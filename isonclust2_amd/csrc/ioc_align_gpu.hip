@@ -718,7 +718,10 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 if (bi >= 0 && uint32_t(bi) < nblocks && has_cols) {
                     const uint32_t i0 = r_lo + uint32_t(bi) * FW_R;
                     // rows past the end (last block of the last band) run on a query byte of 0 and are never looked at
-                    const bool special = lastc >= 0 || (last_band && uint32_t(bi) + 1u == nblocks);
+                    // wave-uniform: the special path is right for every lane (its extras are guarded per lane), and a wave whose
+                    // lanes disagree would run BOTH copies of the cells — in the last strip, where one lane owns the last
+                    // column, for every step of the strip
+                    const bool special = __builtin_amdgcn_ballot_w64(lastc >= 0 || (last_band && uint32_t(bi) + 1u == nblocks)) != 0ull;
                     if (!special) {
 #pragma unroll
                         for (int rr = 0; rr < FW_R; ++rr) {

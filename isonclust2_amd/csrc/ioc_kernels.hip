@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "ioc_kernels.h"
 
@@ -24,7 +25,16 @@
 #define IOC_WAVES (IOC_BLOCK / 64)
 #define IOC_EMPTY 0xFFFFFFFFu
 #define IOC_FLAT_UNROLL 8
+#ifndef IOC_FLAT_TAIL
+#define IOC_FLAT_TAIL 2  // steps per group in the tail of a chunk (flat_traverse_u16)
+#endif
 #define IOC_SHORT_LIST 192
+#ifndef IOC_SCORE_OOB
+#define IOC_SCORE_OOB 1  // k_score_part: the window test of a posting is the LDS allocation's own bounds check (see count_word_u16)
+#endif
+#ifndef IOC_SCORE_TRAV_CAPACITY
+#define IOC_SCORE_TRAV_CAPACITY 0  // 1 (instrumentation builds): IOC_COUNT_TRAVERSED counts the posting SLOTS of the wave steps, filled or not
+#endif
 #ifndef IOC_SCORE_ABL
 #define IOC_SCORE_ABL 0
 #endif
@@ -636,6 +646,13 @@ __device__ __forceinline__ void flat_traverse(const PT* __restrict__ post, uint3
 // Here the window test runs on the raw 16-bit half of the loaded word (v_cmp_lt_u32_sdwa), the counter's LDS address
 // is half * 4 + base in one v_mad_u32_u16 (op_sel picks the half), and the atomic is issued under the compare's mask:
 // 2 VALU + 1 ds_add_u32 per posting; padding (0xFFFF) and the entries of the epoch slack fail the test as before.
+//
+// IOC_SCORE_OOB (default): no window test at all.  k_score_part puts the histogram of its T visible targets at the very END
+// of the workgroup's LDS allocation (counter of target t at end - 4 (T - t)), so the counter address of every entry the test
+// would reject — targets >= T of the epoch slack, the 0xFFFF padding — lies beyond the allocation, and gfx950 discards an
+// LDS atomic there (tools/micro/lds_oob.hip, profiles/r02_lds_oob.txt: the hardware's bound is the allocation rounded up
+// to its 1280-byte granule; 1.4·10^11 atomics above it changed no word of any workgroup's memory).  1 VALU + 1 ds_add_u32
+// per posting, no VCC / EXEC traffic; lanes past the end of the concatenation get a base far outside instead of T = 0.
 __device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t hbase, uint32_t one)
 {
     uint32_t a;
@@ -650,6 +667,19 @@ __device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t 
     w = 0;
     T = T ? 1u : 0u;
 #endif
+#if IOC_SCORE_OOB && IOC_SCORE_ABL == 0
+    uint32_t a2;
+    (void)sv;
+    (void)T;
+    asm volatile(
+        "v_mad_u32_u16 %0, %2, 4, %3 op_sel:[0,0,0,0]\n\t"
+        "v_mad_u32_u16 %1, %2, 4, %3 op_sel:[1,0,0,0]\n\t"
+        "ds_add_u32 %0, %4\n\t"
+        "ds_add_u32 %1, %4"
+        : "=&v"(a), "=&v"(a2)
+        : "v"(w), "v"(hbase), "v"(one)
+        : "memory");
+#else
     asm volatile(
         "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
         "s_and_saveexec_b64 %1, vcc\n\t"
@@ -664,6 +694,7 @@ __device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t 
         : "=&v"(a), "=&s"(sv)
         : "v"(w), "v"(T), "v"(hbase), "v"(one)
         : "vcc", "memory");
+#endif
 }
 
 __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ post, uint32_t o, uint32_t len,
@@ -685,7 +716,7 @@ __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ p
         return;
     }
     const uint4* __restrict__ post4 = reinterpret_cast<const uint4*>(post);
-    trav += 8ull * total;
+    trav += IOC_SCORE_TRAV_CAPACITY ? 512ull * (nwords / IOC_FLAT_UNROLL * IOC_FLAT_UNROLL + (nwords % IOC_FLAT_UNROLL + IOC_FLAT_TAIL - 1) / IOC_FLAT_TAIL * IOC_FLAT_TAIL) : 8ull * total;
     for (uint32_t w = lane; w < nwords + IOC_FLAT_UNROLL; w += 64) bm[w] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -698,35 +729,44 @@ __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ p
     const uint32_t hbase = uint32_t(reinterpret_cast<uintptr_t>(h));  // LDS byte address of the strand's histogram
     const uint32_t one = 1u;
     uint32_t c0 = 0;
-    for (uint32_t w0 = 0; w0 < nwords; w0 += IOC_FLAT_UNROLL) {
-        unsigned long long B[IOC_FLAT_UNROLL];
-        uint32_t r[IOC_FLAT_UNROLL], base[IOC_FLAT_UNROLL];
-        uint4 tg[IOC_FLAT_UNROLL];
+    // U steps of 64 units at a time: lookups, loads and counting of the U steps are interleaved by the compiler
+    auto group = [&](auto ucount, uint32_t w0) {
+        constexpr int U = decltype(ucount)::value;
+        unsigned long long B[U];
+        uint32_t r[U], base[U];
+        uint4 tg[U];
 #pragma unroll
-        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) B[u] = bm[w0 + u];
+        for (int u = 0; u < U; ++u) B[u] = bm[w0 + u];
 #pragma unroll
-        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const uint32_t rr = c0 + uint32_t(__popcll(B[u] & le_mask)) - 1u;
             r[u] = rr < 64u ? rr : 63u;
             c0 += uint32_t(__popcll(B[u]));
         }
 #pragma unroll
-        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) base[u] = wb[r[u]];
+        for (int u = 0; u < U; ++u) base[u] = wb[r[u]];
 #pragma unroll
-        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             const uint32_t p = (w0 + u) * 64u + uint32_t(lane);
             tg[u] = post4[p < total ? base[u] + p : 0u];
         }
 #pragma unroll
-        for (int u = 0; u < IOC_FLAT_UNROLL; ++u) {
+        for (int u = 0; u < U; ++u) {
             // (a lane past the end of the concatenation loaded unit 0: a window of 0 targets rejects all of it)
-            const uint32_t Tl = (w0 + u) * 64u + uint32_t(lane) < total ? T : 0u;
-            count_word_u16(tg[u].x, Tl, hbase, one);
-            count_word_u16(tg[u].y, Tl, hbase, one);
-            count_word_u16(tg[u].z, Tl, hbase, one);
-            count_word_u16(tg[u].w, Tl, hbase, one);
+            const bool inl = (w0 + u) * 64u + uint32_t(lane) < total;
+            const uint32_t Tl = inl ? T : 0u;
+            const uint32_t hb = (IOC_SCORE_OOB && IOC_SCORE_ABL == 0) ? (inl ? hbase : 0x00100000u) : hbase;  // (1 MB: outside any LDS)
+            count_word_u16(tg[u].x, Tl, hb, one);
+            count_word_u16(tg[u].y, Tl, hb, one);
+            count_word_u16(tg[u].z, Tl, hb, one);
+            count_word_u16(tg[u].w, Tl, hb, one);
         }
-    }
+    };
+    // whole groups of IOC_FLAT_UNROLL steps, then the rest two steps at a time: with one loop of 8 the steps past the end of
+    // a chunk (9.8 steps on average on config 2) were 31 % of all the posting slots the kernel issued
+    uint32_t w0 = 0;
+    for (; w0 + IOC_FLAT_UNROLL <= nwords; w0 += IOC_FLAT_UNROLL) group(std::integral_constant<int, IOC_FLAT_UNROLL>{}, w0);
+    for (; w0 < nwords; w0 += IOC_FLAT_TAIL) group(std::integral_constant<int, IOC_FLAT_TAIL>{}, w0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the atomics above are invisible to the compiler's counters)
     __builtin_amdgcn_wave_barrier();
 }
@@ -924,12 +964,12 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
              uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, Epochs E,
-             unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len)
+             unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len, uint32_t dyn_bytes)
 {
     // ONE strand's histogram at a time (L + j counters): half the LDS of a both-strands histogram, twice the workgroups per
     // CU (the kernel is bound by latency as much as by VALU issue and LDS conflicts: 17.6 waves per CU with 24 KB per
     // workgroup); a strand's counts go out as soon as it is done
-    extern __shared__ uint32_t hist[];  // L + j
+    extern __shared__ uint32_t hist_dyn[];  // >= L + j counters
     __shared__ uint32_t s_wb[IOC_WAVES][64];
     __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];
     const int j = n - 1 - int(blockIdx.x / IOC_PARTS);
@@ -937,6 +977,11 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);
     if (T == 0) return;
+    // the T counters end where the workgroup's LDS allocation ends for the hardware (dynamic memory is the last thing in
+    // it; the allocation is a whole number of 1280-byte granules on gfx950): see count_word_u16
+    const uint32_t dyn_base = uint32_t(reinterpret_cast<uintptr_t>(hist_dyn));
+    const uint32_t lds_end = (dyn_base + dyn_bytes + 1279u) / 1280u * 1280u;
+    uint32_t* const hist = IOC_SCORE_OOB ? hist_dyn + ((lds_end - dyn_base) / 4u - T) : hist_dyn;
     uint32_t eword, eshift;
     epoch_field(E, T, eword, eshift);
     const int lane = lane_id(), wave = wave_id();
@@ -2148,11 +2193,11 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
         if (post16)
             hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L,
                                off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, E,
-                               traversed, max_len);
+                               traversed, max_len, uint32_t(lds / 2));
         else
             hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L,
                                off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, E,
-                               traversed, max_len);
+                               traversed, max_len, uint32_t(lds / 2));
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
                            cand_count, audit_valid, audit_sum, top_all, max_len);
         return hipGetLastError();
