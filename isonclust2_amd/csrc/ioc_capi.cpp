@@ -103,7 +103,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -1101,12 +1101,21 @@ static int index_export_compute(ioc_ctx* c)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint32_t nslots = c->cap + 1;
+    const bool tr = getenv("IOC_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* what) {
+        if (tr) {
+            const double t1 = now();
+            fprintf(stderr, "[ioc]   export: %-40s %8.3f ms\n", what, t1 - t0);
+            t0 = t1;
+        }
+    };
     std::vector<uint8_t> valid(size_t(c->n) + 1);
     const void* v = c->cur_valid == 0 ? c->b_valid0.p : c->b_valid1.p;
     if (c->n) HIPCHK(c, hipMemcpyAsync(valid.data(), v, size_t(c->n), hipMemcpyDeviceToHost, s));
-    std::vector<uint32_t> hk(nslots);
-    HIPCHK(c, hipMemcpyAsync(hk.data(), c->b_keys.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    lap("valid to the host");
     // final cluster id of query i that opened a cluster = L + rank among such queries (cluster.cpp:178)
     std::vector<int32_t> cid(size_t(c->n) + 1, -1);
     int32_t next = c->L;
@@ -1118,11 +1127,50 @@ static int index_export_compute(ioc_ctx* c)
     HIPCHK(c, hipMemcpyAsync(c->b_exp_cid.p, cid.data(), (size_t(c->n) + 1) * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, iock_export_count(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, c->post16, uint32_t(c->L),
                                 P<int32_t>(c->b_exp_cid), P<uint32_t>(c->b_exp_cnt)));
-    std::vector<uint32_t> hcnt(nslots);
-    HIPCHK(c, hipMemcpyAsync(hcnt.data(), c->b_exp_cnt.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
     // keys whose every contributor joined another cluster were never inserted by AddMinimizers: no entry (the reference
     // keeps keys with emptied lists only through UpdateMinDB, i.e. in consensus mode)
+    if (env_u32("IOC_EXPORT_HOST_ORDER", 0) == 0) {
+        // the kept keys in ascending order, the offsets of their lists and every slot's place: on the device (ioc_sort.hip)
+        auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+        const size_t tmpb = iock_export_order_temp(nslots);
+        const size_t o_k0 = 0, o_k1 = o_k0 + up(size_t(nslots) * 8), o_v0 = o_k1 + up(size_t(nslots) * 8), o_v1 = o_v0 + up(size_t(nslots) * 4),
+                     o_sc = o_v1 + up(size_t(nslots) * 4), o_so = o_sc + up((size_t(nslots) + 1) * 8), o_ok = o_so + up((size_t(nslots) + 1) * 8),
+                     o_nr = o_ok + up(size_t(nslots) * 4), o_tmp = o_nr + 256;
+        RESERVE(c, c->b_exp_work, o_tmp + tmpb);
+        uint8_t* wk = P<uint8_t>(c->b_exp_work);
+        unsigned long long* d_soff = reinterpret_cast<unsigned long long*>(wk + o_so);
+        uint32_t* d_nrows = reinterpret_cast<uint32_t*>(wk + o_nr);
+        HIPCHK(c, iock_export_order(s, nslots, c->cap, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_exp_cnt),
+                                    reinterpret_cast<unsigned long long*>(wk + o_k0), reinterpret_cast<unsigned long long*>(wk + o_k1),
+                                    reinterpret_cast<uint32_t*>(wk + o_v0), reinterpret_cast<uint32_t*>(wk + o_v1),
+                                    reinterpret_cast<unsigned long long*>(wk + o_sc), d_soff, wk + o_tmp, tmpb, d_nrows,
+                                    reinterpret_cast<uint32_t*>(wk + o_ok), P<int64_t>(c->b_exp_off)));
+        uint32_t nrows = 0;
+        unsigned long long total = 0;
+        HIPCHK(c, hipMemcpyAsync(&nrows, d_nrows, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(&total, d_soff + nslots, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->exp_keys.resize(nrows);
+        c->exp_offs.resize(size_t(nrows) + 1);
+        c->exp_post.resize(size_t(total));
+        if (nrows) HIPCHK(c, hipMemcpyAsync(c->exp_keys.data(), wk + o_ok, size_t(nrows) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->exp_offs.data(), d_soff, (size_t(nrows) + 1) * 8, hipMemcpyDeviceToHost, s));  // (soff[nrows] = total)
+        lap("keys ordered on the device");
+        if (total > 0) {
+            RESERVE(c, c->b_exp_out, size_t(total) * 4);
+            HIPCHK(c, iock_export_fill(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, c->post16, uint32_t(c->L),
+                                       P<int32_t>(c->b_exp_cid), P<uint32_t>(c->b_exp_cnt), P<int64_t>(c->b_exp_off), P<uint32_t>(c->b_exp_out)));
+            HIPCHK(c, hipMemcpyAsync(c->exp_post.data(), c->b_exp_out.p, size_t(total) * 4, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        lap("fill kernel, keys / offsets / postings to the host");
+        c->exp_valid = true;
+        return IOC_OK;
+    }
+    std::vector<uint32_t> hk(nslots), hcnt(nslots);  // (IOC_EXPORT_HOST_ORDER=1: the keys ordered by the host, for comparison)
+    HIPCHK(c, hipMemcpyAsync(hk.data(), c->b_keys.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(hcnt.data(), c->b_exp_cnt.p, size_t(nslots) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
     std::vector<uint64_t> rows;  // key << 32 | slot
     rows.reserve(nslots / 2);
     for (uint32_t sl = 0; sl < nslots; ++sl)
@@ -1141,6 +1189,7 @@ static int index_export_compute(ioc_ctx* c)
     }
     c->exp_offs[rows.size()] = tot;
     c->exp_post.resize(size_t(tot));
+    lap("keys ordered, offsets");
     if (tot > 0) {
         RESERVE(c, c->b_exp_out, size_t(tot) * 4);
         HIPCHK(c, hipMemcpyAsync(c->b_exp_off.p, hoff.data(), size_t(nslots) * 8, hipMemcpyHostToDevice, s));
@@ -1149,6 +1198,7 @@ static int index_export_compute(ioc_ctx* c)
         HIPCHK(c, hipMemcpyAsync(c->exp_post.data(), c->b_exp_out.p, size_t(tot) * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }
+    lap("fill kernel, postings to the host");
     c->exp_valid = true;
     return IOC_OK;
 }

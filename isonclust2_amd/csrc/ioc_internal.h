@@ -62,7 +62,7 @@ struct ioc_ctx {
     // ---- scoring ----
     bool scored = false;
     DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo, b_part, b_diag, b_top_all, b_pmins, b_pbnd;
-    DevBuf b_exp_cid, b_exp_cnt, b_exp_off, b_exp_out;  // ioc_index_export: final ids, per-slot counts / offsets, compact postings
+    DevBuf b_exp_cid, b_exp_cnt, b_exp_off, b_exp_out, b_exp_work;  // ioc_index_export: final ids, per-slot counts / offsets, compact postings
     bool have_guess = false;
     int64_t cand_capacity = 0;
 

@@ -85,6 +85,12 @@ hipError_t iock_export_count(hipStream_t st, uint32_t nslots, const uint32_t* of
                              uint32_t L, const int32_t* cid, uint32_t* out_cnt);
 hipError_t iock_export_fill(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
                             uint32_t L, const int32_t* cid, const uint32_t* out_cnt, const int64_t* out_off, uint32_t* out);
+// ioc_sort.hip: the kept keys in ascending order (okeys), the offsets of their lists (soff, nslots + 1 values: the last is the
+// total), every slot's offset (slot_off), the number of kept keys (n_rows)
+size_t iock_export_order_temp(uint32_t nslots);
+hipError_t iock_export_order(hipStream_t st, uint32_t nslots, uint32_t cap, const uint32_t* keys, const uint32_t* cnt,
+                             unsigned long long* k0, unsigned long long* k1, uint32_t* v0, uint32_t* v1, unsigned long long* scnt,
+                             unsigned long long* soff, void* temp, size_t temp_bytes, uint32_t* n_rows, uint32_t* okeys, int64_t* slot_off);
 hipError_t iock_gather_lists(hipStream_t st, uint32_t nlists, const int64_t* src, const int64_t* dst, const uint32_t* len,
                              const uint32_t* smin, const uint32_t* spos, uint32_t* dmin, uint32_t* dpos);
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
