@@ -1416,15 +1416,34 @@ struct WinStat {
 
 // Pass 2: one wave per pair.  Direction nibble of a cell: bits 0-1 = where H came from (0 diagonal with
 // identical bases, 3 diagonal with different bases, 1 E, 2 F), bit 2 = E extended, bit 3 = F extended.
-__global__ void __launch_bounds__(64)
+constexpr int TR_WAVES = 4;
+// what a barrier is to a one-wave workgroup: LDS operations of a wave complete in order, the compiler must not move them
+__device__ __forceinline__ void tr_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ void __launch_bounds__(64 * TR_WAVES)
 k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, const uint8_t* __restrict__ pool,
               AlnParams P, const int2* __restrict__ ck, const AlnCk* __restrict__ cko, const int4* __restrict__ ends,
-              int32_t* __restrict__ out_score, uint32_t* __restrict__ out_count)
+              int32_t* __restrict__ out_score, uint32_t* __restrict__ out_count, uint32_t count)
 {
-    __shared__ uint16_t dirs[TILE * TR_C / 4][64];  // TR_C nibbles per lane and row (TILE 128: two rows share a word)
-    __shared__ int2 s_left[TILE];
-    __shared__ uint32_t s_q[TILE];
-    const uint32_t pid = order[blockIdx.x];
+    // A workgroup is TR_WAVES = 4 independent waves, one pair each, with LDS of their own: a workgroup of four waves puts
+    // one on every SIMD of its CU, whereas one-wave workgroups were seen three to a SIMD on some CUs (each of them then
+    // half as fast: 14.5 against 7.6 ms) while other SIMDs held one.  No workgroup barrier anywhere: a wave only ever
+    // reads what it wrote itself, in program order.
+    __shared__ uint16_t dirs_all[TR_WAVES][TILE * TR_C / 4][64];  // TR_C nibbles per lane and row (TILE 128: two rows share a word)
+    __shared__ int2 s_left_all[TR_WAVES][TILE];
+    __shared__ uint32_t s_q_all[TR_WAVES][TILE];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t pslot = blockIdx.x * TR_WAVES + wv;
+    if (pslot >= count) return;
+    uint16_t(*dirs)[64] = dirs_all[wv];
+    int2* s_left = s_left_all[wv];
+    uint32_t* s_q = s_q_all[wv];
+    const uint32_t pid = order[pslot];
     const AlnPairDev pr = pairs[pid];
     const uint32_t n = pr.n, m = pr.m;
     const int go = pr.gap_open, il = pr.ilimit;
@@ -1432,7 +1451,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     const uint8_t* __restrict__ r = pool + pr.r_off;
     const int2* __restrict__ rowck = ck + cko[pid].row_off;
     const int2* __restrict__ colck = ck + cko[pid].col_off;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = P.k, kmask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const int4 en = ends[pid];
     if (en.w & 1) {  // the packed forward pass left its 16-bit window: the host sends the pair to the 32-bit kernel
@@ -1512,7 +1531,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             }
             if (jb > 0 && jb <= m) dg = roh[jb - 1] + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);  // H(r0, jb); column 0 holds 0
         }
-        __syncthreads();
+        tr_wave_sync();
 #ifdef TR_PROF
         { const unsigned long long t = __builtin_readcyclecounter(); tp_load += t - tp_t; tp_t = t; ++tp_tiles; }
 #endif
@@ -1567,7 +1586,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             out_e = el;
             out_q = qc;
         }
-        __syncthreads();
+        tr_wave_sync();
 #ifdef TR_PROF
         { const unsigned long long t = __builtin_readcyclecounter(); tp_comp += t - tp_t; tp_t = t; }
 #endif
@@ -1608,7 +1627,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 --i;
             }
         }
-        __syncthreads();
+        tr_wave_sync();
 #ifdef TR_PROF
         { const unsigned long long t = __builtin_readcyclecounter(); tp_walk += t - tp_t; tp_t = t; }
 #endif
@@ -1618,7 +1637,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
         out_score[pid] = en.x;
         out_count[pid] = ws.cnt;
 #ifdef TR_PROF
-        if (pid == order[0]) printf("trace profile (cycles of the 100 MHz counter x tiles %u): load %llu, recompute %llu, walk %llu\n", tp_tiles, tp_load, tp_comp, tp_walk);
+        if (pslot == 0) printf("trace profile (cycles of the 100 MHz counter x tiles %u): load %llu, recompute %llu, walk %llu\n", tp_tiles, tp_load, tp_comp, tp_walk);
 #endif
     }
 }
@@ -2041,9 +2060,11 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             }
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(evs[evi++], s));
-            hipLaunchKernelGGL(k_align_trace, dim3(sl.second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), ord,
-                               static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const int2*>(c->a_ck.p),
-                               static_cast<const AlnCk*>(c->a_cko.p), static_cast<const int4*>(c->a_ends2.p), d_score, d_count);
+            const uint32_t tr_wg = (sl.second + TR_WAVES - 1) / TR_WAVES;  // (an LDS reservation that caps the workgroups per CU changed nothing here)
+            hipLaunchKernelGGL(k_align_trace, dim3(tr_wg), dim3(64 * TR_WAVES), 0, s,
+                               static_cast<const AlnPairDev*>(c->a_pairs.p), ord, static_cast<const uint8_t*>(c->a_pool.p), P,
+                               static_cast<const int2*>(c->a_ck.p), static_cast<const AlnCk*>(c->a_cko.p),
+                               static_cast<const int4*>(c->a_ends2.p), d_score, d_count, sl.second);
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(evs[evi++], s));
         }
