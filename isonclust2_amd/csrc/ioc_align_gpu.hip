@@ -1437,7 +1437,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     __shared__ uint16_t dirs_all[TR_WAVES][TILE * TR_C / 4][64];  // TR_C nibbles per lane and row (TILE 128: two rows share a word)
     __shared__ int2 s_left_all[TR_WAVES][TILE];
     __shared__ uint32_t s_q_all[TR_WAVES][TILE];
-    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wv = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));  // uniform: the pair's state stays in SGPRs
     const uint32_t pslot = blockIdx.x * TR_WAVES + wv;
     if (pslot >= count) return;
     uint16_t(*dirs)[64] = dirs_all[wv];
@@ -1473,14 +1473,18 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     while (i > 0 && j > 0) {
         const uint32_t r0 = ((i - 1) / TILE) * TILE, c0 = ((j - 1) / TILE) * TILE;
         const uint32_t rows = i - r0, cols = j - c0;
+        // The tile is recomputed on the forward pass's own SLANTED scores (see fwd_cells: X* = X + ge (i + j), Hq = H* - gd),
+        // exactly as the checkpoints hold them: a gap extension costs nothing, an opening is already inside Hq, so a cell is
+        // two max + max3 + add + sub, and every decision of the host aligner's cell is a comparison of the same operands
+        // (E extended <=> E* > Hq of the left cell; H from the diagonal <=> H* equals it, which wins ties, else from E if
+        // equal to E*, else from F) — 18 VALU per cell where the unslanted form took 24.  This kernel is bound by VALU
+        // issue on the SIMDs that hold two of its waves.
+        const int gd = go - P.gap_extend, ge = P.gap_extend;
+        const int cm = P.match + 2 * ge + gd, cx = P.mismatch + 2 * ge + gd;
         for (uint32_t x = lane; x < rows; x += 64) {
             s_q[x] = q[r0 + x];
-            int2 le{0, ALN_NEG};
-            if (c0) {  // checkpoints hold slanted values (k_align_fwd): X = X* - ge (i + j), H* = Hq + (go - ge)
-                le = colck[uint64_t(c0 / TILE - 1) * col_pitch(n) + r0 + x];
-                const int sl = P.gap_extend * int(r0 + x + 1 + c0);
-                le = int2{le.x + (go - P.gap_extend) - sl, le.y - sl};
-            }
+            int2 le{ge * int(r0 + x + 1) - gd, ALN_NEG};  // column 0: H = 0, no gap to extend
+            if (c0) le = colck[uint64_t(c0 / TILE - 1) * col_pitch(n) + r0 + x];  // (Hq, E*) as passed between lanes
             s_left[x] = le;
         }
         const uint32_t jb = c0 + lane * TR_C;  // columns to the left of this lane's block
@@ -1491,12 +1495,12 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             for (int e = 0; e < TR_C; ++e) w |= ref_byte(r, m, pr.rc, jb + e) << (8 * e);
             rpk[0] = w;
         }
-        int Hp[TR_C], F[TR_C];
-        int dg = 0;
+        int Hp[TR_C], F[TR_C];  // (Hq, F*) of the row above
+        int dg = ge * int(r0 + jb) - gd;  // Hq(r0, jb) where H = 0: row 0, or column 0
         if (r0 == 0) {
 #pragma unroll
             for (int c = 0; c < TR_C; ++c) {
-                Hp[c] = 0;
+                Hp[c] = ge * int(jb + c + 1) - gd;
                 F[c] = ALN_NEG;
             }
         } else if (en.w & 2) {  // written by k_align_fwd16: 16-bit values + bases, by (wave, tile of the band)
@@ -1507,29 +1511,22 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
 #pragma unroll
             for (int c = 0; c < TR_C; ++c) {
                 int2 v{0, ALN_NEG};
-                if (jb + c < m) {
-                    const int sl = P.gap_extend * int(r0 + jb + c + 1);
-                    v = int2{row16_get(ent, m, hs, 0, jb + c) + (go - P.gap_extend) - sl, row16_get(ent, m, hs, 1, jb + c) - sl};
-                }
+                if (jb + c < m) v = int2{row16_get(ent, m, hs, 0, jb + c), row16_get(ent, m, hs, 1, jb + c)};
                 Hp[c] = v.x;
                 F[c] = v.y;
             }
-            if (jb > 0 && jb <= m) dg = row16_get(ent, m, hs, 0, jb - 1) + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);
+            if (jb > 0 && jb <= m) dg = row16_get(ent, m, hs, 0, jb - 1);
         } else {
             const int* roh = reinterpret_cast<const int*>(rowck + uint64_t(r0 / TILE - 1) * row_pitch(m));
             const int* rof = roh + row_pitch(m);
 #pragma unroll
             for (int c = 0; c < TR_C; ++c) {
                 int2 v{0, ALN_NEG};
-                if (jb + c < m) {
-                    v = int2{roh[jb + c], rof[jb + c]};
-                    const int sl = P.gap_extend * int(r0 + jb + c + 1);
-                    v = int2{v.x + (go - P.gap_extend) - sl, v.y - sl};
-                }
+                if (jb + c < m) v = int2{roh[jb + c], rof[jb + c]};
                 Hp[c] = v.x;
                 F[c] = v.y;
             }
-            if (jb > 0 && jb <= m) dg = roh[jb - 1] + (go - P.gap_extend) - P.gap_extend * int(r0 + jb);  // H(r0, jb); column 0 holds 0
+            if (jb > 0 && jb <= m) dg = roh[jb - 1];
         }
         tr_wave_sync();
 #ifdef TR_PROF
@@ -1539,15 +1536,18 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
         const uint32_t nsteps = rows + nact - 1;
         int out_h = 0, out_e = ALN_NEG;
         uint32_t out_q = 0;
+        // lane 0's inputs of a step (left edge and query byte of row s) are read one step AHEAD, by every lane at one address,
+        // and enter the wave as the `old` operand of the shifts
+        int2 nle = s_left[0];
+        uint32_t nq = s_q[0];
         for (uint32_t s = 0; s < nsteps; ++s) {
-            int hl = int(from_left(uint32_t(out_h)));
-            int el = int(from_left(uint32_t(out_e)));
-            uint32_t qc = from_left(out_q);
-            if (lane == 0 && s < rows) {
-                const int2 le = s_left[s];
-                hl = le.x;
-                el = le.y;
-                qc = s_q[s];
+            int hl = int(from_left_or(uint32_t(out_h), uint32_t(nle.x)));
+            int el = int(from_left_or(uint32_t(out_e), uint32_t(nle.y)));
+            uint32_t qc = from_left_or(out_q, nq);
+            {
+                const uint32_t sn = s + 1u < rows ? s + 1u : rows - 1u;  // (rows past the end are never looked at)
+                nle = s_left[sn];
+                nq = s_q[sn];
             }
             const int ri = int(s) - int(lane);
             if (ri >= 0 && uint32_t(ri) < rows && lane < nact) {
@@ -1555,25 +1555,20 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 uint32_t bits = 0;
 #pragma unroll
                 for (int c = 0; c < TR_C; ++c) {
-                    // the host aligner's cell (ioc_align.cpp): H = diagonal, replaced by E if E > H, then by F if
-                    // F > H — written so that the chain to the next cell is sub, max, max3 and the provenance
-                    // compares hang off it (a dependent VALU op costs 8 cycles and this wave has its SIMD alone)
-                    const int eo = hl - go, ee = el - P.gap_extend;
-                    const bool ex = ee > eo;
-                    const int E = max(ee, eo);
-                    const int fo = Hp[c] - go, fe = F[c] - P.gap_extend;
-                    const bool fx = fe > fo;
-                    const int Fn = max(fe, fo);
+                    const bool ex = el > hl;
+                    const int E = max(el, hl);
+                    const bool fx = F[c] > Hp[c];
+                    const int Fn = max(F[c], Hp[c]);
                     const bool mt = qc == ((rpk[0] >> (8 * c)) & 0xFFu);
-                    const int hd = dg + (mt ? P.match : P.mismatch);
-                    const int hde = max(hd, E);
-                    const int h = max(hde, Fn);
-                    const uint32_t from = Fn > hde ? 2u : (E > hd ? 1u : (mt ? 0u : 3u));
-                    bits |= (from | (ex ? 4u : 0u) | (fx ? 8u : 0u)) << (4 * c);
+                    const int hd = dg + (mt ? cm : cx);
+                    const int h = max(max(hd, E), Fn);
+                    // the host aligner's cell (ioc_align.cpp): H = diagonal, replaced by E if E > H, then by F if F > H
+                    const uint32_t from = h == hd ? (mt ? 0u : 3u << (4 * c)) : (h == E ? 1u << (4 * c) : 2u << (4 * c));
+                    bits |= from | (ex ? 4u << (4 * c) : 0u) | (fx ? 8u << (4 * c) : 0u);
                     dg = Hp[c];
-                    Hp[c] = h;
+                    Hp[c] = h - gd;
                     F[c] = Fn;
-                    hl = h;
+                    hl = h - gd;
                     el = E;
                 }
                 dg = hl_in;
