@@ -507,6 +507,9 @@ static_assert(FW_R == 4, "the look-ahead hands 4 rows per step to lane 0 (one 16
 #ifndef IOC_FWD_WAVES_PER_EU
 #define IOC_FWD_WAVES_PER_EU 3
 #endif
+#ifndef IOC_FWD_STEP_UNROLL
+#define IOC_FWD_STEP_UNROLL 2
+#endif
 template <bool PROF>
 __global__ void __launch_bounds__(64 * ALN_MAXW) __attribute__((amdgpu_waves_per_eu(IOC_FWD_WAVES_PER_EU, 8)))
 k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ order, uint32_t count, uint32_t wpp_main,
@@ -650,6 +653,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             }
             const bool has_cols = jb < m;
             const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
+            const bool strip_has_lastc = uint64_t(p + 1u) * strip_cols >= m;  // (uniform) the last strip
             // this lane's right edge is a column checkpoint (lane 63: the next strip's input)
             const uint32_t jr = jb + FW_C;
             const bool wr_col = (jr % TILE) == 0 && jr < m;
@@ -694,7 +698,9 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 nxe = *reinterpret_cast<const uint4*>(&s_look[1][0]);
                 nxq = *reinterpret_cast<const uint4*>(&s_look[2][0]);
             }
-            for (uint32_t s = 0; s < nsteps; ++s) {
+            // one step of the wave; the loop below runs two per iteration (the compiler cannot unroll a loop with wave-level
+            // operations by itself): half of the register copies that carry the inputs from step to step go away
+            auto step = [&](const uint32_t s) __attribute__((always_inline)) {
                 if ((s & (64 / FW_R - 1)) == 0) {  // steps 16 b .. : publish block b + 1, fetch block b + 2
                     const uint32_t blk = s / (64 / FW_R) + 1u;
                     publish(blk);
@@ -721,7 +727,9 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                     // wave-uniform: the special path is right for every lane (its extras are guarded per lane), and a wave whose
                     // lanes disagree would run BOTH copies of the cells — in the last strip, where one lane owns the last
                     // column, for every step of the strip
-                    const bool special = __builtin_amdgcn_ballot_w64(lastc >= 0 || (last_band && uint32_t(bi) + 1u == nblocks)) != 0ull;
+                    // (in scalar terms: a lane of the strip owns the last column, or some lane — s - lane for a lane 0..63 — is on
+                    // the last row block of the last band)
+                    const bool special = strip_has_lastc || (last_band && s + 1u >= nblocks && s + 1u - nblocks < 64u);
                     if (!special) {
 #pragma unroll
                         for (int rr = 0; rr < FW_R; ++rr) {
@@ -798,10 +806,14 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                     const uint32_t i1 = i0 + FW_R;  // DP index of the block's last row (TILE is a multiple of FW_R)
                     if ((i1 % TILE) == 0 && i1 < n) {
                         const uint32_t jbo = opaque(jb);
-                        // two planes (Hq, F*): each lane's 16 values go out as they sit in its registers
-                        int* rb = reinterpret_cast<int*>(rowck + uint64_t(i1 / TILE - 1) * row_pitch(m)) + jbo;
+                        // two planes (Hq, F*): each lane's 16 values go out as they sit in its registers.  The offset from the
+                        // pair's (uniform) row region is a 32-bit number of ints (the launcher refuses pairs whose region is
+                        // larger): scalar base + one vector offset instead of 64-bit vector address arithmetic in a block
+                        // that two lanes of every wave take in every step
+                        const uint32_t pitch32 = uint32_t(row_pitch(m));
+                        int* rb = reinterpret_cast<int*>(rowck) + ((i1 / TILE - 1u) * (2u * pitch32) + jbo);
                         int4* roh = reinterpret_cast<int4*>(rb);
-                        int4* rof = reinterpret_cast<int4*>(rb + row_pitch(m));
+                        int4* rof = reinterpret_cast<int4*>(rb + pitch32);
 #pragma unroll
                         for (int c = 0; c < FW_C; c += 4) {
                             roh[c / 4] = int4{Hp[c], Hp[c + 1], Hp[c + 2], Hp[c + 3]};
@@ -809,6 +821,16 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                         }
                     }
                 }
+            };
+            {
+                uint32_t s = 0;
+#if IOC_FWD_STEP_UNROLL == 2
+                for (; s + 1u < nsteps; s += 2) {
+                    step(s);
+                    step(s + 1u);
+                }
+#endif
+                for (; s < nsteps; ++s) step(s);
             }
             // the lane that owns the last column hands the band's best to lane 0 (a strip of the last round)
             if (lastc >= 0) {
@@ -1856,6 +1878,12 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         };
         auto ck_units = [&](const AlnPairDev& d) { return row_units(d) + uint64_t((d.m - 1) / TILE) * col_pitch(d.n); };
         const uint64_t lrow_stride = uint64_t((max_m + 64 * FW_C - 1) / (64 * FW_C)) * 64;  // int2 per pair
+        // (the forward pass addresses a pair's row checkpoints by a 32-bit offset in ints: 2^29 int2 units = 4 GB per pair,
+        // reads of ~260 kb against each other)
+        for (uint32_t x = 0; x < np; ++x)
+            if (row_units(dp[x]) >= (uint64_t(1) << 29))
+                return ioc_fail(c, IOC_ERR_CAPACITY, "alignment of " + std::to_string(dp[x].n) + " x " + std::to_string(dp[x].m) +
+                                                        " bases: row checkpoints above 4 GB per pair");
         std::vector<AlnCk> cko(np);
         std::vector<std::pair<uint32_t, uint32_t>> slices;  // [first, count) in `order`
         uint64_t arena = 0;
