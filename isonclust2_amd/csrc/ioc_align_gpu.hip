@@ -507,6 +507,9 @@ static_assert(FW_R == 4, "the look-ahead hands 4 rows per step to lane 0 (one 16
 #ifndef IOC_FWD_WAVES_PER_EU
 #define IOC_FWD_WAVES_PER_EU 3
 #endif
+#ifndef IOC_TR_STEP_UNROLL
+#define IOC_TR_STEP_UNROLL 2
+#endif
 #ifndef IOC_FWD_STEP_UNROLL
 #define IOC_FWD_STEP_UNROLL 2
 #endif
@@ -1562,7 +1565,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
         // and enter the wave as the `old` operand of the shifts
         int2 nle = s_left[0];
         uint32_t nq = s_q[0];
-        for (uint32_t s = 0; s < nsteps; ++s) {
+        auto tstep = [&](const uint32_t s) __attribute__((always_inline)) {
             int hl = int(from_left_or(uint32_t(out_h), uint32_t(nle.x)));
             int el = int(from_left_or(uint32_t(out_e), uint32_t(nle.y)));
             uint32_t qc = from_left_or(out_q, nq);
@@ -1602,6 +1605,22 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             out_h = hl;
             out_e = el;
             out_q = qc;
+        };
+        {   // two steps per iteration (the compiler does not unroll a loop with wave-level operations): fewer register copies
+            uint32_t s = 0;
+#if IOC_TR_STEP_UNROLL == 4
+            for (; s + 3u < nsteps; s += 4) {
+                tstep(s);
+                tstep(s + 1u);
+                tstep(s + 2u);
+                tstep(s + 3u);
+            }
+#endif
+            for (; s + 1u < nsteps; s += 2) {
+                tstep(s);
+                tstep(s + 1u);
+            }
+            if (s < nsteps) tstep(s);
         }
         tr_wave_sync();
 #ifdef TR_PROF
