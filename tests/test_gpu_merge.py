@@ -54,6 +54,27 @@ def test_index_export_equals_oracle_mindb(ctx, cfg, seed):
     assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
 
 
+def test_index_export_ordered_on_the_device_equals_the_host_ordered_one(ctx, monkeypatch):
+    """ioc_index_export orders the keys on the device (ioc_sort.hip); IOC_EXPORT_HOST_ORDER=1 is the host's std::sort
+    of round 2's first version: same CSR, also for a merge (left lists + right lists in one index)."""
+    rs = synth.generate_config("config1", seed=3)
+    _, sbs = _batches(rs, 2)
+    p = api.default_params(11, 15, "fast")
+
+    def run():
+        left = pipeline.cluster_single(ctx, p, sbs[0])
+        both = pipeline.cluster_merge(ctx, p, left, pipeline.cluster_single(ctx, p, sbs[1]))
+        return left.mindb, both.mindb
+
+    dev = run()
+    monkeypatch.setenv("IOC_EXPORT_HOST_ORDER", "1")
+    host = run()
+    for a, b in zip(dev, host):
+        assert len(a[0]) > 1000
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("cfg,seed,nb", [("config1", 1, 2), ("config1", 2, 4), ("short_dup", 1, 3)])
 def test_left_fold_merge_equals_oracle(ctx, cfg, seed, nb):
     """((b0 + b1) + b2) + ... as in the reference README's example fold."""
