@@ -27,6 +27,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ioc_internal.h"
@@ -501,11 +502,14 @@ __device__ __forceinline__ void fwd_cells(int (&Hq)[C], int (&F)[C], const uint3
 // wrote one round earlier.  One barrier per round (~4000 steps) instead of one per step: waves of one pair
 // share SIMDs with other pairs' waves, and per-step lockstep cost 30 % of the throughput.
 constexpr int FW_R = 4;
-static_assert(FW_C == 16, "the last-column select tree assumes 16 columns per lane");
+static_assert(FW_C == 16, "the last-column select tree assumes 16 (or, narrow last strip, 8) columns per lane");
 static_assert(FW_R == 4, "the look-ahead hands 4 rows per step to lane 0 (one 16-byte LDS read per field)");
 
 #ifndef IOC_FWD_WAVES_PER_EU
 #define IOC_FWD_WAVES_PER_EU 3
+#endif
+#ifndef IOC_FWD_NARROW_LAST
+#define IOC_FWD_NARROW_LAST 1
 #endif
 #ifndef IOC_TR_STEP_UNROLL
 #define IOC_TR_STEP_UNROLL 2
@@ -571,6 +575,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
     };
     constexpr uint32_t strip_cols = 64u * FW_C;
     const uint32_t nstrips = (m + strip_cols - 1) / strip_cols;
+    const bool narrow_last = IOC_FWD_NARROW_LAST && m - (nstrips - 1u) * strip_cols <= strip_cols / 2u;  // (uniform) see `strip`
     // this wave's band of rows [r_lo, r_hi), whole tiles
     const uint32_t ntiles = (n + TILE - 1) / TILE, tpb = (ntiles + nwaves - 1) / nwaves;
     const uint32_t r_lo = min(n, wave * tpb * TILE), r_hi = min(n, (wave + 1u) * tpb * TILE);
@@ -607,10 +612,15 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 if (!seen) xbad = true;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            const uint32_t jb = p * strip_cols + lane * FW_C;  // columns to the left of this lane's block
-            uint32_t rpk[FW_C / 4];
+            // The strip with C columns per lane: 16, or — the last strip of a pair when no more than half a strip of
+            // columns is left — 8: a step then costs 45 + 4 x 8 x 5 instructions instead of 45 + 4 x 16 x 5 for the same
+            // number of steps (m = 16.6 kb: 17 strips, the last one 283 columns wide on average — 18 of 64 lanes busy).
+            auto strip = [&](auto cc) __attribute__((always_inline)) {
+            constexpr int C = decltype(cc)::value;
+            const uint32_t jb = p * strip_cols + lane * uint32_t(C);  // columns to the left of this lane's block
+            uint32_t rpk[C / 4];
 #pragma unroll
-            for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+            for (int c4 = 0; c4 < C / 4; ++c4) {
                 uint32_t w = 0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w |= ref_byte(r, m, pr.rc, jb + c4 * 4 + e) << (8 * e);
@@ -622,7 +632,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 for (int code = 0; code < 5; ++code) {
                     const uint32_t b = code < 4 ? (bases >> (8 * code)) & 0xFFu : 0x100u;  // 0x100: equals no byte
 #pragma unroll
-                    for (int c4 = 0; c4 < FW_C / 4; ++c4) {
+                    for (int c4 = 0; c4 < C / 4; ++c4) {
                         uint32_t w = 0;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
@@ -633,12 +643,12 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             }
             // Hq and F* of the row above the band (slanted, see fwd_cells): row 0 of the matrix (free leading
             // gap, H = 0) or the row checkpoint the band above wrote in the previous round
-            int Hp[FW_C], F[FW_C];
+            int Hp[C], F[C];
             int dg;
             if (r_lo == 0) {
                 const int base = K.ge * int(jb) - K.gd;  // per-column parts (ge * c) are scalar
 #pragma unroll
-                for (int c = 0; c < FW_C; ++c) {
+                for (int c = 0; c < C; ++c) {
                     Hp[c] = base + K.ge * (c + 1);
                     F[c] = ALN_NEG;
                 }
@@ -647,7 +657,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 const int* roh = reinterpret_cast<const int*>(rowck + uint64_t(r_lo / TILE - 1) * row_pitch(m));
                 const int* rof = roh + row_pitch(m);
 #pragma unroll
-                for (int c = 0; c < FW_C; ++c) {  // row checkpoints hold the slanted (Hq, F*)
+                for (int c = 0; c < C; ++c) {  // row checkpoints hold the slanted (Hq, F*)
                     const int2 v = (jb + c < m) ? int2{roh[jb + c], rof[jb + c]} : int2{0, 0};
                     Hp[c] = v.x;
                     F[c] = v.y;
@@ -655,10 +665,10 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 dg = (jb > 0 && jb <= m) ? roh[jb - 1] : K.ge * int(r_lo) - K.gd;  // column 0 holds H = 0
             }
             const bool has_cols = jb < m;
-            const int lastc = (m - 1 >= jb && m - 1 < jb + FW_C) ? int(m - 1 - jb) : -1;
+            const int lastc = (m - 1 >= jb && m - 1 < jb + uint32_t(C)) ? int(m - 1 - jb) : -1;
             const bool strip_has_lastc = uint64_t(p + 1u) * strip_cols >= m;  // (uniform) the last strip
             // this lane's right edge is a column checkpoint (lane 63: the next strip's input)
-            const uint32_t jr = jb + FW_C;
+            const uint32_t jr = jb + uint32_t(C);
             const bool wr_col = (jr % TILE) == 0 && jr < m;
             int2* colout = wr_col ? colck + uint64_t(jr / TILE - 1) * col_pitch(n) : colck;
             const int2* colin = p ? colck + uint64_t(p * strip_cols / TILE - 1) * col_pitch(n) : colck;
@@ -739,10 +749,13 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                             const int hl_in = hl[rr];
                             if (PROF) {
                                 const uint4 x = *reinterpret_cast<const uint4*>(&s_prof[0][0][0] + qc[rr] + lane * 4u);
-                                const uint32_t xw[FW_C / 4] = {x.x, x.y, x.z, x.w};
-                                fwd_cells<FW_C, true>(Hp, F, xw, hl[rr], el[rr], dg, qc[rr], K);
+                                const uint32_t x4[4] = {x.x, x.y, x.z, x.w};
+                                uint32_t xw[C / 4];
+#pragma unroll
+                                for (int c4 = 0; c4 < C / 4; ++c4) xw[c4] = x4[c4];
+                                fwd_cells<C, true>(Hp, F, xw, hl[rr], el[rr], dg, qc[rr], K);
                             } else {
-                                fwd_cells<FW_C, false>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                                fwd_cells<C, false>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
                             }
                             dg = hl_in;
                         }
@@ -752,10 +765,13 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                             const int hl_in = hl[rr];
                             if (PROF) {
                                 const uint4 x = *reinterpret_cast<const uint4*>(&s_prof[0][0][0] + qc[rr] + lane * 4u);
-                                const uint32_t xw[FW_C / 4] = {x.x, x.y, x.z, x.w};
-                                fwd_cells<FW_C, true>(Hp, F, xw, hl[rr], el[rr], dg, qc[rr], K);
+                                const uint32_t x4[4] = {x.x, x.y, x.z, x.w};
+                                uint32_t xw[C / 4];
+#pragma unroll
+                                for (int c4 = 0; c4 < C / 4; ++c4) xw[c4] = x4[c4];
+                                fwd_cells<C, true>(Hp, F, xw, hl[rr], el[rr], dg, qc[rr], K);
                             } else {
-                                fwd_cells<FW_C, false>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
+                                fwd_cells<C, false>(Hp, F, rpk, hl[rr], el[rr], dg, qc[rr], K);
                             }
                             dg = hl_in;
                             const uint32_t i = i0 + rr;  // 0-based row
@@ -766,11 +782,16 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                                     // (written out: an index computed in a loop makes the compiler move Hp to LDS)
                                     const bool b0 = lc & 1u, b1 = lc & 2u, b2 = lc & 4u, b3 = lc & 8u;
                                     const int s0 = b0 ? Hp[1] : Hp[0], s1 = b0 ? Hp[3] : Hp[2], s2 = b0 ? Hp[5] : Hp[4],
-                                              s3 = b0 ? Hp[7] : Hp[6], s4 = b0 ? Hp[9] : Hp[8], s5 = b0 ? Hp[11] : Hp[10],
-                                              s6 = b0 ? Hp[13] : Hp[12], s7 = b0 ? Hp[15] : Hp[14];
-                                    const int u0 = b1 ? s1 : s0, u1 = b1 ? s3 : s2, u2 = b1 ? s5 : s4, u3 = b1 ? s7 : s6;
-                                    const int v0 = b2 ? u1 : u0, v1 = b2 ? u3 : u2;
-                                    int hm = b3 ? v1 : v0;
+                                              s3 = b0 ? Hp[7] : Hp[6];
+                                    const int u0 = b1 ? s1 : s0, u1 = b1 ? s3 : s2;
+                                    int hm = b2 ? u1 : u0;
+                                    if constexpr (C == 16) {
+                                        const int s4 = b0 ? Hp[9] : Hp[8], s5 = b0 ? Hp[11] : Hp[10], s6 = b0 ? Hp[13] : Hp[12],
+                                                  s7 = b0 ? Hp[15] : Hp[14];
+                                        const int u2 = b1 ? s5 : s4, u3 = b1 ? s7 : s6;
+                                        const int v1 = b2 ? u3 : u2;
+                                        hm = b3 ? v1 : hm;
+                                    }
                                     hm += K.gd - K.ge * int(opaque(i) + 1 + m);  // true H(i + 1, m)
                                     if (hm > bc) {
                                         bc = hm;
@@ -783,14 +804,14 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                                     const uint32_t jbo = opaque(jb);
                                     const int base = K.gd - K.ge * int(n + jbo);
 #pragma unroll
-                                    for (int c = 0; c < FW_C; ++c) {
+                                    for (int c = 0; c < C; ++c) {
                                         const int ht = Hp[c] + base - K.ge * (c + 1);  // true H(n, jb + c + 1)
                                         if (jbo + c < m && ht > br) {
                                             br = ht;
                                             bj = jbo + c + 1;
                                         }
                                     }
-                                    mylrow[jbo / FW_C] = int2{br, int(bj)};
+                                    mylrow[p * 64u + lane] = int2{br, int(bj)};
                                 }
                             }
                         }
@@ -818,7 +839,7 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                         int4* roh = reinterpret_cast<int4*>(rb);
                         int4* rof = reinterpret_cast<int4*>(rb + pitch32);
 #pragma unroll
-                        for (int c = 0; c < FW_C; c += 4) {
+                        for (int c = 0; c < C; c += 4) {
                             roh[c / 4] = int4{Hp[c], Hp[c + 1], Hp[c + 2], Hp[c + 3]};
                             rof[c / 4] = int4{F[c], F[c + 1], F[c + 2], F[c + 3]};
                         }
@@ -841,6 +862,11 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
                 s_best[wv][1] = int(bc_i);
                 if (cross) X.best[uint64_t(pslot - X.first_pair) * nwaves + wave] = int2{bc, int(bc_i)};
             }
+            };
+            if (narrow_last && p + 1u == nstrips)
+                strip(std::integral_constant<int, 8>{});
+            else
+                strip(std::integral_constant<int, FW_C>{});
             if (cross) {  // this band's checkpoints of the strip are out: tell the band below (and the final reduction)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (lane == 0) __hip_atomic_store(&xflag[uint64_t(wave) * nstrips + p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -875,7 +901,11 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
         int br = 0;  // H(n, 0)
         uint32_t bj = 0;
         for (uint32_t e = lane; e < nstrips * 64u; e += 64) {
-            if (uint64_t(e) * FW_C >= m) continue;  // lane right of the matrix
+            {   // entry e = (strip, lane): lanes right of the matrix wrote nothing
+                const uint32_t ep = e >> 6, el = e & 63u;
+                const uint32_t cpl = (narrow_last && ep + 1u == nstrips) ? 8u : uint32_t(FW_C);
+                if (uint64_t(ep) * strip_cols + el * cpl >= m) continue;
+            }
             const int2 x = mylrow[e];
             if (x.x > br || (x.x == br && uint32_t(x.y) < bj)) {
                 br = x.x;
