@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -1955,7 +1956,11 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         }
         uint32_t max_cnt = 0;
         for (auto& sl : slices) max_cnt = std::max(max_cnt, sl.second);
+        const auto t_res0 = std::chrono::steady_clock::now();
         if ((r = reserve(c, c->a_ck, size_t(arena) * 8)) != IOC_OK) return r;
+        if (getenv("IOC_TRACE"))
+            fprintf(stderr, "[ioc]   aligner: checkpoint arena %.1f MB (%zu slice(s)) reserved in %.3f ms\n", double(arena) * 8e-6, slices.size(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_res0).count());
         if ((r = reserve(c, c->a_cko, size_t(np) * sizeof(AlnCk))) != IOC_OK) return r;
         if ((r = reserve(c, c->a_ends2, size_t(np) * sizeof(int4))) != IOC_OK) return r;
         if ((r = reserve(c, c->a_lrow, size_t(max_cnt) * lrow_stride * 8)) != IOC_OK) return r;
@@ -2146,6 +2151,8 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
             if (hipEventElapsedTime(&a, evs[x], evs[x + 1]) == hipSuccess) c->tm.ms_align_fwd += a;
             if (hipEventElapsedTime(&b, evs[x + 1], evs[x + 2]) == hipSuccess) c->tm.ms_align_trace += b;
         }
+        if (getenv("IOC_TRACE"))
+            fprintf(stderr, "[ioc]   aligner: forward %.3f ms, traceback %.3f ms (device, all slices so far)\n", c->tm.ms_align_fwd, c->tm.ms_align_trace);
         for (auto& e : evs) (void)hipEventDestroy(e);
     }
     c->tm.n_align_pairs += np;
