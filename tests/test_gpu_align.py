@@ -121,7 +121,8 @@ def test_tile_boundaries(ctx, monkeypatch, waves):
     monkeypatch.setenv("IOC_ALIGN_WAVES", waves)
     rng = random.Random(17)
     base = bytes(rng.choice(b"ACGT") for _ in range(2200))
-    lens = [255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1040, 2047, 2049]
+    # (1536 / 1537, 512 / 513: the last strip switches to 8 columns per lane when no more than 512 columns are left)
+    lens = [255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1040, 1535, 1536, 1537, 1544, 2047, 2049]
     seqs = [_mutate(rng, base, 0.1)[:ln] for ln in lens] + [base[:1024], base[:1024]]
     pairs = []
     for a in range(len(lens)):
