@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "ioc_internal.h"
 #include "ioc_kernels.h"
@@ -18,6 +19,21 @@ int ioc_fail(ioc_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg;
     return code;
+}
+
+static uint32_t env_u32(const char* name, uint32_t dflt);
+
+int ioc_wait_uploads(ioc_ctx* c, int stage)
+{
+    if (!c) return IOC_ERR_ARG;
+    while (c->up_stage.load(std::memory_order_acquire) < stage) std::this_thread::yield();
+    if (stage >= 2 && c->up_thread.joinable()) c->up_thread.join();
+    if (c->up_stage.load(std::memory_order_acquire) >= 2 && !c->up_thread.joinable() && !c->up_err.empty()) {
+        const std::string m = c->up_err;
+        c->up_err.clear();
+        return ioc_fail(c, IOC_ERR_HIP, "upload of the query arrays: " + m);
+    }
+    return IOC_OK;
 }
 
 #define HIPCHK(c, call)                                                                              \
@@ -96,7 +112,9 @@ void ioc_ctx_destroy(ioc_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)ioc_wait_uploads(c, 2);
     (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_off_fwd, &c->b_off_rev, &c->b_min, &c->b_pos, &c->b_hpc_len, &c->b_err_cell,
                       &c->b_min_total, &c->b_doff, &c->b_left_err, &c->b_lkeys, &c->b_loffs, &c->b_lpost,
                       &c->b_lslot, &c->b_lset_off, &c->b_lset_val, &c->b_keys, &c->b_cnt, &c->b_off, &c->b_fill,
@@ -195,7 +213,9 @@ int ioc_queries_upload(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int6
         return ioc_fail(c, IOC_ERR_ARG, "null query array");
     for (int i = 0; i < n; ++i)
         if (err_cell[i] < 1 || err_cell[i] > 15) return ioc_fail(c, IOC_ERR_ARG, "err_cell outside 1..15");
-    int r = queries_common(c, n, off_fwd, off_rev, total);
+    int r = ioc_wait_uploads(c, 2);
+    if (r != IOC_OK) return r;
+    r = queries_common(c, n, off_fwd, off_rev, total);
     if (r != IOC_OK) return r;
     RESERVE(c, c->b_off_fwd, size_t(n + 1) * 8);
     RESERVE(c, c->b_off_rev, size_t(n + 1) * 8);
@@ -212,8 +232,35 @@ int ioc_queries_upload(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int6
         HIPCHK(c, hipMemcpyAsync(c->b_err_cell.p, err_cell, size_t(n), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->b_min_total.p, min_total, size_t(n) * 4, hipMemcpyHostToDevice, s));
     }
-    if (total > 0) {
-        HIPCHK(c, hipMemcpyAsync(c->b_min.p, min_val, size_t(total) * 4, hipMemcpyHostToDevice, s));
+    // Inside ioc_cluster_merge (defer_uploads: the caller's arrays outlive the call) a large batch sends only what the
+    // index build reads — the forward lists' values — here; the reverse lists' values (the scoring waits for them) and the
+    // positions (the resolve does) follow on a copy stream from a thread of their own, under the first kernels.
+    int64_t head = total;  // values uploaded here: [0, head)
+    if (c->defer_uploads && total >= (int64_t(1) << 21) && env_u32("IOC_UPLOAD_OVERLAP", 1) == 1) {
+        if (n > 0 && off_fwd[0] == 0 && off_rev[0] >= off_fwd[n]) head = off_fwd[n];  // the usual layout: [all forward][all reverse]
+        if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    }
+    if (head > 0) HIPCHK(c, hipMemcpyAsync(c->b_min.p, min_val, size_t(head) * 4, hipMemcpyHostToDevice, s));
+    if (c->copy_stream && c->defer_uploads && total >= (int64_t(1) << 21) && env_u32("IOC_UPLOAD_OVERLAP", 1) == 1) {
+        c->up_err.clear();
+        c->up_stage.store(0, std::memory_order_release);
+        uint32_t* d_min = P<uint32_t>(c->b_min);
+        uint32_t* d_pos = P<uint32_t>(c->b_pos);
+        const int dev = c->device;
+        hipStream_t cs = c->copy_stream;
+        c->up_thread = std::thread([c, dev, cs, d_min, d_pos, min_val, min_pos, head, total] {
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess && total > head)
+                e = hipMemcpyAsync(d_min + head, min_val + head, size_t(total - head) * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipStreamSynchronize(cs);
+            if (e != hipSuccess) c->up_err = hipGetErrorString(e);
+            c->up_stage.store(1, std::memory_order_release);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_pos, min_pos, size_t(total) * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipStreamSynchronize(cs);
+            if (e != hipSuccess && c->up_err.empty()) c->up_err = hipGetErrorString(e);
+            c->up_stage.store(2, std::memory_order_release);
+        });
+    } else if (total > 0) {
         HIPCHK(c, hipMemcpyAsync(c->b_pos.p, min_pos, size_t(total) * 4, hipMemcpyHostToDevice, s));
     }
     HIPCHK(c, hipStreamSynchronize(s));
@@ -239,7 +286,9 @@ int ioc_queries_upload_devmins(ioc_ctx* c, int32_t n, const int64_t* off_fwd, co
         return ioc_fail(c, IOC_ERR_ARG, "null query array");
     for (int i = 0; i < n; ++i)
         if (err_cell[i] < 1 || err_cell[i] > 15) return ioc_fail(c, IOC_ERR_ARG, "err_cell outside 1..15");
-    int r = queries_common(c, n, off_fwd, off_rev, total);
+    int r = ioc_wait_uploads(c, 2);
+    if (r != IOC_OK) return r;
+    r = queries_common(c, n, off_fwd, off_rev, total);
     if (r != IOC_OK) return r;
     RESERVE(c, c->b_off_fwd, size_t(n + 1) * 8);
     RESERVE(c, c->b_off_rev, size_t(n + 1) * 8);
@@ -272,6 +321,10 @@ int64_t ioc_gather_records_device(ioc_ctx* c, int32_t n_idx, const int32_t* entr
     if (!c || n_idx < 0 || (n_idx > 0 && (!entries || !off_fwd || !off_rev))) return IOC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->h_off_fwd.size() != size_t(c->n) + 1 || !c->d_min || !c->d_pos) return ioc_fail(c, IOC_ERR_STATE, "no queries on the device");
+    {
+        const int rw = ioc_wait_uploads(c, 2);
+        if (rw != IOC_OK) return rw;
+    }
     std::vector<int64_t> src(size_t(2) * n_idx + 1), dst(size_t(2) * n_idx + 1);
     std::vector<uint32_t> len(size_t(2) * n_idx + 1);
     int64_t tot = 0;
@@ -516,6 +569,10 @@ int ioc_score(ioc_ctx* c)
     if (!c) return IOC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->built) return ioc_fail(c, IOC_ERR_STATE, "ioc_index_build first");
+    {
+        const int rw = ioc_wait_uploads(c, 1);  // the reverse lists' values may still be on their way (ioc_queries_upload)
+        if (rw != IOC_OK) return rw;
+    }
     const int n = c->n;
     const uint64_t L = uint64_t(c->L);
     const uint64_t capacity = 2ull * L * uint64_t(n) + uint64_t(n) * uint64_t(n > 0 ? n - 1 : 0);
@@ -643,6 +700,10 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     if (!c) return IOC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->scored) return ioc_fail(c, IOC_ERR_STATE, "ioc_score first");
+    {
+        const int rw = ioc_wait_uploads(c, 2);  // the positions (ioc_queries_upload)
+        if (rw != IOC_OK) return rw;
+    }
     const int n = c->n;
     hipStream_t s = c->stream;
     RESERVE(c, c->b_valid0, size_t(n));

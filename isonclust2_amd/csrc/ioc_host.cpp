@@ -707,13 +707,21 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
         if (stats) *stats = ioc_cluster_stats{next, 0, ng, 0, 0, 0};
         return IOC_OK;
     }
+    struct UploadGuard {
+        ioc_ctx* c;
+        ~UploadGuard() { (void)ioc_wait_uploads(c, 2); }
+    } uploads{c};
     if (rb->minimizers_on_device) {
         if (compact) return ioc_fail(c, IOC_ERR_INPUT, "minimizers_on_device: entries skipped by the gates must carry no minimizers");
         r = ioc_queries_upload_devmins(c, n, rb->off_fwd, rb->off_rev, rb->min_val, rb->min_pos, rb->total, rb->hpc_len, cell.data(),
                                        need.data());
     } else if (!compact) {
+        // (the caller's arrays stay valid until this function returns: part of the upload may run under the first kernels;
+        // `uploads` makes sure it has ended on every way out)
+        c->defer_uploads = true;
         r = ioc_queries_upload(c, n, rb->off_fwd, rb->off_rev, rb->min_val, rb->min_pos, rb->total, rb->hpc_len,
                                cell.data(), need.data());
+        c->defer_uploads = false;
     } else {
         // slow path: gated entries that still carry minimizers are given empty lists
         std::vector<int64_t> of(size_t(n) + 1, 0), orv(size_t(n) + 1, 0);

@@ -5,9 +5,11 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -43,6 +45,14 @@ struct ioc_ctx {
     const uint32_t* d_min_total = nullptr;
     DevBuf b_off_fwd, b_off_rev, b_min, b_pos, b_hpc_len, b_err_cell, b_min_total, b_doff;
     int32_t max_fwd = 0, max_rev = 0;
+    // ioc_cluster_merge (caller's arrays valid for the whole call): the index build needs the forward minimizer values
+    // only, the scoring the reverse ones too, the resolve the positions — the latter two go up on a copy stream from a
+    // thread of their own while the first kernels run (ioc_queries_upload, ioc_wait_uploads)
+    bool defer_uploads = false;
+    std::thread up_thread;
+    std::atomic<int> up_stage{2};  // 1: all minimizer values are in HBM, 2: the positions too
+    std::string up_err;
+    hipStream_t copy_stream = nullptr;
 
     // ---- left state ----
     int32_t L = 0;
@@ -120,6 +130,8 @@ struct ioc_ctx {
 };
 
 int ioc_fail(ioc_ctx* c, int code, const std::string& msg);
+// waits until the background upload of the query arrays has reached `stage` (see ioc_ctx::up_stage); 2 also ends the thread
+int ioc_wait_uploads(ioc_ctx* c, int stage);
 
 
 
