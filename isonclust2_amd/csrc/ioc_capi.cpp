@@ -869,6 +869,7 @@ fprintf(stderr, "[ioc eval diag] evals %llu: total %.0f cyc/eval = clear %.0f + 
     c->resolved = true;
     c->warm_first = n;  // nothing has changed since this fixed point
     c->exp_valid = false;
+    c->exp_dev = false;
     return IOC_OK;
 }
 
@@ -1211,21 +1212,18 @@ static int index_export_compute(ioc_ctx* c)
         HIPCHK(c, hipMemcpyAsync(&nrows, d_nrows, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(&total, d_soff + nslots, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        c->exp_keys.resize(nrows);
-        c->exp_offs.resize(size_t(nrows) + 1);
-        c->exp_post.resize(size_t(total));
-        if (nrows) HIPCHK(c, hipMemcpyAsync(c->exp_keys.data(), wk + o_ok, size_t(nrows) * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->exp_offs.data(), d_soff, (size_t(nrows) + 1) * 8, hipMemcpyDeviceToHost, s));  // (soff[nrows] = total)
         lap("keys ordered on the device");
         if (total > 0) {
             RESERVE(c, c->b_exp_out, size_t(total) * 4);
             HIPCHK(c, iock_export_fill(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, c->post16, uint32_t(c->L),
                                        P<int32_t>(c->b_exp_cid), P<uint32_t>(c->b_exp_cnt), P<int64_t>(c->b_exp_off), P<uint32_t>(c->b_exp_out)));
-            HIPCHK(c, hipMemcpyAsync(c->exp_post.data(), c->b_exp_out.p, size_t(total) * 4, hipMemcpyDeviceToHost, s));
         }
-        HIPCHK(c, hipStreamSynchronize(s));
-        lap("fill kernel, keys / offsets / postings to the host");
-        c->exp_valid = true;
+        // (the result stays on the device: ioc_index_export copies it straight into the caller's arrays)
+        c->exp_nrows = nrows;
+        c->exp_total = total;
+        c->exp_o_keys = o_ok;
+        c->exp_o_offs = o_so;  // (soff[nrows] = total)
+        c->exp_dev = true;
         return IOC_OK;
     }
     std::vector<uint32_t> hk(nslots), hcnt(nslots);  // (IOC_EXPORT_HOST_ORDER=1: the keys ordered by the host, for comparison)
@@ -1269,9 +1267,25 @@ int ioc_index_export(ioc_ctx* c, int64_t* n_keys, int64_t* n_postings, uint32_t*
 {
     if (!c) return IOC_ERR_ARG;
     if (!c->resolved) return ioc_fail(c, IOC_ERR_STATE, "ioc_resolve first");
-    if (!c->exp_valid) {
+    if (!c->exp_valid && !c->exp_dev) {
         int r = index_export_compute(c);
         if (r != IOC_OK) return r;
+    }
+    if (!c->exp_valid) {  // on the device: sizes, and — with arrays — three copies into the caller's memory
+        HIPCHK(c, hipSetDevice(c->device));
+        hipStream_t s = c->stream;
+        const double t0 = getenv("IOC_TRACE") ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+        const uint8_t* wk = P<uint8_t>(c->b_exp_work);
+        if (keys && c->exp_nrows) HIPCHK(c, hipMemcpyAsync(keys, wk + c->exp_o_keys, size_t(c->exp_nrows) * 4, hipMemcpyDeviceToHost, s));
+        if (offs) HIPCHK(c, hipMemcpyAsync(offs, wk + c->exp_o_offs, (size_t(c->exp_nrows) + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (postings && c->exp_total) HIPCHK(c, hipMemcpyAsync(postings, c->b_exp_out.p, size_t(c->exp_total) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (getenv("IOC_TRACE") && (keys || offs || postings))
+            fprintf(stderr, "[ioc]   export: keys / offsets / postings to the caller's arrays %8.3f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+        if (n_keys) *n_keys = int64_t(c->exp_nrows);
+        if (n_postings) *n_postings = int64_t(c->exp_total);
+        return IOC_OK;
     }
     const size_t nk = c->exp_keys.size(), np = c->exp_post.size();
     if (keys && nk) memcpy(keys, c->exp_keys.data(), nk * 4);

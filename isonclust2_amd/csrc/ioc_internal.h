@@ -120,7 +120,12 @@ struct ioc_ctx {
     std::map<std::pair<uint64_t, uint64_t>, double> aln_cache;
 
     // ---- ioc_index_export result of the current resolve ----
-    bool exp_valid = false;
+    bool exp_valid = false;   // exp_keys / exp_offs / exp_post hold the export (consensus driver; IOC_EXPORT_HOST_ORDER)
+    bool exp_dev = false;     // the export is ready ON THE DEVICE: exp_nrows keys at b_exp_work + exp_o_keys, exp_nrows + 1 int64
+                              // offsets at + exp_o_offs, exp_total postings in b_exp_out (copied straight into the caller's arrays)
+    uint32_t exp_nrows = 0;
+    uint64_t exp_total = 0;
+    size_t exp_o_keys = 0, exp_o_offs = 0;
     std::vector<uint32_t> exp_keys, exp_post;
     std::vector<int64_t> exp_offs;
 
