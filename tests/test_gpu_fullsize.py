@@ -64,6 +64,33 @@ def test_config2_fast_full(ctx, batches):
     assert ctx.count_reference_postings() == g["stats"]["postings"]
 
 
+def test_config2_other_array_layouts_and_no_upload_overlap(ctx, batches, monkeypatch):
+    """ioc_cluster_merge sends the forward lists' values first and the rest from a copy thread when the arrays are laid out
+    [all forward][all reverse]; any other layout (here: reverse block first), and IOC_UPLOAD_OVERLAP=0, give the same result."""
+    import dataclasses
+    g = GOLD["config2:1"]
+    sb, n = batches(1)
+    v = sb.view
+    of, orv = np.asarray(v["off_fwd"]), np.asarray(v["off_rev"])
+    assert of[0] == 0 and orv[0] == of[-1]                 # the product's own layout
+    nf, nr = int(of[-1]), int(orv[-1] - orv[0])
+    v2 = dict(v)
+    v2["min_val"] = np.concatenate([v["min_val"][nf:nf + nr], v["min_val"][:nf]])
+    v2["min_pos"] = np.concatenate([v["min_pos"][nf:nf + nr], v["min_pos"][:nf]])
+    v2["off_rev"] = orv - nf
+    v2["off_fwd"] = of + nr
+    sb2 = dataclasses.replace(sb, view=v2)
+    p = api.default_params(K, W, "fast")
+    for batch, env in ((sb2, None), (sb, "0")):
+        if env is not None:
+            monkeypatch.setenv("IOC_UPLOAD_OVERLAP", env)
+        cb = pipeline.cluster_single(ctx, p, batch)
+        acl, ast = cb.assignments(sb.batch_start + n)
+        assert cb.n_clusters == g["clusters"]
+        assert f"{fnv1a(acl[sb.read_ids], ast[sb.read_ids]):016x}" == g["fnv1a"]
+        assert len(cb.mindb[2]) == g["stats"]["index_appends"]
+
+
 def test_config2_sahlin_full(ctx, batches):
     g = GOLD["config2:1:sahlin"]
     cb, cls, strand = _single(ctx, batches, 1, "sahlin")
