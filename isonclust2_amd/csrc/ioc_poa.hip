@@ -1064,11 +1064,6 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = size_t(8) << 30;
     for (;;) {
         const size_t have = p->d_int.cap + p->d_dirs.cap + p->d_eb.cap;
-        // (device allocations cost ~0.1 ms per MB: more, smaller batches cost less than a budget of tens of GB —
-        // 10 GB hold ~400 additions of a 2 kb read to a 2.5 k-node graph, more than the chip runs at a time)
-        size_t budget = std::min((free_b + have) / 2, size_t(10) << 30);
-        if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
-        p->reserve_hint = budget + budget / 16;  // (the cells' direction words are 4/5 of it, their E bytes 1/5)
         std::vector<HostJob> jobs, cand;
         std::vector<std::pair<int, int>> who, who_c;
         size_t used = 0;
@@ -1102,6 +1097,16 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
             G.ensure();
             if (!G.planned && !G.nodes.empty()) G.plan();
         }, 48);
+        // The memory budget of a batch: 10 GB (≈ 400 additions of a 2 kb read to a 2.5 k-node graph, more than the chip runs
+        // at a time; freeing and re-allocating tens of GB costs seconds and serialises concurrent processes in the driver),
+        // or what 32 alignments of the round's largest take (a 16.7 kb read against its graph: 1.5 GB — with 10 GB, six to
+        // a batch, such a batch took twice as long), within half of the free memory and 48 GB.
+        size_t largest = 0;
+        for (const HostJob& j : cand)
+            if (!j.G->nodes.empty() && !j.item->seq.empty()) largest = std::max(largest, j.bytes());
+        size_t budget = std::min(std::min((free_b + have) / 2, size_t(48) << 30), std::max(size_t(10) << 30, 32 * largest));
+        if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
+        p->reserve_hint = budget + budget / 16;  // (the cells' direction words are 4/5 of it, their E bytes 1/5)
         for (size_t x = 0; x < cand.size(); ++x) {
             HostJob& j = cand[x];
             if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
