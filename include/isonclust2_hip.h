@@ -158,7 +158,8 @@ int ioc_query_candidates(ioc_ctx* ctx, int32_t query, int32_t cap, int32_t* targ
                          uint32_t* size, uint32_t* first_index, uint32_t* total_mapped);
 
 /* MinDB after clustering (AddMinimizers applied for every query that opened a cluster): CSR with
- * final cluster ids.  Call with keys == NULL to size (n_keys, n_postings). */
+ * final cluster ids, keys ascending.  Call with keys == NULL to size (n_keys, n_postings): the CSR is
+ * built and kept on the device then, and the call with the arrays copies it straight into them. */
 int ioc_index_export(ioc_ctx* ctx, int64_t* n_keys, int64_t* n_postings, uint32_t* keys,
                      int64_t* offs, uint32_t* postings);
 
@@ -340,7 +341,9 @@ int ioc_cluster_batch(ioc_ctx* ctx, const ioc_params* p, const char* table_path,
  * representative is a query against the left MinDB; out_cls[i] = left cluster the right cluster i
  * ends up in (existing id, or a new id >= left->n_clusters in creation order, or -1 if filtered),
  * out_strand[i] = +1 / -1 (-1: every member's MatchStrand flips, :235-246).  left == NULL is
- * ioc_cluster_batch.  ioc_index_export afterwards returns the merged MinDB. */
+ * ioc_cluster_batch.  ioc_index_export afterwards returns the merged MinDB.  (The arrays of `right`
+ * are read until the call returns: a large batch's reverse lists and positions are still being
+ * uploaded, by a thread of the library, while the first kernels run.) */
 int ioc_cluster_merge(ioc_ctx* ctx, const ioc_params* p, const char* table_path, const ioc_left_view* left,
                       const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
                       ioc_cluster_stats* stats);
