@@ -1490,7 +1490,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
     // one on every SIMD of its CU, whereas one-wave workgroups were seen three to a SIMD on some CUs (each of them then
     // half as fast: 14.5 against 7.6 ms) while other SIMDs held one.  No workgroup barrier anywhere: a wave only ever
     // reads what it wrote itself, in program order.
-    __shared__ uint16_t dirs_all[TR_WAVES][TILE * TR_C / 4][64];  // TR_C nibbles per lane and row (TILE 128: two rows share a word)
+    __shared__ uint16_t dirs_all[TR_WAVES][TILE * TR_C / 4][64];  // TR_C nibbles per lane and row (TILE 128: used as bytes [row][lane])
     __shared__ int2 s_left_all[TR_WAVES][TILE];
     __shared__ uint32_t s_q_all[TR_WAVES][TILE];
     const uint32_t wv = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));  // uniform: the pair's state stays in SGPRs
@@ -1631,7 +1631,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 if (TR_C == 4)
                     dirs[ri][lane] = uint16_t(bits);
                 else
-                    reinterpret_cast<uint8_t*>(&dirs[ri >> 1][lane])[ri & 1] = uint8_t(bits);
+                    reinterpret_cast<uint8_t*>(&dirs[0][0])[uint32_t(ri) * 64u + lane] = uint8_t(bits);  // (TILE 128: a byte per lane and row, row-major)
             }
             out_h = hl;
             out_e = el;
@@ -1662,7 +1662,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
             const uint32_t cj = j - c0 - 1;
             const uint32_t ri = i - r0 - 1;
             const uint32_t t = TR_C == 4 ? (uint32_t(dirs[ri][cj / TR_C]) >> (4 * (cj % TR_C))) & 0xFu
-                                         : (uint32_t(dirs[ri >> 1][cj / TR_C]) >> (8 * (ri & 1) + 4 * (cj % TR_C))) & 0xFu;
+                                         : (uint32_t(reinterpret_cast<const uint8_t*>(&dirs[0][0])[ri * 64u + cj / TR_C]) >> (4 * (cj % TR_C))) & 0xFu;
             if (state == 0) {
                 // look ahead along the diagonal: lane l reads the cell l steps up-left; the run of diagonal moves
                 // from here on goes into the window counter at once
@@ -1671,7 +1671,7 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
                 if (inr) {
                     const uint32_t rl = ri - lane, cl = cj - lane;
                     tl = (TR_C == 4 ? (uint32_t(dirs[rl][cl / TR_C]) >> (4 * (cl % TR_C)))
-                                    : (uint32_t(dirs[rl >> 1][cl / TR_C]) >> (8 * (rl & 1) + 4 * (cl % TR_C)))) & 3u;
+                                    : (uint32_t(reinterpret_cast<const uint8_t*>(&dirs[0][0])[rl * 64u + cl / TR_C]) >> (4 * (cl % TR_C)))) & 3u;
                 }
                 const bool dgl = inr && (tl == 0u || tl == 3u);
                 const unsigned long long dm = __ballot(dgl);
