@@ -1536,7 +1536,8 @@ k_align_trace(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__
         // equal to E*, else from F) — 18 VALU per cell where the unslanted form took 24.  This kernel is bound by VALU
         // issue on the SIMDs that hold two of its waves.
         const int gd = go - P.gap_extend, ge = P.gap_extend;
-        const int cm = P.match + 2 * ge + gd, cx = P.mismatch + 2 * ge + gd;
+        int cm = P.match + 2 * ge + gd, cx = P.mismatch + 2 * ge + gd;
+        asm volatile("" : "+v"(cm), "+v"(cx));  // kept in VGPRs: the select below cannot take two scalars, and the compiler would copy them over in every step
         for (uint32_t x = lane; x < rows; x += 64) {
             s_q[x] = q[r0 + x];
             int2 le{ge * int(r0 + x + 1) - gd, ALN_NEG};  // column 0: H = 0, no gap to extend
