@@ -814,6 +814,11 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         a.lazy = 0;
         first = c->warm_first;
     }
+    // The first exact sweep after the lazy fixed point would repeat, for every query and on the very `valid` the last lazy
+    // sweeps ran on, the first half of a sweep (top, cut, the maximal-Size candidates: all cached): only its second half
+    // runs — the rest of the walk of the queries the lazy sweeps let open a cluster provisionally (their `done` is 0).
+    const bool skip_p1 = env_u32("IOC_RESOLVE_SKIP_P1", 1) == 1;
+    bool p2only = false;
     while (n > 0) {
         if (first >= n) {
             // every query up to the last one is final for THIS stage: a lazy stage that ends on a change of the
@@ -821,22 +826,27 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
             if (!a.lazy) break;
             a.lazy = 0;
             first = 0;
+            p2only = skip_p1;
         }
         uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
         uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
         const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
         HIPCHK(c, hipMemcpyAsync(d_first_changed, init, 16, hipMemcpyHostToDevice, s));
-        HIPCHK(c, iock_copy_prefix_valid(s, first, vin, vout));
+        HIPCHK(c, iock_copy_prefix_valid(s, p2only ? n : first, vin, vout));  // (second half only: `done` queries write nothing)
         a.first = first;
         a.valid_in = vin;
         a.valid_out = vout;
-        HIPCHK(c, iock_decide_sweep(s, &a, n - first, eval_blocks, P<uint32_t>(c->b_misc) + 11));
+        if (p2only)
+            HIPCHK(c, iock_decide_phase2(s, &a, n, eval_blocks, P<uint32_t>(c->b_misc) + 11));
+        else
+            HIPCHK(c, iock_decide_sweep(s, &a, n - first, eval_blocks, P<uint32_t>(c->b_misc) + 11));
         uint32_t res[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(res, d_first_changed, 12, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         sweeps++;
         if (sweeps > 4 * n + 64) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
         if (res[2] != 0) continue;  // work queue overflowed: same sweep again, the cache is fuller now
+        p2only = false;
         iters++;
         c->cur_valid ^= 1;
         const uint32_t fc = res[0];
@@ -844,6 +854,7 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
             if (a.lazy) {  // lazy fixed point reached: switch to the exact sweeps
                 a.lazy = 0;
                 first = 0;
+                p2only = skip_p1;
                 continue;
             }
             break;  // fixed point: valid_out == valid_in

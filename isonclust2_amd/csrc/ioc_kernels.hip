@@ -1702,6 +1702,7 @@ k_decide_pick(DecideArgs a)
     int8_t out_s = 0;
     uint8_t out_f = 0;
     bool decided = true;
+    bool provisional = false;  // a lazy sweep's cluster opener by default: decision written, walk not finished (done stays 0)
     __shared__ uint32_t s_tn, s_tk[IOC_TIE_SLOTS];
     if (a.tie_count) {
         if (threadIdx.x == 0) s_tn = 0;
@@ -1791,6 +1792,7 @@ k_decide_pick(DecideArgs a)
                 // unless this is a lazy sweep, which provisionally lets the query open a cluster (what
                 // almost always happens) and leaves the rest of the walk to the final exact sweeps
                 if (a.phase == 1 && !a.lazy) decided = false;
+                if (a.phase == 1 && a.lazy) provisional = true;
             }
             if (miss) decided = false;
         }
@@ -1800,7 +1802,7 @@ k_decide_pick(DecideArgs a)
             a.tie_count[j] = (cut != IOC_CUT_NEG) ? s_tn : 0u;
             for (int t = 0; t < IOC_TIE_SLOTS; ++t) a.tie_keys[size_t(j) * IOC_TIE_SLOTS + t] = s_tk[t];
         }
-        a.done[j] = decided ? 1 : 0;
+        a.done[j] = (decided && !provisional) ? 1 : 0;
         if (decided) {
             const uint8_t nv = (out_t < 0) ? 1 : 0;
             a.dec_target[j] = out_t;
@@ -2237,6 +2239,21 @@ hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int
     hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     if (a.lazy) return hipGetLastError();
+    a.phase = 2;
+    a.q_count = q_count2;
+    hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+// the second half of an exact sweep alone: for the queries the last lazy sweep left provisional (done == 0), on the cut / top
+// that sweep computed
+hipError_t iock_decide_phase2(hipStream_t st, const void* args_, int nblocks, int eval_blocks, uint32_t* q_count2)
+{
+    if (nblocks <= 0) return hipSuccess;
+    DecideArgs a = *reinterpret_cast<const DecideArgs*>(args_);
+    a.lazy = 0;
     a.phase = 2;
     a.q_count = q_count2;
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
