@@ -480,7 +480,7 @@ int ioc_index_build(ioc_ctx* c)
     RESERVE(c, c->b_dcount, size_t(n) * 4);
     RESERVE(c, c->b_misc, 256);
     HIPCHK(c, iock_distinct(s, n, c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals),
-                            P<uint32_t>(c->b_dcount), pmax));
+                            P<uint32_t>(c->b_dcount), pmax, c->params.k >= 1 && c->params.k <= 16 ? 2 * c->params.k : 32));
 
     // ---- hash table sizing: distinct keys <= min(entries, 4^k); HPC sequences have no equal
     // neighbours, so at most 4*3^(k-1) distinct k-mers occur — used as the first guess only.

@@ -66,7 +66,7 @@ struct DecideArgs {
 
 extern "C" {
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
-                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax);
+                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits);
 hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
                                     const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
                                     uint32_t* cnt, uint32_t* dslot, uint32_t* dpos, uint32_t* err);
