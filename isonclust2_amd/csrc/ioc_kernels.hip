@@ -2126,7 +2126,7 @@ hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const ui
 {
     if (n <= 0) return hipSuccess;
     size_t lds = size_t(pmax) * 4;
-    static const bool radix = !(getenv("IOC_DISTINCT_BITONIC") && atoi(getenv("IOC_DISTINCT_BITONIC")) == 1);
+    const bool radix = !(getenv("IOC_DISTINCT_BITONIC") && atoi(getenv("IOC_DISTINCT_BITONIC")) == 1);  // (=1: round 1's bitonic network, for comparison)
     if (radix && pmax <= IOC_BLOCK * IOC_DR_PER && IOC_BLOCK == 256) {
         const uint32_t pm = pmax < IOC_BLOCK ? IOC_BLOCK : pmax;
         lds = size_t(pm) * 4;

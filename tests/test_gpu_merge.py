@@ -54,6 +54,23 @@ def test_index_export_equals_oracle_mindb(ctx, cfg, seed):
     assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
 
 
+def test_distinct_by_radix_sort_equals_the_bitonic_network(ctx, monkeypatch):
+    """k_distinct_radix (reads of up to 8192 forward minimizers) and k_distinct (longer ones; IOC_DISTINCT_BITONIC=1 forces it)
+    feed the same index: same assignments, same exported MinDB."""
+    rs = synth.generate_config("config1", seed=4)
+    _, sbs = _batches(rs, 1)
+    p = api.default_params(11, 15, "fast")
+    a = pipeline.cluster_single(ctx, p, sbs[0])
+    monkeypatch.setenv("IOC_DISTINCT_BITONIC", "1")
+    b = pipeline.cluster_single(ctx, p, sbs[0])
+    assert a.n_clusters == b.n_clusters
+    for x, y in zip(a.mindb, b.mindb):
+        assert np.array_equal(x, y)
+    ca, sa = a.assignments(rs.n)
+    cb, sb_ = b.assignments(rs.n)
+    assert np.array_equal(ca, cb) and np.array_equal(sa, sb_)
+
+
 def test_index_export_ordered_on_the_device_equals_the_host_ordered_one(ctx, monkeypatch):
     """ioc_index_export orders the keys on the device (ioc_sort.hip); IOC_EXPORT_HOST_ORDER=1 is the host's std::sort
     of round 2's first version: same CSR, also for a merge (left lists + right lists in one index)."""
