@@ -516,7 +516,7 @@ static_assert(FW_R == 4, "the look-ahead hands 4 rows per step to lane 0 (one 16
 #define IOC_TR_STEP_UNROLL 2
 #endif
 #ifndef IOC_FWD_STEP_UNROLL
-#define IOC_FWD_STEP_UNROLL 2
+#define IOC_FWD_STEP_UNROLL 4
 #endif
 template <bool PROF>
 __global__ void __launch_bounds__(64 * ALN_MAXW) __attribute__((amdgpu_waves_per_eu(IOC_FWD_WAVES_PER_EU, 8)))
@@ -849,7 +849,27 @@ k_align_fwd(const AlnPairDev* __restrict__ pairs, const uint32_t* __restrict__ o
             };
             {
                 uint32_t s = 0;
-#if IOC_FWD_STEP_UNROLL == 2
+#if IOC_FWD_STEP_UNROLL == 8
+                for (; s + 7u < nsteps; s += 8) {
+                    step(s);
+                    step(s + 1u);
+                    step(s + 2u);
+                    step(s + 3u);
+                    step(s + 4u);
+                    step(s + 5u);
+                    step(s + 6u);
+                    step(s + 7u);
+                }
+#endif
+#if IOC_FWD_STEP_UNROLL >= 4
+                for (; s + 3u < nsteps; s += 4) {
+                    step(s);
+                    step(s + 1u);
+                    step(s + 2u);
+                    step(s + 3u);
+                }
+#endif
+#if IOC_FWD_STEP_UNROLL >= 2
                 for (; s + 1u < nsteps; s += 2) {
                     step(s);
                     step(s + 1u);
