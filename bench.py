@@ -240,6 +240,120 @@ def cpu_baseline_sahlin(ctx_factory, api, pipeline, rs, order, k, w, sample, max
     return min(times), times, st, mism, sub.n, pin.core
 
 
+_NODE_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+os.sched_setaffinity(0, {{{core}}})
+from isonclust2_amd import synth
+from oracle import pyoracle as po
+rs = synth.generate_config({config!r}, seed={seed})
+R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+R.score_sort({k}, {w})
+B = po.Batch(R, 0, rs.n - 1, po.default_params({k}, {w}))
+print("READY", flush=True)
+sys.stdin.readline()
+t0 = time.perf_counter()
+st = B.cluster(mode="fast")
+dt = time.perf_counter() - t0
+print(json.dumps({{"seed": {seed}, "core": {core}, "seconds": dt, "clusters": B.n_clusters(), "reads": rs.n}}), flush=True)
+"""
+
+
+def cpu_baseline_node(config, k, w, max_procs=8):
+    """SURVEY §8(d) / BASELINE.md §3: the reference's `cluster` is single-threaded, so a NODE runs P single-batch processes on
+    P cores (configs[3]: one batch per process, seeds 1..P).  Here: P oracle processes, each pinned to a core of its own,
+    prepared first (reads, sort stage) and released together; node throughput = all reads / the slowest process."""
+    cores = sorted(os.sched_getaffinity(0))
+    P = min(max_procs, len(cores))
+    if P < 1:
+        return None
+    procs = []
+    try:
+        for i in range(P):
+            code = _NODE_CHILD.format(root=ROOT, core=cores[-1 - i], config=config, seed=1 + i, k=k, w=w)
+            procs.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for pr in procs:
+            if pr.stdout.readline().strip() != "READY":
+                raise RuntimeError("a CPU-baseline child did not come up")
+        t0 = time.perf_counter()
+        for pr in procs:
+            pr.stdin.write("go\n")
+            pr.stdin.flush()
+        res = [json.loads(pr.stdout.readline()) for pr in procs]
+        wall = time.perf_counter() - t0
+        for pr in procs:
+            pr.wait(timeout=60)
+    except Exception as e:  # noqa: BLE001
+        for pr in procs:
+            pr.kill()
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    reads = sum(r["reads"] for r in res)
+    return {"value": reads / wall, "unit": "reads/s", "cores": P, "processes": P, "kind": "port", "mode": "fast", "cpu_model": cpu_model(),
+            "seconds_per_process": [round(r["seconds"], 2) for r in res], "wall_s": round(wall, 2),
+            "sample": f"{P} concurrent single-batch oracle processes (the batches of seeds 1..{P} of {config}: configs[3]'s shape), each pinned "
+                      f"to one core, fast mode, ClusterSortedReads region, released together; value = {reads} reads / the wall time of "
+                      "the slowest; the sahlin leg is not repeated at node level (a read that reaches the scalar aligner costs ~0.5 s: "
+                      "P times the single-core sample at best)"}
+
+
+def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode, torch_merge, timeout_s=240):
+    """The same merge once more through the library's OWN multi-GPU binding (csrc/ioc_dist.cpp: ncclCommInitRank, ragged
+    all-gather as grouped broadcasts, one-pass merge — all in C++), after re-clustering the batch so that its
+    representatives' lists are device-resident again.  Runs in a thread with a deadline: a communicator that does not come
+    up must not cost the bench line."""
+    import threading
+    from isonclust2_amd.digest import fnv1a_reads
+    out = {}
+
+    def work():
+        try:
+            p = api.default_params(k, w, mode)
+            view = sb.view if mode != "fast" else {kk: vv for kk, vv in sb.view.items() if kk not in ("raw_seq", "raw_off")}
+            cb2 = pipeline.cluster_single(ctx, p, pipeline.SortedBatch(view=view, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
+                                                                       batch_start=sb.batch_start, batch_end=sb.batch_end))
+            idist.native_init(ctx, dist, torch)
+            tm = {}
+            t0 = time.perf_counter()
+            mg = idist.merge_all_native(ctx, p, cb2, torch, timing=tm)
+            wall = (time.perf_counter() - t0) * 1e3
+            out.update(clusters_out=mg.n_clusters, reads_assigned=int(len(mg.member_read)), fnv1a=fnv1a_reads(mg),
+                       equals_torch_path=bool(fnv1a_reads(mg) == torch_merge.get("fnv1a") and mg.n_clusters == torch_merge.get("clusters_out")),
+                       wall_ms=idist.max_over_ranks(wall, dist), exchange_lists_ms=idist.max_over_ranks(tm["exchange_lists_ms"], dist),
+                       merge_ms=idist.max_over_ranks(tm["merge_ms"], dist), bytes_lists_this_rank=tm["bytes_lists"],
+                       bytes_records_this_rank=tm["bytes_records"],
+                       binding="C++ over RCCL inside libisonclust2_hip.so (ioc_dist_init / ioc_dist_merge); lists HBM to HBM, "
+                               "ragged all-gather = one ncclBroadcast per rank in one group")
+        except Exception as e:  # noqa: BLE001
+            out["error"] = f"{type(e).__name__}: {e}"[:400]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"error": f"no result within {timeout_s} s (left running; the process exits without joining it)", "timed_out": True}
+    return out
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` on its own: start N ranks (one process per GPU, torch.distributed.run, RCCL) as CHILD
+    processes and pass their one JSON line through.  Nothing here touches a GPU (counting devices does not initialise
+    HIP), so no process that owns a GPU is ever replaced."""
+    import socket
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus and a.backend == "nccl":
+        print(json.dumps({"error": f"--gpus {a.gpus} but {ndev} GPU(s) are visible: RCCL needs one device per rank "
+                                   "(--backend gloo lets ranks share a device: plumbing rehearsal only)", "n_gpus": a.gpus}), flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,7 +363,7 @@ def main():
     ap.add_argument("--mode", default="both", choices=["both", "fast", "sahlin"],
                     help="both (default): headline = sahlin mode (BASELINE.json's metric, configs[2]) with the fast-mode "
                          "result (configs[1]) of the same batch beside it; fast / sahlin = that mode only")
-    ap.add_argument("--cpu-sample", type=int, default=200, help="sahlin: reads in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="sahlin: reads in the CPU-baseline sample (a read that reaches the fallback costs ~0.5 s of scalar alignment)")
     ap.add_argument("--cpu-runs", type=int, default=3, help="CPU baseline: at most this many runs (min is reported)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="CPU baseline: seconds per leg after which no further run starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,7 +374,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-merge", action="store_true", help="N > 1: skip the merge of the ranks' batches after the timed region")
     ap.add_argument("--merge", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--no-native-merge", action="store_true", help="N > 1: skip the second merge leg through the library's own C++ / RCCL binding (ioc_dist_merge)")
+    ap.add_argument("--no-cpu-node", action="store_true", help="skip the node-level CPU leg (P concurrent single-batch oracle processes on P cores)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -366,8 +485,12 @@ def main():
         if want_sahlin:
             core["sahlin"], cb = core_region(ctx, api, pipeline, sb, k, w, "sahlin", 1 if a.no_core else 3)
             cb_merge = cb
+        from isonclust2_amd import dist as idist_
         for m in core:
             core[m]["reads_per_s"] = rs.n / (core[m]["ms_min"] * 1e-3)
+            # the job: every rank's batch, the slowest rank's time (ranks run their core regions side by side)
+            core[m]["ms_min_max_over_ranks"] = idist_.max_over_ranks(core[m]["ms_min"], dist)
+            core[m]["reads_per_s_job"] = total_reads / (core[m]["ms_min_max_over_ranks"] * 1e-3)
 
     # ---- merge of the ranks' batches (configs[3]): the one exchange step of the path ----
     merge = None
@@ -379,6 +502,8 @@ def main():
         except Exception as e:  # noqa: BLE001  (the merge runs after the timed region: the bench line still goes out)
             merge = {"error": f"{type(e).__name__}: {e}"[:400]}
         merge["mode"] = mode
+        if "error" not in merge and not a.no_native_merge and a.backend == "nccl":
+            merge["native_rccl"] = native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb_merge, k, w, mode, merge)
         g4 = golden.get(f"config4:{mode}")
         if "error" not in merge and g4 is not None and not a.same_seed and a.config == "config2" and 2 <= world <= len(g4["seeds"]):
             # the left fold of the first `world` batches is a prefix of the 8-batch fold: cluster counts after every step
@@ -442,6 +567,9 @@ def main():
                                        "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 -DNDEBUG "
                                                  f"-msse3, min of {len(times)} run(s), 1 pinned core; {ost['aln_invoked']} reads reach the fallback"}
                 sah["parity"] = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
+        cpu_node = None
+        if single and not a.no_cpu_node:
+            cpu_node = cpu_baseline_node(a.config, k, w)
         cli = None
         if world == 1 and not a.no_cli:
             cli = {}
@@ -467,13 +595,25 @@ def main():
             "roofline": roof if roof is not None else roof_aln,
             "cpu_baseline": head.get("cpu_baseline"), "parity": head.get("parity"),
             "core": core or None, "cli": cli, "merge": merge, "golden_parity": rank_parity or None,
+            "cpu_baseline_node": cpu_node,
         }
+        if core.get(head_mode):
+            # SURVEY §8(d)'s *core* region beside the resident `value` (bench contract: `value` has its inputs resident in HBM, a
+            # PCIe-inclusive rate is never `value`): host arrays -> assignments + MinDB in host arrays, every rank its batch
+            out["value_core"] = core[head_mode]["reads_per_s_job"]
+            out["value_core_region"] = ("core: ioc_cluster_merge + ioc_index_export from host arrays, H2D of the minimizer SoA (+ sequences) and "
+                                        "every D2H inside; min of 3 runs per rank, all ranks' reads / the slowest rank's time")
+            if head.get("cpu_baseline"):
+                out["value_core_vs_cpu_baseline"] = out["value_core"] / head["cpu_baseline"]["value"]
         if head_mode == "sahlin":
             out["alignment"] = sah["alignment"]
             out["roofline_align"] = roof_aln
             if fast is not None:
                 out["fast_mode"] = fast       # BASELINE.json configs[1] on the same batch
         print(json.dumps(out), flush=True)
+    if merge and isinstance(merge.get("native_rccl"), dict) and merge["native_rccl"].get("timed_out"):
+        sys.stdout.flush()
+        os._exit(0)          # a rank is still inside RCCL in the abandoned thread: no orderly shutdown to be had
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -150,6 +150,11 @@ int ioc_set_aln_verdicts(ioc_ctx* ctx, const int32_t* target, const int8_t* stra
 #define IOC_TIE_SLOTS 16
 int ioc_get_ties(ioc_ctx* ctx, uint32_t* count, uint32_t* keys);
 
+/* The candidate list the SCORING kernels wrote for query q (before any resolve): key = target << 1 | strand (strand bit
+ * 1 = reverse), size = Size, for every (target, strand) with Size >= int(MinShared * MinFraction), in target order.
+ * Returns the count (copies at most cap).  Test instrument: lets the two builds of the scoring kernel (with / without the
+ * per-posting window test, ioc_timings::score_oob) be compared histogram by histogram. */
+int ioc_scored_candidates(ioc_ctx* ctx, int32_t q, int32_t cap, uint32_t* key, uint32_t* size);
 /* Full candidate table of one query against the targets that are clusters under the current
  * decisions, in the fields the reference's hit map holds (src/minimizer.cpp:44-76): target id,
  * strand, Size, Index of the first hitting read minimizer, and totalMapped (0xFFFFFFFF if not
@@ -205,6 +210,13 @@ typedef struct {
     int64_t n_align_pairs;
     int64_t n_align_cells;     /* sum of query length x reference length     */
     int64_t n_align_refused;   /* pairs the packed 16-bit forward pass handed to the 32-bit one */
+    /* the scoring kernel's variant (decided once, in ioc_ctx_create): 1 = counters at the end of the LDS allocation, no
+     * window test (the hardware's bounds check drops what the test would reject), 0 = window test per posting.
+     * score_oob_probe: result of the context's run-time probe of that hardware behaviour — 0 passed, > 0 failed (bit 0 a
+     * word of some workgroup's LDS changed, bit 1 an in-bounds counter lost an add, bit 2 the probe did not finish),
+     * -1 not run (IOC_SCORE_OOB=0 / 1 forces the variant).  A failed probe selects variant 0. */
+    int32_t score_oob;
+    int32_t score_oob_probe;
 } ioc_timings;
 int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
 /* Instrumentation (one extra scoring launch, outside any timed region): the number of postings the
@@ -263,6 +275,10 @@ int ioc_align_pairs(ioc_ctx* ctx, int32_t n_pairs, const ioc_aln_pair* pairs, in
  * contributes to the merge's all-gather — the representatives' records never leave HBM (src/cluster.cpp:537: a right
  * cluster is matched through its representative's Mins / RevMins).  off_fwd / off_rev [n_idx + 1] (host) receive the
  * offsets; cap = capacity of the two buffers in words.  Returns the number of words written or a negative status. */
+/* Generation of the context's queries: changes whenever they are replaced (ioc_queries_upload, ioc_queries_bind_device,
+ * ioc_queries_from_extracted, every ioc_cluster_* driver call).  A caller that keeps entry numbers of a batch for a later
+ * ioc_gather_records_device compares the value it saw after the clustering call. */
+int64_t ioc_queries_generation(const ioc_ctx* ctx);
 int64_t ioc_gather_records_device(ioc_ctx* ctx, int32_t n_idx, const int32_t* entries, uint32_t* d_out_min,
                                   uint32_t* d_out_pos, int64_t cap, int64_t* off_fwd, int64_t* off_rev);
 
@@ -437,6 +453,47 @@ int ioc_cluster_resident(ioc_ctx* ctx, int32_t* out_cls, int8_t* out_strand, ioc
 /* Raw sequences (RawSeq->Str(), concatenated; raw_off[n + 1]) and raw error rates of the resident
  * queries, for the alignment fallback of sahlin mode (cluster.cpp:491-497). */
 int ioc_resident_set_sequences(ioc_ctx* ctx, const char* raw_seq, const int64_t* raw_off, const double* raw_err);
+
+/* ---- multi-GPU: the merge's exchange step over RCCL; one process and one context per GPU -------------
+ * Initial clustering shards batches one per GPU and needs no communication (the reference pipeline runs one `cluster`
+ * process per batch, README.md:105-117).  The merge (`cluster -l L -r R`, src/cluster.cpp:67-322 with two batches) matches a
+ * right cluster through its representative's Mins / RevMins (src/cluster.cpp:537-539): what travels between GPUs is the
+ * representatives' records.  A context owns one communicator; rank 0 makes the id and the host program ships its 128 bytes
+ * to the other ranks however it likes (a file, a socket, MPI, torch.distributed). */
+#define IOC_DIST_ID_BYTES 128
+int ioc_dist_unique_id(uint8_t* id /* [IOC_DIST_ID_BYTES] */);
+int ioc_dist_init(ioc_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world);   /* ncclCommInitRank on the context's device */
+int ioc_dist_shutdown(ioc_ctx* ctx);
+int ioc_dist_info(const ioc_ctx* ctx, int32_t* rank, int32_t* world);              /* (0, 1) without a communicator */
+/* collectives on the context's stream.  *_device: device buffers, HBM to HBM; the others stage host data through HBM and
+ * return when the result is in the caller's arrays. */
+int ioc_dist_allgather_device(ioc_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+/* ragged: rank r contributes counts[r] elements of esize bytes, landing at d_recv + displs[r] * esize on every rank; a
+ * rank's d_send may be its own slot of d_recv.  counts / displs [world]: host arrays, identical on every rank. */
+int ioc_dist_allgatherv_device(ioc_ctx* ctx, const void* d_send, void* d_recv, const int64_t* counts, const int64_t* displs,
+                               int32_t esize);
+int ioc_dist_allgather_i64(ioc_ctx* ctx, int64_t mine, int64_t* all /* [world] */);
+/* ragged host records in rank order; sizes [world] receives the byte counts (recv == NULL: only the sizes) */
+int ioc_dist_allgatherv_host(ioc_ctx* ctx, const void* send, int64_t bytes, void* recv, int64_t* sizes);
+int ioc_dist_allreduce_max(ioc_ctx* ctx, double* x);
+int ioc_dist_barrier(ioc_ctx* ctx);
+typedef struct {
+    float ms_exchange_lists;   /* the four ragged all-gathers of the minimizer lists (HIP events on the stream) */
+    double ms_merge;           /* the one-pass merge on this rank (wall) */
+    int64_t bytes_lists;       /* this rank's contribution: minimizer lists ... */
+    int64_t bytes_records;     /* ... and per-representative records + raw sequences */
+} ioc_dist_merge_times;
+/* The merge of ALL ranks' freshly clustered batches (Depth 0), on every rank: the left fold ((b0 + b1) + b2) ... in rank order
+ * makes the decisions of ONE greedy loop over the representatives of b0, b1, ... in which b0's are clusters from the start
+ * (ioc_batch_view::is_cluster: src/cluster.cpp:178-217 only appends).  reps = THIS rank's cluster representatives, one record
+ * each in cluster order (compact lists; min_val / min_pos host or device per reps->minimizers_on_device — e.g. the output of
+ * ioc_gather_records_device; raw_seq / raw_off for sahlin / furious).  out_counts [world] receives the clusters of every
+ * rank; out_cls / out_strand [sum of counts] the decision for every gathered representative in rank order, as
+ * ioc_cluster_merge reports them (call with out_cls == NULL to learn the counts first).  ioc_index_export afterwards returns
+ * the merged MinDB. */
+int ioc_dist_merge(ioc_ctx* ctx, const ioc_params* p, const char* table_path, const ioc_batch_view* reps, int32_t min_cls_size,
+                   int64_t out_cap, int32_t* out_cls, int8_t* out_strand, int64_t* out_counts, ioc_cluster_stats* stats,
+                   ioc_dist_merge_times* times);
 
 #ifdef __cplusplus
 }

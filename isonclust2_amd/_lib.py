@@ -85,6 +85,10 @@ class AlnPair(C.Structure):  # ioc_aln_pair
                 ("e", C.c_double)]
 
 
+class DistMergeTimes(C.Structure):  # ioc_dist_merge_times
+    _fields_ = [("ms_exchange_lists", C.c_float), ("ms_merge", C.c_double), ("bytes_lists", C.c_int64), ("bytes_records", C.c_int64)]
+
+
 class Timings(C.Structure):
     _fields_ = [("ms_build", C.c_float), ("ms_score", C.c_float), ("ms_resolve", C.c_float),
                 ("resolve_iters", C.c_int32), ("n_queries", C.c_int32), ("n_minimizers", C.c_int64),
@@ -92,7 +96,7 @@ class Timings(C.Structure):
                 ("n_mapped_evals", C.c_int64), ("postings_traversed", C.c_int64),
                 ("ms_align_fwd", C.c_float), ("ms_align_trace", C.c_float), ("n_align_pairs", C.c_int64),
                 ("n_align_cells", C.c_int64),
-                ("n_align_refused", C.c_int64)]
+                ("n_align_refused", C.c_int64), ("score_oob", C.c_int32), ("score_oob_probe", C.c_int32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -110,7 +114,10 @@ SYMBOLS = [
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
     "ioc_index_update", "ioc_left_export", "ioc_cluster_consensus",
     "ioc_poa_create", "ioc_poa_destroy", "ioc_poa_bind", "ioc_poa_graph_export", "ioc_poa_last_alignment",
-    "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_gather_records_device",
+    "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_gather_records_device", "ioc_queries_generation", "ioc_scored_candidates",
+    "ioc_dist_unique_id", "ioc_dist_init", "ioc_dist_shutdown", "ioc_dist_info", "ioc_dist_allgather_device",
+    "ioc_dist_allgatherv_device", "ioc_dist_allgather_i64", "ioc_dist_allgatherv_host", "ioc_dist_allreduce_max",
+    "ioc_dist_barrier", "ioc_dist_merge",
 ]
 
 _lib = None
@@ -147,6 +154,9 @@ def load():
     L.ioc_queries_bind_device.argtypes = [vp, i32, vp, vp, vp, vp, i64, vp, vp, vp, pi64, pi64]
     L.ioc_gather_records_device.argtypes = [vp, i32, pi32, vp, vp, i64, pi64, pi64]
     L.ioc_gather_records_device.restype = i64
+    L.ioc_scored_candidates.argtypes = [vp, i32, i32, pu32, pu32]
+    L.ioc_queries_generation.argtypes = [vp]
+    L.ioc_queries_generation.restype = i64
     L.ioc_left_load.argtypes = [vp, i32, pu8, i64, pu32, pi64, pu32]
     L.ioc_index_update.argtypes = [vp, i32, pu32, i64, pu32, i64, C.c_uint8]
     L.ioc_left_export.argtypes = [vp, pi64, pi64, pu32, pi64, pu32]
@@ -198,5 +208,17 @@ def load():
     L.ioc_align_set_pool.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_int64)]
     L.ioc_align_pairs.argtypes = [vp, i32, C.POINTER(AlnPair), i32, i32, i32, i32, pi32, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double)]
+    L.ioc_dist_unique_id.argtypes = [pu8]
+    L.ioc_dist_init.argtypes = [vp, pu8, i32, i32]
+    L.ioc_dist_shutdown.argtypes = [vp]
+    L.ioc_dist_info.argtypes = [vp, pi32, pi32]
+    L.ioc_dist_allgather_device.argtypes = [vp, vp, vp, i64]
+    L.ioc_dist_allgatherv_device.argtypes = [vp, vp, vp, pi64, pi64, i32]
+    L.ioc_dist_allgather_i64.argtypes = [vp, i64, pi64]
+    L.ioc_dist_allgatherv_host.argtypes = [vp, vp, i64, vp, pi64]
+    L.ioc_dist_allreduce_max.argtypes = [vp, pd]
+    L.ioc_dist_barrier.argtypes = [vp]
+    L.ioc_dist_merge.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(BatchView), i32, i64, pi32, pi8, pi64,
+                                 C.POINTER(ClusterStats), C.POINTER(DistMergeTimes)]
     _lib = L
     return L

@@ -52,7 +52,12 @@ class Context:
             raise IocError(rc, "ioc_ctx_create failed (no MI355X visible?)")
         self.h = h
         self._keep = []
-        self.serial = 0      # bumped whenever the context's queries are replaced
+
+    @property
+    def serial(self):
+        """Generation of the context's queries, kept by the LIBRARY (ioc_queries_generation): it changes with every call
+        that replaces them, whichever method made it."""
+        return int(self.L.ioc_queries_generation(self.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -144,6 +149,13 @@ class Context:
         n = self._chk(self.L.ioc_query_candidates(self.h, q, cap, _p(t, C.c_int32), _p(s, C.c_int8),
                                                   _p(sz, C.c_uint32), _p(fi, C.c_uint32), _p(tm, C.c_uint32)))
         return t[:n], s[:n], sz[:n], fi[:n], tm[:n]
+
+    def scored_candidates(self, q, cap=1 << 16):
+        """(key, size) the scoring kernels wrote for query q: key = target << 1 | strand."""
+        key, size = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        m = self._chk(self.L.ioc_scored_candidates(self.h, q, cap, _p(key, C.c_uint32), _p(size, C.c_uint32)))
+        assert m <= cap
+        return key[:m], size[:m]
 
     def index_export(self):
         nk, npost = C.c_int64(0), C.c_int64(0)
@@ -252,11 +264,8 @@ class Context:
         hpc_err, state, min_qual (the fields of ioc_batch_view).  Returns (cls, strand, stats)."""
         return self.cluster_merge(params, None, batch, table)
 
-    def _merge_call(self, params: Params, left, batch: dict, table, cons=None):
-        """ClusterSortedReads(left, right).  left: None (initial clustering) or dict with cls_hpc_err,
-        keys, offs, postings (the left clusters' representative error rates + MinDB as CSR).
-        batch: the right batch (ioc_batch_view fields; for a clustered right batch one record per
-        right cluster = its representative, plus n_members / depth / min_cls_size)."""
+    def _make_view(self, batch: dict):
+        """ioc_batch_view over the arrays of `batch` (see _merge_call); returns (view, n, objects that must outlive the call)."""
         on_dev = bool(batch.get("minimizers_on_device"))   # min_val / min_pos: device addresses (ints), total = words
         arrs = {
             "off_fwd": np.ascontiguousarray(batch["off_fwd"], np.int64),
@@ -297,6 +306,14 @@ class Context:
                       n_members=_p(nm, C.c_int32) if nm is not None else None,
                       depth=int(batch.get("depth", -1)), min_cls_size=int(batch.get("min_cls_size", 3)),
                       is_cluster=_p(isc, C.c_uint8) if isc is not None else None, minimizers_on_device=1 if on_dev else 0)
+        return v, n, (arrs, nm, rseq, roff, isc)
+
+    def _merge_call(self, params: Params, left, batch: dict, table, cons=None):
+        """ClusterSortedReads(left, right).  left: None (initial clustering) or dict with cls_hpc_err,
+        keys, offs, postings (the left clusters' representative error rates + MinDB as CSR).
+        batch: the right batch (ioc_batch_view fields; for a clustered right batch one record per
+        right cluster = its representative, plus n_members / depth / min_cls_size)."""
+        v, n, _alive = self._make_view(batch)
         lv = None
         if left is not None and left.get("resident"):
             # the left state already on the device (left_load + index_update) is used as it is
@@ -330,7 +347,6 @@ class Context:
                                                    C.byref(ops), _p(cls, C.c_int32), _p(strand, C.c_int8), C.byref(st)))
         self.n = n
         self.params = params
-        self.serial += 1
         self._keep = [batch.get("_keepalive")]   # device tensors borrowed by the context (minimizers_on_device)
         return cls, strand, st.as_dict()
 

@@ -27,10 +27,17 @@ int ioc_wait_uploads(ioc_ctx* c, int stage)
 {
     if (!c) return IOC_ERR_ARG;
     while (c->up_stage.load(std::memory_order_acquire) < stage) std::this_thread::yield();
+    if (c->up_failed.load(std::memory_order_acquire)) {
+        // a failed copy is reported at the FIRST wait behind it (stage 1 included: the scoring must not run over a tail of
+        // the value array that never arrived); the thread ends at once after a failure
+        while (c->up_stage.load(std::memory_order_acquire) < 2) std::this_thread::yield();
+        stage = 2;
+    }
     if (stage >= 2 && c->up_thread.joinable()) c->up_thread.join();
     if (c->up_stage.load(std::memory_order_acquire) >= 2 && !c->up_thread.joinable() && !c->up_err.empty()) {
         const std::string m = c->up_err;
         c->up_err.clear();
+        c->up_failed.store(false, std::memory_order_release);
         return ioc_fail(c, IOC_ERR_HIP, "upload of the query arrays: " + m);
     }
     return IOC_OK;
@@ -104,6 +111,25 @@ int ioc_ctx_create(int device, ioc_ctx** out)
             delete c;
             return IOC_ERR_HIP;
         }
+    // k_score_part's variant without a window test leans on the hardware dropping LDS atomics beyond the workgroup's
+    // allocation: probed here, on this device, before anything depends on it (IOC_SCORE_OOB=0 / 1 forces the variant)
+    const char* force = getenv("IOC_SCORE_OOB");
+    if (force && *force) {
+        c->score_oob = atoi(force) != 0;
+    } else {
+        uint32_t* d_res = nullptr;
+        uint32_t h_res[2] = {~0u, 0u};
+        if (hipMalloc(&d_res, 8) != hipSuccess || iock_lds_oob_probe(c->stream, d_res, h_res) != hipSuccess) {
+            if (d_res) (void)hipFree(d_res);
+            delete c;
+            return IOC_ERR_HIP;
+        }
+        (void)hipFree(d_res);
+        c->score_oob_probe = int(h_res[0]);
+        c->score_oob = h_res[0] == 0;
+        if (h_res[0] != 0 && getenv("IOC_TRACE"))
+            fprintf(stderr, "[ioc] LDS out-of-bounds probe failed (%u): scoring keeps its window test\n", h_res[0]);
+    }
     *out = c;
     return IOC_OK;
 }
@@ -114,6 +140,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
     (void)hipSetDevice(c->device);
     (void)ioc_wait_uploads(c, 2);
     (void)hipStreamSynchronize(c->stream);
+    (void)ioc_dist_shutdown(c);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     DevBuf* bufs[] = {&c->b_off_fwd, &c->b_off_rev, &c->b_min, &c->b_pos, &c->b_hpc_len, &c->b_err_cell,
                       &c->b_min_total, &c->b_doff, &c->b_left_err, &c->b_lkeys, &c->b_loffs, &c->b_lpost,
@@ -122,7 +149,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
                       &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
-                      &c->x_hpc_len, &c->x_hseq, &c->x_hqual};
+                      &c->x_hpc_len, &c->x_hseq, &c->x_hqual, &c->b_dist_min, &c->b_dist_pos};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -139,6 +166,8 @@ int ioc_set_stream(ioc_ctx* c, void* s)
     c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
     return IOC_OK;
 }
+
+int64_t ioc_queries_generation(const ioc_ctx* c) { return c ? int64_t(c->query_gen) : -1; }
 
 int ioc_synchronize(ioc_ctx* c)
 {
@@ -192,6 +221,7 @@ static int queries_common(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const i
     }
     c->n = n;
     c->total = total;
+    ++c->query_gen;
     c->built = c->scored = c->resolved = false;
     c->h_forced_t.assign(size_t(n), INT32_MIN);
     c->h_forced_s.assign(size_t(n), 0);
@@ -243,6 +273,7 @@ int ioc_queries_upload(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int6
     if (head > 0) HIPCHK(c, hipMemcpyAsync(c->b_min.p, min_val, size_t(head) * 4, hipMemcpyHostToDevice, s));
     if (c->copy_stream && c->defer_uploads && total >= (int64_t(1) << 21) && env_u32("IOC_UPLOAD_OVERLAP", 1) == 1) {
         c->up_err.clear();
+        c->up_failed.store(false, std::memory_order_release);
         c->up_stage.store(0, std::memory_order_release);
         uint32_t* d_min = P<uint32_t>(c->b_min);
         uint32_t* d_pos = P<uint32_t>(c->b_pos);
@@ -253,11 +284,17 @@ int ioc_queries_upload(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int6
             if (e == hipSuccess && total > head)
                 e = hipMemcpyAsync(d_min + head, min_val + head, size_t(total - head) * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
-            if (e != hipSuccess) c->up_err = hipGetErrorString(e);
+            if (e != hipSuccess) {
+                c->up_err = hipGetErrorString(e);
+                c->up_failed.store(true, std::memory_order_release);
+            }
             c->up_stage.store(1, std::memory_order_release);
             if (e == hipSuccess) e = hipMemcpyAsync(d_pos, min_pos, size_t(total) * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipStreamSynchronize(cs);
-            if (e != hipSuccess && c->up_err.empty()) c->up_err = hipGetErrorString(e);
+            if (e != hipSuccess && c->up_err.empty()) {
+                c->up_err = hipGetErrorString(e);
+                c->up_failed.store(true, std::memory_order_release);
+            }
             c->up_stage.store(2, std::memory_order_release);
         });
     } else if (total > 0) {
@@ -599,6 +636,7 @@ int ioc_score(ioc_ctx* c)
     uint32_t* d_part = nullptr;
     iock_set_score_variant(int(env_u32("IOC_SCORE_VARIANT", 0)));
     iock_set_part32(int(env_u32("IOC_PART32", 0)));
+    iock_set_score_oob(c->score_oob);
     if (env_u32("IOC_SCORE_PARTS", 1) == 1 && L + uint64_t(n) <= range && capacity * 8 * 4 + (1ull << 28) < have - need) {
         RESERVE(c, c->b_part, size_t(capacity) * 8 * 4);
         RESERVE(c, c->b_pmins, size_t(c->total) * 4);
@@ -909,6 +947,26 @@ int ioc_get_cuts(ioc_ctx* c, int32_t* cut)
     HIPCHK(c, hipMemcpyAsync(cut, c->b_cut.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return IOC_OK;
+}
+
+int ioc_scored_candidates(ioc_ctx* c, int32_t q, int32_t cap, uint32_t* key, uint32_t* size)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->scored) return ioc_fail(c, IOC_ERR_STATE, "ioc_score first");
+    if (q < 0 || q >= c->n || cap < 0 || (cap && (!key || !size))) return ioc_fail(c, IOC_ERR_ARG, "bad query index");
+    const uint32_t L = uint32_t(c->L);
+    const uint64_t cbase = 2ull * L * uint64_t(q) + uint64_t(q) * uint64_t(q > 0 ? q - 1 : 0);
+    uint32_t cc = 0;
+    HIPCHK(c, hipMemcpyAsync(&cc, P<uint32_t>(c->b_cand_count) + q, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t m = std::min<size_t>(cc, size_t(cap));
+    if (m) {
+        HIPCHK(c, hipMemcpyAsync(key, P<uint32_t>(c->b_cand_key) + cbase, m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(size, P<uint32_t>(c->b_cand_size) + cbase, m * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return int(cc);
 }
 
 int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, int8_t* strand, uint32_t* size,
@@ -1318,6 +1376,7 @@ int ioc_count_reference_postings(ioc_ctx* c, int64_t* n_postings)
     HIPCHK(c, hipMemsetAsync(d_sum, 0, 8, s));
     const uint8_t* valid = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
     const uint32_t range = env_u32("IOC_SCORE_RANGE", 8192);
+    iock_set_score_oob(c->score_oob);
     HIPCHK(c, iock_score(s, c->n, uint32_t(c->L), c->d_off_fwd, c->d_off_rev, c->d_min, c->b_rows.p, c->cap,
                          hash_shift(c->cap), c->b_post.p, range, uint32_t(c->keep),
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
@@ -1336,6 +1395,8 @@ int ioc_get_timings(ioc_ctx* c, ioc_timings* out)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0;
+    c->tm.score_oob = c->score_oob;
+    c->tm.score_oob_probe = c->score_oob_probe;
     if (c->built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_build = ms;
     if (c->scored && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->tm.ms_score = ms;
     if (c->resolved && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->tm.ms_resolve = ms;

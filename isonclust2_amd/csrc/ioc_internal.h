@@ -20,6 +20,8 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+struct ioc_dist_state;  // ioc_dist.cpp: the context's RCCL communicator
+
 struct ioc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -51,6 +53,8 @@ struct ioc_ctx {
     bool defer_uploads = false;
     std::thread up_thread;
     std::atomic<int> up_stage{2};  // 1: all minimizer values are in HBM, 2: the positions too
+    std::atomic<bool> up_failed{false};  // a copy of the upload thread failed (up_err holds the text): set before the stage moves on
+    uint64_t query_gen = 0;  // bumped whenever the context's queries are replaced (ioc_queries_generation)
     std::string up_err;
     hipStream_t copy_stream = nullptr;
 
@@ -132,6 +136,10 @@ struct ioc_ctx {
     // ---- instrumentation ----
     hipEvent_t ev[6]{};
     ioc_timings tm{};
+    // ---- multi-GPU (ioc_dist.cpp) ----
+    ioc_dist_state* dist = nullptr;
+    DevBuf b_dist_min, b_dist_pos;  // the gathered representatives' minimizer lists of ioc_dist_merge (used in place as queries)
+    int score_oob = 0, score_oob_probe = -1;  // k_score_part's variant and the probe behind it (ioc_ctx_create)
 };
 
 int ioc_fail(ioc_ctx* c, int code, const std::string& msg);

@@ -116,6 +116,8 @@ hipError_t iock_query_table(hipStream_t st, int j, uint32_t L, const int64_t* of
 size_t iock_decide_args_size();
 void iock_set_score_variant(int v);
 void iock_set_part32(int v);
+void iock_set_score_oob(int v);
+hipError_t iock_lds_oob_probe(hipStream_t st, uint32_t* d_result, uint32_t* h_result);
 
 // ---- sort-stage kernels (ioc_extract.hip) ----
 hipError_t iock_qual_scores(hipStream_t st, int n, const int64_t* offs, const uint8_t* qual, int k,

@@ -35,6 +35,7 @@
 #ifndef IOC_SCORE_TRAV_CAPACITY
 #define IOC_SCORE_TRAV_CAPACITY 0  // 1 (instrumentation builds): IOC_COUNT_TRAVERSED counts the posting SLOTS of the wave steps, filled or not
 #endif
+#define IOC_OOB_FAR_BASE 0x00100000u  // counter base of lanes past the end of a chunk in the OOB variant (1 MB: outside any LDS)
 #ifndef IOC_SCORE_ABL
 #define IOC_SCORE_ABL 0
 #endif
@@ -760,6 +761,7 @@ __device__ __forceinline__ void flat_traverse(const PT* __restrict__ post, uint3
 // LDS atomic there (tools/micro/lds_oob.hip, profiles/r02_lds_oob.txt: the hardware's bound is the allocation rounded up
 // to its 1280-byte granule; 1.4·10^11 atomics above it changed no word of any workgroup's memory).  1 VALU + 1 ds_add_u32
 // per posting, no VCC / EXEC traffic; lanes past the end of the concatenation get a base far outside instead of T = 0.
+template <bool OOB>
 __device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t hbase, uint32_t one)
 {
     uint32_t a;
@@ -774,36 +776,37 @@ __device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t 
     w = 0;
     T = T ? 1u : 0u;
 #endif
-#if IOC_SCORE_OOB && IOC_SCORE_ABL == 0
-    uint32_t a2;
-    (void)sv;
-    (void)T;
-    asm volatile(
-        "v_mad_u32_u16 %0, %2, 4, %3 op_sel:[0,0,0,0]\n\t"
-        "v_mad_u32_u16 %1, %2, 4, %3 op_sel:[1,0,0,0]\n\t"
-        "ds_add_u32 %0, %4\n\t"
-        "ds_add_u32 %1, %4"
-        : "=&v"(a), "=&v"(a2)
-        : "v"(w), "v"(hbase), "v"(one)
-        : "memory");
-#else
-    asm volatile(
-        "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
-        "s_and_saveexec_b64 %1, vcc\n\t"
-        "v_mad_u32_u16 %0, %2, 4, %4 op_sel:[0,0,0,0]\n\t"
-        "ds_add_u32 %0, %5\n\t"
-        "s_mov_b64 exec, %1\n\t"
-        "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n\t"
-        "s_and_saveexec_b64 %1, vcc\n\t"
-        "v_mad_u32_u16 %0, %2, 4, %4 op_sel:[1,0,0,0]\n\t"
-        "ds_add_u32 %0, %5\n\t"
-        "s_mov_b64 exec, %1"
-        : "=&v"(a), "=&s"(sv)
-        : "v"(w), "v"(T), "v"(hbase), "v"(one)
-        : "vcc", "memory");
-#endif
+    if constexpr (OOB && IOC_SCORE_ABL == 0) {
+        uint32_t a2;
+        (void)sv;
+        (void)T;
+        asm volatile(
+            "v_mad_u32_u16 %0, %2, 4, %3 op_sel:[0,0,0,0]\n\t"
+            "v_mad_u32_u16 %1, %2, 4, %3 op_sel:[1,0,0,0]\n\t"
+            "ds_add_u32 %0, %4\n\t"
+            "ds_add_u32 %1, %4"
+            : "=&v"(a), "=&v"(a2)
+            : "v"(w), "v"(hbase), "v"(one)
+            : "memory");
+    } else {
+        asm volatile(
+            "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "s_and_saveexec_b64 %1, vcc\n\t"
+            "v_mad_u32_u16 %0, %2, 4, %4 op_sel:[0,0,0,0]\n\t"
+            "ds_add_u32 %0, %5\n\t"
+            "s_mov_b64 exec, %1\n\t"
+            "v_cmp_lt_u32_sdwa vcc, %2, %3 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "s_and_saveexec_b64 %1, vcc\n\t"
+            "v_mad_u32_u16 %0, %2, 4, %4 op_sel:[1,0,0,0]\n\t"
+            "ds_add_u32 %0, %5\n\t"
+            "s_mov_b64 exec, %1"
+            : "=&v"(a), "=&s"(sv)
+            : "v"(w), "v"(T), "v"(hbase), "v"(one)
+            : "vcc", "memory");
+    }
 }
 
+template <bool OOB>
 __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ post, uint32_t o, uint32_t len,
                                                   uint32_t* __restrict__ wb, unsigned long long* __restrict__ bm,
                                                   uint32_t* __restrict__ h, uint32_t T, unsigned long long& trav, uint32_t& abl)
@@ -862,11 +865,11 @@ __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ p
             // (a lane past the end of the concatenation loaded unit 0: a window of 0 targets rejects all of it)
             const bool inl = (w0 + u) * 64u + uint32_t(lane) < total;
             const uint32_t Tl = inl ? T : 0u;
-            const uint32_t hb = (IOC_SCORE_OOB && IOC_SCORE_ABL == 0) ? (inl ? hbase : 0x00100000u) : hbase;  // (1 MB: outside any LDS)
-            count_word_u16(tg[u].x, Tl, hb, one);
-            count_word_u16(tg[u].y, Tl, hb, one);
-            count_word_u16(tg[u].z, Tl, hb, one);
-            count_word_u16(tg[u].w, Tl, hb, one);
+            const uint32_t hb = (OOB && IOC_SCORE_ABL == 0) ? (inl ? hbase : IOC_OOB_FAR_BASE) : hbase;  // (1 MB: outside any LDS)
+            count_word_u16<OOB>(tg[u].x, Tl, hb, one);
+            count_word_u16<OOB>(tg[u].y, Tl, hb, one);
+            count_word_u16<OOB>(tg[u].z, Tl, hb, one);
+            count_word_u16<OOB>(tg[u].w, Tl, hb, one);
         }
     };
     // whole groups of IOC_FLAT_UNROLL steps, then the rest two steps at a time: with one loop of 8 the steps past the end of
@@ -1066,7 +1069,7 @@ k_partition_mins(int n, const int64_t* __restrict__ off_fwd, const int64_t* __re
     }
 }
 
-template <typename PT>
+template <typename PT, bool OOB>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
@@ -1088,7 +1091,7 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
     // it; the allocation is a whole number of 1280-byte granules on gfx950): see count_word_u16
     const uint32_t dyn_base = uint32_t(reinterpret_cast<uintptr_t>(hist_dyn));
     const uint32_t lds_end = (dyn_base + dyn_bytes + 1279u) / 1280u * 1280u;
-    uint32_t* const hist = IOC_SCORE_OOB ? hist_dyn + ((lds_end - dyn_base) / 4u - T) : hist_dyn;
+    uint32_t* const hist = OOB ? hist_dyn + ((lds_end - dyn_base) / 4u - T) : hist_dyn;
     uint32_t eword, eshift;
     epoch_field(E, T, eword, eshift);
     const int lane = lane_id(), wave = wave_id();
@@ -1117,7 +1120,7 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
                     len = list_lower_bound(post + o, len, T);
             }
             if (sizeof(PT) == 2 && !IOC_SCORE_OLD_TRAVERSE)
-                flat_traverse_u16(reinterpret_cast<const uint16_t*>(post), o, len, wb_, bm_, h, T, trav, abl);
+                flat_traverse_u16<OOB>(reinterpret_cast<const uint16_t*>(post), o, len, wb_, bm_, h, T, trav, abl);
             else
                 flat_traverse<0, PT>(post, o, len, wb_, bm_, h, 0u, T, trav, abl);
         }
@@ -1133,6 +1136,57 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
         __syncthreads();
     }
     if (traversed && lane == 0) atomicAdd(traversed, trav);
+}
+
+// ---- run-time check of what the OOB variant of k_score_part relies on -------------------------------------------------------
+// k_score_part<PT, true> has no window test: the counter address of every posting the test would reject lies in
+// [lds_end, lds_end + 256 KB) or in [IOC_OOB_FAR_BASE, IOC_OOB_FAR_BASE + 256 KB), where lds_end is the workgroup's LDS
+// allocation (static + dynamic) rounded up to the hardware's 1280-byte granule, and the variant is right iff the hardware
+// drops an LDS atomic there.  That is gfx950 behaviour, not a documented guarantee, so ioc_ctx_create PROBES it on the device
+// it runs on, with k_score_part's own static LDS layout and two dynamic sizes: every workgroup of a grid that fills the chip
+// several times over (so that workgroups share CUs) paints its whole allocation, issues one atomic to EVERY word of both
+// ranges, checks that a counter in the granule's slack still counts (the histogram lives there) and that no word of its
+// allocation changed — its own stray atomics would show, and so would a neighbour's.  result[0]: bit 0 = a word changed,
+// bit 1 = an in-bounds atomic was lost; result[1] = workgroups that ran.  A failed probe selects the masked variant.
+__global__ void __launch_bounds__(IOC_BLOCK) k_lds_oob_probe(uint32_t dyn_bytes, uint32_t* __restrict__ result)
+{
+    extern __shared__ uint32_t hist_dyn[];
+    __shared__ uint32_t s_wb[IOC_WAVES][64];
+    __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];
+    s_wb[0][threadIdx.x & 63] = 0;  // (keeps the static arrays, and with them k_score_part's dynamic base, in the kernel)
+    s_bm[0][0] = 0ull;
+    const uint32_t dyn_base = uint32_t(reinterpret_cast<uintptr_t>(hist_dyn));
+    const uint32_t lds_end = (dyn_base + dyn_bytes + 1279u) / 1280u * 1280u;
+    const uint32_t salt = 0x9E3779B9u * (blockIdx.x + 1u);
+    __syncthreads();
+    for (uint32_t a = threadIdx.x * 4u; a < lds_end; a += IOC_BLOCK * 4u) {
+        const uint32_t v = a * 2654435761u ^ salt;
+        asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t one = 1u;
+    // in bounds, in the slack behind the requested dynamic size: the last IOC_BLOCK words of the allocation
+    const uint32_t in_a = lds_end - 4u * (threadIdx.x + 1u);
+    asm volatile("ds_add_u32 %0, %1" ::"v"(in_a), "v"(one) : "memory");
+    for (uint32_t r = 0; r < 2; ++r) {
+        const uint32_t base = r == 0 ? lds_end : IOC_OOB_FAR_BASE;
+        for (uint32_t a = threadIdx.x * 4u; a < 0x40000u + 1280u; a += IOC_BLOCK * 4u) {
+            const uint32_t t = base + a;
+            asm volatile("ds_add_u32 %0, %1" ::"v"(t), "v"(one) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t bad = 0;
+    for (uint32_t a = threadIdx.x * 4u; a < lds_end; a += IOC_BLOCK * 4u) {
+        uint32_t v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        const uint32_t want = (a * 2654435761u ^ salt) + (a + 4u * IOC_BLOCK >= lds_end ? 1u : 0u);
+        if (v != want) bad |= (a + 4u * IOC_BLOCK >= lds_end && v == want - 1u) ? 2u : 1u;
+    }
+    if (bad) atomicOr(&result[0], bad);
+    if (threadIdx.x == 0) atomicAdd(&result[1], 1u);
 }
 
 __global__ void __launch_bounds__(IOC_BLOCK)
@@ -2059,6 +2113,7 @@ __global__ void __launch_bounds__(256) k_query_compact_many(const int32_t* __res
 
 static int g_score_variant = 0;
 static int g_part32 = 0;
+static int g_score_oob = 0;  // k_score_part without a window test (ioc_ctx_create's probe passed, or IOC_SCORE_OOB=1)
 
 namespace {
 // ---- MinDB export (ioc_index_export): the posting lists restricted to the targets that ARE clusters, with final ids ----
@@ -2120,6 +2175,22 @@ extern "C" {
 
 void iock_set_score_variant(int v) { g_score_variant = v; }
 void iock_set_part32(int v) { g_part32 = v; }
+void iock_set_score_oob(int v) { g_score_oob = v; }
+
+hipError_t iock_lds_oob_probe(hipStream_t st, uint32_t* d_result /* 2 words, zeroed here */, uint32_t* h_result)
+{
+    const unsigned grid = 4096;
+    CK(hipMemsetAsync(d_result, 0, 8, st));
+    const uint32_t sizes[2] = {12000u, 60000u};  // config 2's histogram (3000 targets) and a large batch's
+    CK(hipFuncSetAttribute((const void*)k_lds_oob_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    for (uint32_t dyn : sizes) hipLaunchKernelGGL(k_lds_oob_probe, dim3(grid), dim3(IOC_BLOCK), dyn, st, dyn, d_result);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(h_result, d_result, 8, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    if (h_result[1] != 2u * grid) h_result[0] |= 4u;  // the probe itself did not run to the end
+    return hipSuccess;
+}
+
 
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
                          uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits)
@@ -2300,22 +2371,25 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     if (part && pmins && pbnd && tmax <= range && cap >= 1024) {
         const Epochs E = epoch_bounds(L, uint32_t(n));
         if (lds > 40 * 1024) {
-            CK(hipFuncSetAttribute((const void*)k_score_part<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-            CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            CK(hipFuncSetAttribute((const void*)k_score_part<uint32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            CK(hipFuncSetAttribute((const void*)k_score_part<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
             CK(hipFuncSetAttribute((const void*)k_score_compact, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         }
         uint32_t* max_len = pbnd + size_t(n) * 2 * (IOC_PARTS + 1);  // one extra word behind the boundaries
         CK(hipMemsetAsync(max_len, g_part32 ? 0xFF : 0, 4, st));  // IOC_PART32=1 forces u32 partials (tests)
         hipLaunchKernelGGL(k_partition_mins, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd,
                            max_len);
-        if (post16)
-            hipLaunchKernelGGL(k_score_part<uint16_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L,
-                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post_h, part, E,
-                               traversed, max_len, uint32_t(lds / 2));
+#define LAUNCH_PART(PT, OOB, PP)                                                                                          \
+    hipLaunchKernelGGL((k_score_part<PT, OOB>), dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L, off_fwd, \
+                       off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, PP, part, E, traversed, max_len, uint32_t(lds / 2))
+        if (post16 && g_score_oob && IOC_SCORE_OOB)
+            LAUNCH_PART(uint16_t, true, post_h);
+        else if (post16)
+            LAUNCH_PART(uint16_t, false, post_h);
         else
-            hipLaunchKernelGGL(k_score_part<uint32_t>, dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L,
-                               off_fwd, off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, post, part, E,
-                               traversed, max_len, uint32_t(lds / 2));
+            LAUNCH_PART(uint32_t, false, post);   // (u32 postings keep their window test: flat_traverse)
+#undef LAUNCH_PART
         hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
                            cand_count, audit_valid, audit_sum, top_all, max_len);
         return hipGetLastError();

@@ -340,4 +340,97 @@ def timed_merge(ctx, params, cb: ClusteredBatch, dist, torch=None, dev=None):
             "allgather_ms": max_over_ranks(tm["allgather_ms"], dist), "merge_ms": max_over_ranks(tm["merge_ms"], dist),
             "payload_bytes_per_rank": tm["payload_bytes_per_rank"], "fnv1a": fnv1a_reads(merged),
             "merged_on": "every rank (device-resident representative records, replicated one-pass merge)",
+            "replicated": True,
             "aln_invoked": merged.stats.get("n_aln_invoked")}
+
+
+# ---- the same exchange through the library's own C++ / RCCL binding (ioc_dist_*, csrc/ioc_dist.cpp) --------------------------
+def native_init(ctx, dist=None, torch=None):
+    """One RCCL communicator per context, made by the LIBRARY (ncclCommInitRank in C++): rank 0 draws the id, the host
+    program ships its 128 bytes — here through torch.distributed when the ranks were started by torchrun, nowhere at all
+    for a single rank."""
+    import ctypes as C
+    from . import _lib
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    ident = np.zeros(_lib_id_bytes(), np.uint8)
+    if rank == 0:
+        rc = ctx.L.ioc_dist_unique_id(ident.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != 0:
+            raise _lib.IocError(rc, "ioc_dist_unique_id failed")
+    if dist is not None:
+        dev = _device(dist)
+        t = torch.from_numpy(ident).to(dev)
+        dist.broadcast(t, src=0)
+        ident = t.cpu().numpy().copy()
+    ctx._chk(ctx.L.ioc_dist_init(ctx.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world))
+    return rank, world
+
+
+def _lib_id_bytes():
+    return 128   # IOC_DIST_ID_BYTES
+
+
+def merge_all_native(ctx, params, cb: ClusteredBatch, torch=None, min_cls_size=3, export_mindb=False, timing=None):
+    """merge_all_device with every collective made by the library's C++ binding over RCCL (ioc_dist_merge): device gather of
+    this rank's representatives' lists -> ragged all-gather HBM to HBM straight into the query layout -> ONE pass of the
+    merge path on every rank.  Only the reads' membership (the host program's bookkeeping) is exchanged from here, through
+    ioc_dist_allgatherv_host.  Needs native_init."""
+    import ctypes as C
+    import time
+    from . import _lib
+    from .api import _p
+    L = ctx.L
+    t0 = time.perf_counter()
+    rank, world = C.c_int32(0), C.c_int32(1)
+    ctx._chk(L.ioc_dist_info(ctx.h, C.byref(rank), C.byref(world)))
+    W = world.value
+    rv = dict(cb.rep_view)
+    keep = None
+    if torch is not None and cb.rep_entry is not None and cb.ctx_serial == ctx.serial:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mins, poss = gather_local(ctx, cb, torch, dev)                   # the lists never visit the host
+        rv.update(min_val=mins.data_ptr(), min_pos=poss.data_ptr(), total=int(mins.numel()), minimizers_on_device=True)
+        keep = (mins, poss)
+    if cb.rep_seq is not None:
+        rv.update(raw_seq=cb.rep_seq, raw_off=cb.rep_off)
+    view, n, alive = ctx._make_view(rv)
+    counts = np.zeros(W, np.int64)
+    st = _lib.ClusterStats()
+    tms = _lib.DistMergeTimes()
+    ctx._chk(L.ioc_dist_merge(ctx.h, C.byref(params), _lib.TABLE_PATH.encode(), C.byref(view), min_cls_size, 0, None, None,
+                              _p(counts, C.c_int64), None, None))
+    N = int(counts.sum())
+    cls, strand = np.zeros(max(N, 1), np.int32), np.zeros(max(N, 1), np.int8)
+    t1 = time.perf_counter()
+    ctx._chk(L.ioc_dist_merge(ctx.h, C.byref(params), _lib.TABLE_PATH.encode(), C.byref(view), min_cls_size, N,
+                              _p(cls, C.c_int32), _p(strand, C.c_int8), _p(counts, C.c_int64), C.byref(st), C.byref(tms)))
+    t2 = time.perf_counter()
+    del keep, alive
+    cls, strand = cls[:N], strand[:N]
+    # membership of every rank's reads (cluster.cpp:223-261: members move with their representative)
+    mine = np.concatenate([_words(cb.member_cls, np.int32), _words(cb.member_read, np.int64), _words(cb.member_strand, np.int32),
+                           _words([cb.batch_start, cb.batch_end, cb.depth], np.int64)])
+    sizes = np.zeros(W, np.int64)
+    ctx._chk(L.ioc_dist_allgatherv_host(ctx.h, mine.ctypes.data_as(C.c_void_p), mine.nbytes, None, _p(sizes, C.c_int64)))
+    allm = np.zeros(int(sizes.sum()) // 4, np.uint32)
+    ctx._chk(L.ioc_dist_allgatherv_host(ctx.h, mine.ctypes.data_as(C.c_void_p), mine.nbytes, allm.ctypes.data_as(C.c_void_p),
+                                        _p(sizes, C.c_int64)))
+    metas, pos = [], 0
+    for r in range(W):
+        w = int(sizes[r]) // 4
+        blk = allm[pos:pos + w]
+        pos += w
+        nm = (w - 6) // 4
+        mc, mr = blk[:nm].view(np.int32), blk[nm:3 * nm].view(np.int64)
+        ms = blk[3 * nm:4 * nm].view(np.int32)
+        bs, be, dp = (int(x) for x in blk[4 * nm:].view(np.int64))
+        metas.append(ClusteredBatch(rep_view=dict(hpc_len=np.zeros(int(counts[r]), np.uint32)), member_cls=mc, member_read=mr,
+                                    member_strand=ms, mindb=None, depth=dp, batch_start=bs, batch_end=be))
+    mindb = ctx.index_export() if export_mindb else None
+    merged = _assemble(metas, cls, strand, st.as_dict(), mindb=mindb)
+    if timing is not None:
+        timing.update(sizing_ms=(t1 - t0) * 1e3, call_ms=(t2 - t1) * 1e3, exchange_lists_ms=float(tms.ms_exchange_lists),
+                      merge_ms=float(tms.ms_merge), bytes_lists=int(tms.bytes_lists), bytes_records=int(tms.bytes_records),
+                      clusters_in=[int(x) for x in counts])
+    return merged

@@ -217,3 +217,118 @@ def cluster_merge(ctx, params, left: ClusteredBatch, right: ClusteredBatch, min_
                           member_strand=np.concatenate([left.member_strand, mst[keep]]),
                           mindb=(keys, offs, post), depth=left.depth + 1, batch_start=left.batch_start,
                           batch_end=right.batch_end, stats=st)
+
+
+# ---- consensus mode (ConsMaxSize > 0): the same bookkeeping with representatives that change ---------------------------
+def slice_sorted(sb: SortedBatch, a, b, batch_nr=0) -> SortedBatch:
+    """Entries a..b-1 of a sorted read set as a batch of their own (`sort` cuts the globally sorted reads into batches of
+    consecutive entries, src/main.cpp:149-199)."""
+    idx = np.arange(a, b)
+    v = gather_records(sb.view, idx)
+    seq, off = gather_seqs(sb.view.get("raw_seq"), sb.view.get("raw_off"), idx)
+    v.update(raw_seq=seq, raw_off=off)
+    ids = np.asarray(sb.read_ids)[a:b]
+    return SortedBatch(view=v, read_ids=ids, batch_nr=batch_nr, batch_start=sb.batch_start + a, batch_end=sb.batch_start + b - 1)
+
+
+def _patch_reps(rep_view, rep_seq, rep_off, rep_records):
+    """Replace the records of the clusters whose representative became a consensus (ioc_rep_record of the LAST event of
+    each cluster: src/consensus.cpp:93-124 rewrites RawSeq, HpcSeq, Mins, RevMins and both error rates in place)."""
+    last = {}
+    for c, r in rep_records:
+        last[c] = r
+    if not last:
+        return rep_view, rep_seq, rep_off
+    cl = sorted(last)
+    rs = [last[c] for c in cl]
+    nf = np.array([len(r["fwd_min"]) for r in rs], np.int64)
+    nr = np.array([len(r["rev_min"]) for r in rs], np.int64)
+    off_f = np.zeros(len(rs) + 1, np.int64)
+    off_f[1:] = np.cumsum(nf)
+    off_r = np.zeros(len(rs) + 1, np.int64)
+    off_r[1:] = np.cumsum(nr)
+    off_r += off_f[-1]
+    cat = lambda key: np.concatenate([r[key] for r in rs]).astype(np.uint32)
+    patch = dict(off_fwd=off_f, off_rev=off_r, min_val=np.concatenate([cat("fwd_min"), cat("rev_min")]),
+                 min_pos=np.concatenate([cat("fwd_pos"), cat("rev_pos")]), min_qual=rep_view.get("min_qual", 7.0),
+                 raw_len=np.array([r["raw_len"] for r in rs], np.uint32), hpc_len=np.array([r["hpc_len"] for r in rs], np.uint32),
+                 score=np.array([r["score"] for r in rs], np.float64), raw_err=np.array([r["raw_err"] for r in rs], np.float64),
+                 hpc_err=np.array([r["hpc_err"] for r in rs], np.float64), state=np.zeros(len(rs), np.uint8))
+    n = len(rep_view["hpc_len"])
+    idx = np.arange(n)
+    idx[np.array(cl)] = n + np.arange(len(cl))
+    both = concat_records({k: (np.asarray(v) if k != "min_qual" else v) for k, v in rep_view.items() if k in patch}, patch)
+    out = gather_records(both, idx)
+    pseq = b"".join(r["raw_seq"] for r in rs)
+    poff = np.zeros(len(rs) + 1, np.int64)
+    poff[1:] = np.cumsum([len(r["raw_seq"]) for r in rs])
+    seq, off = gather_seqs(rep_seq + pseq, np.concatenate([rep_off, poff[1:] + rep_off[-1]]), idx)
+    return out, seq, off
+
+
+def cluster_consensus_single(ctx, params, sb: SortedBatch, cons, store) -> ClusteredBatch:
+    """`cluster -l batch.cer` of a batch sorted with `-c ConsMaxSize > 0` (src/cluster.cpp:263-309): ioc_cluster_consensus
+    with the caller's graph store (`store.ops`: ioc_consensus_ops; `store.rep_records` receives every replaced
+    representative).  cons = (ConsMinSize, ConsMaxSize, ConsPeriod)."""
+    from . import _lib
+    n0 = len(store.rep_records)
+    cargs = _lib.ConsensusArgs(cons_min_size=cons[0], cons_max_size=cons[1], cons_period=cons[2], left_depth=-1, left_sizes=None)
+    cls, strand, st = ctx.cluster_consensus(params, None, sb.view, cargs, store.ops)
+    keys, offs, post = ctx.index_export()
+    ok = cls >= 0
+    n_cls = int(st["n_clusters"])
+    ent = np.nonzero(ok)[0]
+    uniq, first = np.unique(cls[ent], return_index=True)   # entries are in loop order: the first one of an id created it
+    rep_entry = np.full(n_cls, -1, np.int64)
+    rep_entry[uniq] = ent[first]
+    rep_view = gather_records(sb.view, rep_entry)
+    rep_seq, rep_off = gather_seqs(sb.view.get("raw_seq"), sb.view.get("raw_off"), rep_entry)
+    rep_view, rep_seq, rep_off = _patch_reps(rep_view, rep_seq, rep_off, store.rep_records[n0:])
+    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off, member_cls=cls[ok].astype(np.int32),
+                          member_read=np.asarray(sb.read_ids)[ok].astype(np.int64), member_strand=strand[ok].astype(np.int32),
+                          mindb=(keys, offs, post), depth=0, batch_start=sb.batch_start, batch_end=sb.batch_end, stats=st)
+
+
+def cluster_consensus_merge(ctx, params, left: ClusteredBatch, right: ClusteredBatch, cons, store, min_cls_size=3) -> ClusteredBatch:
+    """`cluster -l L -r R` with consensus on: leftBatch->Depth != -1, so ConsMinSize is 2 and ConsPeriod is ignored
+    (src/cluster.cpp:267-288); a right cluster's graph contributes its sequence count as the weight of the addition
+    (src/consensus.cpp:51-53, 76-81).  store: side 0 = the left clusters' graphs, side 1 = the right clusters'."""
+    from . import _lib
+    import ctypes as C
+    if right.depth > 0 and right.batch_start != left.batch_end + 1:
+        raise ValueError("Trying to merge non-consecutive batches! Giving up!")          # cluster.cpp:81-85
+    if left.depth > 0 and right.depth > left.depth:
+        raise ValueError("The left input batch must have higher depth!")                  # cluster.cpp:87-90
+    n0 = len(store.rep_records)
+    nR = right.n_clusters
+    counts = np.bincount(right.member_cls, minlength=nR).astype(np.int32)
+    lsizes = (np.bincount(left.member_cls, minlength=left.n_clusters) + 1).astype(np.int32)   # + the representative copy
+    rv = dict(right.rep_view)
+    rv.update(n_members=counts, depth=right.depth, min_cls_size=min_cls_size, raw_seq=right.rep_seq, raw_off=right.rep_off)
+    lv = dict(cls_hpc_err=left.rep_view["hpc_err"], keys=left.mindb[0], offs=left.mindb[1], postings=left.mindb[2],
+              rep_seq=left.rep_seq, rep_off=left.rep_off, cls_raw_err=left.rep_view["raw_err"])
+    cargs = _lib.ConsensusArgs(cons_min_size=cons[0], cons_max_size=cons[1], cons_period=cons[2], left_depth=left.depth,
+                               left_sizes=lsizes.ctypes.data_as(C.POINTER(C.c_int32)))
+    cls, strand, st = ctx.cluster_consensus(params, lv, rv, cargs, store.ops)
+    keys, offs, post = ctx.index_export()
+    L = left.n_clusters
+    new = np.nonzero(cls >= L)[0]
+    uniq, first = np.unique(cls[new], return_index=True)
+    created = new[first]                                   # right clusters that became left clusters, in id order
+    assert np.array_equal(uniq, L + np.arange(len(uniq)))
+    rep_view, rep_seq, rep_off = left.rep_view, left.rep_seq, left.rep_off
+    if len(created):
+        rep_view = concat_records(left.rep_view, gather_records(right.rep_view, created))
+        add, ao = gather_seqs(right.rep_seq, right.rep_off, created)
+        rep_seq = left.rep_seq + add
+        rep_off = np.concatenate([left.rep_off, ao[1:] + left.rep_off[-1]])
+    rep_view, rep_seq, rep_off = _patch_reps(rep_view, rep_seq, rep_off, store.rep_records[n0:])
+    mcl = cls[right.member_cls]
+    mst = strand[right.member_cls].astype(np.int32) * right.member_strand
+    keep = mcl >= 0
+    return ClusteredBatch(rep_view=rep_view, rep_seq=rep_seq, rep_off=rep_off,
+                          member_cls=np.concatenate([left.member_cls, mcl[keep].astype(np.int32)]),
+                          member_read=np.concatenate([left.member_read, right.member_read[keep]]),
+                          member_strand=np.concatenate([left.member_strand, mst[keep]]),
+                          mindb=(keys, offs, post), depth=left.depth + 1, batch_start=left.batch_start,
+                          batch_end=right.batch_end, stats=st)

@@ -45,6 +45,7 @@ class ToyGraphs:
         self.g = {0: {}, 1: {}}
         self.calls = 0
         self.rep_events = []
+        self.rep_records = []  # (cluster, full ioc_rep_record as a dict of copies): what a later merge needs of a replaced representative
         self.log = []          # (operation, side, idx, sequence length / weight): compared between the two sides
         for i, s in (right_sizes or {}).items():
             self.g[1][i] = [(b"", 1)] * s
@@ -86,6 +87,13 @@ class ToyGraphs:
             r = rec.contents
             self.rep_events.append((int(cls), int(r.entry), C.string_at(r.raw_seq, r.raw_len), float(r.raw_err), float(r.hpc_err),
                                     int(r.hpc_len), int(r.n_fwd), int(r.n_rev)))
+            import numpy as _np
+            take = lambda ptr, n: _np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else _np.zeros(0, _np.uint32)
+            self.rep_records.append((int(cls), dict(
+                raw_seq=C.string_at(r.raw_seq, r.raw_len), raw_len=int(r.raw_len), raw_err=float(r.raw_err),
+                score=float(r.raw_score), hpc_len=int(r.hpc_len), hpc_err=float(r.hpc_err),
+                fwd_min=take(r.fwd_min, r.n_fwd), fwd_pos=take(r.fwd_pos, r.n_fwd),
+                rev_min=take(r.rev_min, r.n_rev), rev_pos=take(r.rev_pos, r.n_rev), entry=int(r.entry))))
 
         self._keep = (_lib.CONS_CREATE(create), _lib.CONS_SIZE(size), _lib.CONS_ADD(add), _lib.CONS_CONSENSUS(consensus),
                       _lib.CONS_PURGE(purge), _lib.CONS_REP_CHANGED(rep_changed))
@@ -95,6 +103,7 @@ class ToyGraphs:
         self.g = {0: {}, 1: {}}
         self.calls = 0
         self.rep_events = []
+        self.rep_records = []
         self.log = []
         for i, s in (right_sizes or {}).items():
             self.g[1][i] = [(b"", 1)] * s

@@ -80,3 +80,42 @@ def test_two_ranks_cluster_and_merge(mode):
         assert dig == want, (rank, dig, want)                 # every rank holds the same merged clustering = the oracle's fold
         assert ncl == obs[0].n_clusters() and nreads == int((ocl >= 0).sum())
         assert len(nbytes) == world
+
+
+@pytest.mark.parametrize("mode", ["fast", "sahlin"])
+def test_native_rccl_binding_single_rank(mode):
+    """The library's own C++ / RCCL binding (csrc/ioc_dist.cpp) with the one rank a one-GPU box allows: ncclCommInitRank, the
+    size exchange, the grouped-broadcast ragged all-gather HBM to HBM and the host-record exchange all execute; with one rank
+    every representative is a cluster from the start, so the merged clustering must be the batch's own (against the oracle).
+    The multi-rank semantics of the same one-pass merge are covered by merge_gathered (tests above, test_gpu_fullsize.py)."""
+    import torch
+    from isonclust2_amd import api, dist as d, pipeline, synth
+    from isonclust2_amd.digest import fnv1a, fnv1a_reads
+    from tests.helpers import oracle_entry_assignments, oracle_sorted_batch
+    torch.zeros(1, device="cuda:0")
+    rs = synth.generate_config("config1", seed=6)
+    ctx = api.Context(0)
+    sb, order = pipeline.sort_stage(ctx, rs, 11, 15)
+    p = api.default_params(11, 15, mode)
+    cb = pipeline.cluster_single(ctx, p, sb)
+    assert d.native_init(ctx, None, torch) == (0, 1)
+    tm = {}
+    merged = d.merge_all_native(ctx, p, cb, torch, export_mindb=True, timing=tm)     # device-resident lists (gather_local)
+    assert tm["clusters_in"] == [cb.n_clusters] and tm["bytes_lists"] > 0
+    assert merged.n_clusters == cb.n_clusters and fnv1a_reads(merged, rs.n) == fnv1a_reads(cb, rs.n)
+    for a, b in zip(merged.mindb, cb.mindb):
+        assert np.array_equal(a, b)                                                  # the MinDB AddMinimizers makes of the same clusters
+    merged2 = d.merge_all_native(ctx, p, cb, None)                                   # the same from host arrays (H2D inside)
+    assert fnv1a_reads(merged2, rs.n) == fnv1a_reads(cb, rs.n)
+    B, view = oracle_sorted_batch(rs)
+    ocl, ost, _ = oracle_entry_assignments(B, view, mode=mode)
+    acl, ast = merged.assignments(rs.n)
+    assert f"{fnv1a(acl[sb.read_ids], ast[sb.read_ids]):016x}" == f"{fnv1a(ocl, ost):016x}"
+    # the collectives on their own
+    import ctypes as C
+    x = C.c_double(3.5)
+    ctx._chk(ctx.L.ioc_dist_allreduce_max(ctx.h, C.byref(x)))
+    assert x.value == 3.5
+    ctx._chk(ctx.L.ioc_dist_barrier(ctx.h))
+    ctx._chk(ctx.L.ioc_dist_shutdown(ctx.h))
+    ctx.close()
