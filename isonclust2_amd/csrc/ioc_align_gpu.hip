@@ -1774,6 +1774,7 @@ int reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
         return ioc_fail(c, IOC_ERR_CAPACITY, "hipMalloc(" + std::to_string(want) + " B) failed: " + hipGetErrorString(e));
     }
     b.cap = want;
+    ioc_poison(b.p, want);
     return IOC_OK;
 }
 

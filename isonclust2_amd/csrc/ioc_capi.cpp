@@ -23,6 +23,12 @@ int ioc_fail(ioc_ctx* c, int code, const std::string& msg)
 
 static uint32_t env_u32(const char* name, uint32_t dflt);
 
+void ioc_poison(void* p, size_t bytes)
+{
+    static const int v = getenv("IOC_POISON") ? int(strtol(getenv("IOC_POISON"), nullptr, 0)) : -1;
+    if (v >= 0 && p && bytes) (void)hipMemset(p, v & 0xFF, bytes);
+}
+
 int ioc_wait_uploads(ioc_ctx* c, int stage)
 {
     if (!c) return IOC_ERR_ARG;
@@ -68,6 +74,7 @@ static int dev_reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
                         "hipMalloc(" + std::to_string(want) + " B) failed: " + hipGetErrorString(e));
     }
     b.cap = want;
+    ioc_poison(b.p, want);
     return IOC_OK;
 }
 #define RESERVE(c, b, bytes)                     \

@@ -177,6 +177,11 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     std::string lseq;
     std::vector<int64_t> loff;
     std::vector<int32_t> sub_cls, sub_cut;
+    // ALN_INVOKED (cluster.cpp:21, 559): an entry counts iff it reached the alignment fallback in the pass whose decision
+    // stands for it — the flag of an entry is overwritten whenever a later pass walks it again
+    std::vector<int32_t> sub_tgt;
+    std::vector<int8_t> sub_str;
+    std::vector<uint8_t> sub_flg, aln_flag(size_t(rb->n) + 1, 0);
     std::vector<int8_t> sub_strand;
     const int k = p->k, w = p->w;
     int pos = 0;
@@ -317,6 +322,10 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         if (r != IOC_OK) return r;
         sub_cut.assign(size_t(m) + 1, INT32_MAX);
         if (m > 0 && (r = ioc_get_cuts(c, sub_cut.data())) != IOC_OK) return r;
+        sub_tgt.assign(size_t(m) + 1, 0);
+        sub_str.assign(size_t(m) + 1, 0);
+        sub_flg.assign(size_t(m) + 1, 0);
+        if (m > 0 && (r = ioc_get_decisions(c, sub_tgt.data(), sub_str.data(), sub_flg.data())) != IOC_OK) return r;
         ph[1] += now() - t0;
         total.resolve_iters += st.resolve_iters;
         total.n_tie_replays += st.n_tie_replays;
@@ -335,6 +344,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         for (int x = 0; x < m; ++x) {
             const int i = pos + x;
             const int32_t dc = sub_cls[size_t(x)];
+            aln_flag[size_t(i)] = dc >= 0 && (sub_flg[size_t(x)] & 2) ? 1 : 0;
             if (dc < 0) {  // (gated by its quality: no cluster has a say)
                 out_cls[i] = -1;
                 out_strand[i] = 0;
@@ -386,7 +396,6 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 cl.push_back(std::move(ns));
                 out_cls[i] = dc;
                 out_strand[i] = 1;
-                total.n_aln_invoked += 0;
                 continue;
             }
             if (dc > int32_t(cl.size())) return ioc_fail(c, IOC_ERR_STATE, "inconsistent cluster id from the device path");
@@ -722,6 +731,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     // context must not warm-start from it
     c->warm_first = -1;
     total.n_clusters = int64_t(cl.size());
+    total.n_aln_invoked = 0;
+    for (int i = 0; i < rb->n; ++i) total.n_aln_invoked += aln_flag[size_t(i)];
     if (stats) *stats = total;
     return IOC_OK;
 }

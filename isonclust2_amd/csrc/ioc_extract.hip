@@ -413,7 +413,12 @@ struct Tmp {
     {
         if (p) (void)hipFree(p);
     }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t alloc(size_t bytes)
+    {
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e == hipSuccess) ioc_poison(p, bytes ? bytes : 16);
+        return e;
+    }
     template <class T>
     T* as()
     {
@@ -454,6 +459,7 @@ int reserve_x(ioc_ctx* c, DevBuf& b, size_t bytes)
         return ioc_fail(c, IOC_ERR_CAPACITY, "hipMalloc failed in extraction");
     }
     b.cap = want;
+    ioc_poison(b.p, want);
     return IOC_OK;
 }
 

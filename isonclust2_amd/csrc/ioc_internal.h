@@ -20,6 +20,10 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// IOC_POISON=<byte>: every fresh device allocation of the library is filled with that byte (debug aid: a kernel that reads
+// memory nobody wrote gives results that change with the byte; a fresh process otherwise sees zero-filled VRAM and hides it)
+void ioc_poison(void* p, size_t bytes);
+
 struct ioc_dist_state;  // ioc_dist.cpp: the context's RCCL communicator
 
 struct ioc_ctx {

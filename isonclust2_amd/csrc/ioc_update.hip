@@ -176,6 +176,7 @@ static int dev_alloc(ioc_ctx* c, Tmp& t, size_t bytes)
         t.p = nullptr;
         return ioc_fail(c, IOC_ERR_CAPACITY, std::string("hipMalloc failed: ") + hipGetErrorString(e));
     }
+    ioc_poison(t.p, bytes ? bytes : 16);
     return IOC_OK;
 }
 
@@ -268,7 +269,9 @@ int ioc_index_update(ioc_ctx* c, int32_t cls, const uint32_t* old_min, int64_t n
     };
     auto grab = [&](DevBuf& b, size_t bytes) {
         b.cap = bytes ? bytes : 16;
-        return hipMalloc(&b.p, b.cap) == hipSuccess;
+        if (hipMalloc(&b.p, b.cap) != hipSuccess) return false;
+        ioc_poison(b.p, b.cap);
+        return true;
     };
     if ((r = dev_alloc(c, d_abs_key, size_t(n_abs) * 4)) != IOC_OK) return r;
     if ((r = dev_alloc(c, d_abs_ins, size_t(n_abs))) != IOC_OK) return r;

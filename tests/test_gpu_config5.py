@@ -47,7 +47,8 @@ class Tree:
 
     def __init__(self, ctx, per):
         self.ctx, self.per, self.gold = ctx, per, GOLD[f"per{per}"]
-        self.nb = len(self.gold["leaves"])
+        self.nb = c5.NB          # the batches are cuts of ONE global sort over all nb * per reads: nb is part of the workload
+        assert len(self.gold["leaves"]) == self.nb and len(self.gold["merges"]) == len(c5.TREE), "golden record incomplete"
         self.n_total = self.nb * per
         self.p = api.default_params(c5.K, c5.W, c5.MODE)
         self.sorted = None
