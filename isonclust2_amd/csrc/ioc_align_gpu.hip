@@ -1778,9 +1778,224 @@ int reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
     return IOC_OK;
 }
 
+#define ACHK(c, call)                                                                             \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return ioc_fail((c), IOC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#include "ioc_align_v2.inc"
+
+// ---- host side of version 2 -------------------------------------------------------------------------------------------
+// the pairs order[0 .. cnt) (all of the query-profile kind, heaviest first) through k_fwd2 / k_fwd2_ends / k_trace2.
+// Returns IOC_OK with *fell_back = true when a bounded wait of the forward pass ran out (the caller then runs the same
+// pairs through version 1).
+int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* order, uint32_t cnt, const uint32_t* d_order,
+                 const AlnParams& P, int32_t* d_score, uint32_t* d_count, bool* fell_back)
+{
+    *fell_back = false;
+    if (cnt == 0) return IOC_OK;
+    hipStream_t s = c->stream;
+    int r;
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+    if (n_cu < 1) n_cu = 256;
+    size_t free_b = 0, total_b = 0;
+    ACHK(c, hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = uint64_t(free_b + c->a_ck.cap) / 2;
+    if (const char* e = getenv("IOC_ALIGN_CK_BUDGET_MB")) budget = uint64_t(atoll(e)) << 20;
+    uint32_t want_bands = 8;
+    if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
+    const uint32_t np = uint32_t(dp.size());
+    const uint32_t ncouples = (cnt + 1u) / 2u;
+    std::vector<V2Couple> cps(ncouples);
+    std::vector<V2PairCk> pck(np);
+    std::vector<V2PairEnd> pend(np);
+    std::vector<uint64_t> cwords(ncouples);  // arena words of a couple
+    auto up4 = [](uint64_t x) { return (x + 3u) & ~uint64_t(3); };
+    uint32_t lrow_total = 0, best_total = 0;
+    for (uint32_t k2 = 0; k2 < ncouples; ++k2) {
+        V2Couple& cp = cps[k2];
+        cp.pid[0] = order[2u * k2];
+        cp.pid[1] = 2u * k2 + 1u < cnt ? order[2u * k2 + 1u] : 0xFFFFFFFFu;
+        uint32_t nmax = 0, mmax = 0;
+        for (int h = 0; h < 2; ++h)
+            if (cp.pid[h] != 0xFFFFFFFFu) {
+                nmax = std::max(nmax, dp[cp.pid[h]].n);
+                mmax = std::max(mmax, dp[cp.pid[h]].m);
+            }
+        const uint32_t ncoarse = (nmax + CK2 - 1) / CK2;
+        cp.nstrips = (mmax + 64u * FW_C - 1) / (64u * FW_C);
+        // bands of whole coarse rows: enough of them for the anti-diagonals of the tile grid to keep the chip busy, each long
+        // enough (>= 1024 rows = 256 steps) for the 63 steps of pipeline fill to stay small
+        cp.tpb = std::max<uint32_t>(2u, (ncoarse + want_bands - 1) / want_bands);
+        cp.nbands = (ncoarse + cp.tpb - 1) / cp.tpb;
+        cp.mpad = uint32_t((uint64_t(mmax) + 15u) & ~uint64_t(15));
+        cp.nq = (nmax + 3u) / 4u;
+        const uint64_t ncr = (nmax - 1u) / CK2, ncc = (mmax - 1u) / CK2;
+        uint64_t w = 0;
+        cp.rdat = w;
+        w += up4(ncr * 2u * cp.mpad);
+        cp.rbase = w;
+        w += up4(ncr * (cp.mpad / 16u) * 2u);
+        cp.cdat = w;
+        w += up4(ncc * uint64_t(cp.nq) * 8u);
+        cp.cbase = w;
+        w += up4(ncc * uint64_t(cp.nq) * 2u);
+        cwords[k2] = w;
+        for (int h = 0; h < 2; ++h) {
+            cp.lrow0[h] = lrow_total;
+            cp.best0[h] = best_total;
+            if (cp.pid[h] == 0xFFFFFFFFu) continue;
+            const AlnPairDev& d = dp[cp.pid[h]];
+            const uint32_t nstr = (d.m + 64u * FW_C - 1) / (64u * FW_C);
+            pend[cp.pid[h]] = V2PairEnd{lrow_total, best_total, cp.nbands, cp.tpb};
+            lrow_total += nstr * 64u;
+            best_total += cp.nbands;
+        }
+    }
+    // slices of couples whose checkpoints fit the budget together
+    std::vector<std::pair<uint32_t, uint32_t>> slices;
+    uint64_t arena_words = 0;
+    for (uint32_t first = 0; first < ncouples;) {
+        uint64_t used = 0;
+        uint32_t k2 = first;
+        while (k2 < ncouples && (k2 == first || (used + cwords[k2]) * 4ull <= budget)) {
+            V2Couple& cp = cps[k2];
+            cp.rdat += used;
+            cp.rbase += used;
+            cp.cdat += used;
+            cp.cbase += used;
+            for (int h = 0; h < 2; ++h)
+                if (cp.pid[h] != 0xFFFFFFFFu) pck[cp.pid[h]] = V2PairCk{cp.rdat, cp.rbase, cp.cdat, cp.cbase, cp.mpad, cp.nq, uint32_t(h), 0u};
+            used += cwords[k2];
+            ++k2;
+        }
+        arena_words = std::max(arena_words, used);
+        slices.emplace_back(first, k2 - first);
+        first = k2;
+    }
+    const auto t_res0 = std::chrono::steady_clock::now();
+    if ((r = reserve(c, c->a_ck, size_t(arena_words) * 4)) != IOC_OK) return r;
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc]   aligner v2: %u couples, checkpoint arena %.1f MB (%zu slice(s)) reserved in %.3f ms\n", ncouples,
+                double(arena_words) * 4e-6, slices.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_res0).count());
+    // flags and items per slice; the static tables once
+    uint32_t max_items = 0, max_flags = 0, max_pairs = 0;
+    std::vector<std::vector<V2Item>> items(slices.size());
+    for (size_t si = 0; si < slices.size(); ++si) {
+        uint32_t nf = 0;
+        auto& it = items[si];
+        for (uint32_t k2 = slices[si].first; k2 < slices[si].first + slices[si].second; ++k2) {
+            V2Couple& cp = cps[k2];
+            cp.flag0 = nf;
+            nf += cp.nbands * cp.nstrips;
+            for (uint32_t b = 0; b < cp.nbands; ++b)
+                for (uint32_t p = 0; p < cp.nstrips; ++p) it.push_back(V2Item{k2, uint16_t(b), uint16_t(p)});
+        }
+        // anti-diagonal by anti-diagonal, couples side by side: every tile comes after the tile above it and the tile to its left
+        std::stable_sort(it.begin(), it.end(), [](const V2Item& a, const V2Item& b) { return uint32_t(a.band) + a.strip < uint32_t(b.band) + b.strip; });
+        max_items = std::max<uint32_t>(max_items, uint32_t(it.size()));
+        max_flags = std::max(max_flags, nf);
+        max_pairs = std::max(max_pairs, std::min(cnt, 2u * (slices[si].first + slices[si].second)) - 2u * slices[si].first);
+    }
+    const size_t tab_bytes = size_t(ncouples) * sizeof(V2Couple) + size_t(np) * (sizeof(V2PairCk) + sizeof(V2PairEnd)) + size_t(max_items) * sizeof(V2Item) + 256;
+    if ((r = reserve(c, c->a_cko, tab_bytes)) != IOC_OK) return r;
+    uint8_t* tb = static_cast<uint8_t*>(c->a_cko.p);
+    V2Couple* d_cps = reinterpret_cast<V2Couple*>(tb);
+    V2PairCk* d_pck = reinterpret_cast<V2PairCk*>(tb + size_t(ncouples) * sizeof(V2Couple));
+    V2PairEnd* d_pend = reinterpret_cast<V2PairEnd*>(reinterpret_cast<uint8_t*>(d_pck) + size_t(np) * sizeof(V2PairCk));
+    V2Item* d_items = reinterpret_cast<V2Item*>(reinterpret_cast<uint8_t*>(d_pend) + size_t(np) * sizeof(V2PairEnd));
+    ACHK(c, hipMemcpyAsync(d_cps, cps.data(), size_t(ncouples) * sizeof(V2Couple), hipMemcpyHostToDevice, s));
+    ACHK(c, hipMemcpyAsync(d_pck, pck.data(), size_t(np) * sizeof(V2PairCk), hipMemcpyHostToDevice, s));
+    ACHK(c, hipMemcpyAsync(d_pend, pend.data(), size_t(np) * sizeof(V2PairEnd), hipMemcpyHostToDevice, s));
+    if ((r = reserve(c, c->a_ends2, size_t(np) * sizeof(int4))) != IOC_OK) return r;
+    if ((r = reserve(c, c->a_lrow, (size_t(lrow_total) + best_total + 16) * sizeof(int2))) != IOC_OK) return r;
+    int2* d_lrow = static_cast<int2*>(c->a_lrow.p);
+    int2* d_best = d_lrow + lrow_total;
+    // [queue][err][pad ...][flags][ovf per pair]
+    const size_t ctl_words = 16 + size_t(max_flags) + np;
+    if ((r = reserve(c, c->a_xflags, ctl_words * 4)) != IOC_OK) return r;
+    uint32_t* d_ctl = static_cast<uint32_t*>(c->a_xflags.p);
+    if ((r = reserve(c, c->a_bnd, size_t(max_pairs) * sizeof(V2Scratch))) != IOC_OK) return r;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k_fwd2), 64 * V2_WAVES, 0) != hipSuccess) occ = 0;
+    (void)hipGetLastError();
+    if (occ < 1) occ = 3;
+    std::vector<hipEvent_t> evs(slices.size() * 3, nullptr);
+    for (auto& e : evs) ACHK(c, hipEventCreate(&e));
+    size_t evi = 0;
+    bool bad = false;
+    for (size_t si = 0; si < slices.size() && !bad; ++si) {
+        const uint32_t first_pair = 2u * slices[si].first, n_pairs = std::min(cnt, 2u * (slices[si].first + slices[si].second)) - first_pair;
+        const uint32_t n_items = uint32_t(items[si].size());
+        ACHK(c, hipMemcpyAsync(d_items, items[si].data(), size_t(n_items) * sizeof(V2Item), hipMemcpyHostToDevice, s));
+        ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
+        ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
+        ACHK(c, hipEventRecord(evs[evi++], s));
+        // persistent waves: as many workgroups as the chip holds, but no more waves than tiles
+        const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_items + V2_WAVES - 1) / V2_WAVES));
+        hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_items,
+                           d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
+                           d_best, d_ctl + 16 + max_flags);
+        ACHK(c, hipGetLastError());
+        hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, n_pairs,
+                           d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p));
+        ACHK(c, hipGetLastError());
+        ACHK(c, hipEventRecord(evs[evi++], s));
+        hipLaunchKernelGGL(k_trace2, dim3((n_pairs + TR_WAVES - 1) / TR_WAVES), dim3(64 * TR_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p),
+                           d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const uint32_t*>(c->a_ck.p), d_pck,
+                           static_cast<const int4*>(c->a_ends2.p), static_cast<V2Scratch*>(c->a_bnd.p), d_score, d_count, n_pairs);
+        ACHK(c, hipGetLastError());
+        ACHK(c, hipEventRecord(evs[evi++], s));
+        if (getenv("IOC_V2_PROGRESS")) {  // debug watchdog: where are the kernels after 10 s?  (build with -DIOC_V2_MARKS)
+            const auto tw = std::chrono::steady_clock::now();
+            while (hipStreamQuery(s) == hipErrorNotReady) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > 10.0) {
+                    hipStream_t s2 = nullptr;
+                    uint32_t pg[16] = {0};
+                    (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+                    (void)hipMemcpyAsync(pg, d_ctl, sizeof pg, hipMemcpyDeviceToHost, s2);
+                    (void)hipStreamSynchronize(s2);
+                    fprintf(stderr, "[ioc] v2 WATCHDOG: queue %u err %u | dequeued %u, past waits %x, nsteps %u, step %u, after loop %u, published %u, wave exits %x %x %x %x, end marks %u %u %u\n",
+                            pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], pg[7], pg[8], pg[9], pg[10], pg[11], pg[12], pg[13], pg[14]);
+                    fflush(stderr);
+                    abort();
+                }
+            }
+        }
+        uint32_t xe = 0;
+        ACHK(c, hipMemcpyAsync(&xe, d_ctl + 1, 4, hipMemcpyDeviceToHost, s));
+        ACHK(c, hipStreamSynchronize(s));
+        if (getenv("IOC_V2_PROGRESS")) {  // (marks build: cycles the waves spent waiting for tiles / alive / the longest-lived wave)
+            unsigned long long t[3] = {0, 0, 0};
+            uint32_t pg[16] = {0};
+            ACHK(c, hipMemcpy(pg, d_ctl, sizeof pg, hipMemcpyDeviceToHost));
+            memcpy(&t[0], &pg[12], 8);
+            memcpy(&t[1], &pg[14], 8);
+            memcpy(&t[2], &pg[10], 8);
+            fprintf(stderr, "[ioc] v2 marks: waiting %.3e cycles of %.3e wave-cycles alive (%.1f %%), longest wave %.3e cycles, %u workgroups\n", double(t[0]), double(t[1]),
+                    100.0 * double(t[0]) / std::max(1.0, double(t[1])), double(t[2]), n_wg);
+        }
+        if (xe) bad = true;
+    }
+    for (size_t x = 0; x + 2 < evi + 0 && x + 2 < evs.size(); x += 3) {
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, evs[x], evs[x + 1]) == hipSuccess) c->tm.ms_align_fwd += a;
+        if (hipEventElapsedTime(&b, evs[x + 1], evs[x + 2]) == hipSuccess) c->tm.ms_align_trace += b;
+    }
+    for (auto& e : evs) (void)hipEventDestroy(e);
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc]   aligner v2: forward %.3f ms, traceback %.3f ms (device, all slices so far)%s\n", c->tm.ms_align_fwd,
+                c->tm.ms_align_trace, bad ? " — a wait ran out: falling back to version 1" : "");
+    *fell_back = bad;
+    return IOC_OK;
+}
+
 }  // namespace
 
-#define ACHK(c, call)                                                                             \
+#define ACHK_UNUSED(c, call)                                                                             \
     do {                                                                                          \
         hipError_t e__ = (call);                                                                  \
         if (e__ != hipSuccess)                                                                    \
@@ -1919,6 +2134,25 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     AlnParams P{match, mismatch, gap_extend, uint32_t(k), 1u << (32 - k)};
     int32_t* d_score = static_cast<int32_t*>(c->a_out.p);
     uint32_t* d_count = reinterpret_cast<uint32_t*>(d_score + np);
+    // Version 2 (ioc_align_v2.inc) takes the query-profile pairs — the front of `order`: two pairs per wave, tiles scheduled
+    // by dataflow, coarse checkpoints.  IOC_ALIGN_V1=1 keeps everything on the first version (which also serves pairs with
+    // other letters, pairs the 16-bit window refuses, and the whole batch should a bounded wait of version 2 run out).
+    // IOC_ALIGN_ARENA=fat: a long-lived process that can spare the HBM (35 MB per 16.7 kb pair, 56 GB for config 3's batch,
+    // allocated once and kept) takes version 1 — fine checkpoints straight from the forward pass, a traceback half as long,
+    // ~6 % less time per batch.  The default is the lean version: a `cluster` process that starts by allocating tens of GB
+    // pays seconds for the driver to hand them out.
+    uint32_t n_v2 = 0;
+    const char* arena_mode = getenv("IOC_ALIGN_ARENA");
+    const bool v2 = !carry && !packed && !g_force32 && !getenv("IOC_ALIGN_V1") && !(arena_mode && strcmp(arena_mode, "fat") == 0);
+    if (v2) {
+        while (n_v2 < np && dp[order[n_v2]].pad != 0) ++n_v2;
+        bool fell_back = false;
+        if ((r = align_v2_run(c, dp, order.data(), n_v2, static_cast<const uint32_t*>(c->a_order.p), P, d_score, d_count, &fell_back)) != IOC_OK) return r;
+        if (fell_back) {
+            c->tm.n_align_refused += n_v2;
+            n_v2 = 0;
+        }
+    }
     if (carry) {
         const uint64_t bnd_stride = 2ull * 6ull * max_n;
         const uint64_t lrow_entries = uint64_t((max_m + NT * ALN_C - 1) / (NT * ALN_C)) * NT;
@@ -1937,7 +2171,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
                                lrow_stride, d_score, d_count);
             ACHK(c, hipGetLastError());
         }
-    } else {
+    } else if (n_v2 < np) {
         // checkpoint arena: slices of pairs (in `order`) whose checkpoints fit the budget together
         size_t free_b = 0, total_b = 0;
         ACHK(c, hipMemGetInfo(&free_b, &total_b));
@@ -1959,7 +2193,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         std::vector<AlnCk> cko(np);
         std::vector<std::pair<uint32_t, uint32_t>> slices;  // [first, count) in `order`
         uint64_t arena = 0;
-        for (uint32_t first = 0; first < np;) {
+        for (uint32_t first = n_v2; first < np;) {
             uint64_t used = 0;
             uint32_t cnt = 0;
             while (first + cnt < np) {
@@ -2187,7 +2421,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     std::vector<int32_t> again;  // pairs the packed kernel flagged: scores outside its 16-bit window
     for (uint32_t x = 0; x < np; ++x) {
         const uint32_t i = back[x];
-        if (packed && hc[x] == 0xFFFFFFFFu && hs[x] == INT32_MIN) {
+        if ((packed || v2) && hc[x] == 0xFFFFFFFFu && hs[x] == INT32_MIN) {
             again.push_back(int32_t(i));
             continue;
         }
