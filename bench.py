@@ -364,6 +364,9 @@ def main():
                     help="both (default): headline = sahlin mode (BASELINE.json's metric, configs[2]) with the fast-mode "
                          "result (configs[1]) of the same batch beside it; fast / sahlin = that mode only")
     ap.add_argument("--cpu-sample", type=int, default=64, help="sahlin: reads in the CPU-baseline sample (a read that reaches the fallback costs ~0.5 s of scalar alignment)")
+    ap.add_argument("--aligner", default="fat", choices=["fat", "lean"],
+                    help="sahlin headline: fat = IOC_ALIGN_ARENA=fat (fine checkpoints, 56 GB arena kept by the resident process), "
+                         "lean = the library default (coarse checkpoints, 7 GB); the other one is reported beside it")
     ap.add_argument("--cpu-runs", type=int, default=3, help="CPU baseline: at most this many runs (min is reported)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="CPU baseline: seconds per leg after which no further run starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -429,9 +432,22 @@ def main():
                 "clusters": st["n_clusters"]}
         fast_res = (cls, strand, st, tm, acc)
     sah = None
+    sah_lean = None
     if want_sahlin:
         ctx.set_params(api.default_params(k, w, "sahlin"))
+        # The library's default aligner is the LEAN one (version 2: two pairs per wave, coarse checkpoints, 7 GB of arena for this
+        # batch): what a one-shot `cluster` process gets.  A long-lived process that keeps the batch resident can spend 56 GB of
+        # HBM on version 1's fine checkpoints (IOC_ALIGN_ARENA=fat) and halve the traceback.  Both are timed; the headline is the
+        # mode named in `config.aligner`.
+        os.environ.pop("IOC_ALIGN_ARENA", None)
         cls, strand, st, tm, elapsed, acc = timed_steps(ctx, torch, dist, dev, a.steps, a.warmup)
+        g_lean = None
+        sah_lean = {"ms_per_step": elapsed / a.steps * 1e3, "value": total_reads * a.steps / elapsed, "align_fwd_ms": acc["ms_align_fwd"],
+                    "align_trace_ms": acc["ms_align_trace"], "arena_bytes": tm.get("align_arena_bytes"), "aligner_version": tm.get("align_version"),
+                    "clusters": st["n_clusters"], "_res": (cls, strand, st)}
+        if a.aligner == "fat":
+            os.environ["IOC_ALIGN_ARENA"] = "fat"
+            cls, strand, st, tm, elapsed, acc = timed_steps(ctx, torch, dist, dev, a.steps, a.warmup)
         sah = {"value": total_reads * a.steps / elapsed, "unit": "reads/s", "ms_per_step": elapsed / a.steps * 1e3,
                "phase_ms": {"index_build": acc["ms_build"], "score": acc["ms_score"], "resolve_last": acc["ms_resolve"],
                             "align_fwd": acc["ms_align_fwd"], "align_trace": acc["ms_align_trace"]},
@@ -441,6 +457,8 @@ def main():
                              "cells": tm["n_align_cells"],
                              "refused_by_packed_kernel": tm.get("n_align_refused", 0)}}
         sah_res = (cls, strand, st, tm, acc)
+        sah["alignment"].update(arena_bytes=tm.get("align_arena_bytes"), aligner_version=tm.get("align_version"))
+        os.environ.pop("IOC_ALIGN_ARENA", None)     # core / cli / merge below: the library default
 
     # ---- every rank's own result against the committed oracle digest of ITS batch (tests/golden, tools/gen_golden.py) ----
     golden = {}
@@ -450,10 +468,12 @@ def main():
         pass
     from isonclust2_amd.digest import fnv1a
     rank_parity = {}
-    for mode_name, res in (("fast", fast_res if want_fast else None), ("sahlin", sah_res if want_sahlin else None)):
+    lean_res = sah_lean.pop("_res") if sah_lean else None
+    for mode_name, res in (("fast", fast_res if want_fast else None), ("sahlin", sah_res if want_sahlin else None),
+                           ("sahlin_lean", lean_res)):
         if res is None or a.config != "config2":
             continue
-        g = golden.get(f"config2:{seed}" + ("" if mode_name == "fast" else ":sahlin"))
+        g = golden.get(f"config2:{seed}" + ("" if mode_name == "fast" else ":sahlin"))  # (sahlin_lean: the same golden)
         ok = -1 if g is None else int(f"{fnv1a(res[0], res[1]):016x}" == g["fnv1a"] and res[2]["n_clusters"] == g["clusters"])
         if dist is not None:
             t = torch.tensor([ok], dtype=torch.int64, device=dev)
@@ -607,6 +627,9 @@ def main():
                 out["value_core_vs_cpu_baseline"] = out["value_core"] / head["cpu_baseline"]["value"]
         if head_mode == "sahlin":
             out["alignment"] = sah["alignment"]
+            out["config"]["aligner"] = ("IOC_ALIGN_ARENA=fat: version 1, fine checkpoints, arena kept resident" if a.aligner == "fat"
+                                        else "library default: version 2, two pairs per wave, coarse checkpoints")
+            out["alignment_lean"] = sah_lean
             out["roofline_align"] = roof_aln
             if fast is not None:
                 out["fast_mode"] = fast       # BASELINE.json configs[1] on the same batch

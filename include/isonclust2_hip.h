@@ -217,6 +217,12 @@ typedef struct {
      * -1 not run (IOC_SCORE_OOB=0 / 1 forces the variant).  A failed probe selects variant 0. */
     int32_t score_oob;
     int32_t score_oob_probe;
+    /* the aligner's checkpoint arena as the last ioc_align_pairs call sized it (bytes), the launches (slices) it took, and the
+     * version that ran: 2 = two pairs per wave, coarse checkpoints (the default), 1 = one pair per workgroup, fine checkpoints
+     * (IOC_ALIGN_ARENA=fat, pairs with letters other than A C G T, pairs the 16-bit window of version 2 refused) */
+    int64_t align_arena_bytes;
+    int32_t align_slices;
+    int32_t align_version;
 } ioc_timings;
 int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
 /* Instrumentation (one extra scoring launch, outside any timed region): the number of postings the

@@ -1878,6 +1878,9 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     }
     const auto t_res0 = std::chrono::steady_clock::now();
     if ((r = reserve(c, c->a_ck, size_t(arena_words) * 4)) != IOC_OK) return r;
+    c->tm.align_arena_bytes = int64_t(arena_words) * 4;
+    c->tm.align_slices = int32_t(slices.size());
+    c->tm.align_version = 2;
     if (getenv("IOC_TRACE"))
         fprintf(stderr, "[ioc]   aligner v2: %u couples, checkpoint arena %.1f MB (%zu slice(s)) reserved in %.3f ms\n", ncouples,
                 double(arena_words) * 4e-6, slices.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_res0).count());
@@ -2214,6 +2217,9 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         for (auto& sl : slices) max_cnt = std::max(max_cnt, sl.second);
         const auto t_res0 = std::chrono::steady_clock::now();
         if ((r = reserve(c, c->a_ck, size_t(arena) * 8)) != IOC_OK) return r;
+        c->tm.align_arena_bytes = int64_t(arena) * 8;
+        c->tm.align_slices = int32_t(slices.size());
+        c->tm.align_version = 1;
         if (getenv("IOC_TRACE"))
             fprintf(stderr, "[ioc]   aligner: checkpoint arena %.1f MB (%zu slice(s)) reserved in %.3f ms\n", double(arena) * 8e-6, slices.size(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_res0).count());

@@ -132,14 +132,51 @@ def test_tile_boundaries(ctx, monkeypatch, waves):
     _check(ctx, seqs, pairs, 11)
 
 
-def test_checkpoint_arena_slices(ctx, monkeypatch):
-    """A 1 MB checkpoint budget forces several launches (slices) over one batch."""
+@pytest.mark.parametrize("arena", ["lean", "fat"])
+def test_checkpoint_arena_slices(ctx, monkeypatch, arena):
+    """A 1 MB checkpoint budget forces several launches (slices) over one batch — with the coarse checkpoints of version 2
+    (the default: 512-pitch rows and columns of a couple, two pairs to a word) and with version 1's fine ones."""
     monkeypatch.setenv("IOC_ALIGN_CK_BUDGET_MB", "1")
+    monkeypatch.setenv("IOC_ALIGN_ARENA", arena)
     rng = random.Random(23)
     base = bytes(rng.choice(b"ACGT") for _ in range(3000))
     seqs = [_mutate(rng, base, 0.1) for _ in range(12)]
     pairs = [(i, (i + 1) % 12, i % 2, 0.2) for i in range(12)]
     _check(ctx, seqs, pairs, 11)
+    tm = ctx.timings()
+    assert tm["align_version"] == (2 if arena == "lean" else 1) and tm["align_slices"] > 1
+
+
+def test_lean_arena_is_an_eighth_of_the_fat_one(ctx, monkeypatch):
+    """Version 2 keeps (Hq, F*) / (Hq, E*) of every 512th row / column as 16-bit halves of one word per couple; version 1 kept
+    every 128th as 32-bit pairs per pair: 4.4 MB instead of 35 MB per 16.7 kb pair.  Same results from both."""
+    rng = random.Random(31)
+    base = bytes(rng.choice(b"ACGT") for _ in range(6000))
+    seqs = [_mutate(rng, base, 0.1) for _ in range(10)]
+    pairs = [(i, (i + 1) % 10, i % 2, 0.15) for i in range(10)]
+    res, arena = {}, {}
+    for mode in ("lean", "fat"):
+        monkeypatch.setenv("IOC_ALIGN_ARENA", mode)
+        ctx.align_set_pool(seqs)
+        res[mode] = ctx.align_pairs(pairs, 11)
+        arena[mode] = ctx.timings()["align_arena_bytes"]
+    assert np.array_equal(res["lean"][0], res["fat"][0]) and np.array_equal(res["lean"][1], res["fat"][1])
+    assert 0 < arena["lean"] * 6 < arena["fat"], arena
+
+
+def test_couples_of_unequal_pairs_odd_counts_and_other_letters(ctx):
+    """Version 2 packs two pairs into every register: pairs of very different sizes in one couple (the short one's bands and
+    strips run out first), an odd number of pairs (the last couple has one), empty and tiny sequences, and pairs with letters
+    other than A C G T (those take version 1 inside the same call)."""
+    rng = random.Random(37)
+    lens = [5000, 700, 2300, 1025, 1023, 513, 512, 4097, 33, 1, 0, 1500, 2600]
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in lens]
+    seqs += [_mutate(rng, seqs[0], 0.1), _mutate(rng, seqs[2], 0.08), seqs[3][:500] + b"N" + seqs[3][501:], _mutate(rng, seqs[7], 0.12)]
+    n = len(seqs)
+    pairs = [(i, (i * 5 + 3) % n, i % 2, rng.choice([0.05, 0.2, 0.3])) for i in range(n)] + [(0, 13, 0, 0.2), (14, 2, 1, 0.2), (7, 16, 0, 0.1)]
+    assert len(pairs) % 2 == 0
+    _check(ctx, seqs, pairs + [(13, 0, 1, 0.2)], 11)     # odd
+    _check(ctx, seqs, pairs, 7)
 
 
 def test_carry_variant(ctx, monkeypatch):
