@@ -47,17 +47,25 @@ VALU_PEAK_TOPS_DEFAULT = 256 * 4 * 16 * 2.4e9 / 1e12
 ALIGN_VALU_PER_CELL = 5  # fwd_cells: add with byte select, max3, sub, max, max (ioc_align_gpu.hip)
 
 
+def valu_rates():
+    """The JSON line of the issue-rate microbenchmark (tools/micro/valu_rate.hip -> profiles/r03_valu_rate.txt): T lane-op/s per
+    instruction, launches of 50 - 100 ms, best over 1-8 waves per SIMD."""
+    for name in ("r03_valu_rate.txt", "r02_valu_rate.txt"):
+        try:
+            for line in open(os.path.join(ROOT, "profiles", name)):
+                if line.startswith("JSON "):
+                    return json.loads(line[5:]), name
+        except Exception:
+            pass
+    return {}, None
+
+
 def valu_peak():
     """(peak T lane-op/s, source): the best rate any plain int32 VALU instruction reached in the microbenchmark."""
-    p = os.path.join(ROOT, "profiles", "r02_valu_rate.txt")
-    try:
-        for line in open(p):
-            if line.startswith("JSON "):
-                d = json.loads(line[5:])
-                best = max(d[k] for k in ("v_add_u32", "v_max_i32", "v_max3_i32") if k in d)
-                return best, "measured: profiles/r02_valu_rate.txt (best of v_add_u32 / v_max_i32 / v_max3_i32 over 1-8 waves per SIMD)"
-    except Exception:
-        pass
+    d, name = valu_rates()
+    ks = [d[k] for k in ("v_add_u32", "v_max_i32", "v_max3_i32") if k in d]
+    if ks:
+        return max(ks), f"measured: profiles/{name} (best of v_add_u32 / v_max_i32 / v_max3_i32 over 1-8 waves per SIMD)"
     return VALU_PEAK_TOPS_DEFAULT, "assumed 4 cycles per wave64 instruction per SIMD (no measurement file)"
 
 
@@ -582,9 +590,12 @@ def main():
                 # column PAIR (perm, add, 4 packed max, sub), two cells each
                 per_cell = 3.5 if v2 else ALIGN_VALU_PER_CELL
                 ach = cells * per_cell / (ms_fwd * 1e-3) / 1e12
+                rates, _ = valu_rates()
+                mixr = next((v for kk, v in rates.items() if kk.startswith("aligner v2" if v2 else "aligner cell mix")), None)
                 roof_aln = {"bound": "valu-int", "kernel": "k_fwd2 (two pairs per wave, 16-bit halves)" if v2 else "k_align_fwd", "achieved": ach, "peak": peak,
                             "peak_source": src, "unit": "T lane-op/s", "frac": ach / peak, "kernel_ms": ms_fwd,
                             "frac_of_guide_2cycle_issue": ach / (1024 * 32 * 2.4e9 / 1e12),
+                            "frac_of_own_instruction_mix": (ach / mixr) if mixr else None, "instruction_mix_rate": mixr,
                             "cells": cells, "valu_per_cell": per_cell,
                             "gcells_per_s": cells / (ms_fwd * 1e-3) / 1e9}
             if single:

@@ -2,19 +2,24 @@
 // waves per SIMD (developer microbenchmark; its output is kept under profiles/ and sets bench.py's VALU peak).
 // Every wave runs 16 independent dependency chains of the instruction under test; a workgroup is 256 threads = one wave
 // per SIMD, an LDS reservation caps the workgroups per CU at the wanted number and the grid is exactly CUs x that number,
-// so every SIMD holds exactly `wps` waves for the whole launch.  Launches run >= 10 ms after a burn-in (the clock under an
+// so every SIMD holds exactly `wps` waves for the whole launch.  Launches run >= 50 ms after a burn-in (the clock under an
 // all-VALU load settles well below the 2.4 GHz nominal); the shader clock during the launch is read as
 // s_memtime ticks per s_memrealtime tick (100 MHz) by one wave per workgroup.
+// Round 3: the launches are 50 - 100 ms (were 1 - 5: the launch tail was a third of the timed region), the rate and the
+// "cycles of a SIMD per wave-instruction" both come from the EVENT time of the launch (the per-wave cycle counts of round 2
+// under-counted when waves did not all start together: the sub-2-cycle v_add_u32 reading), and the line says how much of
+// the launch the average workgroup was alive.  Added: the instruction mix of the two-pairs-per-wave forward pass.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_rate tools/micro/valu_rate.hip && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 
-enum { FMA_F32, ADD_U32, MAX_I32, MAX3_I32, ADD_SDWA, PK_MAX_I16, PK_ADD_I16, MOV_DPP, MIX_ALIGN, N_MODES };
+enum { FMA_F32, ADD_U32, MAX_I32, MAX3_I32, ADD_SDWA, PK_MAX_I16, PK_ADD_I16, MOV_DPP, MIX_ALIGN, PK_MAX_U16, PERM_B32, MIX_V2, N_MODES };
 static const char* NAMES[N_MODES] = {"v_fma_f32", "v_add_u32", "v_max_i32", "v_max3_i32", "v_add_u32_sdwa (byte sel)",
                                      "v_pk_max_i16", "v_pk_add_i16", "v_mov_b32_dpp wave_shr:1",
-                                     "aligner cell mix (add_sdwa, max3, sub, max, max)"};
-static const int OPS[N_MODES] = {1, 1, 1, 1, 1, 1, 1, 1, 5};
+                                     "aligner cell mix (add_sdwa, max3, sub, max, max)", "v_pk_max_u16", "v_perm_b32",
+                                     "aligner v2 cell-pair mix (perm, add, 4 pk_max_u16, sub)"};
+static const int OPS[N_MODES] = {1, 1, 1, 1, 1, 1, 1, 1, 5, 1, 1, 7};
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters, uint32_t seed)
@@ -36,6 +41,18 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters
             if (MODE == ADD_SDWA) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[i]) : "v"(b));
             if (MODE == PK_MAX_I16) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             if (MODE == PK_ADD_I16) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (MODE == PK_MAX_U16) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (MODE == PERM_B32) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (MODE == MIX_V2) {
+                uint32_t inc, t, fn, e, hh;
+                asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(fn) : "v"(a[(i + 1) & 15]), "v"(c));
+                asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(inc) : "v"(b), "v"(c), "v"(b));
+                asm volatile("v_add_u32 %0, %1, %2" : "=v"(t) : "v"(a[(i + 2) & 15]), "v"(inc));
+                asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(t) : "v"(t), "v"(fn));
+                asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(e) : "v"(a[i]), "v"(b));
+                asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(hh) : "v"(t), "v"(e));
+                asm volatile("v_sub_u32 %0, %1, %2" : "=v"(a[i]) : "v"(hh), "v"(c));
+            }
             if (MODE == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
             if (MODE == MIX_ALIGN) {
                 uint32_t x, e, f;
@@ -61,7 +78,7 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters
 template <int MODE>
 void run(int n_cu, int wps, double* out_rate)
 {
-    const int grid = n_cu * wps, iters = 60000 / wps;
+    const int grid = n_cu * wps, iters = 2400000 / wps / OPS[MODE];   // 50 - 100 ms per launch
     uint32_t* d;
     uint64_t* dc;
     hipMalloc(&d, size_t(grid) * 256 * 4);
@@ -95,9 +112,10 @@ void run(int n_cu, int wps, double* out_rate)
     const double winstr = double(iters) * 16 * OPS[MODE];           // wave-instructions per wave
     const double lane_ops = winstr * 64 * 4 * double(grid);         // lane-operations of the launch
     const double rate = lane_ops / (ms * 1e-3) / 1e12;
-    // cycles of a SIMD per wave-instruction it issued: the wave's own cycles / its instructions / waves sharing the SIMD
-    printf("  %-48s wps %d: %8.3f ms  %6.2f T lane-op/s  %5.2f s_memtime ticks per wave-instr per SIMD  (ticks at %.2f GHz; workgroups busy %.0f %% of the launch)\n",
-           NAMES[MODE], wps, ms, rate, cavg / winstr / wps, ghz, wavg * 1e-5 / ms * 100);
+    // cycles of a SIMD per wave-instruction it issued: the launch's event time x the clock read inside it / (instructions of
+    // a wave x waves sharing the SIMD)
+    printf("  %-56s wps %d: %8.3f ms  %6.2f T lane-op/s  %5.2f cycles of a SIMD per wave-instr  (clock %.2f GHz; workgroups alive %.0f %% of the launch)\n",
+           NAMES[MODE], wps, ms, rate, ms * 1e-3 * ghz * 1e9 / (winstr * wps), ghz, wavg * 1e-5 / ms * 100);
     if (out_rate) *out_rate = rate;
     hipFree(d);
     hipFree(dc);
@@ -106,7 +124,7 @@ void run(int n_cu, int wps, double* out_rate)
 template <int MODE>
 void sweep(int n_cu, double* best)
 {
-    for (int wps : {1, 2, 4, 8}) {
+    for (int wps : {1, 2, 3, 4, 8}) {
         double r = 0;
         run<MODE>(n_cu, wps, &r);
         if (r > best[MODE]) best[MODE] = r;
@@ -129,6 +147,9 @@ int main()
     sweep<PK_ADD_I16>(n_cu, best);
     sweep<MOV_DPP>(n_cu, best);
     sweep<MIX_ALIGN>(n_cu, best);
+    sweep<PK_MAX_U16>(n_cu, best);
+    sweep<PERM_B32>(n_cu, best);
+    sweep<MIX_V2>(n_cu, best);
     printf("JSON {");
     for (int m = 0; m < N_MODES; ++m) printf("%s\"%s\": %.3f", m ? ", " : "", NAMES[m], best[m]);
     printf("}\n");
