@@ -874,6 +874,34 @@ static int main_info(int argc, char** argv)
     return 0;
 }
 
+// the tiny batch whose byte image is spelled out twice: in main_selftest below and — independently, from SURVEY.md App. B and
+// the serialize() member orders — in tests/test_cer_golden.py (`isONclust2-hip golden <path>` writes it)
+static void make_golden_batch(Batch& g)
+{
+    g.BatchNr = 1;
+    g.BatchStart = 2;
+    g.BatchEnd = 3;
+    g.BatchBases = 4;
+    g.TotalReads = 5;
+    g.NrCls = 1;
+    g.SortArgs.InFastq = "a";
+    g.SortArgs.BatchOutFolder = "b";
+    g.SortArgs.Mode = Fast;
+    g.LeftLeaf = "L";
+    g.RightLeaf = "";
+    g.Depth = -1;
+    g.Db = {{9u, {0u}}};
+    auto cl = std::make_shared<Cluster>();
+    auto ps = std::make_shared<ProcSeq>();
+    ps->RawSeq.reset(new Seq{"n", "AC", "II", 1.5, 0.25});
+    ps->Mins = {{1, 2, 3}};
+    ps->MatchStrand = 1;
+    ps->Id = "i";
+    cl->push_back(ps);
+    g.Cls.push_back(cl);
+    g.NrConsGs = 1;
+}
+
 // .cer round trip on a synthetic batch (host only; used by the CPU test-suite)
 static int main_selftest(int argc, char** argv)
 {
@@ -976,28 +1004,7 @@ static int main_selftest(int argc, char** argv)
     // reference-written file, pinned here against silent drift)
     {
         Batch g;
-        g.BatchNr = 1;
-        g.BatchStart = 2;
-        g.BatchEnd = 3;
-        g.BatchBases = 4;
-        g.TotalReads = 5;
-        g.NrCls = 1;
-        g.SortArgs.InFastq = "a";
-        g.SortArgs.BatchOutFolder = "b";
-        g.SortArgs.Mode = Fast;
-        g.LeftLeaf = "L";
-        g.RightLeaf = "";
-        g.Depth = -1;
-        g.Db = {{9u, {0u}}};
-        auto cl = std::make_shared<Cluster>();
-        auto ps = std::make_shared<ProcSeq>();
-        ps->RawSeq.reset(new Seq{"n", "AC", "II", 1.5, 0.25});
-        ps->Mins = {{1, 2, 3}};
-        ps->MatchStrand = 1;
-        ps->Id = "i";
-        cl->push_back(ps);
-        g.Cls.push_back(cl);
-        g.NrConsGs = 1;
+        make_golden_batch(g);
         string want;
         auto p32 = [&](int32_t v) { want.append(reinterpret_cast<const char*>(&v), 4); };
         auto pu32 = [&](uint32_t v) { want.append(reinterpret_cast<const char*>(&v), 4); };
@@ -1057,6 +1064,14 @@ int main(int argc, char** argv)
     if (cmd == "dump") return main_dump(argc - 1, argv + 1);
     if (cmd == "info") return main_info(argc - 1, argv + 1);
     if (cmd == "selftest") return main_selftest(argc - 1, argv + 1);
+    if (cmd == "golden") {  // writes the golden batch of the byte-layout tests (host only)
+        if (argc < 3) die("isONclust2-hip golden out.cer");
+        Batch g;
+        make_golden_batch(g);
+        string err;
+        if (!save_batch(g, argv[2], err)) die(err);
+        return 0;
+    }
     if (cmd == "version") {
         cerr << "isONclust2 version: " << VERSION << endl;
         return 0;
