@@ -1805,7 +1805,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     ACHK(c, hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = uint64_t(free_b + c->a_ck.cap) / 2;
     if (const char* e = getenv("IOC_ALIGN_CK_BUDGET_MB")) budget = uint64_t(atoll(e)) << 20;
-    uint32_t want_bands = 8;
+    uint32_t want_bands = 12;  // (config 3: 11 bands of 1536 rows: 66.8 ms; 7 of 2560: 69.2; 17 of 1024: worse again)
     if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
     const uint32_t np = uint32_t(dp.size());
     const uint32_t ncouples = (cnt + 1u) / 2u;
@@ -1828,9 +1828,43 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         const uint32_t ncoarse = (nmax + CK2 - 1) / CK2;
         cp.nstrips = (mmax + 64u * FW_C - 1) / (64u * FW_C);
         // bands of whole coarse rows: enough of them for the anti-diagonals of the tile grid to keep the chip busy, each long
-        // enough (>= 1024 rows = 256 steps) for the 63 steps of pipeline fill to stay small
-        cp.tpb = std::max<uint32_t>(2u, (ncoarse + want_bands - 1) / want_bands);
-        cp.nbands = (ncoarse + cp.tpb - 1) / cp.tpb;
+        // enough (>= 1024 rows = 256 steps) for the 63 steps of pipeline fill to stay small — except the first and the last
+        // ones, which CAN be short (V2Couple::bstart; IOC_ALIGN_V2_RAMP=1): 1, 2, 4 coarse rows, then the regular height, then 4, 2, 1
+        {
+            const uint32_t reg = std::max<uint32_t>(2u, (ncoarse + want_bands - 1) / want_bands);
+            std::vector<uint32_t> hts;
+            uint32_t left = ncoarse;
+            auto take = [&](uint32_t hgt) {
+                hgt = std::min(hgt, left);
+                if (hgt) hts.push_back(hgt);
+                left -= hgt;
+            };
+            // (measured on config 3: the ramp costs more in pipeline fill than it wins — 69.9 against 69.2 ms at 7 regular bands:
+            // off unless IOC_ALIGN_V2_RAMP=1)
+            const bool ramp = ncoarse >= 4u * reg && getenv("IOC_ALIGN_V2_RAMP") != nullptr;
+            std::vector<uint32_t> tail;
+            if (ramp) {
+                for (uint32_t hgt = 1; hgt < reg; hgt *= 2) take(hgt);
+                for (uint32_t hgt = 1; hgt < reg && left > hgt; hgt *= 2) {
+                    tail.push_back(hgt);
+                    left -= hgt;
+                }
+            }
+            while (left) take(reg);
+            for (size_t x = tail.size(); x-- > 0;) hts.push_back(tail[x]);
+            while (hts.size() > size_t(V2_MAX_BANDS)) {  // (very long pairs: merge from the middle)
+                const size_t mid = hts.size() / 2;
+                hts[mid - 1] += hts[mid];
+                hts.erase(hts.begin() + long(mid));
+            }
+            cp.nbands = uint32_t(hts.size());
+            cp.tpb = reg;
+            uint32_t acc = 0;
+            for (uint32_t b = 0; b <= uint32_t(V2_MAX_BANDS); ++b) {
+                cp.bstart[b] = uint16_t(std::min<uint32_t>(acc, 0xFFFFu));
+                if (b < cp.nbands) acc += hts[b];
+            }
+        }
         cp.mpad = uint32_t((uint64_t(mmax) + 15u) & ~uint64_t(15));
         cp.nq = (nmax + 3u) / 4u;
         const uint64_t ncr = (nmax - 1u) / CK2, ncc = (mmax - 1u) / CK2;
@@ -1850,7 +1884,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             if (cp.pid[h] == 0xFFFFFFFFu) continue;
             const AlnPairDev& d = dp[cp.pid[h]];
             const uint32_t nstr = (d.m + 64u * FW_C - 1) / (64u * FW_C);
-            pend[cp.pid[h]] = V2PairEnd{lrow_total, best_total, cp.nbands, cp.tpb};
+            pend[cp.pid[h]] = V2PairEnd{lrow_total, best_total, cp.nbands, k2};
             lrow_total += nstr * 64u;
             best_total += cp.nbands;
         }
@@ -1943,7 +1977,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                            d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
                            d_best, d_ctl + 16 + max_flags);
         ACHK(c, hipGetLastError());
-        hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, n_pairs,
+        hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
                            d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p));
         ACHK(c, hipGetLastError());
         ACHK(c, hipEventRecord(evs[evi++], s));
