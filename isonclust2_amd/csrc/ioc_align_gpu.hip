@@ -1924,15 +1924,25 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     for (size_t si = 0; si < slices.size(); ++si) {
         uint32_t nf = 0;
         auto& it = items[si];
+        uint32_t maxdiag = 0;
+        size_t total_items = 0;
         for (uint32_t k2 = slices[si].first; k2 < slices[si].first + slices[si].second; ++k2) {
             V2Couple& cp = cps[k2];
             cp.flag0 = nf;
             nf += cp.nbands * cp.nstrips;
-            for (uint32_t b = 0; b < cp.nbands; ++b)
-                for (uint32_t p = 0; p < cp.nstrips; ++p) it.push_back(V2Item{k2, uint16_t(b), uint16_t(p)});
+            total_items += size_t(cp.nbands) * cp.nstrips;
+            maxdiag = std::max(maxdiag, cp.nbands + cp.nstrips - 2u);
         }
         // anti-diagonal by anti-diagonal, couples side by side: every tile comes after the tile above it and the tile to its left
-        std::stable_sort(it.begin(), it.end(), [](const V2Item& a, const V2Item& b) { return uint32_t(a.band) + a.strip < uint32_t(b.band) + b.strip; });
+        // (generated in that order: sorting 150 000 items cost 4 ms of host time per call)
+        it.reserve(total_items);
+        for (uint32_t dg = 0; dg <= maxdiag; ++dg)
+            for (uint32_t k2 = slices[si].first; k2 < slices[si].first + slices[si].second; ++k2) {
+                const V2Couple& cp = cps[k2];
+                if (dg > cp.nbands + cp.nstrips - 2u) continue;
+                const uint32_t b_lo = dg >= cp.nstrips ? dg - cp.nstrips + 1u : 0u, b_hi = std::min(dg, cp.nbands - 1u);
+                for (uint32_t b = b_lo; b <= b_hi; ++b) it.push_back(V2Item{k2, uint16_t(b), uint16_t(dg - b)});
+            }
         max_items = std::max<uint32_t>(max_items, uint32_t(it.size()));
         max_flags = std::max(max_flags, nf);
         max_pairs = std::max(max_pairs, std::min(cnt, 2u * (slices[si].first + slices[si].second)) - 2u * slices[si].first);
