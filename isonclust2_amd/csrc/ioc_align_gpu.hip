@@ -1805,6 +1805,9 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     ACHK(c, hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = uint64_t(free_b + c->a_ck.cap) / 2;
     if (const char* e = getenv("IOC_ALIGN_CK_BUDGET_MB")) budget = uint64_t(atoll(e)) << 20;
+    // the 16-bit window's guard (|relative score| at a rebase): a pair beyond it is flagged and re-run by version 1
+    int guard = P16_GUARD;
+    if (const char* e = getenv("IOC_ALIGN_V2_GUARD")) guard = std::max(1, std::min(P16_GUARD, atoi(e)));
     uint32_t want_bands = 12;  // (config 3: 11 bands of 1536 rows: 66.8 ms; 7 of 2560: 69.2; 17 of 1024: worse again)
     if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
     const uint32_t np = uint32_t(dp.size());
@@ -1980,12 +1983,16 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         ACHK(c, hipMemcpyAsync(d_items, items[si].data(), size_t(n_items) * sizeof(V2Item), hipMemcpyHostToDevice, s));
         ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
         ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
+        if (getenv("IOC_ALIGN_V2_FAKE_TIMEOUT")) {  // (tests: as if a bounded wait had run out — every later wait gives up at once,
+            const uint32_t one = 1;                 // tiles run on whatever is there, the host must fall back to version 1)
+            ACHK(c, hipMemcpyAsync(d_ctl + 1, &one, 4, hipMemcpyHostToDevice, s));
+        }
         ACHK(c, hipEventRecord(evs[evi++], s));
         // persistent waves: as many workgroups as the chip holds, but no more waves than tiles
         const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_items + V2_WAVES - 1) / V2_WAVES));
         hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_items,
                            d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                           d_best, d_ctl + 16 + max_flags);
+                           d_best, d_ctl + 16 + max_flags, guard);
         ACHK(c, hipGetLastError());
         hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
                            d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p));

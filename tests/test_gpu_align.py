@@ -315,3 +315,22 @@ def test_tail_generation_split_in_launch(ctx, monkeypatch):
     s2, w2, _ = ctx.align_pairs(pairs, 11)
     assert np.array_equal(s1, s2) and np.array_equal(w1, w2)
     assert len(set(int(x) for x in w1)) > 50
+
+
+def test_v2_fallbacks(ctx, monkeypatch):
+    """The two ways out of version 2: a pair whose scores leave the 16-bit window is flagged by the guard and re-run by version 1
+    (forced here by a guard of 40: every pair of this size trips it), and a bounded wait that runs out sends the whole batch
+    through version 1 (forced by pre-setting the launch's error word).  Results are the host aligner's either way."""
+    rng = random.Random(41)
+    base = bytes(rng.choice(b"ACGT") for _ in range(2600))
+    seqs = [_mutate(rng, base, 0.1) for _ in range(6)] + [bytes(rng.choice(b"ACGT") for _ in range(1800))]
+    pairs = [(i, (i + 1) % 7, i % 2, 0.2) for i in range(7)]
+    monkeypatch.setenv("IOC_ALIGN_V2_GUARD", "40")
+    t0 = ctx.timings()["n_align_refused"]
+    _check(ctx, seqs, pairs, 11)
+    t1 = ctx.timings()["n_align_refused"]
+    assert t1 - t0 >= 5                      # the guard refused (nearly) every pair; they came back through version 1
+    monkeypatch.delenv("IOC_ALIGN_V2_GUARD")
+    monkeypatch.setenv("IOC_ALIGN_V2_FAKE_TIMEOUT", "1")
+    _check(ctx, seqs, pairs, 11)
+    assert ctx.timings()["n_align_refused"] - t1 == len(pairs) and ctx.timings()["align_version"] == 1
