@@ -330,7 +330,34 @@ def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode,
                        merge_ms=idist.max_over_ranks(tm["merge_ms"], dist), bytes_lists_this_rank=tm["bytes_lists"],
                        bytes_records_this_rank=tm["bytes_records"],
                        binding="C++ over RCCL inside libisonclust2_hip.so (ioc_dist_init / ioc_dist_merge); lists HBM to HBM, "
-                               "ragged all-gather = one ncclBroadcast per rank in one group")
+                               "ragged all-gather = one ncclBroadcast per rank in one group",
+                       sharded=bool(tm.get("sharded")), exchanges=tm.get("exchanges"))
+            world = dist.get_world_size() if dist is not None else 1
+            if world > 1:
+                # fast mode once replicated (every rank scores and decides every representative) and once sharded (rank r
+                # takes the representatives j with j % world == r; `valid` all-reduced over RCCL after every sweep)
+                pf = api.default_params(k, w, "fast")
+                vf = {kk: vv for kk, vv in sb.view.items() if kk not in ("raw_seq", "raw_off")}
+                legs = {}
+                for tag, env in (("replicated", "0"), ("sharded", "1")):
+                    os.environ["IOC_DIST_SHARD"] = env
+                    cbf = pipeline.cluster_single(ctx, pf, pipeline.SortedBatch(view=vf, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
+                                                                                batch_start=sb.batch_start, batch_end=sb.batch_end))
+                    best = None
+                    for _ in range(3):
+                        tf = {}
+                        mf = idist.merge_all_native(ctx, pf, cbf, torch, timing=tf)
+                        t = ctx.timings()
+                        rec = dict(merge_ms=idist.max_over_ranks(tf["merge_ms"], dist), score_ms=idist.max_over_ranks(t["ms_score"], dist),
+                                   resolve_ms=idist.max_over_ranks(t["ms_resolve"], dist), sweeps=t["resolve_iters"], exchanges=tf["exchanges"],
+                                   sharded=bool(tf["sharded"]), clusters_out=mf.n_clusters, fnv1a=fnv1a_reads(mf))
+                        if best is None or rec["merge_ms"] < best["merge_ms"]:
+                            best = rec
+                    legs[tag] = best
+                os.environ.pop("IOC_DIST_SHARD", None)
+                legs["same_clustering"] = legs["replicated"]["fnv1a"] == legs["sharded"]["fnv1a"]
+                legs["representatives"] = int(sum(tf["clusters_in"]))
+                out["fast_mode_sharded_resolve"] = legs
         except Exception as e:  # noqa: BLE001
             out["error"] = f"{type(e).__name__}: {e}"[:400]
 

@@ -488,7 +488,31 @@ typedef struct {
     double ms_merge;           /* the one-pass merge on this rank (wall) */
     int64_t bytes_lists;       /* this rank's contribution: minimizer lists ... */
     int64_t bytes_records;     /* ... and per-representative records + raw sequences */
+    int32_t sharded;           /* 1: score + resolve were sharded over the ranks (ioc_set_shard) */
+    int32_t exchanges;         /* all-reduces the sharded resolve issued */
 } ioc_dist_merge_times;
+/* Sharded score + resolve (fast mode): with world > 1 the context scores and decides only the queries j with
+ * j % world == rank (the same queries, index and forced decisions on every rank), and after each sweep of the resolve the
+ * ranks' shares of `valid` and the sweep's control words are combined through `fn`: an in-place all-reduce over `count`
+ * elements of DEVICE memory at d_buf, ordered after the work already on the context's stream (hip_stream) — kind
+ * IOC_XCHG_MAX_U8 (bytes, maximum), IOC_XCHG_MIN_U32 (words, minimum) or IOC_XCHG_SUM_I32 (words, sum); non-zero = failure.
+ * The decisions end up complete on every rank; they are those of the unsharded resolve (a query's decision depends on its
+ * own candidates and on `valid` of earlier queries only).  sahlin / furious contexts and ioc_cluster_consensus ignore the
+ * setting (their alignment rounds / windowed passes read per-query state of all queries); ioc_scored_candidates of a query
+ * another rank owns reports no candidates.  world <= 1 or fn == NULL switches it off.  ioc_dist_merge installs an RCCL
+ * exchange by itself (IOC_DIST_SHARD=0 keeps the replicated merge); the hook exists for other transports and for tests. */
+#define IOC_XCHG_MAX_U8 0
+#define IOC_XCHG_MIN_U32 1
+#define IOC_XCHG_SUM_I32 2
+typedef int (*ioc_exchange_fn)(void* user, void* d_buf, int64_t count, int32_t kind, void* hip_stream);
+int ioc_set_shard(ioc_ctx* ctx, int32_t world, int32_t rank, ioc_exchange_fn fn, void* user);
+/* all-reduces issued by the last ioc_resolve (0: it was not sharded) */
+int32_t ioc_shard_exchanges(const ioc_ctx* ctx);
+/* The RCCL form of that exchange over the context's communicator (ioc_dist_init), on the context's stream: directly, and
+ * installed as the context's shard setting with the communicator's world and rank (on = 0 removes it). */
+int ioc_dist_exchange(ioc_ctx* ctx, void* d_buf, int64_t count, int32_t kind);
+int ioc_dist_set_shard(ioc_ctx* ctx, int32_t on);
+
 /* The merge of ALL ranks' freshly clustered batches (Depth 0), on every rank: the left fold ((b0 + b1) + b2) ... in rank order
  * makes the decisions of ONE greedy loop over the representatives of b0, b1, ... in which b0's are clusters from the start
  * (ioc_batch_view::is_cluster: src/cluster.cpp:178-217 only appends).  reps = THIS rank's cluster representatives, one record

@@ -86,7 +86,13 @@ class AlnPair(C.Structure):  # ioc_aln_pair
 
 
 class DistMergeTimes(C.Structure):  # ioc_dist_merge_times
-    _fields_ = [("ms_exchange_lists", C.c_float), ("ms_merge", C.c_double), ("bytes_lists", C.c_int64), ("bytes_records", C.c_int64)]
+    _fields_ = [("ms_exchange_lists", C.c_float), ("ms_merge", C.c_double), ("bytes_lists", C.c_int64), ("bytes_records", C.c_int64),
+                ("sharded", C.c_int32), ("exchanges", C.c_int32)]
+
+
+# ioc_exchange_fn (ioc_set_shard): user, device buffer, element count, kind, hip stream
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+XCHG_MAX_U8, XCHG_MIN_U32, XCHG_SUM_I32 = 0, 1, 2
 
 
 class Timings(C.Structure):
@@ -118,7 +124,7 @@ SYMBOLS = [
     "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_gather_records_device", "ioc_queries_generation", "ioc_scored_candidates",
     "ioc_dist_unique_id", "ioc_dist_init", "ioc_dist_shutdown", "ioc_dist_info", "ioc_dist_allgather_device",
     "ioc_dist_allgatherv_device", "ioc_dist_allgather_i64", "ioc_dist_allgatherv_host", "ioc_dist_allreduce_max",
-    "ioc_dist_barrier", "ioc_dist_merge",
+    "ioc_dist_barrier", "ioc_dist_merge", "ioc_set_shard", "ioc_shard_exchanges", "ioc_dist_exchange", "ioc_dist_set_shard",
 ]
 
 _lib = None
@@ -221,5 +227,9 @@ def load():
     L.ioc_dist_barrier.argtypes = [vp]
     L.ioc_dist_merge.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(BatchView), i32, i64, pi32, pi8, pi64,
                                  C.POINTER(ClusterStats), C.POINTER(DistMergeTimes)]
+    L.ioc_set_shard.argtypes = [vp, i32, i32, EXCHANGE_FN, vp]
+    L.ioc_shard_exchanges.argtypes = [vp]
+    L.ioc_dist_exchange.argtypes = [vp, vp, i64, i32]
+    L.ioc_dist_set_shard.argtypes = [vp, i32]
     _lib = L
     return L

@@ -150,6 +150,29 @@ class Context:
                                                   _p(sz, C.c_uint32), _p(fi, C.c_uint32), _p(tm, C.c_uint32)))
         return t[:n], s[:n], sz[:n], fi[:n], tm[:n]
 
+    def set_shard(self, world, rank, fn):
+        """ioc_set_shard: fast-mode score + resolve of the queries j with j % world == rank only; fn(d_ptr, count, kind,
+        stream) is the in-place all-reduce over device memory (kind: _lib.XCHG_*) and returns 0.  world <= 1 or fn None
+        switches it off."""
+        if fn is None or world <= 1:
+            self._shard_cb = None
+            self._chk(self.L.ioc_set_shard(self.h, 1, 0, _lib.EXCHANGE_FN(), None))
+            return
+
+        def tramp(user, buf, count, kind, stream):
+            try:
+                return int(fn(buf, count, kind, stream) or 0)
+            except Exception:      # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._shard_cb = _lib.EXCHANGE_FN(tramp)      # kept alive for as long as the context may call it
+        self._chk(self.L.ioc_set_shard(self.h, world, rank, self._shard_cb, None))
+
+    @property
+    def shard_exchanges(self):
+        return int(self.L.ioc_shard_exchanges(self.h))
+
     def scored_candidates(self, q, cap=1 << 16):
         """(key, size) the scoring kernels wrote for query q: key = target << 1 | strand."""
         key, size = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)

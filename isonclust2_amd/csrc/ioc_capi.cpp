@@ -155,7 +155,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual, &c->b_dist_min, &c->b_dist_pos};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -644,6 +644,9 @@ int ioc_score(ioc_ctx* c)
     iock_set_score_variant(int(env_u32("IOC_SCORE_VARIANT", 0)));
     iock_set_part32(int(env_u32("IOC_PART32", 0)));
     iock_set_score_oob(c->score_oob);
+    const bool aln_mode_s = c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS;
+    c->scored_sharded = c->shard_world > 1 && c->shard_fn && !aln_mode_s;
+    iock_set_score_shard(c->scored_sharded ? c->shard_world : 1, c->shard_rank);
     if (env_u32("IOC_SCORE_PARTS", 1) == 1 && L + uint64_t(n) <= range && capacity * 8 * 4 + (1ull << 28) < have - need) {
         RESERVE(c, c->b_part, size_t(capacity) * 8 * 4);
         RESERVE(c, c->b_pmins, size_t(c->total) * 4);
@@ -659,7 +662,8 @@ int ioc_score(ioc_ctx* c)
                          P<uint32_t>(c->b_cand_key), P<uint32_t>(c->b_cand_size), P<uint32_t>(c->b_cand_count),
                          count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all), c->post16,
                          P<uint32_t>(c->b_pmins), P<uint32_t>(c->b_pbnd)));
-    c->have_guess = d_part != nullptr;
+    iock_set_score_shard(1, 0);
+    c->have_guess = d_part != nullptr && !c->scored_sharded;  // (b_top_all holds the owned queries only)
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
         unsigned long long t = 0;
@@ -740,6 +744,55 @@ int ioc_get_ties(ioc_ctx* c, uint32_t* count, uint32_t* keys)
     return IOC_OK;
 }
 
+int ioc_set_shard(ioc_ctx* c, int32_t world, int32_t rank, ioc_exchange_fn fn, void* user)
+{
+    if (!c) return IOC_ERR_ARG;
+    if (world > 1 && fn) {
+        if (rank < 0 || rank >= world) return ioc_fail(c, IOC_ERR_ARG, "ioc_set_shard: rank outside the world");
+        c->shard_world = world;
+        c->shard_rank = rank;
+        c->shard_fn = fn;
+        c->shard_user = user;
+    } else {
+        c->shard_world = 1;
+        c->shard_rank = 0;
+        c->shard_fn = nullptr;
+        c->shard_user = nullptr;
+    }
+    c->scored = false;  // (candidate tables of the other setting)
+    c->resolved = false;
+    return IOC_OK;
+}
+
+int32_t ioc_shard_exchanges(const ioc_ctx* c) { return c ? c->shard_exchanges : 0; }
+
+}  // extern "C"
+
+// one all-reduce of the sharded path through the caller's hook, on the context's stream
+int ioc_shard_exchange(ioc_ctx* c, void* d_buf, int64_t count, int kind)
+{
+    if (!c->shard_fn) return ioc_fail(c, IOC_ERR_STATE, "ioc_set_shard: no exchange installed");
+    c->shard_exchanges++;
+    if (c->shard_fn(c->shard_user, d_buf, count, kind, (void*)c->stream) != 0)
+        return ioc_fail(c, IOC_ERR_STATE, "ioc_set_shard: the exchange callback failed");
+    return IOC_OK;
+}
+
+// a host array of words summed over the ranks (every rank fills the slots it owns and leaves zeros elsewhere)
+int ioc_shard_sum_host(ioc_ctx* c, int32_t* words, int64_t count)
+{
+    if (count <= 0) return IOC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    RESERVE(c, c->b_shard_stage, size_t(count) * 4);
+    HIPCHK(c, hipMemcpyAsync(c->b_shard_stage.p, words, size_t(count) * 4, hipMemcpyHostToDevice, c->stream));
+    if (int rc = ioc_shard_exchange(c, c->b_shard_stage.p, count, IOC_XCHG_SUM_I32)) return rc;
+    HIPCHK(c, hipMemcpyAsync(words, c->b_shard_stage.p, size_t(count) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IOC_OK;
+}
+
+extern "C" {
+
 int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
 {
     if (!c) return IOC_ERR_ARG;
@@ -780,6 +833,11 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     // since, the first of them at query warm_first: the decisions before it stand (a decision depends on earlier
     // queries only), the exact sweeps go on from there on the previous `valid`.
     const bool warm = c->resolved && c->warm_first >= 0 && c->warm_first <= n && c->aln_verdicts && env_u32("IOC_RESOLVE_WARM", 1) == 1;
+    const bool sharded = c->scored_sharded;
+    if (sharded && (c->aln_verdicts || c->shard_world <= 1 || !c->shard_fn))
+        return ioc_fail(c, IOC_ERR_STATE, "the scores are sharded (ioc_set_shard): ioc_resolve needs the same setting, without alignment verdicts");
+    c->shard_exchanges = 0;
+    auto exchange = [&](void* buf, int64_t count, int kind) -> int { return ioc_shard_exchange(c, buf, count, kind); };
     // initial guess (any guess converges to the same fixed point): "every query opens a cluster".
     // A guess from the all-pairs top Size (IOC_RESOLVE_GUESS=1) was measured SLOWER on config 2
     // (4 sweeps / 3.5 ms vs 3 sweeps / 2.0 ms): many entries with a large top still fail the mapped-ratio
@@ -824,6 +882,8 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.n_evals = d_evals;
     a.min_shared = c->params.min_shared;
     a.min_fraction = c->params.min_fraction;
+    a.own_stride = sharded ? c->shard_world : 1;
+    a.own_offset = sharded ? c->shard_rank : 0;
     if (c->aln_verdicts) {
         a.aln_t = P<int32_t>(c->b_aln_t);
         a.aln_s = P<int8_t>(c->b_aln_s);
@@ -885,9 +945,19 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
             HIPCHK(c, iock_decide_phase2(s, &a, n, eval_blocks, P<uint32_t>(c->b_misc) + 11));
         else
             HIPCHK(c, iock_decide_sweep(s, &a, n - first, eval_blocks, P<uint32_t>(c->b_misc) + 11));
+        if (sharded) {
+            // every rank wrote its own queries' share of valid_out and of the control words: what is not owned is zeroed, the
+            // maximum over the ranks is the whole sweep's valid_out; first_changed is a minimum already and `incomplete` rides
+            // the same all-reduce complemented (see k_shard_mask_u8)
+            const int from = p2only ? 0 : first;
+            HIPCHK(c, iock_shard_mask_u8(s, vout, nullptr, from, n, c->shard_world, c->shard_rank, d_first_changed));
+            if (int rc = exchange(vout + from, int64_t(n - from), IOC_XCHG_MAX_U8)) return rc;
+            if (int rc = exchange(d_first_changed, 3, IOC_XCHG_MIN_U32)) return rc;
+        }
         uint32_t res[3] = {0, 0, 0};
         HIPCHK(c, hipMemcpyAsync(res, d_first_changed, 12, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        if (sharded) res[2] = ~res[2];
         sweeps++;
         if (sweeps > 4 * n + 64) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
         if (res[2] != 0) continue;  // work queue overflowed: same sweep again, the cache is fuller now
@@ -907,6 +977,16 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         // queries <= fc are final: fc was computed from a correct prefix, everything before it
         // did not change ("fixed point of the greedy loop")
         first = int(fc) + 1;
+    }
+    if (sharded && n > 0) {
+        // the decisions, gathered by owner (zero elsewhere: the sum of the words / the maximum of the bytes is the owner's value)
+        HIPCHK(c, iock_shard_mask_i32(s, a.dec_target, n, c->shard_world, c->shard_rank));
+        HIPCHK(c, iock_shard_mask_u8(s, reinterpret_cast<uint8_t*>(a.dec_strand), a.flags, 0, n, c->shard_world, c->shard_rank, nullptr));
+        if (int rc = exchange(a.dec_target, n, IOC_XCHG_SUM_I32)) return rc;
+        if (int rc = exchange(a.dec_strand, n, IOC_XCHG_MAX_U8)) return rc;
+        if (int rc = exchange(a.flags, n, IOC_XCHG_MAX_U8)) return rc;
+        HIPCHK(c, iock_shard_mask_i32(s, a.cut, n, c->shard_world, c->shard_rank));  // (ioc_get_cuts)
+        if (int rc = exchange(a.cut, n, IOC_XCHG_SUM_I32)) return rc;
     }
     HIPCHK(c, hipEventRecord(c->ev[5], s));
     unsigned long long ev = 0;

@@ -125,6 +125,13 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     if (aln_mode && L0 > 0 && (!left->rep_seq || !left->rep_off || !left->cls_raw_err))
         return ioc_fail(c, IOC_ERR_ARG, "sahlin/furious need the left representatives' sequences");
 
+    // the windowed passes below read per-query state of every query of a pass: never sharded (ioc_set_shard)
+    struct ShardOff {
+        ioc_ctx* c;
+        int world;
+        explicit ShardOff(ioc_ctx* x) : c(x), world(x->shard_world) { c->shard_world = 1; }
+        ~ShardOff() { c->shard_world = world; }
+    } shard_off(c);
     // ---- left state on the host: MinDB as an ordered map, one ClState per cluster ----
     std::map<uint32_t, std::vector<uint32_t>> db;
     std::vector<ClState> cl(static_cast<size_t>(L0));

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,6 +53,17 @@ static int reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
     HCK(c, hipMalloc(&b.p, bytes ? bytes : 256));
     b.cap = bytes ? bytes : 256;
     return IOC_OK;
+}
+
+// ioc_set_shard's exchange over the context's communicator: in-place all-reduce on the context's stream
+static int rccl_exchange(void* user, void* d_buf, int64_t count, int32_t kind, void* hip_stream)
+{
+    ioc_dist_state* d = static_cast<ioc_dist_state*>(user);
+    if (!d || !d->comm || count < 0) return 1;
+    if (count == 0) return 0;
+    ncclDataType_t t = kind == IOC_XCHG_MAX_U8 ? ncclUint8 : kind == IOC_XCHG_MIN_U32 ? ncclUint32 : ncclInt32;
+    ncclRedOp_t op = kind == IOC_XCHG_MAX_U8 ? ncclMax : kind == IOC_XCHG_MIN_U32 ? ncclMin : ncclSum;
+    return ncclAllReduce(d_buf, d_buf, size_t(count), t, op, d->comm, static_cast<hipStream_t>(hip_stream)) == ncclSuccess ? 0 : 1;
 }
 
 extern "C" {
@@ -206,6 +218,23 @@ struct RepMeta {
     double score, raw_err, hpc_err;
 };
 
+// the all-reduce ioc_dist_merge hands to ioc_set_shard, callable by a host program that drives ioc_cluster_merge itself
+int ioc_dist_exchange(ioc_ctx* c, void* d_buf, int64_t count, int32_t kind)
+{
+    if (int rc = need_dist(c)) return rc;
+    if (!d_buf || count < 0 || kind < IOC_XCHG_MAX_U8 || kind > IOC_XCHG_SUM_I32) return IOC_ERR_ARG;
+    HCK(c, hipSetDevice(c->device));
+    if (rccl_exchange(c->dist, d_buf, count, kind, c->stream) != 0) return ioc_fail(c, IOC_ERR_HIP, "RCCL: ncclAllReduce failed");
+    return IOC_OK;
+}
+
+int ioc_dist_set_shard(ioc_ctx* c, int32_t on)
+{
+    if (int rc = need_dist(c)) return rc;
+    if (on && c->dist->world > 1) return ioc_set_shard(c, c->dist->world, c->dist->rank, rccl_exchange, c->dist);
+    return ioc_set_shard(c, 1, 0, nullptr, nullptr);
+}
+
 int ioc_dist_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_batch_view* reps, int32_t min_cls_size,
                    int64_t out_cap, int32_t* out_cls, int8_t* out_strand, int64_t* out_counts, ioc_cluster_stats* stats,
                    ioc_dist_merge_times* times)
@@ -351,8 +380,16 @@ int ioc_dist_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, cons
     v.minimizers_on_device = 1;
     HCK(c, hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
+    // fast mode: score + resolve sharded over the ranks (query j on rank j % W), `valid` all-reduced after every sweep
+    const char* es = getenv("IOC_DIST_SHARD");
+    const bool shard = W > 1 && p->mode == IOC_MODE_FAST && !(es && es[0] == '0');
+    if (shard && ioc_dist_set_shard(c, 1) != IOC_OK) return IOC_ERR_STATE;
     const int rc = ioc_cluster_merge(c, p, table_path, nullptr, &v, out_cls, out_strand, stats);
+    const int exchanges = ioc_shard_exchanges(c);
+    if (shard) (void)ioc_dist_set_shard(c, 0);
     if (times) {
+        times->sharded = shard ? 1 : 0;
+        times->exchanges = exchanges;
         times->ms_exchange_lists = ms_comm;
         times->ms_merge = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         times->bytes_lists = (fw + rw) * 8;

@@ -603,6 +603,11 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     for (int i = 0; i < n; ++i)
         if (!gated[size_t(i)] && tgt[size_t(i)] < 0) cid[size_t(i)] = next++;
     int64_t joined = 0, ngated = 0, ties = 0;
+    // sharded score + resolve: the candidate table of a query lives on the rank that owns it, so that rank replays the
+    // query's order; the winners travel in one all-reduce afterwards (every rank sees the same flags, hence the same slots)
+    const bool sharded = c->scored_sharded;
+    std::vector<int> tie_q;
+    std::vector<int32_t> tie_words;
     for (int i = 0; i < n; ++i) {
         if (gated[size_t(i)]) {
             out_cls[i] = -1;
@@ -621,8 +626,17 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         if (flg[size_t(i)] & 1) {
             int32_t rt = -1;
             int8_t rs = 0;
-            if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs)) != IOC_OK) return r;
-            if (rt < 0) return ioc_fail(c, IOC_ERR_STATE, "tie replay found no passing candidate");
+            const bool mine = !sharded || (i % c->shard_world) == c->shard_rank;
+            if (mine) {
+                if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs)) != IOC_OK) return r;
+                if (rt < 0) return ioc_fail(c, IOC_ERR_STATE, "tie replay found no passing candidate");
+            }
+            if (sharded) {
+                tie_q.push_back(i);
+                tie_words.push_back(mine ? rt + 1 : 0);  // (+1: cluster 0 is a value, zero is "not mine")
+                tie_words.push_back(mine ? int32_t(rs) : 0);
+                rt = 0;
+            }
             cls = rt;
             s = rs;
             ties++;
@@ -631,6 +645,14 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         out_cls[i] = cls;
         out_strand[i] = s;
         joined++;
+    }
+    if (sharded && !tie_q.empty()) {
+        if ((r = ioc_shard_sum_host(c, tie_words.data(), int64_t(tie_words.size()))) != IOC_OK) return r;
+        for (size_t x = 0; x < tie_q.size(); ++x) {
+            if (tie_words[2 * x] <= 0) return ioc_fail(c, IOC_ERR_STATE, "tie replay: no rank reported a winner");
+            out_cls[tie_q[x]] = tie_words[2 * x] - 1;
+            out_strand[tie_q[x]] = int8_t(tie_words[2 * x + 1]);
+        }
     }
     tr.mark("final ids + tie replays");
     if (stats) {

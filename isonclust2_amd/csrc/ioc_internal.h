@@ -143,10 +143,20 @@ struct ioc_ctx {
     // ---- multi-GPU (ioc_dist.cpp) ----
     ioc_dist_state* dist = nullptr;
     DevBuf b_dist_min, b_dist_pos;  // the gathered representatives' minimizer lists of ioc_dist_merge (used in place as queries)
+    // sharded score + resolve (ioc_set_shard): this rank owns the queries j with j % shard_world == shard_rank
+    int shard_world = 1, shard_rank = 0;
+    ioc_exchange_fn shard_fn = nullptr;
+    void* shard_user = nullptr;
+    bool scored_sharded = false;  // the candidate tables hold the owned queries only
+    int shard_exchanges = 0;
+    DevBuf b_shard_stage;
     int score_oob = 0, score_oob_probe = -1;  // k_score_part's variant and the probe behind it (ioc_ctx_create)
 };
 
 int ioc_fail(ioc_ctx* c, int code, const std::string& msg);
+// sharded score + resolve (ioc_set_shard): one all-reduce through the caller's hook / a host array of words summed over ranks
+int ioc_shard_exchange(ioc_ctx* c, void* d_buf, int64_t count, int kind);
+int ioc_shard_sum_host(ioc_ctx* c, int32_t* words, int64_t count);
 // waits until the background upload of the query arrays has reached `stage` (see ioc_ctx::up_stage); 2 also ends the thread
 int ioc_wait_uploads(ioc_ctx* c, int stage);
 

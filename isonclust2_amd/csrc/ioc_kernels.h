@@ -52,6 +52,7 @@ struct DecideArgs {
     uint8_t* done;          // per query: decided in phase 1
     unsigned long long* diag;  // diagnostic cycle sums (IOC_EVAL_DIAG), normally nullptr
     int lazy;               // lazy sweep: only the maximal-Size candidates are walked (see ioc_resolve)
+    int own_stride, own_offset;  // sharded merge: this rank decides the queries j with j % own_stride == own_offset (stride <= 1: all)
     // alignment fallback (sahlin / furious): verdict of the alignment for a query, used only if its
     // mapping walk finds nothing although top >= MinShared (INT32_MIN = none yet, -1 = no hit either);
     // the candidates tied at the top Size (the ones getBestClusterAln tries) are reported per query
@@ -117,6 +118,9 @@ size_t iock_decide_args_size();
 void iock_set_score_variant(int v);
 void iock_set_part32(int v);
 void iock_set_score_oob(int v);
+void iock_set_score_shard(int stride, int offset);
+hipError_t iock_shard_mask_u8(hipStream_t st, uint8_t* a, uint8_t* b, int from, int n, int stride, int offset, uint32_t* ctl);
+hipError_t iock_shard_mask_i32(hipStream_t st, int32_t* a, int n, int stride, int offset);
 hipError_t iock_lds_oob_probe(hipStream_t st, uint32_t* d_result, uint32_t* h_result);
 
 // ---- sort-stage kernels (ioc_extract.hip) ----

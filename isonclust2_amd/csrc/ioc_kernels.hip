@@ -881,6 +881,28 @@ __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ p
     __builtin_amdgcn_wave_barrier();
 }
 
+// Sharded merge (ioc_set_shard): this rank's queries are j = own_offset (mod own_stride); they are DENSE in blockIdx (a
+// strided blockIdx would put every owned workgroup on the same XCD: workgroups are dealt round-robin over the 8 XCDs).
+// The b-th owned query counted from the top of [0, n) (scoring visits the long target ranges first) / from `from` upwards.
+__device__ __forceinline__ int owned_from_top(int n, int b, int stride, int offset)
+{
+    if (stride <= 1) return n - 1 - b;
+    const int top = (n - 1) - (((n - 1) - offset) % stride + stride) % stride;  // largest j <= n - 1 with j % stride == offset
+    return top - b * stride;
+}
+__device__ __forceinline__ int owned_from(int from, int b, int stride, int offset)
+{
+    if (stride <= 1) return from + b;
+    const int j0 = from + ((offset - from) % stride + stride) % stride;  // smallest j >= from with j % stride == offset
+    return j0 + b * stride;
+}
+static inline int owned_count(int from, int n, int stride, int offset)
+{
+    if (stride <= 1) return n > from ? n - from : 0;
+    const int j0 = from + ((offset - from) % stride + stride) % stride;
+    return j0 < n ? (n - j0 + stride - 1) / stride : 0;
+}
+
 template <int V, typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
@@ -888,13 +910,13 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
         const PT* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
         unsigned long long* __restrict__ traversed, Epochs E,
-        const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum)
+        const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum, int own_stride, int own_offset)
 {
     extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
     __shared__ uint32_t s_wb[IOC_WAVES][64];                       // per compacted list: address base
     __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];   // bitmap of list starts
-    const int j = n - 1 - int(blockIdx.x);
+    const int j = owned_from_top(n, int(blockIdx.x), own_stride, own_offset);
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);  // visible targets: [0, T)
     // first epoch boundary >= T: the field of the row info that holds its cut
@@ -1031,10 +1053,10 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_partition_mins(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
                  const uint32_t* __restrict__ mins, uint32_t shift, uint32_t* __restrict__ pmins,
-                 uint32_t* __restrict__ pbnd, uint32_t* __restrict__ max_len)
+                 uint32_t* __restrict__ pbnd, uint32_t* __restrict__ max_len, int own_stride, int own_offset)
 {
     __shared__ uint32_t cnt[IOC_PARTS], cur[IOC_PARTS];
-    const int j = blockIdx.x;
+    const int j = owned_from(0, int(blockIdx.x), own_stride, own_offset);
     if (j >= n) return;
     const uint32_t pshift = (32u - shift) - 3u;
     for (int s = 0; s < 2; ++s) {
@@ -1074,7 +1096,7 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
              uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, Epochs E,
-             unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len, uint32_t dyn_bytes)
+             unsigned long long* __restrict__ traversed, const uint32_t* __restrict__ max_len, uint32_t dyn_bytes, int own_stride, int own_offset)
 {
     // ONE strand's histogram at a time (L + j counters): half the LDS of a both-strands histogram, twice the workgroups per
     // CU (the kernel is bound by latency as much as by VALU issue and LDS conflicts: 17.6 waves per CU with 24 KB per
@@ -1082,7 +1104,7 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
     extern __shared__ uint32_t hist_dyn[];  // >= L + j counters
     __shared__ uint32_t s_wb[IOC_WAVES][64];
     __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];
-    const int j = n - 1 - int(blockIdx.x / IOC_PARTS);
+    const int j = owned_from_top(n, int(blockIdx.x / IOC_PARTS), own_stride, own_offset);
     const uint32_t x = blockIdx.x % IOC_PARTS;
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);
@@ -1194,12 +1216,12 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
                 uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_size,
                 uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ audit_valid,
                 unsigned long long* __restrict__ audit_sum, uint32_t* __restrict__ top_all,
-                const uint32_t* __restrict__ max_len)
+                const uint32_t* __restrict__ max_len, int own_stride, int own_offset)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
     __shared__ uint32_t wtop[IOC_WAVES];
-    const int j = n - 1 - int(blockIdx.x);
+    const int j = owned_from_top(n, int(blockIdx.x), own_stride, own_offset);
     if (j < 0) return;
     const uint32_t T = L + uint32_t(j);
     const int lane = lane_id(), wave = wave_id();
@@ -1306,7 +1328,7 @@ k_decide_scan(DecideArgs a)
 {
     __shared__ uint32_t red[IOC_WAVES];
     __shared__ uint32_t s_top;
-    const int j = a.first + int(blockIdx.x);
+    const int j = owned_from(a.first, int(blockIdx.x), a.own_stride, a.own_offset);  // (sharded merge: this rank's queries)
     if (j >= a.n) return;
     const int lane = lane_id(), wave = wave_id();
     const uint32_t L = a.L;
@@ -1840,7 +1862,7 @@ __global__ void __launch_bounds__(IOC_BLOCK)
 k_decide_pick(DecideArgs a)
 {
     __shared__ uint32_t rs[IOC_WAVES], re[IOC_WAVES], rc[IOC_WAVES], rm[IOC_WAVES];
-    const int j = a.first + int(blockIdx.x);
+    const int j = owned_from(a.first, int(blockIdx.x), a.own_stride, a.own_offset);
     if (j >= a.n) return;
     const int lane = lane_id(), wave = wave_id();
     const uint32_t L = a.L;
@@ -2114,6 +2136,8 @@ __global__ void __launch_bounds__(256) k_query_compact_many(const int32_t* __res
 static int g_score_variant = 0;
 static int g_part32 = 0;
 static int g_score_oob = 0;  // k_score_part without a window test (ioc_ctx_create's probe passed, or IOC_SCORE_OOB=1)
+// sharded merge: this rank scores the queries j with j % stride == offset 
+static int g_own_stride = 1, g_own_offset = 0;
 
 namespace {
 // ---- MinDB export (ioc_index_export): the posting lists restricted to the targets that ARE clusters, with final ids ----
@@ -2176,6 +2200,11 @@ extern "C" {
 void iock_set_score_variant(int v) { g_score_variant = v; }
 void iock_set_part32(int v) { g_part32 = v; }
 void iock_set_score_oob(int v) { g_score_oob = v; }
+void iock_set_score_shard(int stride, int offset)
+{
+    g_own_stride = stride > 1 ? stride : 1;
+    g_own_offset = stride > 1 ? offset : 0;
+}
 
 hipError_t iock_lds_oob_probe(hipStream_t st, uint32_t* d_result /* 2 words, zeroed here */, uint32_t* h_result)
 {
@@ -2365,6 +2394,11 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     const uint32_t* post = (const uint32_t*)post_;
     const uint16_t* post_h = (const uint16_t*)post_;
     if (n <= 0) return hipSuccess;
+    // sharded merge: one workgroup (or IOC_PARTS of them) per OWNED query; the others have no candidates here
+    const int own_s = audit_valid ? 1 : g_own_stride, own_o = audit_valid ? 0 : g_own_offset;  // (an audit launch visits every query)
+    const int nown = owned_count(0, n, own_s, own_o);
+    if (nown != n) CK(hipMemsetAsync(cand_count, 0, size_t(n) * 4, st));
+    if (nown <= 0) return hipSuccess;
     uint32_t tmax = L + uint32_t(n - 1);
     uint32_t r = tmax < range ? (tmax ? tmax : 1) : range;
     size_t lds = size_t(2) * r * 4;
@@ -2378,11 +2412,11 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
         }
         uint32_t* max_len = pbnd + size_t(n) * 2 * (IOC_PARTS + 1);  // one extra word behind the boundaries
         CK(hipMemsetAsync(max_len, g_part32 ? 0xFF : 0, 4, st));  // IOC_PART32=1 forces u32 partials (tests)
-        hipLaunchKernelGGL(k_partition_mins, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd,
-                           max_len);
+        hipLaunchKernelGGL(k_partition_mins, dim3(nown), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, mins, shift, pmins, pbnd,
+                           max_len, own_s, own_o);
 #define LAUNCH_PART(PT, OOB, PP)                                                                                          \
-    hipLaunchKernelGGL((k_score_part<PT, OOB>), dim3(unsigned(n) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L, off_fwd, \
-                       off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, PP, part, E, traversed, max_len, uint32_t(lds / 2))
+    hipLaunchKernelGGL((k_score_part<PT, OOB>), dim3(unsigned(nown) * IOC_PARTS), dim3(IOC_BLOCK), lds / 2, st, n, L, off_fwd, \
+                       off_rev, pmins, pbnd, (const uint4*)rows, cap, shift, PP, part, E, traversed, max_len, uint32_t(lds / 2), own_s, own_o)
         if (post16 && g_score_oob && IOC_SCORE_OOB)
             LAUNCH_PART(uint16_t, true, post_h);
         else if (post16)
@@ -2390,8 +2424,8 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
         else
             LAUNCH_PART(uint32_t, false, post);   // (u32 postings keep their window test: flat_traverse)
 #undef LAUNCH_PART
-        hipLaunchKernelGGL(k_score_compact, dim3(n), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
-                           cand_count, audit_valid, audit_sum, top_all, max_len);
+        hipLaunchKernelGGL(k_score_compact, dim3(nown), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
+                           cand_count, audit_valid, audit_sum, top_all, max_len, own_s, own_o);
         return hipGetLastError();
     }
     const Epochs E = epoch_bounds(L, uint32_t(n));
@@ -2399,9 +2433,9 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
     do {                                                                                                             \
         if (lds > 48 * 1024)                                                                                         \
             CK(hipFuncSetAttribute((const void*)k_score_t<V, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); \
-        hipLaunchKernelGGL((k_score_t<V, PT>), dim3(n), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,      \
+        hipLaunchKernelGGL((k_score_t<V, PT>), dim3(nown), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,   \
                            (const uint4*)rows, cap, shift, PP, range, keep, cand_key, cand_size, cand_count,         \
-                           traversed, E, audit_valid, audit_sum);                                           \
+                           traversed, E, audit_valid, audit_sum, own_s, own_o);                 \
     } while (0)
     if (post16) {
         LAUNCH_SCORE(0, uint16_t, post_h);
@@ -2422,8 +2456,9 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
 
 hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int eval_blocks, uint32_t* q_count2)
 {
-    if (nblocks <= 0) return hipSuccess;
     DecideArgs a = *reinterpret_cast<const DecideArgs*>(args_);
+    if (a.own_stride > 1) nblocks = owned_count(a.first, a.n, a.own_stride, a.own_offset);  // this rank's queries from a.first on
+    if (nblocks <= 0) return hipSuccess;
     a.phase = 1;
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
@@ -2441,14 +2476,47 @@ hipError_t iock_decide_sweep(hipStream_t st, const void* args_, int nblocks, int
 // that sweep computed
 hipError_t iock_decide_phase2(hipStream_t st, const void* args_, int nblocks, int eval_blocks, uint32_t* q_count2)
 {
-    if (nblocks <= 0) return hipSuccess;
     DecideArgs a = *reinterpret_cast<const DecideArgs*>(args_);
+    if (a.own_stride > 1) nblocks = owned_count(a.first, a.n, a.own_stride, a.own_offset);
+    if (nblocks <= 0) return hipSuccess;
     a.lazy = 0;
     a.phase = 2;
     a.q_count = q_count2;
     hipLaunchKernelGGL(k_decide_scan, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_eval, dim3(eval_blocks), dim3(IOC_BLOCK), 0, st, a);
     hipLaunchKernelGGL(k_decide_pick, dim3(nblocks), dim3(IOC_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+// sharded merge: what this rank does not own is zeroed, so that an all-reduce (maximum of bytes / sum of words) over the ranks
+// is a gather by owner; thread 0 also complements the "incomplete" word next to first_changed, so that ONE all-reduce with
+// minimum over the control words carries the minimum of first_changed and the maximum of incomplete
+__global__ void __launch_bounds__(256) k_shard_mask_u8(uint8_t* __restrict__ a, uint8_t* __restrict__ b, int from, int n, int stride, int offset,
+                                                        uint32_t* __restrict__ ctl)
+{
+    const int j = from + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ctl) ctl[2] = ~ctl[2];
+    if (j >= n) return;
+    if ((j % stride) != offset) {
+        a[j] = 0;
+        if (b) b[j] = 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_shard_mask_i32(int32_t* __restrict__ a, int n, int stride, int offset)
+{
+    const int j = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j < n && (j % stride) != offset) a[j] = 0;
+}
+hipError_t iock_shard_mask_u8(hipStream_t st, uint8_t* a, uint8_t* b, int from, int n, int stride, int offset, uint32_t* ctl)
+{
+    const int m = n - from;
+    hipLaunchKernelGGL(k_shard_mask_u8, dim3(m > 0 ? (m + 255) / 256 : 1), dim3(256), 0, st, a, b, from, n, stride, offset, ctl);
+    return hipGetLastError();
+}
+hipError_t iock_shard_mask_i32(hipStream_t st, int32_t* a, int n, int stride, int offset)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shard_mask_i32, dim3((n + 255) / 256), dim3(256), 0, st, a, n, stride, offset);
     return hipGetLastError();
 }
 

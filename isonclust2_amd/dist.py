@@ -344,6 +344,39 @@ def timed_merge(ctx, params, cb: ClusteredBatch, dist, torch=None, dev=None):
             "aln_invoked": merged.stats.get("n_aln_invoked")}
 
 
+def torch_exchange(ctx, dist, torch):
+    """An ioc_set_shard exchange over a torch.distributed group, for transports other than the library's RCCL binding (and
+    for two test ranks on ONE card, which RCCL refuses): the buffer is wrapped in place through __cuda_array_interface__;
+    with gloo it is reduced on the host.  The context's stream is drained before and torch's after, so the order the C ABI
+    asks for (after the work already on the stream, before what follows) holds."""
+    from . import _lib
+    dev = torch.device("cuda", torch.cuda.current_device())
+    on_host = _device(dist).type != "cuda"
+
+    class Wrap:
+        def __init__(self, ptr, count, typestr):
+            self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+    def fn(ptr, count, kind, stream):
+        if count <= 0:
+            return 0
+        ctx.synchronize()
+        t = torch.as_tensor(Wrap(ptr, count, "|u1" if kind == _lib.XCHG_MAX_U8 else "<i4"), device=dev)
+        if kind == _lib.XCHG_MAX_U8:
+            w, op = t.clone(), dist.ReduceOp.MAX
+        elif kind == _lib.XCHG_MIN_U32:
+            w, op = t.to(torch.int64) & 0xFFFFFFFF, dist.ReduceOp.MIN           # unsigned order
+        else:
+            w, op = t.clone(), dist.ReduceOp.SUM
+        if on_host:
+            w = w.cpu()
+        dist.all_reduce(w, op=op)
+        t.copy_(w.to(dev).to(t.dtype) if kind != _lib.XCHG_MIN_U32 else (w.to(dev) & 0xFFFFFFFF).to(torch.int32))
+        torch.cuda.synchronize()
+        return 0
+    return fn
+
+
 # ---- the same exchange through the library's own C++ / RCCL binding (ioc_dist_*, csrc/ioc_dist.cpp) --------------------------
 def native_init(ctx, dist=None, torch=None):
     """One RCCL communicator per context, made by the LIBRARY (ncclCommInitRank in C++): rank 0 draws the id, the host
@@ -432,5 +465,5 @@ def merge_all_native(ctx, params, cb: ClusteredBatch, torch=None, min_cls_size=3
     if timing is not None:
         timing.update(sizing_ms=(t1 - t0) * 1e3, call_ms=(t2 - t1) * 1e3, exchange_lists_ms=float(tms.ms_exchange_lists),
                       merge_ms=float(tms.ms_merge), bytes_lists=int(tms.bytes_lists), bytes_records=int(tms.bytes_records),
-                      clusters_in=[int(x) for x in counts])
+                      clusters_in=[int(x) for x in counts], sharded=int(tms.sharded), exchanges=int(tms.exchanges))
     return merged

@@ -117,5 +117,106 @@ def test_native_rccl_binding_single_rank(mode):
     ctx._chk(ctx.L.ioc_dist_allreduce_max(ctx.h, C.byref(x)))
     assert x.value == 3.5
     ctx._chk(ctx.L.ioc_dist_barrier(ctx.h))
+    # the three all-reduces of the sharded resolve (ioc_dist_set_shard) run on RCCL's own data types and operators
+    from isonclust2_amd import _lib
+    for kind, t in ((_lib.XCHG_MAX_U8, torch.arange(0, 200, dtype=torch.uint8, device="cuda:0")),
+                    (_lib.XCHG_MIN_U32, torch.tensor([-1, 7, 0], dtype=torch.int32, device="cuda:0")),
+                    (_lib.XCHG_SUM_I32, torch.tensor([-5, 9, 1 << 30], dtype=torch.int32, device="cuda:0"))):
+        want = t.clone()
+        torch.cuda.synchronize()
+        ctx._chk(ctx.L.ioc_dist_exchange(ctx.h, t.data_ptr(), t.numel(), kind))
+        ctx.synchronize()
+        assert torch.equal(t, want)
+    ctx._chk(ctx.L.ioc_dist_set_shard(ctx.h, 1))          # one rank: nothing to shard, the setting stays off
+    cb1 = pipeline.cluster_single(ctx, p, sb)
+    assert ctx.shard_exchanges == 0 and fnv1a_reads(cb1, rs.n) == fnv1a_reads(cb, rs.n)
     ctx._chk(ctx.L.ioc_dist_shutdown(ctx.h))
     ctx.close()
+
+
+def _worker_shard(rank, world, port, q):
+    """Every rank holds the SAME queries; score + resolve sharded by query (ioc_set_shard) against the unsharded run."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    import faulthandler
+    import traceback
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    log = open(os.path.join(ROOT, "gpurun_out", f"shard_rank{rank}.log"), "w", buffering=1)
+    faulthandler.enable(log)
+    try:
+        import torch
+        import torch.distributed as dist
+        torch.zeros(1, device="cuda:0")
+        from isonclust2_amd import api, dist as d, pipeline, synth
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=90))    # a lost peer fails the run, not hangs it
+        ctx = api.Context(0)
+        out = []
+
+        def same(a, b):
+            return (np.array_equal(a.member_cls, b.member_cls) and np.array_equal(a.member_strand, b.member_strand)
+                    and np.array_equal(a.member_read, b.member_read) and all(np.array_equal(x, y) for x, y in zip(a.mindb, b.mindb)))
+
+        def run(p, sb):
+            half = len(sb.read_ids) // 2
+            whole = pipeline.cluster_single(ctx, p, sb)
+            it_whole = ctx.timings()["resolve_iters"]
+            x0 = ctx.shard_exchanges          # all-reduces of the last resolve: 2 per sweep + 4 for the decisions and cuts
+            print("  whole", whole.n_clusters, it_whole, x0, file=log)
+            a = pipeline.cluster_single(ctx, p, pipeline.slice_sorted(sb, 0, half, batch_nr=0))
+            b = pipeline.cluster_single(ctx, p, pipeline.slice_sorted(sb, half, len(sb.read_ids), batch_nr=1))
+            merged = pipeline.cluster_merge(ctx, p, a, b)          # L > 0: queries against a left MinDB
+            print("  merged", merged.n_clusters, file=log)
+            return whole, merged, it_whole, x0
+
+        for name, seed, rng in (("tiny", 1, None), ("short_dup", 2, None), ("config2", 3, None), ("short_dup", 5, "512")):
+            # (IOC_SCORE_RANGE below the batch size: the scoring kernel of large merges, several target ranges per query)
+            os.environ.pop("IOC_SCORE_RANGE", None)
+            if rng:
+                os.environ["IOC_SCORE_RANGE"] = rng
+            rs = synth.generate_config(name, seed=seed)
+            sb, _ = pipeline.sort_stage(ctx, rs, 11, 15)
+            p = api.default_params(11, 15, "fast")
+            ctx.set_shard(1, 0, None)
+            print(name, "unsharded", file=log)
+            w0, m0, it0, x0 = run(p, sb)
+            ctx.set_shard(world, rank, d.torch_exchange(ctx, dist, torch))
+            print(name, "sharded", file=log)
+            w1, m1, it1, x1 = run(p, sb)
+            ok = same(w0, w1) and same(m0, m1) and x0 == 0 and x1 >= 2 * it1 + 4 and it1 == it0
+            out.append((name, ok, w0.n_clusters, w1.n_clusters, m0.n_clusters, m1.n_clusters, it0, it1, x0, x1))
+            if name == "tiny" and not rng:      # sahlin ignores the setting: no exchange, same result
+                ps = api.default_params(11, 15, "sahlin")
+                s1 = pipeline.cluster_single(ctx, ps, sb)
+                xs = ctx.shard_exchanges
+                ctx.set_shard(1, 0, None)
+                s0 = pipeline.cluster_single(ctx, ps, sb)
+                out.append(("tiny/sahlin", same(s0, s1) and xs == 0, s0.n_clusters, s1.n_clusters, 0, 0, 0, 0, 0, xs))
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+        ctx.close()
+    except BaseException:
+        traceback.print_exc(file=log)
+        q.put((rank, [("worker failed", False, traceback.format_exc())]))
+        raise
+
+
+def test_sharded_score_and_resolve_two_ranks():
+    """ioc_set_shard: two ranks on the one card, each scoring and deciding every second query and
+    all-reducing `valid` after every sweep (gloo through dist.torch_exchange; ioc_dist_merge installs the RCCL form of the
+    same hook), give the assignments and the MinDB of the unsharded run, in the same number of sweeps."""
+    world = 2
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    ps = [mpc.Process(target=_worker_shard, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=400) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=120)
+    for rank, out in res:
+        for rec in out:
+            assert rec[1], (rank, rec)
+    assert all(p.exitcode == 0 for p in ps)
