@@ -192,9 +192,9 @@ def cli_region(rs, mode, runs=3):
         out = {"process_wall_ms_min": best["process_wall_ms"], "process_wall_ms_all": [round(j["process_wall_ms"], 1) for j in res],
                "phases_of_that_run": best, "runs": runs, "sort_process_s": t_sort, "batch_cer_MB": os.path.getsize(batch) / 1e6}
         if mode != "fast":
-            out["note"] = ("a `cluster` process in an alignment mode allocates the aligner's checkpoint arena (56 GB for this batch); "
-                           "started right after another process released as much, its hipMalloc waits ~2 s for the driver to wipe "
-                           "the released VRAM (0.5 s process on a quiet GPU): DESIGN.md, round-2 table")
+            out["note"] = ("a `cluster` process in an alignment mode allocates the aligner's checkpoint arena: 8 GB for this batch with "
+                           "the default aligner (version 2, coarse checkpoints); round 2's 56 GB arena made a process started right "
+                           "after another one wait ~2 s for the driver to wipe the released VRAM")
         return out
     finally:
         subprocess.call(["rm", "-rf", d])
