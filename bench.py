@@ -307,11 +307,16 @@ def cpu_baseline_node(config, k, w, max_procs=8):
 def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode, torch_merge, timeout_s=240):
     """The same merge once more through the library's OWN multi-GPU binding (csrc/ioc_dist.cpp: ncclCommInitRank, ragged
     all-gather as grouped broadcasts, one-pass merge — all in C++), after re-clustering the batch so that its
-    representatives' lists are device-resident again.  Runs in a thread with a deadline: a communicator that does not come
-    up must not cost the bench line."""
+    representatives' lists are device-resident again; then, in fast mode, the merge once replicated and once with scoring and
+    resolve sharded over the ranks (ioc_set_shard over RCCL).  The library's collectives run in a thread with a deadline: a
+    communicator that does not come up must not cost the bench line.  Every torch.distributed collective of this leg (the
+    id's broadcast, the agreement on the outcome, the maxima over ranks) is made by the MAIN thread, in the same order on
+    every rank whatever happened inside the thread."""
     import threading
     from isonclust2_amd.digest import fnv1a_reads
-    out = {}
+    world = dist.get_world_size() if dist is not None else 1
+    ident = idist.native_unique_id(ctx, dist, torch)
+    loc = {}
 
     def work():
         try:
@@ -319,20 +324,15 @@ def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode,
             view = sb.view if mode != "fast" else {kk: vv for kk, vv in sb.view.items() if kk not in ("raw_seq", "raw_off")}
             cb2 = pipeline.cluster_single(ctx, p, pipeline.SortedBatch(view=view, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
                                                                        batch_start=sb.batch_start, batch_end=sb.batch_end))
-            idist.native_init(ctx, dist, torch)
+            idist.native_init(ctx, dist, torch, ident=ident)
             tm = {}
             t0 = time.perf_counter()
             mg = idist.merge_all_native(ctx, p, cb2, torch, timing=tm)
             wall = (time.perf_counter() - t0) * 1e3
-            out.update(clusters_out=mg.n_clusters, reads_assigned=int(len(mg.member_read)), fnv1a=fnv1a_reads(mg),
-                       equals_torch_path=bool(fnv1a_reads(mg) == torch_merge.get("fnv1a") and mg.n_clusters == torch_merge.get("clusters_out")),
-                       wall_ms=idist.max_over_ranks(wall, dist), exchange_lists_ms=idist.max_over_ranks(tm["exchange_lists_ms"], dist),
-                       merge_ms=idist.max_over_ranks(tm["merge_ms"], dist), bytes_lists_this_rank=tm["bytes_lists"],
-                       bytes_records_this_rank=tm["bytes_records"],
-                       binding="C++ over RCCL inside libisonclust2_hip.so (ioc_dist_init / ioc_dist_merge); lists HBM to HBM, "
-                               "ragged all-gather = one ncclBroadcast per rank in one group",
-                       sharded=bool(tm.get("sharded")), exchanges=tm.get("exchanges"))
-            world = dist.get_world_size() if dist is not None else 1
+            loc["main"] = dict(clusters_out=mg.n_clusters, reads_assigned=int(len(mg.member_read)), fnv1a=fnv1a_reads(mg),
+                               wall_ms=wall, exchange_lists_ms=tm["exchange_lists_ms"], merge_ms=tm["merge_ms"],
+                               bytes_lists_this_rank=tm["bytes_lists"], bytes_records_this_rank=tm["bytes_records"],
+                               sharded=bool(tm.get("sharded")), exchanges=tm.get("exchanges"))
             if world > 1:
                 # fast mode once replicated (every rank scores and decides every representative) and once sharded (rank r
                 # takes the representatives j with j % world == r; `valid` all-reduced over RCCL after every sweep)
@@ -348,24 +348,45 @@ def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode,
                         tf = {}
                         mf = idist.merge_all_native(ctx, pf, cbf, torch, timing=tf)
                         t = ctx.timings()
-                        rec = dict(merge_ms=idist.max_over_ranks(tf["merge_ms"], dist), score_ms=idist.max_over_ranks(t["ms_score"], dist),
-                                   resolve_ms=idist.max_over_ranks(t["ms_resolve"], dist), sweeps=t["resolve_iters"], exchanges=tf["exchanges"],
-                                   sharded=bool(tf["sharded"]), clusters_out=mf.n_clusters, fnv1a=fnv1a_reads(mf))
+                        rec = dict(merge_ms=tf["merge_ms"], score_ms=t["ms_score"], resolve_ms=t["ms_resolve"], sweeps=t["resolve_iters"],
+                                   exchanges=tf["exchanges"], sharded=bool(tf["sharded"]), clusters_out=mf.n_clusters, fnv1a=fnv1a_reads(mf),
+                                   representatives=int(sum(tf["clusters_in"])))
                         if best is None or rec["merge_ms"] < best["merge_ms"]:
                             best = rec
                     legs[tag] = best
                 os.environ.pop("IOC_DIST_SHARD", None)
-                legs["same_clustering"] = legs["replicated"]["fnv1a"] == legs["sharded"]["fnv1a"]
-                legs["representatives"] = int(sum(tf["clusters_in"]))
-                out["fast_mode_sharded_resolve"] = legs
+                loc["fast"] = legs
         except Exception as e:  # noqa: BLE001
-            out["error"] = f"{type(e).__name__}: {e}"[:400]
+            loc["error"] = f"{type(e).__name__}: {e}"[:400]
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
     th.join(timeout_s)
-    if th.is_alive():
-        return {"error": f"no result within {timeout_s} s (left running; the process exits without joining it)", "timed_out": True}
+    status = 2 if th.is_alive() else (1 if "error" in loc else 0)
+    worst = int(idist.max_over_ranks(status, dist))
+    if worst == 2:
+        return {"error": f"no result within {timeout_s} s on " + ("this rank" if status == 2 else "another rank") +
+                         " (thread left running; every rank exits without joining it)", "timed_out": True}
+    if worst == 1:
+        return {"error": loc.get("error", "another rank failed")}
+    mx = lambda v: idist.max_over_ranks(v, dist)  # noqa: E731
+    m = loc["main"]
+    out = dict(m, wall_ms=mx(m["wall_ms"]), exchange_lists_ms=mx(m["exchange_lists_ms"]), merge_ms=mx(m["merge_ms"]),
+               equals_torch_path=bool(m["fnv1a"] == torch_merge.get("fnv1a") and m["clusters_out"] == torch_merge.get("clusters_out")),
+               binding="C++ over RCCL inside libisonclust2_hip.so (ioc_dist_init / ioc_dist_merge); lists HBM to HBM, "
+                       "ragged all-gather = one ncclBroadcast per rank in one group")
+    if "fast" in loc:
+        legs = {}
+        for tag in ("replicated", "sharded"):
+            r = dict(loc["fast"][tag])
+            for key in ("merge_ms", "score_ms", "resolve_ms"):
+                r[key] = mx(r[key])
+            legs[tag] = r
+        legs["same_clustering"] = legs["replicated"]["fnv1a"] == legs["sharded"]["fnv1a"]
+        legs["note"] = ("fast-mode merge of all ranks' representatives through ioc_dist_merge: IOC_DIST_SHARD=0 (every rank scores and "
+                        "decides every representative) against the default (rank r owns j % world == r, `valid` all-reduced per sweep); "
+                        "min of 3, maxima over ranks; score_ms / resolve_ms are the device phases inside merge_ms")
+        out["fast_mode_sharded_resolve"] = legs
     return out
 
 
@@ -562,7 +583,9 @@ def main():
         except Exception as e:  # noqa: BLE001  (the merge runs after the timed region: the bench line still goes out)
             merge = {"error": f"{type(e).__name__}: {e}"[:400]}
         merge["mode"] = mode
-        if "error" not in merge and not a.no_native_merge and a.backend == "nccl":
+        # (IOC_BENCH_NATIVE_ANY_BACKEND=1: rehearsal of this leg's control flow with ranks that share a card — RCCL then refuses
+        # the communicator and the leg must report that on every rank and let the line go out)
+        if "error" not in merge and not a.no_native_merge and (a.backend == "nccl" or os.environ.get("IOC_BENCH_NATIVE_ANY_BACKEND") == "1"):
             merge["native_rccl"] = native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb_merge, k, w, mode, merge)
         g4 = golden.get(f"config4:{mode}")
         if "error" not in merge and g4 is not None and not a.same_seed and a.config == "config2" and 2 <= world <= len(g4["seeds"]):
@@ -682,9 +705,18 @@ def main():
             if fast is not None:
                 out["fast_mode"] = fast       # BASELINE.json configs[1] on the same batch
         print(json.dumps(out), flush=True)
-    if merge and isinstance(merge.get("native_rccl"), dict) and merge["native_rccl"].get("timed_out"):
+    # a rank whose native merge leg ran out of time is still inside RCCL in the abandoned thread: no orderly shutdown to be had,
+    # on ANY rank (the others would wait in the barrier below for a peer that has left) — the ranks agree on it first
+    stuck = 1.0 if (merge and isinstance(merge.get("native_rccl"), dict) and merge["native_rccl"].get("timed_out")) else 0.0
+    if dist is not None:
+        try:
+            from isonclust2_amd import dist as idist_x
+            stuck = idist_x.max_over_ranks(stuck, dist)
+        except Exception:  # noqa: BLE001
+            stuck = 1.0
+    if stuck:
         sys.stdout.flush()
-        os._exit(0)          # a rank is still inside RCCL in the abandoned thread: no orderly shutdown to be had
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

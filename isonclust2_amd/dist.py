@@ -378,14 +378,12 @@ def torch_exchange(ctx, dist, torch):
 
 
 # ---- the same exchange through the library's own C++ / RCCL binding (ioc_dist_*, csrc/ioc_dist.cpp) --------------------------
-def native_init(ctx, dist=None, torch=None):
-    """One RCCL communicator per context, made by the LIBRARY (ncclCommInitRank in C++): rank 0 draws the id, the host
-    program ships its 128 bytes — here through torch.distributed when the ranks were started by torchrun, nowhere at all
-    for a single rank."""
+def native_unique_id(ctx, dist=None, torch=None):
+    """The 128 bytes a communicator is made of: rank 0 draws them (ncclGetUniqueId in the library), the host program ships
+    them — here through torch.distributed when the ranks were started by torchrun, nowhere at all for a single rank."""
     import ctypes as C
     from . import _lib
     rank = dist.get_rank() if dist is not None else 0
-    world = dist.get_world_size() if dist is not None else 1
     ident = np.zeros(_lib_id_bytes(), np.uint8)
     if rank == 0:
         rc = ctx.L.ioc_dist_unique_id(ident.ctypes.data_as(C.POINTER(C.c_uint8)))
@@ -396,6 +394,17 @@ def native_init(ctx, dist=None, torch=None):
         t = torch.from_numpy(ident).to(dev)
         dist.broadcast(t, src=0)
         ident = t.cpu().numpy().copy()
+    return ident
+
+
+def native_init(ctx, dist=None, torch=None, ident=None):
+    """One RCCL communicator per context, made by the LIBRARY (ncclCommInitRank in C++).  ident: the id from
+    native_unique_id, when the caller wants the torch collective that ships it on another thread than the init."""
+    import ctypes as C
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    if ident is None:
+        ident = native_unique_id(ctx, dist, torch)
     ctx._chk(ctx.L.ioc_dist_init(ctx.h, ident.ctypes.data_as(C.POINTER(C.c_uint8)), rank, world))
     return rank, world
 
