@@ -747,6 +747,7 @@ static int main_cluster(int argc, char** argv)
                 "{\"entries\": %d, \"clusters\": %lld, \"core_ms\": %.3f, \"cli_ms\": %.3f, \"resolve_sweeps\": %d, "
                 "\"load_ms\": %.3f, \"flatten_ms\": %.3f, \"ctx_ms\": %.3f, \"bookkeeping_ms\": %.3f, \"save_ms\": %.3f}\n",
                 n, (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters, load_ms, flatten_ms, ctx_ms, book_ms, save_ms);
+    if (poa && getenv("IOC_TRACE")) ioc_poa_destroy(poa);  // (prints the engine's counters)
     // the output is on disk: leave without unwinding a gigabyte of host structures and the HIP runtime
     fflush(nullptr);
     std::cout.flush();
