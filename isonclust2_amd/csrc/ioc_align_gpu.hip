@@ -1810,8 +1810,6 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if (const char* e = getenv("IOC_ALIGN_V2_GUARD")) guard = std::max(1, std::min(P16_GUARD, atoi(e)));
     uint32_t want_bands = 12;  // (config 3: 11 bands of 1536 rows: 66.8 ms; 7 of 2560: 69.2; 17 of 1024: worse again)
     if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
-    // fine checkpoints of the diagonal blocks out of the forward pass (IOC_ALIGN_V2_FINE=0: every block recomputed by the traceback)
-    const bool fine_on = !(getenv("IOC_ALIGN_V2_FINE") && atoi(getenv("IOC_ALIGN_V2_FINE")) == 0);
     const uint32_t np = uint32_t(dp.size());
     const uint32_t ncouples = (cnt + 1u) / 2u;
     std::vector<V2Couple> cps(ncouples);
@@ -1863,6 +1861,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                 hts.erase(hts.begin() + long(mid));
             }
             cp.nbands = uint32_t(hts.size());
+            cp.tpb = reg;
             uint32_t acc = 0;
             for (uint32_t b = 0; b <= uint32_t(V2_MAX_BANDS); ++b) {
                 cp.bstart[b] = uint16_t(std::min<uint32_t>(acc, 0xFFFFu));
@@ -1881,9 +1880,6 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         w += up4(ncc * uint64_t(cp.nq) * 8u);
         cp.cbase = w;
         w += up4(ncc * uint64_t(cp.nq) * 2u);
-        cp.nfb = fine_on ? std::min((nmax + CK2 - 1u) / CK2, (mmax + CK2 - 1u) / CK2) : 0u;
-        cp.fine = w;
-        w += uint64_t(cp.nfb) * V2_FINE_WORDS;
         cwords[k2] = w;
         for (int h = 0; h < 2; ++h) {
             cp.lrow0[h] = lrow_total;
@@ -1908,9 +1904,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             cp.rbase += used;
             cp.cdat += used;
             cp.cbase += used;
-            cp.fine += used;
             for (int h = 0; h < 2; ++h)
-                if (cp.pid[h] != 0xFFFFFFFFu) pck[cp.pid[h]] = V2PairCk{cp.rdat, cp.rbase, cp.cdat, cp.cbase, cp.mpad, cp.nq, uint32_t(h), cp.nfb, cp.fine};
+                if (cp.pid[h] != 0xFFFFFFFFu) pck[cp.pid[h]] = V2PairCk{cp.rdat, cp.rbase, cp.cdat, cp.cbase, cp.mpad, cp.nq, uint32_t(h), 0u};
             used += cwords[k2];
             ++k2;
         }
@@ -2048,16 +2043,16 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return recs[a].a.x > recs[b].a.x; });
             double sum = 0;
             for (auto& r2 : recs) sum += double(r2.a.x) * 256.0;
-            fprintf(stderr, "[ioc] k_trace2 walks: %u pairs, mean %.3e ticks (s_memtime, 100 MHz), slowest first:\n", n_pairs, sum / n_pairs);
+            fprintf(stderr, "[ioc] k_trace2 walks: %u pairs, mean %.3e cycles (s_memtime), slowest first:\n", n_pairs, sum / n_pairs);
             for (uint32_t x = 0; x < std::min(n_pairs, 12u); ++x) {
                 const Rec& r2 = recs[idx[x]];
                 const AlnPairDev& d = dp[size_t(r2.a.y)];
-                fprintf(stderr, "[ioc]   pair %d: %.3e ticks, n %u m %u, blocks %u (fine %u), tiles %d, gap steps %d, windows %d\n", r2.a.y, double(r2.a.x) * 256.0,
+                fprintf(stderr, "[ioc]   pair %d: %.3e cycles, n %u m %u, blocks %u (%u on the diagonal), tiles %d, gap steps %d, windows %d\n", r2.a.y, double(r2.a.x) * 256.0,
                         d.n, d.m, uint32_t(r2.b.x) & 0xFFFFu, uint32_t(r2.b.x) >> 16, r2.b.y, r2.cc.x, r2.cc.y);
             }
             for (uint32_t q : {n_pairs / 4u, n_pairs / 2u, 3u * n_pairs / 4u}) {
                 const Rec& r2 = recs[idx[q]];
-                fprintf(stderr, "[ioc]   rank %u: %.3e ticks, blocks %u (fine %u), tiles %d, gap steps %d\n", q, double(r2.a.x) * 256.0, uint32_t(r2.b.x) & 0xFFFFu,
+                fprintf(stderr, "[ioc]   rank %u: %.3e cycles, blocks %u (%u on the diagonal), tiles %d, gap steps %d\n", q, double(r2.a.x) * 256.0, uint32_t(r2.b.x) & 0xFFFFu,
                         uint32_t(r2.b.x) >> 16, r2.b.y, r2.cc.x);
             }
         }
