@@ -155,7 +155,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual, &c->b_dist_min, &c->b_dist_pos};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -191,6 +191,7 @@ int ioc_set_params(ioc_ctx* c, const ioc_params* p, const int32_t gap_limit[225]
     HIPCHK(c, hipSetDevice(c->device));
     c->params = *p;
     memcpy(c->h_glim, gap_limit, sizeof(c->h_glim));
+    c->gap_bound_gen = ~0ull;  // (the bounds of totalMapped follow the gap limits)
     for (int i = 0; i < 225; ++i)
         if (gap_limit[i] < -1) return ioc_fail(c, IOC_ERR_ARG, "gap_limit < -1");
     // Candidates with Size < keep can never be walked: top >= MinShared is required
@@ -884,6 +885,17 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.min_fraction = c->params.min_fraction;
     a.own_stride = sharded ? c->shard_world : 1;
     a.own_offset = sharded ? c->shard_rank : 0;
+    // the upper bound of totalMapped per (query, strand, target error cell): once per set of queries and gap limits
+    a.gap_bound = nullptr;
+    if (n > 0 && env_u32("IOC_RESOLVE_BOUND", 1) == 1) {
+        RESERVE(c, c->b_gap_bound, size_t(n) * 2 * 15 * sizeof(uint2));
+        if (c->gap_bound_gen != c->query_gen) {
+            HIPCHK(c, iock_gap_bounds(s, n, c->d_off_fwd, c->d_off_rev, c->d_pos, c->d_hpc_len, c->d_err_cell, P<int32_t>(c->b_glim),
+                                      P<uint2>(c->b_gap_bound)));
+            c->gap_bound_gen = c->query_gen;
+        }
+        a.gap_bound = P<uint2>(c->b_gap_bound);
+    }
     if (c->aln_verdicts) {
         a.aln_t = P<int32_t>(c->b_aln_t);
         a.aln_s = P<int8_t>(c->b_aln_s);

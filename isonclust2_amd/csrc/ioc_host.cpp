@@ -266,6 +266,7 @@ static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint
     if (top < unsigned(c->params.min_shared)) return IOC_OK;
     for (auto& o : order) {
         if (int(o.size) < int(double(top) * c->params.min_fraction)) break;
+        if (o.mapped == 0xFFFFFFFEu) continue;  // rejected by the upper bound of totalMapped (k_gap_bounds): fails
         if (o.mapped == 0xFFFFFFFFu)
             return ioc_fail(c, IOC_ERR_STATE, "tie replay met a candidate the device did not evaluate");
         if (o.mapped >= need) {

@@ -150,6 +150,8 @@ struct ioc_ctx {
     bool scored_sharded = false;  // the candidate tables hold the owned queries only
     int shard_exchanges = 0;
     DevBuf b_shard_stage;
+    DevBuf b_gap_bound;            // k_gap_bounds' table of the current queries
+    uint64_t gap_bound_gen = ~0ull;  // query_gen + parameters it was computed for
     int score_oob = 0, score_oob_probe = -1;  // k_score_part's variant and the probe behind it (ioc_ctx_create)
 };
 

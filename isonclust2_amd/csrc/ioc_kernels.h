@@ -52,6 +52,8 @@ struct DecideArgs {
     uint8_t* done;          // per query: decided in phase 1
     unsigned long long* diag;  // diagnostic cycle sums (IOC_EVAL_DIAG), normally nullptr
     int lazy;               // lazy sweep: only the maximal-Size candidates are walked (see ioc_resolve)
+    // upper bound of totalMapped (k_gap_bounds): [query][strand][error cell of the target] -> (D, head + tail); null = no bound test
+    const uint2* gap_bound;
     int own_stride, own_offset;  // sharded merge: this rank decides the queries j with j % own_stride == own_offset (stride <= 1: all)
     // alignment fallback (sahlin / furious): verdict of the alignment for a query, used only if its
     // mapping walk finds nothing although top >= MinShared (INT32_MIN = none yet, -1 = no hit either);
@@ -101,6 +103,8 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
                       uint32_t range, uint32_t keep, uint32_t* cand_key, uint32_t* cand_size, uint32_t* cand_count,
                       unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
                       uint32_t* part, uint32_t* top_all, int post16, uint32_t* pmins, uint32_t* pbnd);
+hipError_t iock_gap_bounds(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev, const uint32_t* pos,
+                           const uint32_t* hpc_len, const uint8_t* err_cell, const int32_t* glim, uint2* out);
 hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* top_all, uint8_t* valid);
 hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks, uint32_t* q_count2);

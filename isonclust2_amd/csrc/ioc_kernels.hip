@@ -1319,6 +1319,95 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
 //   k_decide_pick  per query: winner = passing candidate of maximal Size (= the first passing one
 //                  in descending-Size order); >= 2 passing at that Size -> order-dependent tie flag.
 // =====================================================================================================
+// ---- an upper bound of totalMapped that needs no walk over the minimizers --------------------------------------------------
+// totalMapped (src/cluster.cpp:324-353) adds the distance of two consecutive hits when fewer than limEx query minimizers lie
+// between them without a hit, the position of the first hit when its index is < limEx, and the distance of the last hit from the
+// end when fewer than limEx minimizers follow it.  With H hits (= the candidate's Size: one hit per query minimizer whose value
+// the target holds) there are H - 1 gaps, and a gap that counts spans at most D(limEx) = max_i pos[i + limEx] - pos[i]:
+//     totalMapped <= (H - 1) * D + max_{i < limEx} pos[i] + max_{i >= M - limEx} (hpcLen - pos[i]).
+// limEx depends on the query's and the target's error cells only (15 x 15 table), so k_gap_bounds leaves (D, head + tail) per
+// (query, strand, target cell) and the sweeps reject a candidate whose bound is below the query's threshold without queueing
+// its evaluation (IOC_MAPPED_REJECTED in the cache: "evaluated, fails").  Unrelated reads share ~M^2 / 4*3^(k-1) minimizers by
+// chance (90 of 4000 at k = 11): enough to be candidates of every query that opens a cluster, never enough to pass.
+#define IOC_MAPPED_REJECTED 0xFFFFFFFEu
+__global__ void __launch_bounds__(IOC_BLOCK)
+k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev, const uint32_t* __restrict__ pos,
+             const uint32_t* __restrict__ hpc_len, const uint8_t* __restrict__ err_cell, const int32_t* __restrict__ glim,
+             uint2* __restrict__ out)
+{
+    __shared__ uint32_t red[IOC_WAVES];
+    const int j = blockIdx.x;
+    if (j >= n) return;
+    const int lane = lane_id(), wave = wave_id();
+    const int ecr = int(err_cell[j]) - 1;
+    const uint32_t hl = hpc_len[j];
+    for (int s = 0; s < 2; ++s) {
+        const int64_t b = s ? off_rev[j] : off_fwd[j];
+        const uint32_t M = uint32_t((s ? off_rev[j + 1] : off_fwd[j + 1]) - b);
+        const uint32_t* p = pos + b;
+        for (int ecl = 0; ecl < 15; ++ecl) {
+            uint2 r = make_uint2(0u, 0u);
+            if (ecr >= 0 && M > 0) {
+                const uint32_t lim = uint32_t(glim[ecl * 15 + ecr] + 1);
+                uint32_t d = 0;
+                for (uint32_t i = threadIdx.x; i < M; i += IOC_BLOCK) {
+                    const uint32_t hi = (i + lim < M && i + lim >= i) ? i + lim : M - 1u;
+                    const uint32_t a0 = p[i], a1 = p[hi];
+                    const uint32_t span = a1 > a0 ? a1 - a0 : 0u;
+                    d = span > d ? span : d;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t t = __shfl_down(d, o);
+                    d = t > d ? t : d;
+                }
+                if (lane == 0) red[wave] = d;
+                __syncthreads();
+                uint32_t D = 0;
+                for (int w = 0; w < IOC_WAVES; ++w) D = red[w] > D ? red[w] : D;
+                __syncthreads();
+                // positions ascend with the index (extraction order): the farthest head is pos[min(lim, M) - 1], the longest tail
+                // starts at pos[max(M - lim, 0)]; a maximum over the range covers lists that do not ascend
+                uint32_t hd = 0, tl = 0;
+                const uint32_t nh = lim < M ? lim : M;
+                for (uint32_t i = threadIdx.x; i < nh; i += IOC_BLOCK) {
+                    const uint32_t a0 = p[i], a1 = p[M - 1u - i];
+                    hd = a0 > hd ? a0 : hd;
+                    const uint32_t t = hl > a1 ? hl - a1 : 0u;
+                    tl = t > tl ? t : tl;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t t = __shfl_down(hd, o), u = __shfl_down(tl, o);
+                    hd = t > hd ? t : hd;
+                    tl = u > tl ? u : tl;
+                }
+                if (lane == 0) red[wave] = hd;
+                __syncthreads();
+                uint32_t HD = 0;
+                for (int w = 0; w < IOC_WAVES; ++w) HD = red[w] > HD ? red[w] : HD;
+                __syncthreads();
+                if (lane == 0) red[wave] = tl;
+                __syncthreads();
+                uint32_t TL = 0;
+                for (int w = 0; w < IOC_WAVES; ++w) TL = red[w] > TL ? red[w] : TL;
+                __syncthreads();
+                r = make_uint2(D, HD + TL);
+            }
+            if (threadIdx.x == 0) out[(size_t(j) * 2 + size_t(s)) * 15 + size_t(ecl)] = r;
+        }
+    }
+}
+
+// true: the candidate (key, Size sz) of query j cannot reach `need` (see k_gap_bounds)
+__device__ __forceinline__ bool bound_rejects(const DecideArgs& a, int j, uint32_t key, uint32_t sz, uint32_t need)
+{
+    const uint32_t tg = key >> 1;
+    const int ecl = (tg < a.L ? int(a.left_err[tg]) : int(a.err_cell[tg - a.L])) - 1;
+    if (ecl < 0 || sz == 0) return false;
+    const uint2 b = a.gap_bound[(size_t(j) * 2 + size_t(key & 1u)) * 15 + size_t(ecl)];
+    const unsigned long long B = (unsigned long long)(sz - 1u) * b.x + b.y;
+    return B < (unsigned long long)need;
+}
+
 #define IOC_CUT_NEG INT32_MAX
 #define IOC_BITWORDS 256    // 16384 minimizers per strand per pass (slow path)
 #define IOC_EVAL_ILP 8
@@ -1391,6 +1480,10 @@ k_decide_scan(DecideArgs a)
             bool ok = (tg < L) || a.valid_in[tg - L];
             const uint32_t sz = a.cand_size[cbase + c];
             f = ok && (a.phase == 1 ? sz == top : int(sz) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
+            if (f && a.gap_bound && bound_rejects(a, j, a.cand_key[cbase + c], sz, a.min_total[j])) {
+                a.cand_mapped[cbase + c] = IOC_MAPPED_REJECTED;  // (the second loop below reads it back: same thread, same entry)
+                f = false;
+            }
         }
         mine += uint32_t(__popcll(__ballot(f)));
     }
@@ -1908,6 +2001,7 @@ k_decide_pick(DecideArgs a)
             }
             if (!ok || (a.phase == 1 ? sz != top : int(sz) < cut)) continue;
             const uint32_t tm = a.cand_mapped[cbase + c];
+            if (tm == IOC_MAPPED_REJECTED) continue;  // fails by its upper bound
             if (tm == 0xFFFFFFFFu) {
                 miss = 1;
                 continue;
@@ -2517,6 +2611,14 @@ hipError_t iock_shard_mask_i32(hipStream_t st, int32_t* a, int n, int stride, in
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_shard_mask_i32, dim3((n + 255) / 256), dim3(256), 0, st, a, n, stride, offset);
+    return hipGetLastError();
+}
+
+hipError_t iock_gap_bounds(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev, const uint32_t* pos,
+                           const uint32_t* hpc_len, const uint8_t* err_cell, const int32_t* glim, uint2* out)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gap_bounds, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, pos, hpc_len, err_cell, glim, out);
     return hipGetLastError();
 }
 
