@@ -151,14 +151,18 @@ int ioc_set_aln_verdicts(ioc_ctx* ctx, const int32_t* target, const int8_t* stra
 int ioc_get_ties(ioc_ctx* ctx, uint32_t* count, uint32_t* keys);
 
 /* The candidate list the SCORING kernels wrote for query q (before any resolve): key = target << 1 | strand (strand bit
- * 1 = reverse), size = Size, for every (target, strand) with Size >= int(MinShared * MinFraction), in target order.
+ * 1 = reverse), size = Size, for every (target, strand) with Size >= int(MinShared * MinFraction), in target order — in fast
+ * mode: with Size >= the smallest Size that can pass the query's mapped-fraction test at all (an upper bound of totalMapped
+ * from the query's minimizer positions and gap limits; IOC_SCORE_KEEPQ=0 keeps the uniform threshold).
  * Returns the count (copies at most cap).  Test instrument: lets the two builds of the scoring kernel (with / without the
  * per-posting window test, ioc_timings::score_oob) be compared histogram by histogram. */
 int ioc_scored_candidates(ioc_ctx* ctx, int32_t q, int32_t cap, uint32_t* key, uint32_t* size);
 /* Full candidate table of one query against the targets that are clusters under the current
  * decisions, in the fields the reference's hit map holds (src/minimizer.cpp:44-76): target id,
  * strand, Size, Index of the first hitting read minimizer, and totalMapped (0xFFFFFFFF if not
- * evaluated).  Returns the count (<= cap) or a negative status. */
+ * evaluated; 0xFFFFFFFE if the candidate was rejected without an evaluation because an upper bound of its totalMapped —
+ * (Size - 1) x the widest span of a passing gap + the widest head and tail — is below the query's threshold: it fails).
+ * Returns the count (<= cap) or a negative status. */
 int ioc_query_candidates(ioc_ctx* ctx, int32_t query, int32_t cap, int32_t* target, int8_t* strand,
                          uint32_t* size, uint32_t* first_index, uint32_t* total_mapped);
 

@@ -155,7 +155,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_keep_q, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual, &c->b_dist_min, &c->b_dist_pos};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -646,6 +646,32 @@ int ioc_score(ioc_ctx* c)
     iock_set_part32(int(env_u32("IOC_PART32", 0)));
     iock_set_score_oob(c->score_oob);
     const bool aln_mode_s = c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS;
+    // Upper bounds of totalMapped (k_gap_bounds): the sweeps of ioc_resolve reject candidates by them, and in fast mode the
+    // candidate lists are cut at the smallest Size that passes any bound of the query (below it nothing passes, and the top
+    // Size only matters when a candidate at or above it exists).  The alignment modes keep every candidate: the tie set of
+    // the fallback is made of candidates that fail the mapping.
+    c->keep_q_on = false;
+    c->h_keep_q.clear();
+    if (n > 0 && env_u32("IOC_RESOLVE_BOUND", 1) == 1) {
+        {
+            const int rw = ioc_wait_uploads(c, 2);  // the positions
+            if (rw != IOC_OK) return rw;
+        }
+        RESERVE(c, c->b_gap_bound, size_t(n) * 2 * 15 * sizeof(uint2));
+        RESERVE(c, c->b_keep_q, size_t(n) * 4);
+        const bool cut_lists = !aln_mode_s && env_u32("IOC_SCORE_KEEPQ", 1) == 1;
+        // (a function of the queries, the gap limits and the thresholds: kept across calls on the same queries)
+        if (c->gap_bound_gen != c->query_gen || c->gap_bound_cut != cut_lists) {
+            HIPCHK(c, iock_gap_bounds(c->stream, n, c->d_off_fwd, c->d_off_rev, c->d_pos, c->d_hpc_len, c->d_err_cell, P<int32_t>(c->b_glim),
+                                      P<uint2>(c->b_gap_bound), c->d_min_total, uint32_t(c->keep), cut_lists ? P<uint32_t>(c->b_keep_q) : nullptr));
+            c->gap_bound_gen = c->query_gen;
+            c->gap_bound_cut = cut_lists;
+        }
+        c->keep_q_on = cut_lists;
+    } else {
+        c->gap_bound_gen = ~0ull;
+    }
+    iock_set_score_keep(c->keep_q_on ? P<uint32_t>(c->b_keep_q) : nullptr);
     c->scored_sharded = c->shard_world > 1 && c->shard_fn && !aln_mode_s;
     iock_set_score_shard(c->scored_sharded ? c->shard_world : 1, c->shard_rank);
     if (env_u32("IOC_SCORE_PARTS", 1) == 1 && L + uint64_t(n) <= range && capacity * 8 * 4 + (1ull << 28) < have - need) {
@@ -664,6 +690,7 @@ int ioc_score(ioc_ctx* c)
                          count_trav ? d_trav : nullptr, nullptr, nullptr, d_part, P<uint32_t>(c->b_top_all), c->post16,
                          P<uint32_t>(c->b_pmins), P<uint32_t>(c->b_pbnd)));
     iock_set_score_shard(1, 0);
+    iock_set_score_keep(nullptr);
     c->have_guess = d_part != nullptr && !c->scored_sharded;  // (b_top_all holds the owned queries only)
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (count_trav) {
@@ -885,17 +912,8 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.min_fraction = c->params.min_fraction;
     a.own_stride = sharded ? c->shard_world : 1;
     a.own_offset = sharded ? c->shard_rank : 0;
-    // the upper bound of totalMapped per (query, strand, target error cell): once per set of queries and gap limits
-    a.gap_bound = nullptr;
-    if (n > 0 && env_u32("IOC_RESOLVE_BOUND", 1) == 1) {
-        RESERVE(c, c->b_gap_bound, size_t(n) * 2 * 15 * sizeof(uint2));
-        if (c->gap_bound_gen != c->query_gen) {
-            HIPCHK(c, iock_gap_bounds(s, n, c->d_off_fwd, c->d_off_rev, c->d_pos, c->d_hpc_len, c->d_err_cell, P<int32_t>(c->b_glim),
-                                      P<uint2>(c->b_gap_bound)));
-            c->gap_bound_gen = c->query_gen;
-        }
-        a.gap_bound = P<uint2>(c->b_gap_bound);
-    }
+    // the upper bound of totalMapped per (query, strand, target error cell): ioc_score left it (ioc_gap_bounds_ready)
+    a.gap_bound = (n > 0 && c->gap_bound_gen == c->query_gen && c->b_gap_bound.p) ? P<uint2>(c->b_gap_bound) : nullptr;
     if (c->aln_verdicts) {
         a.aln_t = P<int32_t>(c->b_aln_t);
         a.aln_s = P<int8_t>(c->b_aln_s);
@@ -1068,6 +1086,21 @@ int ioc_scored_candidates(ioc_ctx* c, int32_t q, int32_t cap, uint32_t* key, uin
     return int(cc);
 }
 
+}  // extern "C"
+
+// host copy of the per-query compaction thresholds (fast mode): a candidate that is missing from a query's list although its
+// Size reaches the uniform `keep` was cut because it cannot pass any bound of totalMapped — exported as "rejected"
+static int ensure_keep_host(ioc_ctx* c)
+{
+    if (!c->keep_q_on || !c->h_keep_q.empty() || c->n <= 0) return IOC_OK;
+    c->h_keep_q.resize(size_t(c->n));
+    HIPCHK(c, hipMemcpyAsync(c->h_keep_q.data(), c->b_keep_q.p, size_t(c->n) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return IOC_OK;
+}
+
+extern "C" {
+
 int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, int8_t* strand, uint32_t* size,
                          uint32_t* first_index, uint32_t* total_mapped)
 {
@@ -1079,6 +1112,11 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
     const uint32_t L = uint32_t(c->L);
     const uint32_t T = L + uint32_t(q);
     if (T == 0) return 0;
+    {
+        const int rk = ensure_keep_host(c);
+        if (rk != IOC_OK) return rk;
+    }
+    const uint32_t cut_below = c->keep_q_on ? c->h_keep_q[size_t(q)] : 0u;
     // (called once per tied / order-dependent query of a round, thousands of times on a large batch: scratch
     // buffers are kept in the context and everything comes back with one synchronisation — the candidate list
     // is copied at its capacity, its fill count arrives with it)
@@ -1157,7 +1195,7 @@ int ioc_query_candidates(ioc_ctx* c, int32_t q, int32_t cap, int32_t* target, in
                 auto it = std::lower_bound(mapped.begin(), mapped.end(), std::make_pair(h.idx, 0u),
                                            [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
                 // (the last entry of a cell wins, as the dense table's overwrite did)
-                uint32_t mv = 0xFFFFFFFFu;
+                uint32_t mv = h.size < cut_below ? 0xFFFFFFFEu : 0xFFFFFFFFu;  // (cut from the list: rejected by the bound)
                 for (; it != mapped.end() && it->first == h.idx; ++it) mv = it->second;
                 total_mapped[out] = mv;
             }
@@ -1180,6 +1218,10 @@ int ioc_query_candidates_many(ioc_ctx* c, const std::vector<int>& qs, std::vecto
         if (q < 0 || q >= c->n) return ioc_fail(c, IOC_ERR_ARG, "bad query index");
     out.resize(qs.size());
     if (qs.empty()) return IOC_OK;
+    {
+        const int rk = ensure_keep_host(c);
+        if (rk != IOC_OK) return rk;
+    }
     hipStream_t s = c->stream;
     const uint32_t L = uint32_t(c->L);
     const size_t n = size_t(c->n);
@@ -1287,7 +1329,7 @@ int ioc_query_candidates_many(ioc_ctx* c, const std::vector<int>& qs, std::vecto
                 t.sz[i] = hits[i].size;
                 t.fi[i] = hits[i].first;
                 auto it = std::lower_bound(mapped.begin(), mapped.end(), std::make_pair(hits[i].idx, 0u), by_cell);
-                uint32_t mv = 0xFFFFFFFFu;
+                uint32_t mv = (c->keep_q_on && hits[i].size < c->h_keep_q[size_t(q)]) ? 0xFFFFFFFEu : 0xFFFFFFFFu;  // (cut from the list: rejected by the bound)
                 for (; it != mapped.end() && it->first == hits[i].idx; ++it) mv = it->second;
                 t.tm[i] = mv;
             }

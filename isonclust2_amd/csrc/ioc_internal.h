@@ -150,8 +150,11 @@ struct ioc_ctx {
     bool scored_sharded = false;  // the candidate tables hold the owned queries only
     int shard_exchanges = 0;
     DevBuf b_shard_stage;
-    DevBuf b_gap_bound;            // k_gap_bounds' table of the current queries
-    uint64_t gap_bound_gen = ~0ull;  // query_gen + parameters it was computed for
+    DevBuf b_gap_bound, b_keep_q;  // k_gap_bounds' table of the current queries; the per-query compaction threshold (fast mode)
+    uint64_t gap_bound_gen = ~0ull;  // query_gen the table was computed for (ioc_set_params resets it)
+    bool gap_bound_cut = false;      // ... with keep_q written
+    bool keep_q_on = false;          // the candidate lists of the last ioc_score were cut at b_keep_q
+    std::vector<uint32_t> h_keep_q;  // host copy, fetched when a candidate table is exported
     int score_oob = 0, score_oob_probe = -1;  // k_score_part's variant and the probe behind it (ioc_ctx_create)
 };
 

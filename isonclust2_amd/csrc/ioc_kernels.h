@@ -104,7 +104,9 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
                       unsigned long long* traversed, const uint8_t* audit_valid, unsigned long long* audit_sum,
                       uint32_t* part, uint32_t* top_all, int post16, uint32_t* pmins, uint32_t* pbnd);
 hipError_t iock_gap_bounds(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev, const uint32_t* pos,
-                           const uint32_t* hpc_len, const uint8_t* err_cell, const int32_t* glim, uint2* out);
+                           const uint32_t* hpc_len, const uint8_t* err_cell, const int32_t* glim, uint2* out, const uint32_t* min_total,
+                           uint32_t keep, uint32_t* keep_q);
+void iock_set_score_keep(const uint32_t* keep_q);
 hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev,
                             const uint32_t* top_all, uint8_t* valid);
 hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks, uint32_t* q_count2);

@@ -910,7 +910,8 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
         const PT* __restrict__ post, uint32_t range, uint32_t keep, uint32_t* __restrict__ cand_key,
         uint32_t* __restrict__ cand_size, uint32_t* __restrict__ cand_count,
         unsigned long long* __restrict__ traversed, Epochs E,
-        const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum, int own_stride, int own_offset)
+        const uint8_t* __restrict__ audit_valid, unsigned long long* __restrict__ audit_sum, int own_stride, int own_offset,
+        const uint32_t* __restrict__ keep_q)
 {
     extern __shared__ uint32_t hist[];  // 2 * min(range, L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
@@ -918,6 +919,7 @@ k_score_t(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t*
     __shared__ unsigned long long s_bm[IOC_WAVES][IOC_BM_WORDS + IOC_FLAT_UNROLL];   // bitmap of list starts
     const int j = owned_from_top(n, int(blockIdx.x), own_stride, own_offset);
     if (j < 0) return;
+    if (keep_q) keep = keep_q[j];  // (fast mode: below this Size no candidate of this query can pass, see k_gap_bounds)
     const uint32_t T = L + uint32_t(j);  // visible targets: [0, T)
     // first epoch boundary >= T: the field of the row info that holds its cut
     uint32_t eword, eshift;
@@ -1216,13 +1218,14 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
                 uint32_t* __restrict__ cand_key, uint32_t* __restrict__ cand_size,
                 uint32_t* __restrict__ cand_count, const uint8_t* __restrict__ audit_valid,
                 unsigned long long* __restrict__ audit_sum, uint32_t* __restrict__ top_all,
-                const uint32_t* __restrict__ max_len, int own_stride, int own_offset)
+                const uint32_t* __restrict__ max_len, int own_stride, int own_offset, const uint32_t* __restrict__ keep_q)
 {
     extern __shared__ uint32_t hist[];  // 2 * (L + j)
     __shared__ uint32_t wcount[IOC_WAVES];
     __shared__ uint32_t wtop[IOC_WAVES];
     const int j = owned_from_top(n, int(blockIdx.x), own_stride, own_offset);
     if (j < 0) return;
+    if (keep_q) keep = keep_q[j];
     const uint32_t T = L + uint32_t(j);
     const int lane = lane_id(), wave = wave_id();
     const uint64_t cbase = 2ull * L * uint64_t(j) + uint64_t(j) * uint64_t(j > 0 ? j - 1 : 0);
@@ -1333,68 +1336,117 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev, const uint32_t* __restrict__ pos,
              const uint32_t* __restrict__ hpc_len, const uint8_t* __restrict__ err_cell, const int32_t* __restrict__ glim,
-             uint2* __restrict__ out)
+             uint2* __restrict__ out, const uint32_t* __restrict__ min_total, uint32_t keep, uint32_t* __restrict__ keep_q)
 {
-    __shared__ uint32_t red[IOC_WAVES];
+    // one pass over the positions of a strand serves the 15 target cells at once: per cell three running maxima per thread
+    // (widest span of limEx consecutive minimizers, farthest head, longest tail), reduced once at the end
+    __shared__ uint32_t red[3][15][IOC_WAVES];
+    constexpr uint32_t GB_CHUNK = 4096, GB_HALO = 64;
+    __shared__ uint32_t s_pos[GB_CHUNK + GB_HALO];
     const int j = blockIdx.x;
     if (j >= n) return;
     const int lane = lane_id(), wave = wave_id();
     const int ecr = int(err_cell[j]) - 1;
     const uint32_t hl = hpc_len[j];
+    // smallest Size that passes SOME bound of this query (any strand, any target cell): candidates below it never pass
+    // (keep_q: fast mode only — the tie sets of the alignment fallback are made of candidates that fail the mapping)
+    const uint32_t need = min_total ? min_total[j] : 0u;
+    uint32_t smin = 0xFFFFFFFFu;
+    uint32_t lim[15];
+#pragma unroll
+    for (int e = 0; e < 15; ++e) lim[e] = ecr >= 0 ? uint32_t(glim[e * 15 + ecr] + 1) : 0u;
     for (int s = 0; s < 2; ++s) {
         const int64_t b = s ? off_rev[j] : off_fwd[j];
         const uint32_t M = uint32_t((s ? off_rev[j + 1] : off_fwd[j + 1]) - b);
         const uint32_t* p = pos + b;
-        for (int ecl = 0; ecl < 15; ++ecl) {
-            uint2 r = make_uint2(0u, 0u);
-            if (ecr >= 0 && M > 0) {
-                const uint32_t lim = uint32_t(glim[ecl * 15 + ecr] + 1);
-                uint32_t d = 0;
-                for (uint32_t i = threadIdx.x; i < M; i += IOC_BLOCK) {
-                    const uint32_t hi = (i + lim < M && i + lim >= i) ? i + lim : M - 1u;
-                    const uint32_t a0 = p[i], a1 = p[hi];
-                    const uint32_t span = a1 > a0 ? a1 - a0 : 0u;
-                    d = span > d ? span : d;
+        uint32_t d[15], hd[15], tl[15];
+#pragma unroll
+        for (int e = 0; e < 15; ++e) d[e] = hd[e] = tl[e] = 0;
+        if (ecr >= 0 && M > 0) {
+            // the widest span of lim[e] consecutive minimizers: the limits of a column of the table ascend with the target's cell,
+            // equal neighbours (6 - 13 distinct values of 15) share their maximum
+            // (the positions pass through LDS, GB_CHUNK at a time with a halo of GB_HALO behind them: the 6 - 13 reads per entry
+            // are latency in global memory; a limit above the halo — none in the reference's table — reads global memory)
+            for (uint32_t c0 = 0; c0 < M; c0 += GB_CHUNK) {
+                const uint32_t cn = (M - c0 < GB_CHUNK + GB_HALO) ? M - c0 : GB_CHUNK + GB_HALO;  // staged entries
+                __syncthreads();
+                for (uint32_t x = threadIdx.x; x < cn; x += IOC_BLOCK) s_pos[x] = p[c0 + x];
+                __syncthreads();
+                const uint32_t ce = (M - c0 < GB_CHUNK) ? M - c0 : GB_CHUNK;
+                const bool in_lds = lim[14] <= GB_HALO;
+                for (uint32_t x = threadIdx.x; x < ce; x += IOC_BLOCK) {
+                    const uint32_t a0 = s_pos[x];
+                    const uint32_t left = M - 1u - (c0 + x);  // minimizers behind this one
+#pragma unroll
+                    for (int e = 0; e < 15; ++e) {
+                        if (e > 0 && lim[e] == lim[e - 1]) continue;  // (uniform)
+                        const uint32_t st = lim[e] < left ? lim[e] : left;
+                        const uint32_t a1 = in_lds ? s_pos[x + st] : p[c0 + x + st];
+                        const uint32_t span = a1 > a0 ? a1 - a0 : 0u;
+                        d[e] = span > d[e] ? span : d[e];
+                    }
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const uint32_t t = __shfl_down(d, o);
-                    d = t > d ? t : d;
-                }
-                if (lane == 0) red[wave] = d;
-                __syncthreads();
-                uint32_t D = 0;
-                for (int w = 0; w < IOC_WAVES; ++w) D = red[w] > D ? red[w] : D;
-                __syncthreads();
-                // positions ascend with the index (extraction order): the farthest head is pos[min(lim, M) - 1], the longest tail
-                // starts at pos[max(M - lim, 0)]; a maximum over the range covers lists that do not ascend
-                uint32_t hd = 0, tl = 0;
-                const uint32_t nh = lim < M ? lim : M;
-                for (uint32_t i = threadIdx.x; i < nh; i += IOC_BLOCK) {
-                    const uint32_t a0 = p[i], a1 = p[M - 1u - i];
-                    hd = a0 > hd ? a0 : hd;
-                    const uint32_t t = hl > a1 ? hl - a1 : 0u;
-                    tl = t > tl ? t : tl;
-                }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const uint32_t t = __shfl_down(hd, o), u = __shfl_down(tl, o);
-                    hd = t > hd ? t : hd;
-                    tl = u > tl ? u : tl;
-                }
-                if (lane == 0) red[wave] = hd;
-                __syncthreads();
-                uint32_t HD = 0;
-                for (int w = 0; w < IOC_WAVES; ++w) HD = red[w] > HD ? red[w] : HD;
-                __syncthreads();
-                if (lane == 0) red[wave] = tl;
-                __syncthreads();
-                uint32_t TL = 0;
-                for (int w = 0; w < IOC_WAVES; ++w) TL = red[w] > TL ? red[w] : TL;
-                __syncthreads();
-                r = make_uint2(D, HD + TL);
             }
-            if (threadIdx.x == 0) out[(size_t(j) * 2 + size_t(s)) * 15 + size_t(ecl)] = r;
+#pragma unroll
+            for (int e = 1; e < 15; ++e)
+                if (lim[e] == lim[e - 1]) d[e] = d[e - 1];
+            // the farthest head (a first hit at index < lim still counts its position) and the longest tail (a last hit with fewer
+            // than lim minimizers behind it still counts the rest of the sequence): the first / last lim[14] entries
+            const uint32_t lmax = lim[14] < M ? lim[14] : M;
+            for (uint32_t i = threadIdx.x; i < lmax; i += IOC_BLOCK) {
+                const uint32_t a0 = p[i], a1 = p[M - 1u - i];
+                const uint32_t t1 = hl > a1 ? hl - a1 : 0u;
+#pragma unroll
+                for (int e = 0; e < 15; ++e)
+                    if (i < lim[e]) {
+                        hd[e] = a0 > hd[e] ? a0 : hd[e];
+                        tl[e] = t1 > tl[e] ? t1 : tl[e];
+                    }
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 15; ++e) {
+            uint32_t x = d[e], y = hd[e], z = tl[e];
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t tx = __shfl_down(x, o), ty = __shfl_down(y, o), tz = __shfl_down(z, o);
+                x = tx > x ? tx : x;
+                y = ty > y ? ty : y;
+                z = tz > z ? tz : z;
+            }
+            if (lane == 0) {
+                red[0][e][wave] = x;
+                red[1][e][wave] = y;
+                red[2][e][wave] = z;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 15) {
+            const int e = threadIdx.x;
+            uint32_t D = 0, HD = 0, TL = 0;
+            for (int w = 0; w < IOC_WAVES; ++w) {
+                D = red[0][e][w] > D ? red[0][e][w] : D;
+                HD = red[1][e][w] > HD ? red[1][e][w] : HD;
+                TL = red[2][e][w] > TL ? red[2][e][w] : TL;
+            }
+            uint2 r = make_uint2(0u, 0u);
+            uint32_t thr = 0xFFFFFFFFu;
+            if (ecr >= 0 && M > 0) {
+                r = make_uint2(D, HD + TL);
+                // (Size - 1) * D + HT >= need  <=>  Size >= ceil((need - HT) / D) + 1
+                const uint32_t ht = HD + TL;
+                thr = need <= ht ? 0u : (D ? (need - ht + D - 1u) / D + 1u : 0xFFFFFFFFu);
+            }
+            out[(size_t(j) * 2 + size_t(s)) * 15 + size_t(e)] = r;
+            // minimum over the 15 cells (lanes 0..14 of wave 0)
+            for (int o = 8; o > 0; o >>= 1) {
+                const uint32_t t = __shfl_down(thr, o);
+                if (lane + o < 15) thr = t < thr ? t : thr;
+            }
+            if (threadIdx.x == 0) smin = thr < smin ? thr : smin;
+        }
+        __syncthreads();
     }
+    if (keep_q && threadIdx.x == 0) keep_q[j] = (ecr >= 0 && smin != 0xFFFFFFFFu && smin > keep) ? smin : keep;
 }
 
 // true: the candidate (key, Size sz) of query j cannot reach `need` (see k_gap_bounds)
@@ -2232,6 +2284,7 @@ static int g_part32 = 0;
 static int g_score_oob = 0;  // k_score_part without a window test (ioc_ctx_create's probe passed, or IOC_SCORE_OOB=1)
 // sharded merge: this rank scores the queries j with j % stride == offset 
 static int g_own_stride = 1, g_own_offset = 0;
+static const uint32_t* g_keep_q = nullptr;  // per-query compaction threshold (fast mode; null: the uniform `keep`)
 
 namespace {
 // ---- MinDB export (ioc_index_export): the posting lists restricted to the targets that ARE clusters, with final ids ----
@@ -2294,6 +2347,7 @@ extern "C" {
 void iock_set_score_variant(int v) { g_score_variant = v; }
 void iock_set_part32(int v) { g_part32 = v; }
 void iock_set_score_oob(int v) { g_score_oob = v; }
+void iock_set_score_keep(const uint32_t* keep_q) { g_keep_q = keep_q; }
 void iock_set_score_shard(int stride, int offset)
 {
     g_own_stride = stride > 1 ? stride : 1;
@@ -2519,7 +2573,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
             LAUNCH_PART(uint32_t, false, post);   // (u32 postings keep their window test: flat_traverse)
 #undef LAUNCH_PART
         hipLaunchKernelGGL(k_score_compact, dim3(nown), dim3(IOC_BLOCK), lds, st, n, L, part, keep, cand_key, cand_size,
-                           cand_count, audit_valid, audit_sum, top_all, max_len, own_s, own_o);
+                           cand_count, audit_valid, audit_sum, top_all, max_len, own_s, own_o, audit_valid ? nullptr : g_keep_q);
         return hipGetLastError();
     }
     const Epochs E = epoch_bounds(L, uint32_t(n));
@@ -2529,7 +2583,7 @@ hipError_t iock_score(hipStream_t st, int n, uint32_t L, const int64_t* off_fwd,
             CK(hipFuncSetAttribute((const void*)k_score_t<V, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))); \
         hipLaunchKernelGGL((k_score_t<V, PT>), dim3(nown), dim3(IOC_BLOCK), lds, st, n, L, off_fwd, off_rev, mins,   \
                            (const uint4*)rows, cap, shift, PP, range, keep, cand_key, cand_size, cand_count,         \
-                           traversed, E, audit_valid, audit_sum, own_s, own_o);                 \
+                           traversed, E, audit_valid, audit_sum, own_s, own_o, audit_valid ? nullptr : g_keep_q); \
     } while (0)
     if (post16) {
         LAUNCH_SCORE(0, uint16_t, post_h);
@@ -2615,10 +2669,12 @@ hipError_t iock_shard_mask_i32(hipStream_t st, int32_t* a, int n, int stride, in
 }
 
 hipError_t iock_gap_bounds(hipStream_t st, int n, const int64_t* off_fwd, const int64_t* off_rev, const uint32_t* pos,
-                           const uint32_t* hpc_len, const uint8_t* err_cell, const int32_t* glim, uint2* out)
+                           const uint32_t* hpc_len, const uint8_t* err_cell, const int32_t* glim, uint2* out, const uint32_t* min_total,
+                           uint32_t keep, uint32_t* keep_q)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gap_bounds, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, pos, hpc_len, err_cell, glim, out);
+    hipLaunchKernelGGL(k_gap_bounds, dim3(n), dim3(IOC_BLOCK), 0, st, n, off_fwd, off_rev, pos, hpc_len, err_cell, glim, out, min_total, keep,
+                       keep_q);
     return hipGetLastError();
 }
 
