@@ -108,7 +108,8 @@ int ioc_ctx_create(int device, ioc_ctx** out)
     ioc_ctx* c = new (std::nothrow) ioc_ctx;
     if (!c) return IOC_ERR_CAPACITY;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), 256, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return IOC_ERR_HIP;
     }
@@ -160,6 +161,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -565,10 +567,11 @@ int ioc_index_build(ioc_ctx* c)
                                            d_err));
         // posting lists start 16-byte aligned and are padded to a multiple of 4 entries (0xFFFFFFFF)
         HIPCHK(c, iock_exclusive_scan(s, P<uint32_t>(c->b_cnt), nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_scan), pmask));
-        uint32_t h_err = 0, h_total = 0;
-        HIPCHK(c, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(&h_total, P<uint32_t>(c->b_off) + nslots, 4, hipMemcpyDeviceToHost, s));
+        // (into pinned memory: two pageable 4-byte read-backs cost ~60 us of host time between them)
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 8, d_err, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 9, P<uint32_t>(c->b_off) + nslots, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        const uint32_t h_err = static_cast<volatile uint32_t*>(c->h_pin)[8], h_total = static_cast<volatile uint32_t*>(c->h_pin)[9];
         if (h_err != 0) {
             if (cap >= cap_safe) return ioc_fail(c, IOC_ERR_CAPACITY, "hash table overflow at safe capacity");
             cap = std::min<uint64_t>(uint64_t(cap) * 4, cap_safe);
@@ -965,9 +968,9 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         }
         uint8_t* vin = c->cur_valid == 0 ? P<uint8_t>(c->b_valid0) : P<uint8_t>(c->b_valid1);
         uint8_t* vout = c->cur_valid == 0 ? P<uint8_t>(c->b_valid1) : P<uint8_t>(c->b_valid0);
-        const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
-        HIPCHK(c, hipMemcpyAsync(d_first_changed, init, 16, hipMemcpyHostToDevice, s));
-        HIPCHK(c, iock_copy_prefix_valid(s, p2only ? n : first, vin, vout));  // (second half only: `done` queries write nothing)
+        // (the control words are reset by the same launch that copies the final prefix of `valid`; they come back into pinned
+        // memory: a pageable 16-byte upload and a pageable 12-byte read-back cost 45 us of host time per sweep between them)
+        HIPCHK(c, iock_copy_prefix_valid(s, p2only ? n : first, vin, vout, d_first_changed));  // (second half only: `done` queries write nothing)
         a.first = first;
         a.valid_in = vin;
         a.valid_out = vout;
@@ -984,13 +987,13 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
             if (int rc = exchange(vout + from, int64_t(n - from), IOC_XCHG_MAX_U8)) return rc;
             if (int rc = exchange(d_first_changed, 3, IOC_XCHG_MIN_U32)) return rc;
         }
-        uint32_t res[3] = {0, 0, 0};
-        HIPCHK(c, hipMemcpyAsync(res, d_first_changed, 12, hipMemcpyDeviceToHost, s));
+        volatile uint32_t* res = c->h_pin;
+        HIPCHK(c, hipMemcpyAsync(c->h_pin, d_first_changed, 12, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        if (sharded) res[2] = ~res[2];
         sweeps++;
         if (sweeps > 4 * n + 64) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
-        if (res[2] != 0) continue;  // work queue overflowed: same sweep again, the cache is fuller now
+        const uint32_t res2 = sharded ? ~res[2] : res[2];
+        if (res2 != 0) continue;  // work queue overflowed: same sweep again, the cache is fuller now
         p2only = false;
         iters++;
         c->cur_valid ^= 1;

@@ -111,7 +111,7 @@ hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const
                             const uint32_t* top_all, uint8_t* valid);
 hipError_t iock_decide_sweep(hipStream_t st, const void* args, int nblocks, int eval_blocks, uint32_t* q_count2);
 hipError_t iock_decide_phase2(hipStream_t st, const void* args, int nblocks, int eval_blocks, uint32_t* q_count2);
-hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout);
+hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout, uint32_t* ctl = nullptr);
 hipError_t iock_query_compact(hipStream_t st, const uint32_t* hist, const uint32_t* first, uint32_t n2, uint32_t cap, uint32_t* out);
 hipError_t iock_query_table_many(hipStream_t st, int nq, const int32_t* qlist, uint64_t stride, uint32_t L, const int64_t* off_fwd,
                                  const int64_t* off_rev, const uint32_t* mins, const void* rows, uint32_t cap, uint32_t shift,

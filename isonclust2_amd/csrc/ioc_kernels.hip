@@ -2159,10 +2159,16 @@ k_guess_valid(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restr
 }
 
 __global__ void __launch_bounds__(IOC_BLOCK)
-k_copy_prefix_valid(int first, const uint8_t* __restrict__ vin, uint8_t* __restrict__ vout)
+k_copy_prefix_valid(int first, const uint8_t* __restrict__ vin, uint8_t* __restrict__ vout, uint32_t* __restrict__ ctl)
 {
     int i = blockIdx.x * IOC_BLOCK + threadIdx.x;
     if (i < first) vout[i] = vin[i];
+    if (ctl && i == 0) {  // the sweep's control words: first changed query, the two queue counters, "queue overflowed"
+        ctl[0] = 0xFFFFFFFFu;
+        ctl[1] = 0u;
+        ctl[2] = 0u;
+        ctl[3] = 0u;
+    }
 }
 
 // =====================================================================================================
@@ -2687,11 +2693,12 @@ hipError_t iock_guess_valid(hipStream_t st, int n, const int64_t* off_fwd, const
     return hipGetLastError();
 }
 
-hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout)
+// the prefix of `valid` that is final already, and (ctl != null) the reset of the sweep's control words in the same launch
+hipError_t iock_copy_prefix_valid(hipStream_t st, int first, const uint8_t* vin, uint8_t* vout, uint32_t* ctl)
 {
-    if (first <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_copy_prefix_valid, dim3((first + IOC_BLOCK - 1) / IOC_BLOCK), dim3(IOC_BLOCK), 0, st, first,
-                       vin, vout);
+    if (first <= 0 && !ctl) return hipSuccess;
+    const int nb = first > 0 ? (first + IOC_BLOCK - 1) / IOC_BLOCK : 1;
+    hipLaunchKernelGGL(k_copy_prefix_valid, dim3(nb), dim3(IOC_BLOCK), 0, st, first, vin, vout, ctl);
     return hipGetLastError();
 }
 
