@@ -76,7 +76,8 @@ int ioc_set_params(ioc_ctx* ctx, const ioc_params* p, const int32_t gap_limit[22
 
 /* ---- queries (right batch) ------------------------------------------------------------------- */
 /* Host -> device upload of the query SoA.  off_fwd/off_rev: [n+1] element offsets into
- * min_val/min_pos (total = number of minimizers, fwd and rev, of all queries).  err_cell in 1..15 =
+ * min_val/min_pos (total = number of minimizers, fwd and rev, of all queries; the positions of a list ascend with the index,
+ * as the extractor's do: getMappedRatio subtracts consecutive ones as unsigned numbers).  err_cell in 1..15 =
  * clamp(round(100 * HpcSeq.ErrorRate)) (src/p_emp_prob.cpp:66-84).  min_total[j] = smallest integer
  * T with float(double(T)/double(hpc_len[j])) >= MappedThreshold (src/cluster.cpp:390-400). */
 int ioc_queries_upload(ioc_ctx* ctx, int32_t n, const int64_t* off_fwd, const int64_t* off_rev,

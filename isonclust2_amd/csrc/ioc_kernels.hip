@@ -1343,8 +1343,11 @@ k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restri
     __shared__ uint32_t red[3][15][IOC_WAVES];
     constexpr uint32_t GB_CHUNK = 4096, GB_HALO = 64;
     __shared__ uint32_t s_pos[GB_CHUNK + GB_HALO];
+    __shared__ uint32_t s_nonmono;
     const int j = blockIdx.x;
     if (j >= n) return;
+    if (threadIdx.x == 0) s_nonmono = 0u;
+    __syncthreads();
     const int lane = lane_id(), wave = wave_id();
     const int ecr = int(err_cell[j]) - 1;
     const uint32_t hl = hpc_len[j];
@@ -1370,7 +1373,11 @@ k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restri
             for (uint32_t c0 = 0; c0 < M; c0 += GB_CHUNK) {
                 const uint32_t cn = (M - c0 < GB_CHUNK + GB_HALO) ? M - c0 : GB_CHUNK + GB_HALO;  // staged entries
                 __syncthreads();
-                for (uint32_t x = threadIdx.x; x < cn; x += IOC_BLOCK) s_pos[x] = p[c0 + x];
+                for (uint32_t x = threadIdx.x; x < cn; x += IOC_BLOCK) {
+                    const uint32_t v = p[c0 + x];
+                    s_pos[x] = v;
+                    if (c0 + x + 1u < M && p[c0 + x + 1u] < v) s_nonmono = 1u;  // (a list that does not ascend: no bound for this query)
+                }
                 __syncthreads();
                 const uint32_t ce = (M - c0 < GB_CHUNK) ? M - c0 : GB_CHUNK;
                 const bool in_lds = lim[14] <= GB_HALO;
@@ -1435,6 +1442,10 @@ k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restri
                 // (Size - 1) * D + HT >= need  <=>  Size >= ceil((need - HT) / D) + 1
                 const uint32_t ht = HD + TL;
                 thr = need <= ht ? 0u : (D ? (need - ht + D - 1u) / D + 1u : 0xFFFFFFFFu);
+                if (s_nonmono) {  // the spans above assume ascending positions (the extractor's lists do): a bound that rejects nothing
+                    r = make_uint2(0u, 0xFFFFFFFFu);
+                    thr = 0u;
+                }
             }
             out[(size_t(j) * 2 + size_t(s)) * 15 + size_t(e)] = r;
             // minimum over the 15 cells (lanes 0..14 of wave 0)

@@ -79,3 +79,21 @@ def test_candidate_tables_and_mapped_totals(ctx, cfg, seed, step):
     # every getMappedRatio call of the traced entries was seen
     assert n_walked == int(np.isin(calls["entry"], entries).sum())
     assert n_dev >= n_walked
+
+
+def test_bound_of_total_mapped_is_a_pure_shortcut(ctx, monkeypatch):
+    """The upper bound of totalMapped (k_gap_bounds) and the cut of the candidate lists change no decision: with them, without
+    the list cut, without both — on a tie-prone read set, a tiny one and the CPU-runnable configuration."""
+    for cfg, seed in (("short_dup", 3), ("tiny", 5), ("config1", 2)):
+        rs = synth.generate_config(cfg, seed=seed)
+        _, view = oracle_sorted_batch(rs)
+        p = api.default_params(11, 15, "fast")
+        res = []
+        for bound, keepq in (("1", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("IOC_RESOLVE_BOUND", bound)
+            monkeypatch.setenv("IOC_SCORE_KEEPQ", keepq)
+            cls, strand, st = ctx.cluster_batch(p, view)
+            res.append((cls.copy(), strand.copy(), int(st["n_clusters"]), int(ctx.timings()["n_mapped_evals"])))
+        for r in res[1:]:
+            assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and r[2] == res[0][2], cfg
+        assert res[0][3] <= res[1][3] <= res[2][3]          # each half only ever removes evaluations
