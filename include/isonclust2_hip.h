@@ -279,6 +279,14 @@ int ioc_align_set_pool(ioc_ctx* ctx, int32_t n_seqs, const char* seqs, const int
 int ioc_align_pairs(ioc_ctx* ctx, int32_t n_pairs, const ioc_aln_pair* pairs, int32_t k, int32_t match,
                     int32_t mismatch, int32_t gap_extend, int32_t* out_score, int64_t* out_windows,
                     double* out_ratio);
+/* Verdict mode.  The clustering loop only ever asks whether out_ratio >= AlignedThreshold (src/cluster.cpp:503).  With a
+ * threshold > 0 set here, the traceback of a pair may stop as soon as that comparison is decided — the count of good windows
+ * has reached the smallest count whose ratio passes (what is still to come can only add), or can no longer reach it (every
+ * further column of the alignment ends at most one more window) — and out_windows / out_ratio are then lower bounds that
+ * compare with the threshold exactly as the full counts would (out_score is always exact).  <= 0 (the default): exact
+ * counts.  The cluster drivers (ioc_cluster_batch / merge / consensus) switch it on around their own alignment batches
+ * unless IOC_ALIGN_VERDICT=0. */
+int ioc_align_set_verdict_threshold(ioc_ctx* ctx, double aligned_threshold);
 
 /* The minimizer lists of the entries `entries[0..n_idx)` of the context's CURRENT queries (ioc_queries_upload /
  * ioc_queries_from_extracted / the batch of the last ioc_cluster_batch), gathered on the device into caller-owned

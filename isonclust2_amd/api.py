@@ -205,6 +205,10 @@ class Context:
         blob = b"".join(seqs)
         self._chk(self.L.ioc_align_set_pool(self.h, len(seqs), blob, _p(offs, C.c_int64)))
 
+    def align_set_verdict_threshold(self, thr):
+        """ioc_align_set_verdict_threshold: > 0 lets tracebacks stop once ratio >= thr is decided (windows / ratio become bounds)."""
+        self._chk(self.L.ioc_align_set_verdict_threshold(self.h, float(thr)))
+
     def align_pairs(self, pairs, k, match=2, mismatch=-2, gap_extend=1):
         """ParasailAlign + getAlnRatio (src/cluster.cpp:408-459) for (query, ref, ref_revcomp, e) tuples:
         returns (score, qualifying windows, ratio) arrays."""

@@ -46,6 +46,9 @@ struct AlnPairDev {
     int32_t gap_open, ilimit;
     uint32_t rc;         // reference is read reverse-complemented
     uint32_t pad;
+    // verdict mode (ioc_align_set_verdict_threshold): the traceback may stop once the count of good windows has reached stop_at
+    // (the ratio is >= the threshold whatever follows) or can no longer reach it; 0 = walk to the end
+    uint32_t stop_at, pad2;
 };
 
 struct AlnParams {
@@ -2114,6 +2117,13 @@ int ioc_align_set_pool(ioc_ctx* c, int32_t n_seqs, const char* seqs, const int64
     return IOC_OK;
 }
 
+int ioc_align_set_verdict_threshold(ioc_ctx* c, double aligned_threshold)
+{
+    if (!c) return IOC_ERR_ARG;
+    c->aln_verdict_thr = aligned_threshold > 0.0 ? aligned_threshold : -1.0;
+    return IOC_OK;
+}
+
 int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int32_t k, int32_t match, int32_t mismatch,
                     int32_t gap_extend, int32_t* out_score, int64_t* out_windows, double* out_ratio)
 {
@@ -2153,6 +2163,14 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         d.gap_open = ioc_host_gap_open(a.e);
         d.ilimit = il;
         d.rc = a.ref_revcomp ? 1u : 0u;
+        d.stop_at = 0;
+        if (c->aln_verdict_thr > 0.0 && n > 0) {
+            // smallest count a with double(a) / double(n) >= threshold: the comparison the caller will make (getAlnRatio / slen)
+            double a0 = std::ceil(c->aln_verdict_thr * double(n));
+            while (a0 > 0 && (a0 - 1.0) / double(n) >= c->aln_verdict_thr) a0 -= 1.0;
+            while (a0 / double(n) < c->aln_verdict_thr) a0 += 1.0;
+            d.stop_at = a0 >= 1.0 && a0 < 4.0e9 ? uint32_t(a0) : 0u;
+        }
         {   // query-profile kernel: four-letter sequences, diagonal increments that fit a byte
             const int gd = d.gap_open - gap_extend, cm = match + 2 * gap_extend + gd, cx = mismatch + 2 * gap_extend + gd;
             const bool ok = !c->aln_other[size_t(a.query)] && !c->aln_other[size_t(a.ref)] && cm >= 0 && cm <= 255 &&

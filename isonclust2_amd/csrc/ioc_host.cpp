@@ -400,7 +400,12 @@ struct AlnDriver {
             pairs[i].e = sa->r_err[todo[i].first] + err_of(target);
         }
         std::vector<double> ratio(todo.size());
+        // (the ratios are only ever compared with AlignedThreshold: the tracebacks may stop once that comparison is decided)
+        const double saved_thr = c->aln_verdict_thr;
+        const char* ev = getenv("IOC_ALIGN_VERDICT");
+        if (!(ev && ev[0] == '0')) (void)ioc_align_set_verdict_threshold(c, c->params.aligned_threshold);
         int r = ioc_align_pairs(c, int32_t(pairs.size()), pairs.data(), c->params.k, 2, -2, 1, nullptr, nullptr, ratio.data());
+        c->aln_verdict_thr = saved_thr;
         if (r != IOC_OK) return r;
         for (size_t i = 0; i < todo.size(); ++i) {
             cache[key(todo[i].first, todo[i].second)] = ratio[i];

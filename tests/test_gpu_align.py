@@ -334,3 +334,34 @@ def test_v2_fallbacks(ctx, monkeypatch):
     monkeypatch.setenv("IOC_ALIGN_V2_FAKE_TIMEOUT", "1")
     _check(ctx, seqs, pairs, 11)
     assert ctx.timings()["n_align_refused"] - t1 == len(pairs) and ctx.timings()["align_version"] == 1
+
+
+def test_verdict_mode_decides_every_comparison_like_the_full_count(ctx):
+    """ioc_align_set_verdict_threshold: tracebacks stop once `ratio >= threshold` is decided.  For related pairs (pass early),
+    unrelated ones (fail late), pairs near the threshold and degenerate lengths: the comparison comes out as with the exact
+    counts at every threshold, the scores are exact, a stopped walk never reports more windows than the full one — and related
+    long pairs do stop early (fewer windows than the full count)."""
+    rng = random.Random(43)
+    base = bytes(rng.choice(b"ACGT") for _ in range(5000))
+    other = bytes(rng.choice(b"ACGT") for _ in range(4800))
+    seqs = [base, _mutate(rng, base, 0.06), _mutate(rng, base, 0.15), _mutate(rng, base, 0.3), other, _mutate(rng, other, 0.1),
+            base[:700] + other[700:3000], base[:40], b"ACGT" * 3, b""]
+    n = len(seqs)
+    pairs = [(i, j, (i + j) % 2, 0.12) for i in range(n) for j in range(n) if i != j and (i + 2 * j) % 3 != 0]
+    ctx.align_set_pool(seqs)
+    ctx.align_set_verdict_threshold(0.0)
+    s0, w0, r0 = ctx.align_pairs(pairs, 11)
+    stopped = 0
+    try:
+        for thr in (0.2, 0.05, 0.6, 0.95):
+            ctx.align_set_verdict_threshold(thr)
+            s1, w1, r1 = ctx.align_pairs(pairs, 11)
+            assert np.array_equal(s0, s1)
+            assert np.array_equal(r0 >= thr, r1 >= thr), thr
+            assert np.all(w1 <= w0)
+            stopped += int(np.count_nonzero(w1 < w0))
+    finally:
+        ctx.align_set_verdict_threshold(0.0)
+    assert stopped > len(pairs) // 4
+    s2, w2, r2 = ctx.align_pairs(pairs, 11)                     # exact again
+    assert np.array_equal(w2, w0) and np.array_equal(r2, r0)
