@@ -1971,7 +1971,16 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     const size_t ctl_words = 16 + size_t(max_flags) + np;
     if ((r = reserve(c, c->a_xflags, ctl_words * 4)) != IOC_OK) return r;
     uint32_t* d_ctl = static_cast<uint32_t*>(c->a_xflags.p);
-    if ((r = reserve(c, c->a_bnd, size_t(max_pairs) * sizeof(V2Scratch))) != IOC_OK) return r;
+    // the traceback in two launches: walks that need more than `deadline` blocks go on in the second one, with helper waves
+    // (IOC_TRACE2_DEADLINE=0: one launch).  Per pair: its own scratch, 15 helper buffers (0.5 MB), 16 words of parked state and records.
+    uint32_t deadline = 18;
+    if (const char* e = getenv("IOC_TRACE2_DEADLINE")) deadline = uint32_t(std::max(0, atoi(e)));
+    const size_t scratch_per_pair = deadline ? 1 + size_t(V2_NHELP) * V2_HBUF : 1;
+    if ((r = reserve(c, c->a_bnd, size_t(max_pairs) * scratch_per_pair * sizeof(V2Scratch) + (size_t(np) * V2_RESUME_WORDS + size_t(max_pairs) + 1u) * 4)) != IOC_OK) return r;
+    V2Scratch* d_scratch = static_cast<V2Scratch*>(c->a_bnd.p);
+    V2Scratch* d_hscratch = d_scratch + max_pairs;
+    uint32_t* d_resume = reinterpret_cast<uint32_t*>(d_scratch + size_t(max_pairs) * scratch_per_pair);
+    uint32_t* d_park = d_resume + size_t(np) * V2_RESUME_WORDS;  // [count][pair slots of the slice]
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k_fwd2), 64 * V2_WAVES, 0) != hipSuccess) occ = 0;
     (void)hipGetLastError();
@@ -2001,10 +2010,18 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                            d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p));
         ACHK(c, hipGetLastError());
         ACHK(c, hipEventRecord(evs[evi++], s));
+        ACHK(c, hipMemsetAsync(d_resume, 0, (size_t(np) * V2_RESUME_WORDS + size_t(max_pairs) + 1u) * 4, s));  // (parked state and the list of parked walks)
         hipLaunchKernelGGL(k_trace2, dim3((n_pairs + TR_WAVES - 1) / TR_WAVES), dim3(64 * TR_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p),
                            d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const uint32_t*>(c->a_ck.p), d_pck,
-                           static_cast<const int4*>(c->a_ends2.p), static_cast<V2Scratch*>(c->a_bnd.p), d_score, d_count, n_pairs);
+                           static_cast<const int4*>(c->a_ends2.p), d_scratch, d_resume, d_park, d_score, d_count, n_pairs, deadline);
         ACHK(c, hipGetLastError());
+        if (deadline) {  // (one workgroup per compute unit: a walker and its helpers fill one; more parked walks than that take turns)
+            hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, uint32_t(n_cu))), dim3(64 * V2_HWAVES), 0, s,
+                               static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P,
+                               static_cast<const uint32_t*>(c->a_ck.p), d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
+                               d_park, d_score, d_count, n_pairs);
+            ACHK(c, hipGetLastError());
+        }
         ACHK(c, hipEventRecord(evs[evi++], s));
         if (getenv("IOC_V2_PROGRESS")) {  // debug watchdog: where are the kernels after 10 s?  (build with -DIOC_V2_MARKS)
             const auto tw = std::chrono::steady_clock::now();
@@ -2036,28 +2053,30 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                     100.0 * double(t[0]) / std::max(1.0, double(t[1])), double(t[2]), n_wg);
         }
         if (getenv("IOC_V2_TRACE_TIMES")) {  // developer aid: the slowest walks of the slice (k_trace2 ends when its slowest wave does)
-            struct Rec { int2 a, b, cc; };
-            std::vector<Rec> recs(n_pairs);
-            const V2Scratch* dsc = static_cast<const V2Scratch*>(c->a_bnd.p);
-            for (uint32_t x = 0; x < n_pairs; ++x)
-                ACHK(c, hipMemcpy(&recs[x], &dsc[x].fcol[0][0], sizeof(Rec), hipMemcpyDeviceToHost));
-            std::vector<uint32_t> idx(n_pairs);
-            for (uint32_t x = 0; x < n_pairs; ++x) idx[x] = x;
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return recs[a].a.x > recs[b].a.x; });
+            std::vector<uint32_t> rw(size_t(np) * V2_RESUME_WORDS);
+            ACHK(c, hipMemcpy(rw.data(), d_resume, rw.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> ids(n_pairs);
+            for (uint32_t x = 0; x < n_pairs; ++x) ids[x] = order[first_pair + x];
+            // (first launch + second launch: the second starts when the first has ended, so the sum orders the pairs by what they cost)
+            auto rec = [&](uint32_t pid, uint32_t w) { return rw[size_t(pid) * V2_RESUME_WORDS + w]; };
+            auto cost = [&](uint32_t pid) { return (double(rec(pid, 8)) + double(rec(pid, 12))) * 256.0; };
+            std::sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
             double sum = 0;
-            for (auto& r2 : recs) sum += double(r2.a.x) * 256.0;
-            fprintf(stderr, "[ioc] k_trace2 walks: %u pairs, mean %.3e cycles (s_memtime), slowest first:\n", n_pairs, sum / n_pairs);
-            for (uint32_t x = 0; x < std::min(n_pairs, 12u); ++x) {
-                const Rec& r2 = recs[idx[x]];
-                const AlnPairDev& d = dp[size_t(r2.a.y)];
-                fprintf(stderr, "[ioc]   pair %d: %.3e cycles, n %u m %u, blocks %u (%u on the diagonal), tiles %d, gap steps %d, windows %d\n", r2.a.y, double(r2.a.x) * 256.0,
-                        d.n, d.m, uint32_t(r2.b.x) & 0xFFFFu, uint32_t(r2.b.x) >> 16, r2.b.y, r2.cc.x, r2.cc.y);
+            uint32_t parked = 0;
+            for (uint32_t pid : ids) {
+                sum += cost(pid);
+                parked += rec(pid, 6) ? 1u : 0u;
             }
-            for (uint32_t q : {n_pairs / 4u, n_pairs / 2u, 3u * n_pairs / 4u}) {
-                const Rec& r2 = recs[idx[q]];
-                fprintf(stderr, "[ioc]   rank %u: %.3e cycles, blocks %u (%u on the diagonal), tiles %d, gap steps %d\n", q, double(r2.a.x) * 256.0, uint32_t(r2.b.x) & 0xFFFFu,
-                        uint32_t(r2.b.x) >> 16, r2.b.y, r2.cc.x);
-            }
+            fprintf(stderr, "[ioc] k_trace2: %u pairs, %u walks went on in the second launch (deadline %u blocks); mean %.3e cycles (s_memtime), slowest first:\n", n_pairs, parked,
+                    deadline, sum / n_pairs);
+            auto line = [&](const char* tag, uint32_t pid) {
+                const AlnPairDev& d = dp[pid];
+                fprintf(stderr, "[ioc]   %s pair %u: %.3e + %.3e cycles, n %u m %u, blocks %u (%u on the diagonal) + %u (%u by helpers), tiles %u + %u, gap steps %u, windows %u\n", tag, pid,
+                        double(rec(pid, 8)) * 256.0, double(rec(pid, 12)) * 256.0, d.n, d.m, rec(pid, 9) & 0xFFFFu, rec(pid, 9) >> 16, rec(pid, 13) & 0xFFFFu, rec(pid, 13) >> 16,
+                        rec(pid, 10), rec(pid, 14), rec(pid, 11), rec(pid, 15));
+            };
+            for (uint32_t x = 0; x < std::min(n_pairs, 10u); ++x) line("", ids[x]);
+            for (uint32_t qx : {n_pairs / 4u, n_pairs / 2u, 3u * n_pairs / 4u}) line("rank", ids[qx]);
         }
         if (xe) bad = true;
     }
