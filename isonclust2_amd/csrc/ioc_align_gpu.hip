@@ -1973,7 +1973,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     uint32_t* d_ctl = static_cast<uint32_t*>(c->a_xflags.p);
     // the traceback in two launches: walks that need more than `deadline` blocks go on in the second one, with helper waves
     // (IOC_TRACE2_DEADLINE=0: one launch).  Per pair: its own scratch, 20 helper buffers (0.66 MB), 16 words of parked state and records.
-    uint32_t deadline = 18;
+    uint32_t deadline = 4;  // (blocks of slack on top of what a pair of one transcript needs to be decided: 2 per 512 windows of its threshold)
     if (const char* e = getenv("IOC_TRACE2_DEADLINE")) deadline = uint32_t(std::max(0, atoi(e)));
     // ... or that are still undecided after this many cycles of the first launch (s_memtime; 0: the block count alone)
     unsigned long long deadline_cycles = 0;
