@@ -1972,17 +1972,19 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if ((r = reserve(c, c->a_xflags, ctl_words * 4)) != IOC_OK) return r;
     uint32_t* d_ctl = static_cast<uint32_t*>(c->a_xflags.p);
     // the traceback in two launches: walks that need more than `deadline` blocks go on in the second one, with helper waves
-    // (IOC_TRACE2_DEADLINE=0: one launch).  Per pair: its own scratch, 20 helper buffers (0.66 MB), 16 words of parked state and records.
+    // (IOC_TRACE2_DEADLINE=0: one launch).  Per pair: its own scratch and 16 words of parked state and records.
     uint32_t deadline = 4;  // (blocks of slack on top of what a pair of one transcript needs to be decided: 2 per 512 windows of its threshold)
     if (const char* e = getenv("IOC_TRACE2_DEADLINE")) deadline = uint32_t(std::max(0, atoi(e)));
     // ... or that are still undecided after this many cycles of the first launch (s_memtime; 0: the block count alone)
     unsigned long long deadline_cycles = 0;
     if (const char* e = getenv("IOC_TRACE2_CYCLES")) deadline_cycles = (unsigned long long)std::max(0.0, atof(e));
-    const size_t scratch_per_pair = deadline ? 1 + size_t(V2_NHELP) * V2_HBUF : 1;
-    if ((r = reserve(c, c->a_bnd, size_t(max_pairs) * scratch_per_pair * sizeof(V2Scratch) + (size_t(np) * V2_RESUME_WORDS + size_t(max_pairs) + 1u) * 4)) != IOC_OK) return r;
+    // (the helper buffers belong to the second launch's WORKGROUPS — one per compute unit — not to the pairs: 0.66 MB each)
+    const uint32_t help_wgs = deadline ? std::min<uint32_t>(max_pairs, uint32_t(n_cu)) : 0u;
+    const size_t n_scratch = size_t(max_pairs) + size_t(help_wgs) * V2_NHELP * V2_HBUF;
+    if ((r = reserve(c, c->a_bnd, n_scratch * sizeof(V2Scratch) + (size_t(np) * V2_RESUME_WORDS + size_t(max_pairs) + 1u) * 4)) != IOC_OK) return r;
     V2Scratch* d_scratch = static_cast<V2Scratch*>(c->a_bnd.p);
     V2Scratch* d_hscratch = d_scratch + max_pairs;
-    uint32_t* d_resume = reinterpret_cast<uint32_t*>(d_scratch + size_t(max_pairs) * scratch_per_pair);
+    uint32_t* d_resume = reinterpret_cast<uint32_t*>(d_scratch + n_scratch);
     uint32_t* d_park = d_resume + size_t(np) * V2_RESUME_WORDS;  // [count][pair slots of the slice]
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k_fwd2), 64 * V2_WAVES, 0) != hipSuccess) occ = 0;
@@ -2019,7 +2021,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                            static_cast<const int4*>(c->a_ends2.p), d_scratch, d_resume, d_park, d_score, d_count, n_pairs, deadline, deadline_cycles);
         ACHK(c, hipGetLastError());
         if (deadline) {  // (one workgroup per compute unit: a walker and its helpers fill one; more parked walks than that take turns)
-            hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, uint32_t(n_cu))), dim3(64 * V2_HWAVES), 0, s,
+            hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, help_wgs)), dim3(64 * V2_HWAVES), 0, s,
                                static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P,
                                static_cast<const uint32_t*>(c->a_ck.p), d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
                                d_park, d_score, d_count, n_pairs);
