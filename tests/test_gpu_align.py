@@ -365,3 +365,24 @@ def test_verdict_mode_decides_every_comparison_like_the_full_count(ctx):
     assert stopped > len(pairs) // 4
     s2, w2, r2 = ctx.align_pairs(pairs, 11)                     # exact again
     assert np.array_equal(w2, w0) and np.array_equal(r2, r0)
+
+
+def test_second_traceback_launch_takes_turns_when_many_walks_park(ctx):
+    """More undecided walks than the second launch has workgroups (one per compute unit): 700 pairs of unrelated 5 kb sequences
+    in verdict mode all park after a few blocks and go on with helper waves, two or three per workgroup one after the other;
+    among them a few related pairs that are decided in the first launch.  Scores exact, every comparison as with the full count."""
+    rng = random.Random(47)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(4500, 5500))) for _ in range(60)]
+    seqs += [_mutate(rng, seqs[i], 0.08) for i in range(5)]
+    pairs = [(i, (i * 7 + 1 + j) % 60, (i + j) % 2, 0.12) for i in range(60) for j in range(12) if (i * 7 + 1 + j) % 60 != i][:700]
+    pairs += [(60 + i, i, 0, 0.12) for i in range(5)] + [(i, 60 + i, 1, 0.12) for i in range(5)]
+    ctx.align_set_pool(seqs)
+    ctx.align_set_verdict_threshold(0.0)
+    s0, w0, r0 = ctx.align_pairs(pairs, 11)
+    try:
+        ctx.align_set_verdict_threshold(0.2)
+        s1, w1, r1 = ctx.align_pairs(pairs, 11)
+    finally:
+        ctx.align_set_verdict_threshold(0.0)
+    assert np.array_equal(s0, s1) and np.array_equal(r0 >= 0.2, r1 >= 0.2) and np.all(w1 <= w0)
+    assert int(np.count_nonzero(r0 >= 0.2)) >= 5 and int(np.count_nonzero(r0 < 0.2)) >= 600
