@@ -1811,10 +1811,21 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     // the 16-bit window's guard (|relative score| at a rebase): a pair beyond it is flagged and re-run by version 1
     int guard = P16_GUARD;
     if (const char* e = getenv("IOC_ALIGN_V2_GUARD")) guard = std::max(1, std::min(P16_GUARD, atoi(e)));
-    uint32_t want_bands = 12;  // (config 3: 11 bands of 1536 rows: 66.8 ms; 7 of 2560: 69.2; 17 of 1024: worse again)
-    if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
     const uint32_t np = uint32_t(dp.size());
     const uint32_t ncouples = (cnt + 1u) / 2u;
+    // Bands per couple.  A full batch (config 3: 811 couples) is bound by throughput: 11 bands of 1536 rows (66.8 ms; 7 of 2560:
+    // 69.2; 17 of 1024: worse again).  A small one (a merge aligns a few hundred representatives) is bound by ONE couple's
+    // critical path, (bands + strips - 1) tiles of rows / (4 bands) + 63 steps: more, shorter bands shorten it as long as the
+    // waves the chip holds outnumber the tiles in flight.
+    uint32_t want_bands = 12;
+    {
+        int occ0 = 3;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ0, reinterpret_cast<const void*>(k_fwd2), 64 * V2_WAVES, 0) != hipSuccess || occ0 < 1) occ0 = 3;
+        (void)hipGetLastError();
+        const uint32_t waves = uint32_t(occ0) * uint32_t(n_cu) * uint32_t(V2_WAVES);
+        want_bands = std::max(12u, std::min(uint32_t(V2_MAX_BANDS), (waves + ncouples - 1u) / std::max(1u, ncouples)));
+    }
+    if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
     std::vector<V2Couple> cps(ncouples);
     std::vector<V2PairCk> pck(np);
     std::vector<V2PairEnd> pend(np);
@@ -1837,7 +1848,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         // enough (>= 1024 rows = 256 steps) for the 63 steps of pipeline fill to stay small — except the first and the last
         // ones, which CAN be short (V2Couple::bstart; IOC_ALIGN_V2_RAMP=1): 1, 2, 4 coarse rows, then the regular height, then 4, 2, 1
         {
-            const uint32_t reg = std::max<uint32_t>(2u, (ncoarse + want_bands - 1) / want_bands);
+            const uint32_t reg = std::max<uint32_t>(want_bands > 16u ? 1u : 2u, (ncoarse + want_bands - 1) / want_bands);  // (coarse rows per band)
             std::vector<uint32_t> hts;
             uint32_t left = ncoarse;
             auto take = [&](uint32_t hgt) {
