@@ -156,7 +156,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_keep_q, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_keep_q, &c->b_bsort, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual, &c->b_dist_min, &c->b_dist_pos};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -543,7 +543,78 @@ int ioc_index_build(ioc_ctx* c)
     };
     uint32_t cap = pow2_at_least(2.0 * guess);
     const uint32_t cap_safe = pow2_at_least(2.0 * ub);
-    for (;;) {
+    // ---- the build without global atomics (ioc_build_sort.hip): a stable radix sort of the (value, target) pairs ----
+    const int value_bits = (k >= 1 && k <= 16) ? 2 * k : 32;
+    const bool sorted_build = value_bits < 32 && ub_entries > 0 && env_u32("IOC_BUILD_SORT", 1) == 1;
+    if (sorted_build) {
+        const int64_t NP = ub_entries;  // (the unused tails of the queries' lists ride along as sentinels)
+        IocBuildSort a{};
+        a.n = n;
+        a.L = uint32_t(c->L);
+        a.doff = P<int64_t>(c->b_doff);
+        a.dcount = P<uint32_t>(c->b_dcount);
+        a.dvals = P<uint32_t>(c->b_dvals);
+        a.n_left_keys = c->n_left_keys;
+        a.n_left_post = c->n_left_post;
+        a.lkeys = P<uint32_t>(c->b_lkeys);
+        a.loffs = P<int64_t>(c->b_loffs);
+        a.lpost = P<uint32_t>(c->b_lpost);
+        a.P = NP;
+        a.post16 = c->post16;
+        a.value_bits = value_bits;
+        a.pad_mask = pmask;
+        a.temp_bytes = iock_build_sort_temp_bytes(NP, c->post16, value_bits);
+        // one arena: [pk_in][pk_out][rid][roff][run_start][lens][scan scratch][ctl][pv_in][pv_out][temp]
+        const size_t w = size_t(NP) + 4;
+        const size_t words = 6 * w + (size_t(NP) / 1024 + 8) + 4;
+        const size_t pvb = (size_t(NP) * psize + 255) & ~size_t(255);
+        RESERVE(c, c->b_bsort, words * 4 + 2 * pvb + a.temp_bytes + 1024);
+        uint32_t* wp = P<uint32_t>(c->b_bsort);
+        a.pk_in = wp;
+        a.pk_out = wp + w;
+        a.rid = wp + 2 * w;
+        a.roff = wp + 3 * w;
+        a.run_start = wp + 4 * w;
+        a.lens = wp + 5 * w;
+        a.scan_scratch = wp + 6 * w;
+        a.ctl = a.scan_scratch + (size_t(NP) / 1024 + 8);
+        uint8_t* bp = reinterpret_cast<uint8_t*>(wp) + ((words * 4 + 255) & ~size_t(255));
+        a.pv_in = bp;
+        a.pv_out = bp + pvb;
+        a.temp = bp + 2 * pvb;
+        HIPCHK(c, iock_build_sort_phase1(s, &a));
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 8, a.ctl, 4, hipMemcpyDeviceToHost, s));        // real pairs
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 9, a.rid + NP, 4, hipMemcpyDeviceToHost, s));    // runs = distinct keys
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 10, a.roff + NP, 4, hipMemcpyDeviceToHost, s));  // padded postings
+        HIPCHK(c, hipStreamSynchronize(s));
+        const uint32_t n_real = static_cast<volatile uint32_t*>(c->h_pin)[8], R = static_cast<volatile uint32_t*>(c->h_pin)[9],
+                       h_total = static_cast<volatile uint32_t*>(c->h_pin)[10];
+        cap = pow2_at_least(2.0 * double(R ? R : 1));  // (the number of keys is known: no retry)
+        const uint32_t nslots = cap + 1;
+        uint32_t bits = 0;
+        while ((1u << bits) < cap) bits++;
+        const uint32_t shift = 32 - bits;
+        RESERVE(c, c->b_keys, size_t(nslots) * 4);
+        RESERVE(c, c->b_cnt, size_t(nslots + 1) * 4);
+        RESERVE(c, c->b_off, size_t(nslots + 1) * 4);
+        RESERVE(c, c->b_rows, size_t(nslots) * 16);
+        RESERVE(c, c->b_qinfo, size_t(nslots) * 8);
+        HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(nslots) * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(nslots + 1) * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_off.p, 0, size_t(nslots + 1) * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
+        if (uint64_t(h_total) >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 padded index postings");
+        c->cap = cap;
+        c->n_post = h_total;
+        RESERVE(c, c->b_post, size_t(h_total) * psize + 256);
+        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, size_t(h_total) * psize + 256, s));
+        HIPCHK(c, iock_build_sort_phase2(s, &a, R, n_real, P<uint32_t>(c->b_keys), cap, shift, P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_off), c->b_post.p,
+                                         P<uint32_t>(c->b_misc)));
+        HIPCHK(c, iock_sort_lists(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048,
+                                  P<uint32_t>(c->b_qinfo), c->post16, /*sorted=*/1));
+        HIPCHK(c, iock_pack_rows(s, nslots, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_qinfo), c->b_rows.p));
+    }
+    for (; !sorted_build;) {
         const uint32_t nslots = cap + 1;
         uint32_t bits = 0;
         while ((1u << bits) < cap) bits++;

@@ -152,6 +152,7 @@ struct ioc_ctx {
     DevBuf b_shard_stage;
     double aln_verdict_thr = -1.0;  // ioc_align_set_verdict_threshold (<= 0: exact counts)
     uint32_t* h_pin = nullptr;     // 256 bytes of pinned host memory: the read-backs of the resolve's sweeps
+    DevBuf b_bsort;                // the sorted index build's arena (ioc_build_sort.hip)
     DevBuf b_gap_bound, b_keep_q;  // k_gap_bounds' table of the current queries; the per-query compaction threshold (fast mode)
     uint64_t gap_bound_gen = ~0ull;  // query_gen the table was computed for (ioc_set_params resets it)
     bool gap_bound_cut = false;      // ... with keep_q written

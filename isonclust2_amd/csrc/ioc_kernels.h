@@ -83,7 +83,7 @@ hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, c
 hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* doff, const uint32_t* dcount,
                              const uint32_t* dslot, const uint32_t* dpos, const uint32_t* off, void* post, int post16);
 hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, void* post,
-                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16);
+                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16, int sorted = 0);
 hipError_t iock_export_count(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
                              uint32_t L, const int32_t* cid, uint32_t* out_cnt);
 hipError_t iock_export_fill(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, const void* post, int post16,
@@ -141,5 +141,34 @@ hipError_t iock_minimizers(hipStream_t st, int n, const int64_t* offs, const uin
                            const int64_t* off_rev, uint32_t* cnt_fwd, uint32_t* cnt_rev, uint32_t* omin,
                            uint32_t* opos, uint32_t max_hlen);
 }
+
+// ---- index build without global atomics (ioc_build_sort.hip) ----
+struct IocBuildSort {
+    int n;                        // queries
+    uint32_t L;                   // left clusters: query j is target L + j
+    const int64_t* doff;          // [n + 1] capacity offsets of the queries' distinct lists
+    const uint32_t* dcount;       // [n]
+    const uint32_t* dvals;
+    int64_t n_left_keys, n_left_post;
+    const uint32_t* lkeys;        // left MinDB (CSR): keys, offsets, postings
+    const int64_t* loffs;
+    const uint32_t* lpost;
+    int64_t P;                    // pairs incl. the unused tails of the queries' lists: n_left_post + doff[n]
+    int post16, value_bits;
+    uint32_t pad_mask;            // lists are padded to whole 16-byte units
+    uint32_t *pk_in, *pk_out;     // [P]   (pk_in holds the run flags after the sort)
+    void *pv_in, *pv_out;         // [P] postings (u16 / u32)
+    uint32_t *rid, *roff;         // [P + 1]
+    uint32_t *run_start;          // [P + 1]
+    uint32_t *lens;               // [P]
+    uint32_t *scan_scratch;       // [P / 1024 + 4]
+    uint32_t* ctl;                // 4 words
+    void* temp;
+    size_t temp_bytes;
+};
+size_t iock_build_sort_temp_bytes(int64_t P, int post16, int value_bits);
+hipError_t iock_build_sort_phase1(hipStream_t st, const IocBuildSort* a);
+hipError_t iock_build_sort_phase2(hipStream_t st, const IocBuildSort* a, uint32_t R, uint32_t n_real, uint32_t* keys, uint32_t cap, uint32_t shift,
+                                  uint32_t* cnt, uint32_t* off, void* post, uint32_t* err);
 
 #endif

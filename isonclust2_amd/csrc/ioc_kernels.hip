@@ -499,7 +499,7 @@ k_fill_queries(int n, uint32_t L, const int64_t* __restrict__ doff, const uint32
 template <typename PT>
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-             PT* __restrict__ post, uint32_t L, uint32_t words_per_wave, Epochs E, uint2* __restrict__ qinfo)
+             PT* __restrict__ post, uint32_t L, uint32_t words_per_wave, Epochs E, uint2* __restrict__ qinfo, int sorted)
 {
     extern __shared__ uint32_t sbits[];  // IOC_WAVES * words_per_wave
     const uint32_t gw = (blockIdx.x * IOC_BLOCK + threadIdx.x) >> 6;  // global wave id
@@ -530,7 +530,7 @@ k_sort_lists(uint32_t nslots, const uint32_t* __restrict__ off, const uint32_t* 
             }
             if (lane == 0) qinfo[slot] = info;
         }
-        if (c < 2) continue;
+        if (c < 2 || sorted) continue;  // (sorted: the lists of ioc_build_sort.hip come out ascending)
         const uint32_t o = off[slot];
         // the left part (values < L) was copied first and is already ascending: it is a prefix by position
         uint32_t a = 0, b2 = c;
@@ -2473,7 +2473,7 @@ static Epochs epoch_bounds(uint32_t L, uint32_t n)
 }
 
 hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off, const uint32_t* cnt, void* post,
-                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16)
+                           uint32_t L, uint32_t n, uint32_t nblocks, uint32_t* qinfo, int post16, int sorted)
 {
     const Epochs E = epoch_bounds(L, n);
     uint32_t words = (n + 31) / 32;
@@ -2483,12 +2483,12 @@ hipError_t iock_sort_lists(hipStream_t st, uint32_t nslots, const uint32_t* off,
         if (lds > 48 * 1024)
             CK(hipFuncSetAttribute((const void*)k_sort_lists<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(k_sort_lists<uint16_t>, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt,
-                           (uint16_t*)post, L, words, E, (uint2*)qinfo);
+                           (uint16_t*)post, L, words, E, (uint2*)qinfo, sorted);
     } else {
         if (lds > 48 * 1024)
             CK(hipFuncSetAttribute((const void*)k_sort_lists<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         hipLaunchKernelGGL(k_sort_lists<uint32_t>, dim3(nblocks), dim3(IOC_BLOCK), lds, st, nslots, off, cnt,
-                           (uint32_t*)post, L, words, E, (uint2*)qinfo);
+                           (uint32_t*)post, L, words, E, (uint2*)qinfo, sorted);
     }
     return hipGetLastError();
 }
