@@ -11,8 +11,8 @@
 //   pairs     [left postings (key of their list, cluster id)] [query j's distinct values, capacity of its forward list: the
 //             unused tail holds a sentinel key above every value]
 //   sort      by key, stable, value bits + 1 (the sentinel sorts last)
-//   runs      a flag where the key changes, exclusive scan = run number, run starts, run lengths (their padded sum tells the
-//             host how many postings to allocate)
+//   runs      a flag where the key changes, exclusive scan (rocPRIM) = run number, run starts, run lengths (their padded sum
+//             tells the host how many postings to allocate)
 //   slots     one hash insert per RUN (distinct keys only, no contention on a slot), cnt[slot] = the run's length, then the
 //             exclusive scan of the padded counts over the SLOTS: keys / cnt / off exactly as the atomic build leaves them —
 //             everything downstream (rows, export, the query tables, the scoring kernels' partitions) is unchanged
@@ -24,6 +24,9 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "ioc_kernels.h"
 
@@ -81,44 +84,46 @@ k_bs_pairs_left(int64_t nkeys, const uint32_t* __restrict__ lkeys, const int64_t
     }
 }
 
-// flag = 1 at the first pair of every run of real keys; ctl[0] = number of real pairs
-__global__ void __launch_bounds__(BS_BLOCK)
-k_bs_flags(int64_t P, const uint32_t* __restrict__ pk, uint32_t sentinel, uint32_t* __restrict__ flags, uint32_t* __restrict__ ctl)
-{
-    const int64_t i = int64_t(blockIdx.x) * BS_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t key = pk[i];
-    const bool real = key < sentinel;
-    flags[i] = (real && (i == 0 || pk[i - 1] != key)) ? 1u : 0u;
-    if (real && (i + 1 == P || pk[i + 1] >= sentinel)) ctl[0] = uint32_t(i + 1);
-}
+// 1 at the first pair of every run of real keys (the scan's input, computed on the fly from the sorted keys)
+struct BsFlag {
+    const uint32_t* pk;
+    uint32_t sentinel;
+    size_t P;
+    __device__ uint32_t operator()(size_t i) const
+    {
+        if (i >= P) return 0u;
+        const uint32_t k = pk[i];
+        return (k < sentinel && (i == 0 || pk[i - 1] != k)) ? 1u : 0u;
+    }
+};
 
-// run_start[r] = index of run r's first pair; run_start[R] = number of real pairs
+// run_start[r] = index of run r's first pair; run_start[R] = number of real pairs = ctl[0]; ctl[1] = R
 __global__ void __launch_bounds__(BS_BLOCK)
-k_bs_starts(int64_t P, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ rid, const uint32_t* __restrict__ ctl,
+k_bs_starts(int64_t P, const uint32_t* __restrict__ pk, uint32_t sentinel, const uint32_t* __restrict__ rid, uint32_t* __restrict__ ctl,
             uint32_t* __restrict__ run_start)
 {
     const int64_t i = int64_t(blockIdx.x) * BS_BLOCK + threadIdx.x;
     if (i >= P) return;
-    if (flags[i]) run_start[rid[i]] = uint32_t(i);
-    if (i == 0) run_start[rid[P]] = ctl[0];  // (rid[P] = R: the scan's total)
-}
-
-__global__ void __launch_bounds__(BS_BLOCK)
-k_bs_lens(int64_t P, const uint32_t* __restrict__ rid, const uint32_t* __restrict__ run_start, uint32_t* __restrict__ lens)
-{
-    const int64_t r = int64_t(blockIdx.x) * BS_BLOCK + threadIdx.x;
-    if (r >= P) return;
-    lens[r] = r < int64_t(rid[P]) ? run_start[r + 1] - run_start[r] : 0u;
+    const uint32_t key = pk[i];
+    if (key >= sentinel) return;
+    const bool first = i == 0 || pk[i - 1] != key;
+    const uint32_t r = first ? rid[i] : rid[i] - 1u;
+    if (first) run_start[r] = uint32_t(i);
+    if (i + 1 == P || pk[i + 1] >= sentinel) {  // the last real pair
+        run_start[r + 1] = uint32_t(i + 1);
+        ctl[0] = uint32_t(i + 1);
+        ctl[1] = r + 1u;
+    }
 }
 
 // one thread per run: its key's slot (inserted here: distinct keys only) and the list's length.  The lists are laid out in SLOT
 // order afterwards (an exclusive scan of the padded counts over the slots, as the atomic build does): the scoring kernels cut
 // the table into 8 partitions by the top slot bits and want a partition's postings contiguous.
+template <typename PT>
 __global__ void __launch_bounds__(BS_BLOCK)
-k_bs_slots(uint32_t R, const uint32_t* __restrict__ pk, const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ lens,
+k_bs_slots(uint32_t R, const uint32_t* __restrict__ pk, const PT* __restrict__ pv, const uint32_t* __restrict__ run_start,
            uint32_t* __restrict__ run_slot, uint32_t* __restrict__ keys, uint32_t cap, uint32_t shift, uint32_t* __restrict__ cnt,
-           uint32_t* __restrict__ err)
+           uint2* __restrict__ qinfo, Epochs E, uint32_t* __restrict__ err)
 {
     const uint32_t r = blockIdx.x * BS_BLOCK + threadIdx.x;
     if (r >= R) return;
@@ -127,18 +132,38 @@ k_bs_slots(uint32_t R, const uint32_t* __restrict__ pk, const uint32_t* __restri
         atomicAdd(err, 1u);
         return;
     }
-    cnt[slot] = lens[r];
+    const uint32_t c = run_start[r + 1] - run_start[r];
+    cnt[slot] = c;
     run_slot[r] = slot;
+    // the row's epoch cuts (index_lookup): per boundary the number of entries below it, in units of 8 postings — the run is
+    // ascending, a binary search per boundary
+    uint2 info = make_uint2(c, 0x80000000u);
+    if (c < IOC_EPOCH_LONG) {
+        const PT* p = pv + run_start[r];
+        uint32_t b[IOC_EPOCHS];
+#pragma unroll
+        for (int i = 0; i < IOC_EPOCHS; ++i) {
+            uint32_t lo = 0, hi = c;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (uint32_t(p[mid]) < E.e[i]) lo = mid + 1; else hi = mid;
+            }
+            b[i] = (lo + 7u) >> 3;
+        }
+        info.x = c | (b[0] << 10) | (b[1] << 17) | (b[2] << 24);
+        info.y = b[3] | (b[4] << 7) | (b[5] << 14) | (b[6] << 21);
+    }
+    qinfo[slot] = info;
 }
 
 template <typename PT>
 __global__ void __launch_bounds__(BS_BLOCK)
-k_bs_place(uint32_t n_real, const PT* __restrict__ pv, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ rid,
+k_bs_place(uint32_t n_real, const uint32_t* __restrict__ pk, const PT* __restrict__ pv, const uint32_t* __restrict__ rid,
            const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ run_slot, const uint32_t* __restrict__ off, PT* __restrict__ post)
 {
     const uint32_t i = blockIdx.x * BS_BLOCK + threadIdx.x;
     if (i >= n_real) return;
-    const uint32_t r = flags[i] ? rid[i] : rid[i] - 1u;
+    const uint32_t r = (i == 0 || pk[i - 1] != pk[i]) ? rid[i] : rid[i] - 1u;
     post[off[run_slot[r]] + (i - run_start[r])] = pv[i];
 }
 
@@ -155,10 +180,15 @@ size_t iock_build_sort_temp_bytes(int64_t P, int post16, int value_bits)
         uint32_t* v = nullptr;
         (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, v, v, size_t(P), 0, unsigned(value_bits + 1));
     }
-    return tmp + 256;
+    size_t tmp2 = 0;
+    {
+        auto flag_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), BsFlag{k, 0u, size_t(P)});
+        (void)rocprim::exclusive_scan(nullptr, tmp2, flag_it, k, 0u, size_t(P), rocprim::plus<uint32_t>());
+    }
+    return (tmp > tmp2 ? tmp : tmp2) + 256;
 }
 
-// phase 1: pairs, sort, runs, padded offsets.  Afterwards ctl[0] = real pairs, rid[P] = runs, roff[P] = padded postings.
+// phase 1: pairs, sort, runs.  Afterwards ctl[0] = real pairs, ctl[1] = runs (= distinct keys).
 hipError_t iock_build_sort_phase1(hipStream_t st, const IocBuildSort* a)
 {
     const int64_t P = a->P;
@@ -195,34 +225,36 @@ hipError_t iock_build_sort_phase1(hipStream_t st, const IocBuildSort* a)
                                       unsigned(a->value_bits + 1), st);
     if (e != hipSuccess) return e;
     const dim3 gp(unsigned((P + BS_BLOCK - 1) / BS_BLOCK));
-    uint32_t* flags = a->pk_in;  // (free again)
-    hipLaunchKernelGGL(k_bs_flags, gp, dim3(BS_BLOCK), 0, st, P, a->pk_out, sentinel, flags, a->ctl);
-    e = iock_exclusive_scan(st, flags, P, a->rid, a->scan_scratch, 0u);
+    // run numbers: exclusive scan of the run-start flags
+    tmp = a->temp_bytes;
+    auto flag_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), BsFlag{a->pk_out, sentinel, size_t(P)});
+    e = rocprim::exclusive_scan(a->temp, tmp, flag_it, a->rid, 0u, size_t(P), rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bs_starts, gp, dim3(BS_BLOCK), 0, st, P, flags, a->rid, a->ctl, a->run_start);
-    hipLaunchKernelGGL(k_bs_lens, gp, dim3(BS_BLOCK), 0, st, P, a->rid, a->run_start, a->lens);
-    e = iock_exclusive_scan(st, a->lens, P, a->roff, a->scan_scratch, a->pad_mask);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bs_starts, gp, dim3(BS_BLOCK), 0, st, P, a->pk_out, sentinel, a->rid, a->ctl, a->run_start);
     return hipGetLastError();
 }
 
 // phase 2 (the host knows R, the real pairs and the table's capacity now): slots and postings
 hipError_t iock_build_sort_phase2(hipStream_t st, const IocBuildSort* a, uint32_t R, uint32_t n_real, uint32_t* keys, uint32_t cap, uint32_t shift,
-                                  uint32_t* cnt, uint32_t* off, void* post, uint32_t* err)
+                                  uint32_t* cnt, uint32_t* off, void* post, uint32_t* qinfo, uint32_t n_targets, uint32_t* err)
 {
     if (R == 0) return hipSuccess;
-    uint32_t* run_slot = a->roff;  // (the padded offsets in run order have told the host the total: the array is free)
-    hipLaunchKernelGGL(k_bs_slots, dim3((R + BS_BLOCK - 1) / BS_BLOCK), dim3(BS_BLOCK), 0, st, R, a->pk_out, a->run_start, a->lens, run_slot, keys, cap, shift, cnt,
-                       err);
+    const Epochs E = iock_epoch_bounds(a->L, n_targets);
+    const dim3 gr((R + BS_BLOCK - 1) / BS_BLOCK);
+    if (a->post16)
+        hipLaunchKernelGGL(k_bs_slots<uint16_t>, gr, dim3(BS_BLOCK), 0, st, R, a->pk_out, static_cast<const uint16_t*>(a->pv_out), a->run_start,
+                           a->run_slot, keys, cap, shift, cnt, reinterpret_cast<uint2*>(qinfo), E, err);
+    else
+        hipLaunchKernelGGL(k_bs_slots<uint32_t>, gr, dim3(BS_BLOCK), 0, st, R, a->pk_out, static_cast<const uint32_t*>(a->pv_out), a->run_start,
+                           a->run_slot, keys, cap, shift, cnt, reinterpret_cast<uint2*>(qinfo), E, err);
     hipError_t e = iock_exclusive_scan(st, cnt, int64_t(cap) + 1, off, a->scan_scratch, a->pad_mask);
     if (e != hipSuccess) return e;
-    const uint32_t* flags = a->pk_in;
     const dim3 g((n_real + BS_BLOCK - 1) / BS_BLOCK);
     if (a->post16)
-        hipLaunchKernelGGL(k_bs_place<uint16_t>, g, dim3(BS_BLOCK), 0, st, n_real, static_cast<const uint16_t*>(a->pv_out), flags, a->rid, a->run_start, run_slot,
+        hipLaunchKernelGGL(k_bs_place<uint16_t>, g, dim3(BS_BLOCK), 0, st, n_real, a->pk_out, static_cast<const uint16_t*>(a->pv_out), a->rid, a->run_start, a->run_slot,
                            off, static_cast<uint16_t*>(post));
     else
-        hipLaunchKernelGGL(k_bs_place<uint32_t>, g, dim3(BS_BLOCK), 0, st, n_real, static_cast<const uint32_t*>(a->pv_out), flags, a->rid, a->run_start, run_slot,
+        hipLaunchKernelGGL(k_bs_place<uint32_t>, g, dim3(BS_BLOCK), 0, st, n_real, a->pk_out, static_cast<const uint32_t*>(a->pv_out), a->rid, a->run_start, a->run_slot,
                            off, static_cast<uint32_t*>(post));
     return hipGetLastError();
 }

@@ -573,45 +573,61 @@ int ioc_index_build(ioc_ctx* c)
         a.pk_in = wp;
         a.pk_out = wp + w;
         a.rid = wp + 2 * w;
-        a.roff = wp + 3 * w;
+        a.run_slot = wp + 3 * w;
         a.run_start = wp + 4 * w;
-        a.lens = wp + 5 * w;
         a.scan_scratch = wp + 6 * w;
         a.ctl = a.scan_scratch + (size_t(NP) / 1024 + 8);
         uint8_t* bp = reinterpret_cast<uint8_t*>(wp) + ((words * 4 + 255) & ~size_t(255));
         a.pv_in = bp;
         a.pv_out = bp + pvb;
         a.temp = bp + 2 * pvb;
+        // Everything whose size does not hang on the sort's outcome is queued BEFORE the one read-back: the table at the capacity
+        // the k-mer space suggests (twice the distinct keys that can occur), the postings at their upper bound (every pair a list of
+        // its own, padded).  The host only has to queue the two kernels of phase 2 afterwards.
+        uint32_t nslots = cap + 1;
+        // (every pair + the padding of as many lists as the table is sized for; more lists than that: the slow way round below)
+        const size_t post_ub = size_t(NP) + size_t(pmask) * std::min<size_t>(size_t(NP), size_t(cap) / 2 + 1) + 64;
+        auto table = [&](uint32_t slots) -> int {
+            RESERVE(c, c->b_keys, size_t(slots) * 4);
+            RESERVE(c, c->b_cnt, size_t(slots + 1) * 4);
+            RESERVE(c, c->b_off, size_t(slots + 1) * 4);
+            RESERVE(c, c->b_rows, size_t(slots) * 16);
+            RESERVE(c, c->b_qinfo, size_t(slots) * 8);
+            HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(slots) * 4, s));
+            HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(slots + 1) * 4, s));
+            HIPCHK(c, hipMemsetAsync(c->b_qinfo.p, 0, size_t(slots) * 8, s));
+            HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
+            return IOC_OK;
+        };
+        {
+            const int rt = table(nslots);
+            if (rt != IOC_OK) return rt;
+        }
+        RESERVE(c, c->b_post, post_ub * psize + 256);
+        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, post_ub * psize + 256, s));
         HIPCHK(c, iock_build_sort_phase1(s, &a));
-        HIPCHK(c, hipMemcpyAsync(c->h_pin + 8, a.ctl, 4, hipMemcpyDeviceToHost, s));        // real pairs
-        HIPCHK(c, hipMemcpyAsync(c->h_pin + 9, a.rid + NP, 4, hipMemcpyDeviceToHost, s));    // runs = distinct keys
-        HIPCHK(c, hipMemcpyAsync(c->h_pin + 10, a.roff + NP, 4, hipMemcpyDeviceToHost, s));  // padded postings
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 8, a.ctl, 8, hipMemcpyDeviceToHost, s));  // real pairs, runs = distinct keys
         HIPCHK(c, hipStreamSynchronize(s));
-        const uint32_t n_real = static_cast<volatile uint32_t*>(c->h_pin)[8], R = static_cast<volatile uint32_t*>(c->h_pin)[9],
-                       h_total = static_cast<volatile uint32_t*>(c->h_pin)[10];
-        cap = pow2_at_least(2.0 * double(R ? R : 1));  // (the number of keys is known: no retry)
-        const uint32_t nslots = cap + 1;
+        const uint32_t n_real = static_cast<volatile uint32_t*>(c->h_pin)[8], R = static_cast<volatile uint32_t*>(c->h_pin)[9];
+        const uint64_t h_total = uint64_t(n_real) + uint64_t(pmask) * R;  // (an upper bound of the padded postings; the exact figure: ioc_get_timings)
+        if (h_total >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 padded index postings");
+        if (size_t(h_total) > post_ub) {  // (more lists than the k-mer space suggested)
+            RESERVE(c, c->b_post, size_t(h_total) * psize + 256);
+            HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, size_t(h_total) * psize + 256, s));
+        }
+        if (2.0 * double(R) > double(cap)) {  // (more distinct keys than the k-mer space suggested: a larger table)
+            cap = pow2_at_least(2.0 * double(R));
+            nslots = cap + 1;
+            const int rt = table(nslots);
+            if (rt != IOC_OK) return rt;
+        }
         uint32_t bits = 0;
         while ((1u << bits) < cap) bits++;
         const uint32_t shift = 32 - bits;
-        RESERVE(c, c->b_keys, size_t(nslots) * 4);
-        RESERVE(c, c->b_cnt, size_t(nslots + 1) * 4);
-        RESERVE(c, c->b_off, size_t(nslots + 1) * 4);
-        RESERVE(c, c->b_rows, size_t(nslots) * 16);
-        RESERVE(c, c->b_qinfo, size_t(nslots) * 8);
-        HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(nslots) * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(nslots + 1) * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->b_off.p, 0, size_t(nslots + 1) * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
-        if (uint64_t(h_total) >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 padded index postings");
         c->cap = cap;
-        c->n_post = h_total;
-        RESERVE(c, c->b_post, size_t(h_total) * psize + 256);
-        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, size_t(h_total) * psize + 256, s));
+        c->n_post = -1;  // (b_off[nslots], fetched when the timings are asked for)
         HIPCHK(c, iock_build_sort_phase2(s, &a, R, n_real, P<uint32_t>(c->b_keys), cap, shift, P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_off), c->b_post.p,
-                                         P<uint32_t>(c->b_misc)));
-        HIPCHK(c, iock_sort_lists(s, nslots, P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), c->b_post.p, uint32_t(c->L), uint32_t(n > 0 ? n : 1), 2048,
-                                  P<uint32_t>(c->b_qinfo), c->post16, /*sorted=*/1));
+                                         P<uint32_t>(c->b_qinfo), uint32_t(n > 0 ? n : 1), P<uint32_t>(c->b_misc)));
         HIPCHK(c, iock_pack_rows(s, nslots, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_qinfo), c->b_rows.p));
     }
     for (; !sorted_build;) {
@@ -1612,6 +1628,12 @@ int ioc_get_timings(ioc_ctx* c, ioc_timings* out)
     float ms = 0;
     c->tm.score_oob = c->score_oob;
     c->tm.score_oob_probe = c->score_oob_probe;
+    if (c->built && c->n_post < 0 && c->b_off.p) {  // (the sorted build does not read its postings count back)
+        uint32_t t = 0;
+        HIPCHK(c, hipMemcpy(&t, P<uint32_t>(c->b_off) + size_t(c->cap) + 1, 4, hipMemcpyDeviceToHost));
+        c->n_post = t;
+        c->tm.n_index_postings = t;
+    }
     if (c->built && hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_build = ms;
     if (c->scored && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->tm.ms_score = ms;
     if (c->resolved && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->tm.ms_resolve = ms;

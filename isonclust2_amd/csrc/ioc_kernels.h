@@ -142,6 +142,14 @@ hipError_t iock_minimizers(hipStream_t st, int n, const int64_t* offs, const uin
                            uint32_t* opos, uint32_t max_hlen);
 }
 
+// epoch cuts of the index rows (ioc_kernels.hip, index_lookup): 7 boundaries that cut the target ids into 8 equal ranges
+#define IOC_EPOCHS 7
+#define IOC_EPOCH_LONG 1016u
+struct Epochs {
+    uint32_t e[IOC_EPOCHS];
+};
+extern "C" Epochs iock_epoch_bounds(uint32_t L, uint32_t n);
+
 // ---- index build without global atomics (ioc_build_sort.hip) ----
 struct IocBuildSort {
     int n;                        // queries
@@ -156,11 +164,10 @@ struct IocBuildSort {
     int64_t P;                    // pairs incl. the unused tails of the queries' lists: n_left_post + doff[n]
     int post16, value_bits;
     uint32_t pad_mask;            // lists are padded to whole 16-byte units
-    uint32_t *pk_in, *pk_out;     // [P]   (pk_in holds the run flags after the sort)
+    uint32_t *pk_in, *pk_out;     // [P]
     void *pv_in, *pv_out;         // [P] postings (u16 / u32)
-    uint32_t *rid, *roff;         // [P + 1]
+    uint32_t *rid, *run_slot;     // [P + 1]: run number of every pair (exclusive scan of the flags); hash slot of every run
     uint32_t *run_start;          // [P + 1]
-    uint32_t *lens;               // [P]
     uint32_t *scan_scratch;       // [P / 1024 + 4]
     uint32_t* ctl;                // 4 words
     void* temp;
@@ -169,6 +176,6 @@ struct IocBuildSort {
 size_t iock_build_sort_temp_bytes(int64_t P, int post16, int value_bits);
 hipError_t iock_build_sort_phase1(hipStream_t st, const IocBuildSort* a);
 hipError_t iock_build_sort_phase2(hipStream_t st, const IocBuildSort* a, uint32_t R, uint32_t n_real, uint32_t* keys, uint32_t cap, uint32_t shift,
-                                  uint32_t* cnt, uint32_t* off, void* post, uint32_t* err);
+                                  uint32_t* cnt, uint32_t* off, void* post, uint32_t* qinfo, uint32_t n_targets, uint32_t* err);
 
 #endif

@@ -58,11 +58,7 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t v, uint32_t shift)
 // below T: f_i = ceil(#entries below the epoch boundary e_i / 8), 7 bits each, for the 7 boundaries e_1 < ... < e_7 that cut
 // the target ids into 8 equal ranges — w2 = len | f1 << 10 | f2 << 17 | f3 << 24, w3 = f4 | f5 << 7 | f6 << 14 | f7 << 21.
 // (Round 1 had 3 boundaries: a query then walked, on average, an eighth of every list beyond its window; now a sixteenth.)
-#define IOC_EPOCHS 7
-#define IOC_EPOCH_LONG 1016u
-struct Epochs {
-    uint32_t e[IOC_EPOCHS];
-};
+// (IOC_EPOCHS, IOC_EPOCH_LONG, struct Epochs: ioc_kernels.h — the sorted index build fills the same fields)
 // which field holds the cut of a query with window T: (word 0 = w2 / 1 = w3, shift); word 2 = no cut (T beyond e_7)
 __device__ __forceinline__ void epoch_field(const Epochs& E, uint32_t T, uint32_t& word, uint32_t& shift)
 {
@@ -2465,7 +2461,9 @@ hipError_t iock_fill_queries(hipStream_t st, int n, uint32_t L, const int64_t* d
     return hipGetLastError();
 }
 
-static Epochs epoch_bounds(uint32_t L, uint32_t n)
+Epochs iock_epoch_bounds(uint32_t L, uint32_t n);
+static Epochs epoch_bounds(uint32_t L, uint32_t n) { return iock_epoch_bounds(L, n); }
+Epochs iock_epoch_bounds(uint32_t L, uint32_t n)
 {
     Epochs E;
     for (int i = 0; i < IOC_EPOCHS; ++i) E.e[i] = L + uint32_t((uint64_t(n) * uint64_t(i + 1) + IOC_EPOCHS) / (IOC_EPOCHS + 1));
