@@ -193,7 +193,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     const int k = p->k, w = p->w;
     int pos = 0;
     // phase clock for IOC_TRACE: [0] left view, [1] device pass, [2] graph hooks, [3] new representative
-    double ph[4] = {0, 0, 0, 0};
+    double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ([4] flush, [5] collect, [6] verification + UpdateMinDB, [7] rollback / commit)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // A pass decides a WINDOW of entries, not all that remain: a decision depends on earlier entries only, so a
     // prefix of the batch gives the same decisions, and everything behind the next consensus event would be thrown
@@ -540,6 +540,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 double t1 = now();
                 n_spec_flushes++;
                 if (spec->flush(ops->user, evs[0].i) < 0) return hook_fail(c, "flush");
+                ph[4] += now() - t1;
                 const size_t ne = evs.size();
                 std::vector<std::string> cons(ne);
                 std::vector<char> buf(size_t(1) << 22);
@@ -551,6 +552,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                         return ioc_fail(c, IOC_ERR_INPUT, "consensus shorter than 2k and w (the reference re-minimizes an empty sequence here)");
                 }
                 ph[2] += now() - t1;
+                ph[5] += now() - t1;
                 t1 = now();
                 // the new representatives: fixed quality character, HPC, minimizers — ONE extractor call for all of them
                 std::vector<int64_t> xoff(ne + 1, 0);
@@ -660,6 +662,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                         continue;
                     }
                 }
+                ph[6] += now() - t1;
+                const double t2 = now();
                 if (violation >= 0) {
                     // ---- undo what the walk did for the entries [violation, stop_x), newest first ----
                     n_spec_rollbacks++;
@@ -694,6 +698,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     if (spec->commit(ops->user) < 0) return hook_fail(c, "commit");
                 }
                 ph[3] += now() - t1;
+                ph[7] += now() - t2;
             } else if (spec->commit(ops->user) < 0) {
                 return hook_fail(c, "commit");
             }
@@ -720,8 +725,9 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         fprintf(stderr, "[ioc] deferred consensus: %lld events in %lld flushes, %lld rollbacks\n", (long long)n_spec_events, (long long)n_spec_flushes,
                 (long long)n_spec_rollbacks);
     if (getenv("IOC_TRACE"))
-        fprintf(stderr, "[ioc] consensus phases: left view %.1f ms, device passes %.1f ms, graph hooks %.1f ms, new representatives %.1f ms\n",
-                ph[0], ph[1], ph[2], ph[3]);
+        fprintf(stderr, "[ioc] consensus phases: left view %.1f ms, device passes %.1f ms, graph hooks %.1f ms (flush %.1f, flush + collect %.1f), new representatives %.1f ms "
+                        "(verification + UpdateMinDB %.1f, rollback / commit %.1f)\n",
+                ph[0], ph[1], ph[2], ph[4], ph[5], ph[3], ph[6], ph[7]);
     // the final MinDB is what ioc_index_export returns
     c->exp_keys.clear();
     c->exp_offs.clear();

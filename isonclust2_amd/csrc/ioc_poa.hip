@@ -547,18 +547,17 @@ __global__ void __launch_bounds__(64) k_poa_trace(const PoaJob* __restrict__ job
 }
 
 // ---- host side: the graph ----------------------------------------------------------------------------------
-struct PNode {
-    char base = 0;
-    std::vector<int> in, out;      // edge ids
-    std::vector<int> aligned;      // nodes at the same position with another letter
-};
-struct PEdge {
-    int from = 0, to = 0;
-    int64_t w = 0;
-};
+// Flat: every member is one array over the nodes, the edges or a pool, so that a copy of a graph (the snapshot a deferred
+// consensus pass takes of every graph it is about to touch, and its release) is a dozen memcpys instead of three heap
+// vectors per node — 3.4 s of a 31 250-read leaf's 16.9 s went into those copies.  Edge lists and aligned-node lists are
+// singly linked in INSERTION order (the DP's and the consensus' tie-breaks follow that order).
 struct PGraph {
-    std::vector<PNode> nodes;
-    std::vector<PEdge> edges;
+    std::vector<char> base;
+    std::vector<int> in_head, in_tail, out_head, out_tail, in_deg;  // per node: edge ids (-1: none), number of in-edges
+    std::vector<int> al_head, al_tail;                              // per node: its aligned nodes (same position, another letter), pool entries
+    std::vector<int> al_val, al_next;                               // the pool
+    std::vector<int> e_from, e_to, e_in_next, e_out_next;           // per edge
+    std::vector<int64_t> e_w;
     std::vector<int> rank;  // topological order: rank[i] = node id
     int nseq = 0;
     // a graph seeded with one sequence is a chain: it is built when somebody first looks at it (most clusters of a
@@ -566,6 +565,8 @@ struct PGraph {
     std::string seed;
     int64_t seed_w = 0;
     bool seeded = false;
+    size_t n_nodes() const { return base.size(); }
+    size_t n_edges() const { return e_from.size(); }
     void seed_with(const char* s, int len, int64_t w)
     {
         if (len <= 0) return;
@@ -585,28 +586,63 @@ struct PGraph {
 
     int add_node(char b)
     {
-        nodes.emplace_back();
-        nodes.back().base = b;
-        return int(nodes.size()) - 1;
+        base.push_back(b);
+        in_head.push_back(-1);
+        in_tail.push_back(-1);
+        out_head.push_back(-1);
+        out_tail.push_back(-1);
+        in_deg.push_back(0);
+        al_head.push_back(-1);
+        al_tail.push_back(-1);
+        return int(base.size()) - 1;
+    }
+    void al_push(int v, int x)  // x joins the aligned list of v
+    {
+        const int q = int(al_val.size());
+        al_val.push_back(x);
+        al_next.push_back(-1);
+        if (al_tail[size_t(v)] >= 0)
+            al_next[size_t(al_tail[size_t(v)])] = q;
+        else
+            al_head[size_t(v)] = q;
+        al_tail[size_t(v)] = q;
+    }
+    void link_edge(int u, int v, int64_t w)  // a new edge at the end of u's out-list and v's in-list
+    {
+        const int e = int(e_from.size());
+        e_from.push_back(u);
+        e_to.push_back(v);
+        e_w.push_back(w);
+        e_in_next.push_back(-1);
+        e_out_next.push_back(-1);
+        if (out_tail[size_t(u)] >= 0)
+            e_out_next[size_t(out_tail[size_t(u)])] = e;
+        else
+            out_head[size_t(u)] = e;
+        out_tail[size_t(u)] = e;
+        if (in_tail[size_t(v)] >= 0)
+            e_in_next[size_t(in_tail[size_t(v)])] = e;
+        else
+            in_head[size_t(v)] = e;
+        in_tail[size_t(v)] = e;
+        in_deg[size_t(v)]++;
     }
     void add_edge(int u, int v, int64_t w)
     {
-        for (int e : nodes[size_t(u)].out)
-            if (edges[size_t(e)].to == v) {
-                edges[size_t(e)].w += w;
+        for (int e = out_head[size_t(u)]; e >= 0; e = e_out_next[size_t(e)])
+            if (e_to[size_t(e)] == v) {
+                e_w[size_t(e)] += w;
                 return;
             }
-        edges.push_back(PEdge{u, v, w});
-        nodes[size_t(u)].out.push_back(int(edges.size()) - 1);
-        nodes[size_t(v)].in.push_back(int(edges.size()) - 1);
+        link_edge(u, v, w);
     }
-    int add_chain(const char* s, int a, int b, int64_t w)  // nodes for s[a..b), returns the first; last in *tail
+    int add_chain(const char* s, int a, int b, int64_t w)  // nodes for s[a..b), returns the first
     {
         int first = -1, prev = -1;
         for (int i = a; i < b; ++i) {
             const int v = add_node(s[i]);
             if (first < 0) first = v;
-            if (prev >= 0) add_edge(prev, v, w);
+            if (prev >= 0) link_edge(prev, v, w);  // (both nodes are new: no such edge yet)
             prev = v;
         }
         return first;
@@ -614,9 +650,8 @@ struct PGraph {
     void toposort()
     {
         // Kahn, smallest node id first: deterministic, independent of edge insertion order
-        const size_t n = nodes.size();
-        std::vector<int> indeg(n);
-        for (size_t i = 0; i < n; ++i) indeg[i] = int(nodes[i].in.size());
+        const size_t n = n_nodes();
+        std::vector<int> indeg(in_deg);
         std::vector<int> heap;
         auto cmp = [](int a, int b) { return a > b; };
         for (size_t i = 0; i < n; ++i)
@@ -629,8 +664,8 @@ struct PGraph {
             const int u = heap.back();
             heap.pop_back();
             rank.push_back(u);
-            for (int e : nodes[size_t(u)].out) {
-                const int v = edges[size_t(e)].to;
+            for (int e = out_head[size_t(u)]; e >= 0; e = e_out_next[size_t(e)]) {
+                const int v = e_to[size_t(e)];
                 if (--indeg[size_t(v)] == 0) {
                     heap.push_back(v);
                     std::push_heap(heap.begin(), heap.end(), cmp);
@@ -643,43 +678,47 @@ struct PGraph {
     {
         if (len <= 0) return;
         planned = false;
-        std::vector<int> pos_of;
+        int first_pos = -1, last_pos = -1;
         for (auto& a : aln)
-            if (a.second >= 0) pos_of.push_back(a.second);
-        if (pos_of.empty()) {
+            if (a.second >= 0) {
+                if (first_pos < 0) first_pos = a.second;
+                last_pos = a.second;
+            }
+        if (first_pos < 0) {
             add_chain(s, 0, len, w);
             ++nseq;
             toposort();
             return;
         }
-        const int first_pos = pos_of.front(), last_pos = pos_of.back();
         int head = -1;
         if (first_pos > 0) {
             add_chain(s, 0, first_pos, w);
-            head = int(nodes.size()) - 1;
+            head = int(n_nodes()) - 1;
         }
+        std::vector<int> grp;
         for (auto& a : aln) {
             if (a.second < 0) continue;
             const char letter = s[a.second];
             int cur;
             if (a.first < 0) {
                 cur = add_node(letter);
-            } else if (nodes[size_t(a.first)].base == letter) {
+            } else if (base[size_t(a.first)] == letter) {
                 cur = a.first;
             } else {
                 cur = -1;
-                for (int x : nodes[size_t(a.first)].aligned)
-                    if (nodes[size_t(x)].base == letter) {
-                        cur = x;
+                for (int q = al_head[size_t(a.first)]; q >= 0; q = al_next[size_t(q)])
+                    if (base[size_t(al_val[size_t(q)])] == letter) {
+                        cur = al_val[size_t(q)];
                         break;
                     }
                 if (cur < 0) {
                     cur = add_node(letter);
-                    std::vector<int> grp = nodes[size_t(a.first)].aligned;
+                    grp.clear();
+                    for (int q = al_head[size_t(a.first)]; q >= 0; q = al_next[size_t(q)]) grp.push_back(al_val[size_t(q)]);
                     grp.push_back(a.first);
                     for (int x : grp) {
-                        nodes[size_t(x)].aligned.push_back(cur);
-                        nodes[size_t(cur)].aligned.push_back(x);
+                        al_push(x, cur);
+                        al_push(cur, x);
                     }
                 }
             }
@@ -693,30 +732,35 @@ struct PGraph {
         ++nseq;
         toposort();
     }
-    // heaviest bundle: per node the heaviest in-edge (ties: the predecessor with the higher score), the best
-    // end node, then forward along the heaviest out-edges to a sink
     // rows = nodes in topological order (+1: row 0 is the virtual source); predecessor rows; which rows keep their
     // H / F1 / F2 in memory: those a later row cannot find in its tile's LDS ring (it sits in a lower tile or more
-    // than POA_RING rows on).  On a chain that is one row in 64.
-    std::vector<int32_t> p_poff, p_pred, p_slot;
-    int32_t p_nkeep = 1;
+    // than POA_RING rows on).  On a chain that is one row in 64.  p_base / p_pslot: what the kernels read per row /
+    // per predecessor entry besides (bases in row order, the plane row of each predecessor) — the batch layout copies
+    // the five arrays as they are.
+    std::vector<int32_t> p_poff, p_pred, p_slot, p_pslot;
+    std::vector<uint8_t> p_base;
+    int32_t p_nkeep = 1, p_max_preds = 0;
     bool planned = false;
     void plan()
     {
-        const int R = int(nodes.size());
+        const int R = int(n_nodes());
         std::vector<int> row_of(static_cast<size_t>(R), 0);
         for (int i = 0; i < R; ++i) row_of[size_t(rank[size_t(i)])] = i + 1;
         p_poff.assign(size_t(R) + 2, 0);
         p_pred.clear();
+        p_base.assign(size_t(R) + 1, 0);
+        p_max_preds = 0;
         std::vector<uint8_t> keep(size_t(R) + 1, 0);
         keep[0] = 1;
         for (int i = 0; i < R; ++i) {
-            const PNode& nd = nodes[size_t(rank[size_t(i)])];
+            const int u = rank[size_t(i)];
             const int q = i + 1;
+            p_base[size_t(q)] = uint8_t(base[size_t(u)]);
+            p_max_preds = std::max(p_max_preds, in_deg[size_t(u)]);
             p_poff[size_t(q)] = int32_t(p_pred.size());
-            if (nd.in.empty()) p_pred.push_back(0);
-            for (int e : nd.in) {
-                const int pr = row_of[size_t(edges[size_t(e)].from)];
+            if (in_head[size_t(u)] < 0) p_pred.push_back(0);
+            for (int e = in_head[size_t(u)]; e >= 0; e = e_in_next[size_t(e)]) {
+                const int pr = row_of[size_t(e_from[size_t(e)])];
                 p_pred.push_back(pr);
                 if ((pr - 1) / POA_RB != (q - 1) / POA_RB || q - pr > POA_RING) keep[size_t(pr)] = 1;
             }
@@ -726,22 +770,27 @@ struct PGraph {
         p_nkeep = 0;
         for (int r = 0; r <= R; ++r)
             if (keep[size_t(r)]) p_slot[size_t(r)] = p_nkeep++;
+        p_pslot.resize(p_pred.size());
+        for (size_t y = 0; y < p_pred.size(); ++y) p_pslot[y] = p_slot[size_t(p_pred[y])];
         planned = true;
     }
+    // heaviest bundle: per node the heaviest in-edge (ties: the predecessor with the higher score), the best
+    // end node, then forward along the heaviest out-edges to a sink
     std::string consensus() const
     {
-        const size_t n = nodes.size();
+        const size_t n = n_nodes();
         if (n == 0) return std::string();
         std::vector<int64_t> score(n, 0);
         std::vector<int> from(n, -1);
         int best = rank.empty() ? 0 : rank[0];
         for (int u : rank) {
             int64_t bw = -1;
-            for (int e : nodes[size_t(u)].in) {
-                const PEdge& ed = edges[size_t(e)];
-                if (from[size_t(u)] < 0 || ed.w > bw || (ed.w == bw && score[size_t(ed.from)] > score[size_t(from[size_t(u)])])) {
-                    bw = ed.w;
-                    from[size_t(u)] = ed.from;
+            for (int e = in_head[size_t(u)]; e >= 0; e = e_in_next[size_t(e)]) {
+                const int f = e_from[size_t(e)];
+                const int64_t w = e_w[size_t(e)];
+                if (from[size_t(u)] < 0 || w > bw || (w == bw && score[size_t(f)] > score[size_t(from[size_t(u)])])) {
+                    bw = w;
+                    from[size_t(u)] = f;
                 }
             }
             if (from[size_t(u)] >= 0) score[size_t(u)] = bw + score[size_t(from[size_t(u)])];
@@ -750,16 +799,16 @@ struct PGraph {
         std::vector<int> path;
         for (int u = best; u >= 0; u = from[size_t(u)]) path.push_back(u);
         std::reverse(path.begin(), path.end());
-        for (int u = best; !nodes[size_t(u)].out.empty();) {
-            int be = nodes[size_t(u)].out[0];
-            for (int e : nodes[size_t(u)].out)
-                if (edges[size_t(e)].w > edges[size_t(be)].w) be = e;
-            u = edges[size_t(be)].to;
+        for (int u = best; out_head[size_t(u)] >= 0;) {
+            int be = out_head[size_t(u)];
+            for (int e = be; e >= 0; e = e_out_next[size_t(e)])
+                if (e_w[size_t(e)] > e_w[size_t(be)]) be = e;
+            u = e_to[size_t(be)];
             path.push_back(u);
         }
         std::string s;
         s.reserve(path.size());
-        for (int u : path) s.push_back(nodes[size_t(u)].base);
+        for (int u : path) s.push_back(base[size_t(u)]);
         return s;
     }
 };
@@ -802,6 +851,9 @@ struct ioc_poa {
     int32_t last_score = 0;
     int64_t n_batches = 0, n_aligned = 0;
     double ms_layout = 0, ms_alloc = 0, ms_gpu = 0, ms_graph = 0;  // IOC_TRACE: host layout of the batches, launches + copies, AddAlignment
+    double ms_snap = 0, ms_mark = 0, ms_plan = 0, ms_post = 0;     // snapshots, consensus at markers, row plans, alignments back into node ids
+    double ms_dev[3] = {0, 0, 0};                                  // (events) uploads, kernels, downloads
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
     size_t reserve_hint = 0;  // the memory budget of a batch (poa_flush): what a large buffer is sized for at once
 };
@@ -849,9 +901,11 @@ struct HostJob {
     const PoaPending* item = nullptr;
     std::vector<std::pair<int, int>> aln;  // out: forward order, NODE IDS
     int32_t score = 0;
+    std::string cons;  // the consensus right after this addition, when the queue asks for it next (computed with the graph update, in parallel)
+    bool have_cons = false;
     size_t bytes() const  // device memory of the alignment: direction word + E byte per cell, 3 planes of kept rows
     {
-        const size_t W = item->seq.size() + 1, R1 = G->nodes.size() + 1;
+        const size_t W = item->seq.size() + 1, R1 = G->n_nodes() + 1;
         return R1 * W * 5 + size_t(G->p_nkeep) * W * 12 + (W / POA_CB + 1) * R1 * sizeof(int4) + (size_t(1) << 20);
     }
 };
@@ -879,7 +933,7 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         const PGraph& G = *jobs[x].G;
         const std::string& seq = jobs[x].item->seq;
         Lay& l = lay[x];
-        l.R = int(G.nodes.size());
+        l.R = int(G.n_nodes());
         l.L = int(seq.size());
         if (l.L + 1 > POA_MAX_COLS) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: sequences above 2^20 bases are not supported");
         l.ncb = (l.L + 1 + POA_CB - 1) / POA_CB;
@@ -907,22 +961,18 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
             small.insert(small.end(), reinterpret_cast<const uint8_t*>(v.data()), reinterpret_cast<const uint8_t*>(v.data() + v.size()));
             return o;
         };
-        align16();
-        l.o_base = small.size();
-        small.resize(small.size() + size_t(l.R) + 1, 0);
-        for (int i = 0; i < l.R; ++i) {
-            const PNode& nd = G.nodes[size_t(G.rank[size_t(i)])];
-            small[l.o_base + size_t(i) + 1] = uint8_t(nd.base);
-            if (nd.in.size() > size_t(POA_MAX_PREDS)) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
-        }
-        const HostJob& hj = jobs[x];
-        const PGraph& hg = *hj.G;
-        std::vector<int32_t> pslot(hg.p_pred.size());
-        for (size_t y = 0; y < hg.p_pred.size(); ++y) pslot[y] = hg.p_slot[size_t(hg.p_pred[y])];
-        l.o_poff = put32(hg.p_poff);
-        l.o_pred = put32(hg.p_pred);
-        l.o_pslot = put32(pslot);
-        l.o_slot = put32(hg.p_slot);
+        if (G.p_max_preds > POA_MAX_PREDS) return ioc_fail(c, IOC_ERR_CAPACITY, "POA: a node with more than 127 predecessors");
+        auto put8 = [&](const std::vector<uint8_t>& v) {
+            align16();
+            const size_t o = small.size();
+            small.insert(small.end(), v.begin(), v.end());
+            return o;
+        };
+        l.o_base = put8(G.p_base);
+        l.o_poff = put32(G.p_poff);
+        l.o_pred = put32(G.p_pred);
+        l.o_pslot = put32(G.p_pslot);
+        l.o_slot = put32(G.p_slot);
         l.o_seq = small.size();
         small.insert(small.end(), seq.begin(), seq.end());
         align16();
@@ -973,8 +1023,13 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     }
     const double t_gpu = now();
     p->ms_layout += t_gpu - t_in;
+    const bool trace = getenv("IOC_TRACE") != nullptr;
+    if (trace && !p->ev[0])
+        for (auto& e : p->ev) PCHK(p, hipEventCreate(&e));
+    if (trace) PCHK(p, hipEventRecord(p->ev[0], s));
     PCHK(p, hipMemcpyAsync(sm, small.data(), small.size(), hipMemcpyHostToDevice, s));
     PCHK(p, hipMemcpyAsync(p->d_jobs.p, dj.data(), K * sizeof(PoaJob), hipMemcpyHostToDevice, s));
+    if (trace) PCHK(p, hipEventRecord(p->ev[1], s));
     const PoaJob* djobs = static_cast<const PoaJob*>(p->d_jobs.p);
     hipLaunchKernelGGL(k_poa_init, dim3(unsigned((max_w + 255) / 256), unsigned(K)), dim3(256), 0, s, djobs);
     PCHK(p, hipGetLastError());
@@ -986,13 +1041,21 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
     PCHK(p, hipGetLastError());
     hipLaunchKernelGGL(k_poa_trace, dim3(unsigned(K)), dim3(64), 0, s, djobs);
     PCHK(p, hipGetLastError());
+    if (trace) PCHK(p, hipEventRecord(p->ev[2], s));
     std::vector<uint8_t> back(small.size());
     std::vector<int32_t> haln(tot_aln);
     PCHK(p, hipMemcpyAsync(back.data(), sm, small.size(), hipMemcpyDeviceToHost, s));
     PCHK(p, hipMemcpyAsync(haln.data(), p->d_aln.p, tot_aln * 4, hipMemcpyDeviceToHost, s));
+    if (trace) PCHK(p, hipEventRecord(p->ev[3], s));
     PCHK(p, hipStreamSynchronize(s));
     p->ms_gpu += now() - t_gpu;
-    for (size_t x = 0; x < K; ++x) {
+    if (trace)
+        for (int x = 0; x < 3; ++x) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p->ev[x], p->ev[x + 1]) == hipSuccess) p->ms_dev[x] += double(ms);
+        }
+    const double t_post = now();
+    ioc_parallel_for(K, [&](size_t x) {
         const Lay& l = lay[x];
         const PGraph& G = *jobs[x].G;
         int32_t hb[3], hn;
@@ -1004,7 +1067,8 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
         const int32_t* nd = haln.data() + l.o_aln;
         const int32_t* ps = nd + l.cap;
         for (int i = hn - 1; i >= 0; --i) jobs[x].aln.emplace_back(nd[i] > 0 ? G.rank[size_t(nd[i]) - 1] : -1, ps[i]);
-    }
+    }, 16);
+    p->ms_post += now() - t_post;
     p->n_batches++;
     p->n_aligned += int64_t(K);
     return IOC_OK;
@@ -1012,22 +1076,26 @@ int poa_align_batch(ioc_poa* p, std::vector<HostJob>& jobs)
 
 // work off every queue: one addition per graph and round, as many graphs per batch as the memory budget allows
 // a consensus marker at the head of a queue: the consensus of the graph as it is now
-void poa_take_markers(ioc_poa* p, int side, int idx, std::vector<PoaPending>& q)
+void poa_take_markers(ioc_poa* p, int side, int idx, std::vector<PoaPending>& q, const std::string* ready = nullptr)
 {
+    const auto tm0 = std::chrono::steady_clock::now();
+    const bool timed = !q.empty() && q.front().marker;
     while (!q.empty() && q.front().marker) {
         auto sn = p->snap[side].find(idx);
         if (sn != p->snap[side].end()) sn->second.max_tag = std::max(sn->second.max_tag, q.front().tag);
         auto it = p->g[side].find(idx);
         if (it != p->g[side].end()) {
             it->second.ensure();
-            p->deferred[std::make_tuple(side, idx, q.front().tag)] = it->second.consensus();
+            p->deferred[std::make_tuple(side, idx, q.front().tag)] = ready ? *ready : it->second.consensus();
         }
         q.erase(q.begin());
     }
+    if (timed) p->ms_mark += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count();
 }
 void poa_snapshot(ioc_poa* p, int side, int idx)
 {
     if (p->snap[side].count(idx)) return;
+    const auto ts0 = std::chrono::steady_clock::now();
     ioc_poa::Snap s;
     auto it = p->g[side].find(idx);
     s.existed = it != p->g[side].end();
@@ -1035,6 +1103,7 @@ void poa_snapshot(ioc_poa* p, int side, int idx)
     auto pq = p->pending[side].find(idx);
     if (pq != p->pending[side].end()) s.q = pq->second;
     p->snap[side][idx] = std::move(s);
+    p->ms_snap += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count();
 }
 
 // only_marked: work off the queues of the graphs that hold a consensus marker (those graphs are snapshotted first) — as many
@@ -1092,24 +1161,26 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
                 who_c.emplace_back(side, kv.first);
             }
         // seeded graphs are built, and the row plans of graphs that changed are renewed, on the host's cores
+        const auto tp0 = std::chrono::steady_clock::now();
         ioc_parallel_for(cand.size(), [&](size_t x) {
             PGraph& G = *cand[x].G;
             G.ensure();
-            if (!G.planned && !G.nodes.empty()) G.plan();
+            if (!G.planned && G.n_nodes()) G.plan();
         }, 48);
+        p->ms_plan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
         // The memory budget of a batch: 10 GB (≈ 400 additions of a 2 kb read to a 2.5 k-node graph, more than the chip runs
         // at a time; freeing and re-allocating tens of GB costs seconds and serialises concurrent processes in the driver),
         // or what 32 alignments of the round's largest take (a 16.7 kb read against its graph: 1.5 GB — with 10 GB, six to
         // a batch, such a batch took twice as long), within half of the free memory and 48 GB.
         size_t largest = 0;
         for (const HostJob& j : cand)
-            if (!j.G->nodes.empty() && !j.item->seq.empty()) largest = std::max(largest, j.bytes());
+            if (j.G->n_nodes() && !j.item->seq.empty()) largest = std::max(largest, j.bytes());
         size_t budget = std::min(std::min((free_b + have) / 2, size_t(48) << 30), std::max(size_t(10) << 30, 32 * largest));
         if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
         p->reserve_hint = budget + budget / 16;  // (the cells' direction words are 4/5 of it, their E bytes 1/5)
         for (size_t x = 0; x < cand.size(); ++x) {
             HostJob& j = cand[x];
-            if (j.G->nodes.empty() || j.item->seq.empty()) {  // nothing to align: a chain of its own
+            if (!j.G->n_nodes() || j.item->seq.empty()) {  // nothing to align: a chain of its own
                 jobs.push_back(j);
                 who.push_back(who_c[x]);
                 continue;
@@ -1124,7 +1195,7 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
         std::vector<HostJob> run;
         std::vector<size_t> run_ix;
         for (size_t x = 0; x < jobs.size(); ++x)
-            if (!jobs[x].G->nodes.empty() && !jobs[x].item->seq.empty()) {
+            if (jobs[x].G->n_nodes() && !jobs[x].item->seq.empty()) {
                 run.push_back(jobs[x]);
                 run_ix.push_back(x);
             }
@@ -1140,6 +1211,11 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
         ioc_parallel_for(jobs.size(), [&](size_t x) {
             HostJob& j = jobs[x];
             j.G->add_alignment(j.aln, j.item->seq.data(), int(j.item->seq.size()), j.item->weight);
+            const auto& q = p->pending[who[x].first].find(who[x].second)->second;  // (j.item is its head)
+            if (q.size() > 1 && q[1].marker) {
+                j.cons = j.G->consensus();
+                j.have_cons = true;
+            }
         }, 16);
         for (size_t x = 0; x < jobs.size(); ++x) {
             HostJob& j = jobs[x];
@@ -1158,7 +1234,7 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
                 if (sn != p->snap[who[x].first].end()) sn->second.max_tag = std::max(sn->second.max_tag, q.front().tag);
             }
             q.erase(q.begin());
-            poa_take_markers(p, who[x].first, who[x].second, q);
+            poa_take_markers(p, who[x].first, who[x].second, q, j.have_cons ? &j.cons : nullptr);
         }
         p->ms_graph += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count();
     }
@@ -1349,6 +1425,12 @@ void ioc_poa_destroy(ioc_poa* p)
     if (getenv("IOC_TRACE"))
         fprintf(stderr, "[ioc] POA: %lld alignments in %lld batches; batch layout %.1f ms (%.1f ms of it device allocations), launches + copies %.1f ms, graph updates %.1f ms\n",
                 (long long)p->n_aligned, (long long)p->n_batches, p->ms_layout, p->ms_alloc, p->ms_gpu, p->ms_graph);
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc] POA: device uploads %.1f ms, kernels %.1f ms, downloads %.1f ms; snapshots %.1f ms, consensus at markers %.1f ms, row plans %.1f ms, "
+                        "alignments into node ids %.1f ms\n",
+                p->ms_dev[0], p->ms_dev[1], p->ms_dev[2], p->ms_snap, p->ms_mark, p->ms_plan, p->ms_post);
+    for (auto& e : p->ev)
+        if (e) (void)hipEventDestroy(e);
     for (DevBuf* b : {&p->d_int, &p->d_dirs, &p->d_eb, &p->d_carry, &p->d_tbest, &p->d_small, &p->d_aln, &p->d_jobs})
         if (b->p) (void)hipFree(b->p);
     delete p;
@@ -1378,16 +1460,16 @@ int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_
     if (it == p->g[side].end()) return IOC_ERR_ARG;
     it->second.ensure();
     const PGraph& G = it->second;
-    if (n_nodes) *n_nodes = int32_t(G.nodes.size());
-    if (n_edges) *n_edges = int32_t(G.edges.size());
-    for (size_t i = 0; i < G.nodes.size(); ++i) {
-        if (bases) bases[i] = G.nodes[i].base;
+    if (n_nodes) *n_nodes = int32_t(G.n_nodes());
+    if (n_edges) *n_edges = int32_t(G.n_edges());
+    for (size_t i = 0; i < G.n_nodes(); ++i) {
+        if (bases) bases[i] = G.base[i];
         if (rank) rank[i] = G.rank[i];
     }
-    for (size_t i = 0; i < G.edges.size(); ++i) {
-        if (edge_from) edge_from[i] = G.edges[i].from;
-        if (edge_to) edge_to[i] = G.edges[i].to;
-        if (edge_w) edge_w[i] = G.edges[i].w;
+    for (size_t i = 0; i < G.n_edges(); ++i) {
+        if (edge_from) edge_from[i] = G.e_from[i];
+        if (edge_to) edge_to[i] = G.e_to[i];
+        if (edge_w) edge_w[i] = G.e_w[i];
     }
     return IOC_OK;
 }
@@ -1411,17 +1493,20 @@ int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t 
     auto put32 = [&](int32_t v) { put(&v, 4); };
     put("IOCPOA1", 8);
     put32(G.nseq);
-    put32(int32_t(G.nodes.size()));
-    put32(int32_t(G.edges.size()));
-    for (auto& nd : G.nodes) {
-        put(&nd.base, 1);
-        put32(int32_t(nd.aligned.size()));
-        for (int x : nd.aligned) put32(x);
+    put32(int32_t(G.n_nodes()));
+    put32(int32_t(G.n_edges()));
+    b.reserve(32 + G.n_nodes() * 5 + G.al_val.size() * 4 + G.n_edges() * 16);
+    for (size_t v = 0; v < G.n_nodes(); ++v) {
+        put(&G.base[v], 1);
+        int32_t na = 0;
+        for (int q = G.al_head[v]; q >= 0; q = G.al_next[size_t(q)]) ++na;
+        put32(na);
+        for (int q = G.al_head[v]; q >= 0; q = G.al_next[size_t(q)]) put32(G.al_val[size_t(q)]);
     }
-    for (auto& e : G.edges) {
-        put32(e.from);
-        put32(e.to);
-        put(&e.w, 8);
+    for (size_t e = 0; e < G.n_edges(); ++e) {
+        put32(G.e_from[e]);
+        put32(G.e_to[e]);
+        put(&G.e_w[e], 8);
     }
     if (out) {
         if (cap < int64_t(b.size())) return IOC_ERR_CAPACITY;
@@ -1457,33 +1542,34 @@ int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t
     G.nseq = get32();
     const int32_t nn = get32(), ne = get32();
     if (!ok || nn < 0 || ne < 0) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");
-    G.nodes.resize(size_t(nn));
+    if (int64_t(nn) > len || int64_t(ne) > len) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");  // (a node takes 5 bytes at least)
+    for (int32_t i = 0; i < nn; ++i) G.add_node(0);
     for (int32_t i = 0; ok && i < nn; ++i) {
-        get(&G.nodes[size_t(i)].base, 1);
+        get(&G.base[size_t(i)], 1);
         const int32_t na = get32();
         if (na < 0 || na > nn) ok = false;
         for (int32_t x = 0; ok && x < na; ++x) {
             const int32_t a = get32();
-            if (a < 0 || a >= nn) ok = false;
-            G.nodes[size_t(i)].aligned.push_back(a);
+            if (a < 0 || a >= nn) {
+                ok = false;
+                break;
+            }
+            G.al_push(i, a);
         }
     }
     for (int32_t i = 0; ok && i < ne; ++i) {
-        PEdge ed;
-        ed.from = get32();
-        ed.to = get32();
-        get(&ed.w, 8);
-        if (ed.from < 0 || ed.from >= nn || ed.to < 0 || ed.to >= nn) {
+        const int32_t from = get32(), to = get32();
+        int64_t w = 0;
+        get(&w, 8);
+        if (!ok || from < 0 || from >= nn || to < 0 || to >= nn) {
             ok = false;
             break;
         }
-        G.edges.push_back(ed);
-        G.nodes[size_t(ed.from)].out.push_back(i);
-        G.nodes[size_t(ed.to)].in.push_back(i);
+        G.link_edge(from, to, w);
     }
     if (!ok) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");
     G.toposort();
-    if (G.rank.size() != G.nodes.size()) return ioc_fail(p->ctx, IOC_ERR_INPUT, "graph with a cycle");
+    if (G.rank.size() != G.n_nodes()) return ioc_fail(p->ctx, IOC_ERR_INPUT, "graph with a cycle");
     p->g[side][idx] = std::move(G);
     return IOC_OK;
 }
