@@ -178,8 +178,10 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
 
     ioc_cluster_stats total{};
     std::vector<int64_t> of, orv, roff;
-    std::vector<uint32_t> keys, post;
-    std::vector<int64_t> offs;
+    std::vector<uint32_t> keys, post, keys2, post2, dirty_keys;
+    std::vector<int64_t> offs, offs2;
+    bool have_view = false;
+    const bool view_check = getenv("IOC_CONS_VIEW_CHECK") != nullptr;
     std::vector<double> herr, rerr;
     std::string lseq;
     std::vector<int64_t> loff;
@@ -244,16 +246,68 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         double t0 = now();
         // ---- left view of the current state ----
         const int32_t Lc = int32_t(cl.size());
-        keys.clear();
-        offs.clear();
-        post.clear();
-        for (auto& kv : db) {
-            if (kv.second.empty()) continue;  // lists emptied by UpdateMinDB stay in the MinDB but match nothing
-            keys.push_back(kv.first);
-            offs.push_back(int64_t(post.size()));
-            post.insert(post.end(), kv.second.begin(), kv.second.end());
+        // The MinDB as flat arrays.  Walking the map (half a million keys, a heap vector behind each) cost 10 ms per pass; a
+        // pass touches a few thousand keys, so the arrays of the previous pass are patched instead: untouched stretches are
+        // copied, the keys written since (dirty_keys: AddMinimizers, UpdateMinDB; a rollback only touches keys of its own pass)
+        // are looked up in the map.  IOC_CONS_VIEW_CHECK=1 builds it both ways and compares.
+        auto full_view = [&](std::vector<uint32_t>& K, std::vector<int64_t>& O, std::vector<uint32_t>& P) {
+            K.clear();
+            O.clear();
+            P.clear();
+            for (auto& kv : db) {
+                if (kv.second.empty()) continue;  // lists emptied by UpdateMinDB stay in the MinDB but match nothing
+                K.push_back(kv.first);
+                O.push_back(int64_t(P.size()));
+                P.insert(P.end(), kv.second.begin(), kv.second.end());
+            }
+            O.push_back(int64_t(P.size()));
+        };
+        if (!have_view) {
+            full_view(keys, offs, post);
+            have_view = true;
+        } else if (!dirty_keys.empty()) {
+            std::sort(dirty_keys.begin(), dirty_keys.end());
+            dirty_keys.erase(std::unique(dirty_keys.begin(), dirty_keys.end()), dirty_keys.end());
+            keys2.clear();
+            offs2.clear();
+            post2.clear();
+            keys2.reserve(keys.size() + dirty_keys.size());
+            offs2.reserve(keys.size() + dirty_keys.size() + 1);
+            post2.reserve(post.size() + post.size() / 16 + 4096);
+            const size_t nk = keys.size();
+            size_t a = 0;
+            auto copy_range = [&](size_t from, size_t to) {  // entries [from, to) of the previous arrays, as they are
+                if (from >= to) return;
+                const int64_t delta = int64_t(post2.size()) - offs[from];
+                keys2.insert(keys2.end(), keys.begin() + int64_t(from), keys.begin() + int64_t(to));
+                const size_t o = offs2.size();
+                offs2.resize(o + (to - from));
+                for (size_t x = from; x < to; ++x) offs2[o + (x - from)] = offs[x] + delta;
+                post2.insert(post2.end(), post.begin() + offs[from], post.begin() + offs[to]);
+            };
+            for (uint32_t dk : dirty_keys) {
+                const size_t b = size_t(std::lower_bound(keys.begin() + int64_t(a), keys.end(), dk) - keys.begin());
+                copy_range(a, b);
+                a = b;
+                if (a < nk && keys[a] == dk) ++a;
+                auto it = db.find(dk);
+                if (it != db.end() && !it->second.empty()) {
+                    keys2.push_back(dk);
+                    offs2.push_back(int64_t(post2.size()));
+                    post2.insert(post2.end(), it->second.begin(), it->second.end());
+                }
+            }
+            copy_range(a, nk);
+            offs2.push_back(int64_t(post2.size()));
+            keys.swap(keys2);
+            offs.swap(offs2);
+            post.swap(post2);
         }
-        offs.push_back(int64_t(post.size()));
+        dirty_keys.clear();
+        if (view_check) {
+            full_view(keys2, offs2, post2);
+            if (keys2 != keys || offs2 != offs || post2 != post) return ioc_fail(c, IOC_ERR_STATE, "consensus driver: the patched left view differs from a rebuilt one");
+        }
         herr.resize(size_t(Lc));
         rerr.resize(size_t(Lc));
         c->aln_lid.resize(size_t(Lc));
@@ -397,6 +451,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     journal.push_back(std::move(u));
                 }
                 for (uint32_t v : ns.vals) db[v].push_back(uint32_t(dc));
+                dirty_keys.insert(dirty_keys.end(), ns.vals.begin(), ns.vals.end());
                 // (before the first event of a pass nothing is ever undone: no snapshot needed)
                 if ((spec && !evs.empty() ? spec->create_tagged(ops->user, 0, dc, rseq, rlen, i) : ops->create(ops->user, 0, dc, rseq, rlen)) < 0)
                     return hook_fail(c, "create");
@@ -490,6 +545,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     lst.push_back(uint32_t(dc));
                     std::sort(lst.begin(), lst.end());
                 }
+                dirty_keys.insert(dirty_keys.end(), to_del.begin(), to_del.end());
+                dirty_keys.insert(dirty_keys.end(), to_ins.begin(), to_ins.end());
             }
             dirty.add_cluster(b.vals, nv);
             b.vals.swap(nv);
@@ -617,12 +674,14 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                                 t2.erase(std::remove(t2.begin(), t2.end(), uint32_t(ev.dc)), t2.end());
                                 lst.swap(t2);
                                 upd_keys.push_back(v);
+                                dirty_keys.push_back(v);
                             }
                             for (uint32_t v : to_ins) {
                                 auto& lst = db[v];
                                 lst.push_back(uint32_t(ev.dc));
                                 std::sort(lst.begin(), lst.end());
                                 upd_keys.push_back(v);
+                                dirty_keys.push_back(v);
                             }
                         }
                         dirty_b.add_cluster(b.vals, nv);

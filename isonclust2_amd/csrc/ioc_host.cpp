@@ -20,9 +20,89 @@
 #include <memory>
 #include <unordered_map>
 #include <utility>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <pthread.h>
 #include <vector>
 
 #include "ioc_internal.h"
+
+// ---- the worker pool behind ioc_parallel_for ---------------------------------------------------------------------------
+namespace {
+struct IocPool {
+    std::mutex mu, region;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(size_t)>* fn = nullptr;
+    std::atomic<size_t> next{0};
+    size_t count = 0, want = 0, active = 0, n_workers = 0;
+    uint64_t gen = 0;
+};
+IocPool* g_pool = nullptr;  // (never destroyed: its threads wait on it until the process ends)
+std::once_flag g_pool_once;
+thread_local bool t_pool_worker = false;
+
+void pool_worker(IocPool* P, size_t idx)
+{
+    t_pool_worker = true;
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(P->mu);
+    for (;;) {
+        P->cv_work.wait(lk, [&] { return P->gen != seen; });
+        seen = P->gen;
+        if (idx >= P->want) continue;  // (a region for fewer threads)
+        const std::function<void(size_t)>* f = P->fn;
+        const size_t cnt = P->count;
+        lk.unlock();
+        for (size_t x = P->next.fetch_add(1); x < cnt; x = P->next.fetch_add(1)) (*f)(x);
+        lk.lock();
+        if (--P->active == 0) P->cv_done.notify_one();
+    }
+}
+void spawn_run(size_t count, size_t nt, const std::function<void(size_t)>& f)
+{
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            for (size_t x = next.fetch_add(1); x < count; x = next.fetch_add(1)) f(x);
+        });
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
+void ioc_pool_run(size_t count, size_t nt, const std::function<void(size_t)>& f)
+{
+    std::call_once(g_pool_once, [] {
+        IocPool* P = new IocPool;
+        P->n_workers = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency())) - 1;
+        for (size_t i = 0; i < P->n_workers; ++i) std::thread(pool_worker, P, i).detach();
+        // (a forked child has no workers: it starts threads per call, as does every region while g_pool is null)
+        pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; });
+        g_pool = P;
+    });
+    IocPool* P = g_pool;
+    std::unique_lock<std::mutex> region;
+    if (P && !t_pool_worker) region = std::unique_lock<std::mutex>(P->region, std::try_to_lock);
+    if (!P || !region.owns_lock() || P->n_workers == 0) {
+        spawn_run(count, nt, f);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->fn = &f;
+        P->count = count;
+        P->next.store(0);
+        P->want = std::min(nt - 1, P->n_workers);  // the caller works as well
+        P->active = P->want;
+        P->gen++;
+    }
+    P->cv_work.notify_all();
+    for (size_t x = P->next.fetch_add(1); x < count; x = P->next.fetch_add(1)) f(x);
+    std::unique_lock<std::mutex> lk(P->mu);
+    P->cv_done.wait(lk, [&] { return P->active == 0; });
+    P->fn = nullptr;
+}
 
 namespace {
 
@@ -690,8 +770,24 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
     if (L < 0) return ioc_fail(c, IOC_ERR_ARG, "negative left cluster count");
     const int n = rb->n;
     if (n < 0) return ioc_fail(c, IOC_ERR_ARG, "negative batch size");
+    PhaseTrace tr0;
     int32_t glim[225];
-    int r = ioc_host_gap_limits(table_path, p->k, p->w, p->min_prob_no_hits, glim, nullptr);
+    int r = IOC_OK;
+    {   // (the consensus driver comes here once per pass with the same table: the file and its 225 pow() searches are kept)
+        static std::mutex mu;
+        static std::string key;
+        static int32_t kept[225];
+        char tag[96];
+        snprintf(tag, sizeof tag, "|%d|%d|%.17g", p->k, p->w, p->min_prob_no_hits);
+        const std::string want = std::string(table_path) + tag;
+        std::lock_guard<std::mutex> lk(mu);
+        if (key != want) {
+            key.clear();
+            r = ioc_host_gap_limits(table_path, p->k, p->w, p->min_prob_no_hits, kept, nullptr);
+            if (r == IOC_OK) key = want;
+        }
+        if (r == IOC_OK) memcpy(glim, kept, sizeof glim);
+    }
     if (r != IOC_OK) return ioc_fail(c, r, "empirical probability lookup failure (k, w outside the table)");
     if ((r = ioc_set_params(c, p, glim)) != IOC_OK) return r;
     if (p->mode == IOC_MODE_NONE) {
@@ -785,6 +881,7 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
                                need.data());
     }
     if (r != IOC_OK) return r;
+    tr0.mark("gates + query upload");
     if (left && left->n_keys == -1 && !left->keys) {
         // the left state stays as it is on the device (persisted MinDB + any ioc_index_update)
         if (L != c->L) return ioc_fail(c, IOC_ERR_STATE, "resident left state holds a different number of clusters");
@@ -801,6 +898,7 @@ int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, c
         r = ioc_left_load(c, 0, nullptr, 0, nullptr, nullptr, nullptr);
     }
     if (r != IOC_OK) return r;
+    tr0.mark("left state load");
     SeqAccess sa;
     sa.r_seq = rb->raw_seq;
     sa.r_off = rb->raw_off;

@@ -187,10 +187,13 @@ extern "C" int ioc_queries_upload_devmins(ioc_ctx* c, int32_t n, const int64_t* 
                                           const uint32_t* min_total);
 
 
-// f(0) .. f(count - 1) on the host's cores (independent items only)
+// f(0) .. f(count - 1) on the host's cores (independent items only).  The workers are a pool that lives with the process
+// (ioc_host.cpp): the consensus path comes here ~1000 times per batch, and starting 16 threads per call cost 0.4 s of it.
+// A region entered while another one runs (another context on another thread, or a nested call) starts threads of its own.
 #include <atomic>
+#include <functional>
 #include <thread>
-// (threads are started per call: `serial_below` items or fewer are not worth it)
+void ioc_pool_run(size_t count, size_t nthreads, const std::function<void(size_t)>& f);
 template <typename F>
 static inline void ioc_parallel_for(size_t count, F f, size_t serial_below = 4)
 {
@@ -200,13 +203,7 @@ static inline void ioc_parallel_for(size_t count, F f, size_t serial_below = 4)
         for (size_t x = 0; x < count; ++x) f(x);
         return;
     }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t)
-        th.emplace_back([&]() {
-            for (size_t x = next.fetch_add(1); x < count; x = next.fetch_add(1)) f(x);
-        });
-    for (auto& t : th) t.join();
+    ioc_pool_run(count, nt, std::function<void(size_t)>(std::ref(f)));
 }
 
 #endif

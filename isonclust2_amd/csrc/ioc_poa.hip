@@ -57,7 +57,10 @@ struct PoaScores {
 constexpr int POA_CB = POA_THREADS;  // columns per tile: one per thread
 constexpr int POA_RB = 64;           // rows per tile
 constexpr int POA_WAVES = POA_THREADS / 64;
-constexpr int POA_RING = 16;         // rows of the tile kept in LDS behind the current one
+#ifndef IOC_POA_RING
+#define IOC_POA_RING 8
+#endif
+constexpr int POA_RING = IOC_POA_RING;  // rows of the tile kept in LDS behind the current one (a power of two)
 constexpr int POA_PRED_LDS = 448;    // predecessor entries of a tile staged in LDS (the rest is read from memory)
 
 // One alignment of a batch (blockIdx.y): a read against one graph.  Graphs are independent, so the pending
@@ -107,21 +110,23 @@ using GI32 = __attribute__((address_space(1))) int32_t;
 using GU32 = __attribute__((address_space(1))) uint32_t;
 using GU8 = __attribute__((address_space(1))) uint8_t;
 
-// lanes without a source (and rows masked off) receive POA_NEG, the identity of max
+// lanes without a source (and rows masked off) receive INT32_MIN, THE identity of a signed maximum: the compiler folds such
+// a move into the maximum that consumes it (v_max_i32_dpp, one instruction per stage instead of identity + move + maximum;
+// with POA_NEG in its place it does not).  The value only ever meets max(), never an addition.
 template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ int dpp_or_neg(int v)
+__device__ __forceinline__ int dpp_or_self(int v)
 {
-    return __builtin_amdgcn_update_dpp(POA_NEG, v, CTRL, ROW_MASK, 0xf, false);
+    return __builtin_amdgcn_update_dpp(INT32_MIN, v, CTRL, ROW_MASK, 0xf, false);
 }
 // inclusive prefix maximum over the 64 lanes of a wave: row_shr 1 2 4 8, then row_bcast 15 and 31
 __device__ __forceinline__ int wave_prefix_max(int v)
 {
-    v = max(v, dpp_or_neg<0x111>(v));
-    v = max(v, dpp_or_neg<0x112>(v));
-    v = max(v, dpp_or_neg<0x114>(v));
-    v = max(v, dpp_or_neg<0x118>(v));
-    v = max(v, dpp_or_neg<0x142, 0xa>(v));
-    v = max(v, dpp_or_neg<0x143, 0xc>(v));
+    v = max(v, dpp_or_self<0x111>(v));
+    v = max(v, dpp_or_self<0x112>(v));
+    v = max(v, dpp_or_self<0x114>(v));
+    v = max(v, dpp_or_self<0x118>(v));
+    v = max(v, dpp_or_self<0x142, 0xa>(v));
+    v = max(v, dpp_or_self<0x143, 0xc>(v));
     return v;
 }
 // LDS traffic of this wave done, then the workgroup barrier: global stores stay in flight (a __syncthreads
@@ -171,6 +176,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     const int j = cb * POA_CB + tid;
     const bool active = j < W;
     const int jj = min(j, W - 1);  // threads past the last column run along and store nothing
+    const uint32_t jb4 = uint32_t(jj) * 4u;  // (W <= 2^20: fits)
     const int r_lo = rb * POA_RB + 1, r_hi = min(R, r_lo + POA_RB - 1);
     const GI32* cin_row = carry + int64_t(max(cb, 1) - 1) * (R + 1) * 4;
     GI32* cout_row = carry + int64_t(cb) * (R + 1) * 4;
@@ -359,16 +365,17 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             sF2[sl][tid] = f2;
             if (lane == 63 && wave < POA_WAVES - 1) s_carry[wave + 1][t] = int4{vx, vy, hn, h};
             if (active) {
+                // (row bases are uniform: scalar arithmetic, the lane adds its 32-bit column offset)
                 const int64_t ro = int64_t(r) * W;
                 const int ks = __builtin_amdgcn_readfirstlane(my_slot);
                 if (ks >= 0) {  // some later row reads this one from memory (it is above that row's tile or out of its ring)
                     const int64_t ko = int64_t(ks) * W;
-                    H[ko + j] = h;
-                    F1[ko + j] = f1;
-                    F2[ko + j] = f2;
+                    *(GI32*)((GU8*)(H + ko) + jb4) = h;
+                    *(GI32*)((GU8*)(F1 + ko) + jb4) = f1;
+                    *(GI32*)((GU8*)(F2 + ko) + jb4) = f2;
                 }
-                dirs[ro + j] = d;
-                ebits[ro + j] = uint8_t(eb);
+                *(GU32*)((GU8*)(dirs + ro) + jb4) = d;
+                *((ebits + ro) + uint32_t(j)) = uint8_t(eb);
                 if (h > my_best) {  // rows ascend in time: the first row wins ties
                     my_best = h;
                     my_r = r;

@@ -22,6 +22,7 @@ CLI=isonclust2_amd/bin/isONclust2-hip
 $CLI sort -B $((2*PER)) -M $PER -g 20 -c 100 -P 400 -o $D/s $D/r.fq > /dev/null 2>&1 || exit 1
 ( time IOC_TRACE=1 ISONCLUST2_STATS_JSON=1 $CLI cluster -l $D/s/batches/isONbatch_0.cer -o $D/o.cer -x sahlin ) 2> gpurun_out/leaf_$TAG/trace.err || exit 1
 grep -v "consensus pass from\|deferred:\|candidate tables\|aligner v2" gpurun_out/leaf_$TAG/trace.err | grep "consensus phases\|POA\|^{\|real" 
+[ -n "${NOPROF:-}" ] && exit 0
 IOC_CLI_CLEAN_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/leaf_$TAG/prof -- $CLI cluster -l $D/s/batches/isONbatch_0.cer -o $D/o2.cer -x sahlin > gpurun_out/leaf_$TAG/prof.log 2>&1
 cmp $D/o.cer $D/o2.cer && echo "outputs identical"
 F=$(find gpurun_out/leaf_$TAG/prof -name "*kernel_stats.csv" | head -1)
