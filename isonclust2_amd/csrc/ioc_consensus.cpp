@@ -22,6 +22,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "ioc_internal.h"
@@ -133,7 +134,18 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         ~ShardOff() { c->shard_world = world; }
     } shard_off(c);
     // ---- left state on the host: MinDB as an ordered map, one ClState per cluster ----
-    std::map<uint32_t, std::vector<uint32_t>> db;
+    // (hashed: UpdateMinDB looks up hundreds of keys per event, among half a million; where the reference's std::map order
+    // matters — the flat view, the export — the keys are sorted)
+    std::unordered_map<uint32_t, std::vector<uint32_t>> db;
+    if (left && left->n_keys > 0) db.reserve(size_t(left->n_keys) * 2);
+    auto sorted_keys = [&](bool with_empty) {
+        std::vector<uint32_t> ks;
+        ks.reserve(db.size());
+        for (auto& kv : db)
+            if (with_empty || !kv.second.empty()) ks.push_back(kv.first);
+        std::sort(ks.begin(), ks.end());
+        return ks;
+    };
     std::vector<ClState> cl(static_cast<size_t>(L0));
     // sequence identities: right entry i -> i; left representatives and consensus sequences -> n, n + 1, ...
     uint64_t next_seq_id = uint64_t(n);
@@ -254,11 +266,11 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             K.clear();
             O.clear();
             P.clear();
-            for (auto& kv : db) {
-                if (kv.second.empty()) continue;  // lists emptied by UpdateMinDB stay in the MinDB but match nothing
-                K.push_back(kv.first);
+            K = sorted_keys(false);  // lists emptied by UpdateMinDB stay in the MinDB but match nothing
+            for (uint32_t k2 : K) {
+                const auto& lst = db.find(k2)->second;
                 O.push_back(int64_t(P.size()));
-                P.insert(P.end(), kv.second.begin(), kv.second.end());
+                P.insert(P.end(), lst.begin(), lst.end());
             }
             O.push_back(int64_t(P.size()));
         };
@@ -791,10 +803,11 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     c->exp_keys.clear();
     c->exp_offs.clear();
     c->exp_post.clear();
-    for (auto& kv : db) {
-        c->exp_keys.push_back(kv.first);
+    for (uint32_t k2 : sorted_keys(true)) {
+        const auto& lst = db.find(k2)->second;
+        c->exp_keys.push_back(k2);
         c->exp_offs.push_back(int64_t(c->exp_post.size()));
-        c->exp_post.insert(c->exp_post.end(), kv.second.begin(), kv.second.end());
+        c->exp_post.insert(c->exp_post.end(), lst.begin(), lst.end());
     }
     c->exp_offs.push_back(int64_t(c->exp_post.size()));
     c->exp_valid = true;

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
@@ -553,6 +554,9 @@ __global__ void __launch_bounds__(64) k_poa_trace(const PoaJob* __restrict__ job
     if (lane == 0) *J.out_n = n;
 }
 
+std::atomic<int64_t> g_row_stats[4];  // rows planned: chain rows, rows with 1-2 / more predecessors all in the LDS ring, rows that read memory
+bool g_row_stats_on = false;
+
 // ---- host side: the graph ----------------------------------------------------------------------------------
 // Flat: every member is one array over the nodes, the edges or a pool, so that a copy of a graph (the snapshot a deferred
 // consensus pass takes of every graph it is about to touch, and its release) is a dozen memcpys instead of three heap
@@ -773,6 +777,24 @@ struct PGraph {
             }
         }
         p_poff[size_t(R) + 1] = int32_t(p_pred.size());
+        if (g_row_stats_on) {  // (IOC_TRACE: what kinds of rows the tile kernel meets)
+            int64_t k[4] = {0, 0, 0, 0};
+            for (int q = 1; q <= R; ++q) {
+                const int a = p_poff[size_t(q)], b = p_poff[size_t(q) + 1];
+                bool ring = true;
+                for (int x = a; x < b; ++x) {
+                    const int pr = p_pred[size_t(x)];
+                    if ((pr - 1) / POA_RB != (q - 1) / POA_RB || q - pr > POA_RING || pr == 0) ring = false;
+                }
+                if (b - a == 1 && ring && p_pred[size_t(a)] == q - 1)
+                    k[0]++;
+                else if (ring)
+                    k[b - a <= 2 ? 1 : 2]++;
+                else
+                    k[3]++;
+            }
+            for (int x = 0; x < 4; ++x) g_row_stats[x].fetch_add(k[x], std::memory_order_relaxed);
+        }
         p_slot.assign(size_t(R) + 1, -1);
         p_nkeep = 0;
         for (int r = 0; r <= R; ++r)
@@ -1421,6 +1443,7 @@ int ioc_poa_create(ioc_ctx* ctx, int32_t m, int32_t n, int32_t g, int32_t e, int
     ioc_poa* p = new ioc_poa;
     p->ctx = ctx;
     p->S = PoaScores{m, n, g, e, q, c};
+    g_row_stats_on = getenv("IOC_TRACE") != nullptr;
     if (const char* e2 = getenv("IOC_POA_PRED_LDS")) p->pred_lds = std::max(1, std::min(POA_PRED_LDS, atoi(e2)));
     *out = p;
     return IOC_OK;
@@ -1436,6 +1459,9 @@ void ioc_poa_destroy(ioc_poa* p)
         fprintf(stderr, "[ioc] POA: device uploads %.1f ms, kernels %.1f ms, downloads %.1f ms; snapshots %.1f ms, consensus at markers %.1f ms, row plans %.1f ms, "
                         "alignments into node ids %.1f ms\n",
                 p->ms_dev[0], p->ms_dev[1], p->ms_dev[2], p->ms_snap, p->ms_mark, p->ms_plan, p->ms_post);
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc] POA: rows planned: %lld chain rows, %lld with 1-2 predecessors in the LDS ring, %lld with more, %lld that read memory\n",
+                (long long)g_row_stats[0].load(), (long long)g_row_stats[1].load(), (long long)g_row_stats[2].load(), (long long)g_row_stats[3].load());
     for (auto& e : p->ev)
         if (e) (void)hipEventDestroy(e);
     for (DevBuf* b : {&p->d_int, &p->d_dirs, &p->d_eb, &p->d_carry, &p->d_tbest, &p->d_small, &p->d_aln, &p->d_jobs})
@@ -1495,31 +1521,35 @@ int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t 
     if (it == p->g[side].end()) return IOC_ERR_ARG;
     it->second.ensure();
     const PGraph& G = it->second;
-    std::vector<uint8_t> b;
-    auto put = [&](const void* v, size_t n) { b.insert(b.end(), static_cast<const uint8_t*>(v), static_cast<const uint8_t*>(v) + n); };
+    // (written in place: the command line saves thousands of graphs of thousands of nodes)
+    const int64_t need = 8 + 12 + int64_t(G.n_nodes()) * 5 + int64_t(G.al_val.size()) * 4 + int64_t(G.n_edges()) * 16;
+    if (!out) return need;
+    if (cap < need) return IOC_ERR_CAPACITY;
+    uint8_t* w = out;
+    auto put = [&](const void* v, size_t n) {
+        memcpy(w, v, n);
+        w += n;
+    };
     auto put32 = [&](int32_t v) { put(&v, 4); };
     put("IOCPOA1", 8);
     put32(G.nseq);
     put32(int32_t(G.n_nodes()));
     put32(int32_t(G.n_edges()));
-    b.reserve(32 + G.n_nodes() * 5 + G.al_val.size() * 4 + G.n_edges() * 16);
     for (size_t v = 0; v < G.n_nodes(); ++v) {
-        put(&G.base[v], 1);
+        *w++ = uint8_t(G.base[v]);
+        uint8_t* cnt = w;
+        w += 4;
         int32_t na = 0;
-        for (int q = G.al_head[v]; q >= 0; q = G.al_next[size_t(q)]) ++na;
-        put32(na);
-        for (int q = G.al_head[v]; q >= 0; q = G.al_next[size_t(q)]) put32(G.al_val[size_t(q)]);
+        for (int q = G.al_head[v]; q >= 0; q = G.al_next[size_t(q)], ++na) put32(G.al_val[size_t(q)]);
+        memcpy(cnt, &na, 4);
     }
     for (size_t e = 0; e < G.n_edges(); ++e) {
         put32(G.e_from[e]);
         put32(G.e_to[e]);
         put(&G.e_w[e], 8);
     }
-    if (out) {
-        if (cap < int64_t(b.size())) return IOC_ERR_CAPACITY;
-        memcpy(out, b.data(), b.size());
-    }
-    return int64_t(b.size());
+    if (w - out != need) return ioc_fail(p->ctx, IOC_ERR_STATE, "POA: graph blob size mismatch");
+    return need;
 }
 
 int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t len)
