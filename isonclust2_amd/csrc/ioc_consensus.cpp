@@ -52,6 +52,21 @@ void sorted_unique(std::vector<uint32_t>& v)
     v.erase(std::unique(v.begin(), v.end()), v.end());
 }
 
+// UpdateMinDB's removal (minimizer.cpp:143-147): the list sorted, made unique, without the cluster.  The lists are strictly
+// ascending already unless a caller loaded something else: then the one entry is cut out in place.
+void drop_cluster(std::vector<uint32_t>& lst, uint32_t cls)
+{
+    bool ascending = true;
+    for (size_t x = 1; x < lst.size() && ascending; ++x) ascending = lst[x - 1] < lst[x];
+    if (ascending) {
+        auto it = std::lower_bound(lst.begin(), lst.end(), cls);
+        if (it != lst.end() && *it == cls) lst.erase(it);
+        return;
+    }
+    sorted_unique(lst);
+    lst.erase(std::remove(lst.begin(), lst.end(), cls), lst.end());
+}
+
 }  // namespace
 
 // Values of the clusters whose representative changed during the current pass (old and new minimizer sets):
@@ -547,10 +562,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 std::set_difference(nv.begin(), nv.end(), b.vals.begin(), b.vals.end(), std::back_inserter(to_ins));
                 for (uint32_t v : to_del) {
                     auto& lst = db[v];
-                    std::vector<uint32_t> t2(lst);
-                    sorted_unique(t2);
-                    t2.erase(std::remove(t2.begin(), t2.end(), uint32_t(dc)), t2.end());
-                    lst.swap(t2);
+                    drop_cluster(lst, uint32_t(dc));
                 }
                 for (uint32_t v : to_ins) {
                     auto& lst = db[v];
@@ -681,10 +693,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                             std::set_difference(nv.begin(), nv.end(), b.vals.begin(), b.vals.end(), std::back_inserter(to_ins));
                             for (uint32_t v : to_del) {
                                 auto& lst = db[v];
-                                std::vector<uint32_t> t2(lst);
-                                sorted_unique(t2);
-                                t2.erase(std::remove(t2.begin(), t2.end(), uint32_t(ev.dc)), t2.end());
-                                lst.swap(t2);
+                                drop_cluster(lst, uint32_t(ev.dc));
                                 upd_keys.push_back(v);
                                 dirty_keys.push_back(v);
                             }
