@@ -88,7 +88,8 @@ def full(ctx):
     return Tree(ctx, c5.PER)
 
 
-def test_config5_reduced_tree(small):
+def test_config5_reduced_tree(small, monkeypatch):
+    monkeypatch.setenv("IOC_CONS_VIEW_CHECK", "1")   # the left view patched across passes must equal a rebuilt one
     for b in range(small.nb):
         small.leaf(b)
     for s in range(len(small.gold["merges"])):

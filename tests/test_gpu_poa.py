@@ -311,6 +311,7 @@ def _run_consensus(ctx, rs, mode, cons, window=None, speculate=True, monkeypatch
         events.append((int(cls), int(r.entry), C.string_at(r.raw_seq, r.raw_len), int(r.hpc_len), int(r.n_fwd), int(r.n_rev)))
 
     monkeypatch.setenv("IOC_CONS_SPECULATE", "1" if speculate else "0")
+    monkeypatch.setenv("IOC_CONS_VIEW_CHECK", "1")   # every pass: the patched left view against a rebuilt one (an error if they differ)
     if window:
         monkeypatch.setenv("IOC_CONS_WINDOW", str(window))
     else:
