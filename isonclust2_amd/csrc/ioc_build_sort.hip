@@ -206,7 +206,7 @@ hipError_t iock_build_sort_phase1(hipStream_t st, const IocBuildSort* a)
             hipLaunchKernelGGL(k_bs_pairs_left<uint32_t>, grid, dim3(BS_BLOCK), 0, st, a->n_left_keys, a->lkeys, a->loffs, a->lpost, a->pk_in,
                                static_cast<uint32_t*>(a->pv_in));
     }
-    if (a->n > 0) {
+    if (a->n > 0 && !a->pairs_done) {
         if (a->post16)
             hipLaunchKernelGGL(k_bs_pairs_queries<uint16_t>, dim3(a->n), dim3(BS_BLOCK), 0, st, a->n, a->L, a->doff, a->dcount, a->dvals, a->n_left_post,
                                sentinel, a->pk_in, static_cast<uint16_t*>(a->pv_in));

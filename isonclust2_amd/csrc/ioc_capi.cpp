@@ -162,6 +162,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_pin_big) (void)hipHostFree(c->h_pin_big);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -236,6 +237,8 @@ static int queries_common(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const i
     c->h_forced_t.assign(size_t(n), INT32_MIN);
     c->h_forced_s.assign(size_t(n), 0);
     c->forced_dirty = true;
+    c->forced_host_clear = true;
+    c->forced_dev_clear = false;
     c->aln_verdicts = false;
     c->have_res_seq = false;
     RESERVE(c, c->b_doff, size_t(n + 1) * 8);
@@ -526,9 +529,6 @@ int ioc_index_build(ioc_ctx* c)
     RESERVE(c, c->b_fill, size_t(nfwd_total) * 4);  // position of each distinct value inside its posting list
     RESERVE(c, c->b_dcount, size_t(n) * 4);
     RESERVE(c, c->b_misc, 256);
-    HIPCHK(c, iock_distinct(s, n, c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals),
-                            P<uint32_t>(c->b_dcount), pmax, c->params.k >= 1 && c->params.k <= 16 ? 2 * c->params.k : 32));
-
     // ---- hash table sizing: distinct keys <= min(entries, 4^k); HPC sequences have no equal
     // neighbours, so at most 4*3^(k-1) distinct k-mers occur — used as the first guess only.
     const int k = c->params.k;
@@ -546,9 +546,9 @@ int ioc_index_build(ioc_ctx* c)
     // ---- the build without global atomics (ioc_build_sort.hip): a stable radix sort of the (value, target) pairs ----
     const int value_bits = (k >= 1 && k <= 16) ? 2 * k : 32;
     const bool sorted_build = value_bits < 32 && ub_entries > 0 && env_u32("IOC_BUILD_SORT", 1) == 1;
+    const int64_t NP = ub_entries;  // (the unused tails of the queries' lists ride along as sentinels)
+    IocBuildSort a{};
     if (sorted_build) {
-        const int64_t NP = ub_entries;  // (the unused tails of the queries' lists ride along as sentinels)
-        IocBuildSort a{};
         a.n = n;
         a.L = uint32_t(c->L);
         a.doff = P<int64_t>(c->b_doff);
@@ -581,6 +581,17 @@ int ioc_index_build(ioc_ctx* c)
         a.pv_in = bp;
         a.pv_out = bp + pvb;
         a.temp = bp + 2 * pvb;
+    }
+    {   // distinct values per query; with the sorted build the same kernel writes the queries' (value, target) pairs
+        int written = 0;
+        const uint32_t sentinel = value_bits < 32 ? 1u << value_bits : 0u;
+        uint32_t* qk = sorted_build ? a.pk_in + c->n_left_post : nullptr;
+        void* qv = sorted_build ? static_cast<void*>(static_cast<uint8_t*>(a.pv_in) + size_t(c->n_left_post) * psize) : nullptr;
+        HIPCHK(c, iock_distinct(s, n, c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals), P<uint32_t>(c->b_dcount), pmax,
+                                value_bits, qk, qv, c->post16, uint32_t(c->L), sentinel, &written));
+        a.pairs_done = written;
+    }
+    if (sorted_build) {
         // Everything whose size does not hang on the sort's outcome is queued BEFORE the one read-back: the table at the capacity
         // the k-mer space suggests (twice the distinct keys that can occur), the postings at their upper bound (every pair a list of
         // its own, padded).  The host only has to queue the two kernels of phase 2 afterwards.
@@ -625,10 +636,11 @@ int ioc_index_build(ioc_ctx* c)
         while ((1u << bits) < cap) bits++;
         const uint32_t shift = 32 - bits;
         c->cap = cap;
-        c->n_post = -1;  // (b_off[nslots], fetched when the timings are asked for)
+        c->n_post = -1;  // (b_off[nslots]: on its way into pinned memory behind phase 2, read when the timings are asked for)
         HIPCHK(c, iock_build_sort_phase2(s, &a, R, n_real, P<uint32_t>(c->b_keys), cap, shift, P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_off), c->b_post.p,
                                          P<uint32_t>(c->b_qinfo), uint32_t(n > 0 ? n : 1), P<uint32_t>(c->b_misc)));
         HIPCHK(c, iock_pack_rows(s, nslots, P<uint32_t>(c->b_keys), P<uint32_t>(c->b_off), P<uint32_t>(c->b_cnt), P<uint32_t>(c->b_qinfo), c->b_rows.p));
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + 40, P<uint32_t>(c->b_off) + nslots, 4, hipMemcpyDeviceToHost, s));
     }
     for (; !sorted_build;) {
         const uint32_t nslots = cap + 1;
@@ -802,6 +814,7 @@ int ioc_force_decision(ioc_ctx* c, int32_t q, int32_t target, int32_t strand)
     c->h_forced_t[size_t(q)] = target < 0 ? (target == -2 ? -2 : -1) : target;  // -2: excluded (gated) entry
     c->h_forced_s[size_t(q)] = int8_t(target < 0 ? 0 : strand);
     c->forced_dirty = true;
+    c->forced_host_clear = false;
     c->warm_first = -1;
     return IOC_OK;
 }
@@ -809,8 +822,11 @@ int ioc_force_decision(ioc_ctx* c, int32_t q, int32_t target, int32_t strand)
 int ioc_clear_forced(ioc_ctx* c)
 {
     if (!c) return IOC_ERR_ARG;
+    c->warm_first = -1;
+    if (c->forced_host_clear && (c->forced_dev_clear || c->forced_dirty)) return IOC_OK;  // (cleared already, here and — or soon — there)
     std::fill(c->h_forced_t.begin(), c->h_forced_t.end(), INT32_MIN);
     std::fill(c->h_forced_s.begin(), c->h_forced_s.end(), 0);
+    c->forced_host_clear = true;
     c->forced_dirty = true;
     c->warm_first = -1;
     return IOC_OK;
@@ -934,6 +950,7 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
         HIPCHK(c, hipMemcpyAsync(c->b_forced_t.p, c->h_forced_t.data(), size_t(n) * 4, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->b_forced_s.p, c->h_forced_s.data(), size_t(n), hipMemcpyHostToDevice, s));
         c->forced_dirty = false;
+        c->forced_dev_clear = c->forced_host_clear;
     }
     if (c->aln_verdicts) {
         RESERVE(c, c->b_aln_t, size_t(n) * 4);
@@ -1075,7 +1092,9 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
             if (int rc = exchange(d_first_changed, 3, IOC_XCHG_MIN_U32)) return rc;
         }
         volatile uint32_t* res = c->h_pin;
-        HIPCHK(c, hipMemcpyAsync(c->h_pin, d_first_changed, 12, hipMemcpyDeviceToHost, s));
+        // (control words at b_misc + 32 .. 44, the evaluation counter at b_misc + 128: one copy brings both, the counter of the
+        // last sweep is the call's)
+        HIPCHK(c, hipMemcpyAsync(c->h_pin, d_first_changed, 104, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         sweeps++;
         if (sweeps > 4 * n + 64) return ioc_fail(c, IOC_ERR_STATE, "resolve did not converge");
@@ -1110,8 +1129,8 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     }
     HIPCHK(c, hipEventRecord(c->ev[5], s));
     unsigned long long ev = 0;
-    HIPCHK(c, hipMemcpyAsync(&ev, d_evals, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (sweeps > 0) memcpy(&ev, const_cast<uint32_t*>(static_cast<volatile uint32_t*>(c->h_pin)) + 24, 8);
+    if (sharded) HIPCHK(c, hipStreamSynchronize(s));  // (the gathers above)
     c->tm.n_mapped_evals = int64_t(ev);
     if (diag) {
         unsigned long long d[8];
@@ -1137,10 +1156,32 @@ int ioc_get_decisions(ioc_ctx* c, int32_t* target, int8_t* strand, uint8_t* flag
     const size_t n = size_t(c->n);
     hipStream_t s = c->stream;
     if (n == 0) return IOC_OK;
-    if (target) HIPCHK(c, hipMemcpyAsync(target, c->b_dec_target.p, n * 4, hipMemcpyDeviceToHost, s));
-    if (strand) HIPCHK(c, hipMemcpyAsync(strand, c->b_dec_strand.p, n, hipMemcpyDeviceToHost, s));
-    if (flags) HIPCHK(c, hipMemcpyAsync(flags, c->b_flags.p, n, hipMemcpyDeviceToHost, s));
+    // (through pinned memory: three pageable read-backs cost 40 us of host time between them, once per resolve)
+    const size_t need_b = n * 6 + 64;
+    if (c->h_pin_big_cap < need_b) {
+        if (c->h_pin_big) (void)hipHostFree(c->h_pin_big);
+        c->h_pin_big = nullptr;
+        c->h_pin_big_cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pin_big), need_b * 2, hipHostMallocDefault) == hipSuccess)
+            c->h_pin_big_cap = need_b * 2;
+        else
+            (void)hipGetLastError();
+    }
+    if (!c->h_pin_big) {
+        if (target) HIPCHK(c, hipMemcpyAsync(target, c->b_dec_target.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (strand) HIPCHK(c, hipMemcpyAsync(strand, c->b_dec_strand.p, n, hipMemcpyDeviceToHost, s));
+        if (flags) HIPCHK(c, hipMemcpyAsync(flags, c->b_flags.p, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return IOC_OK;
+    }
+    uint8_t* st = c->h_pin_big;
+    if (target) HIPCHK(c, hipMemcpyAsync(st, c->b_dec_target.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (strand) HIPCHK(c, hipMemcpyAsync(st + n * 4, c->b_dec_strand.p, n, hipMemcpyDeviceToHost, s));
+    if (flags) HIPCHK(c, hipMemcpyAsync(st + n * 5, c->b_flags.p, n, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (target) memcpy(target, st, n * 4);
+    if (strand) memcpy(strand, st + n * 4, n);
+    if (flags) memcpy(flags, st + n * 5, n);
     return IOC_OK;
 }
 
@@ -1628,9 +1669,8 @@ int ioc_get_timings(ioc_ctx* c, ioc_timings* out)
     float ms = 0;
     c->tm.score_oob = c->score_oob;
     c->tm.score_oob_probe = c->score_oob_probe;
-    if (c->built && c->n_post < 0 && c->b_off.p) {  // (the sorted build does not read its postings count back)
-        uint32_t t = 0;
-        HIPCHK(c, hipMemcpy(&t, P<uint32_t>(c->b_off) + size_t(c->cap) + 1, 4, hipMemcpyDeviceToHost));
+    if (c->built && c->n_post < 0 && c->b_off.p) {  // (the sorted build does not wait for its postings count: it lands in pinned memory)
+        const uint32_t t = static_cast<volatile uint32_t*>(c->h_pin)[40];
         c->n_post = t;
         c->tm.n_index_postings = t;
     }

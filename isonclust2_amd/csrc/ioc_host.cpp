@@ -950,12 +950,16 @@ int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_c
     if (!c->have_params) return ioc_fail(c, IOC_ERR_STATE, "ioc_set_params first");
     const int n = c->n;
     std::vector<uint8_t> gated(size_t(n) + 1, 0);
-    std::vector<uint32_t> need(size_t(n) + 1, 0);
-    // thresholds live on the device; the tie replay needs them on the host
-    if (n > 0) {
-        hipError_t e = hipMemcpy(need.data(), c->d_min_total, size_t(n) * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
+    // thresholds live on the device; the tie replay needs them on the host: fetched once per set of queries
+    if (c->h_min_total_gen != c->query_gen || c->h_min_total.size() != size_t(n) + 1) {
+        c->h_min_total.assign(size_t(n) + 1, 0);
+        if (n > 0) {
+            hipError_t e = hipMemcpy(c->h_min_total.data(), c->d_min_total, size_t(n) * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return ioc_fail(c, IOC_ERR_HIP, hipGetErrorString(e));
+        }
+        c->h_min_total_gen = c->query_gen;
     }
+    const std::vector<uint32_t>& need = c->h_min_total;
     if (c->params.mode == IOC_MODE_FURIOUS || c->params.mode == IOC_MODE_NONE)
         return ioc_fail(c, IOC_ERR_STATE, "ioc_cluster_resident runs fast and sahlin mode: use ioc_cluster_batch for furious / none");
     if (c->params.mode == IOC_MODE_SAHLIN) {

@@ -92,6 +92,11 @@ struct ioc_ctx {
     std::vector<int32_t> h_forced_t;
     std::vector<int8_t> h_forced_s;
     bool forced_dirty = false;
+    bool forced_host_clear = false, forced_dev_clear = false;  // nothing forced in the host arrays / in what the device holds (no upload then)
+    std::vector<uint32_t> h_min_total;  // host copy of d_min_total for ioc_cluster_resident's tie replays, of queries `h_min_total_gen`
+    uint64_t h_min_total_gen = ~0ull;
+    uint8_t* h_pin_big = nullptr;   // pinned staging for the per-call read-backs of n-sized arrays (decisions)
+    size_t h_pin_big_cap = 0;
 
     // ---- extraction (K1) outputs ----
     DevBuf x_min, x_pos, x_off_fwd, x_off_rev, x_hpc_len, x_hseq, x_hqual;

@@ -68,8 +68,11 @@ struct DecideArgs {
 #endif
 
 extern "C" {
+// pk / pv (optional): the sorted index build's (value, target) pairs of the queries, target0 + j for query j, `sentinel` keys behind a
+// query's distinct values; *pairs_written says whether the kernel that ran wrote them (the bitonic fallback does not)
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
-                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits);
+                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits, uint32_t* pk = nullptr, void* pv = nullptr,
+                         int pv16 = 0, uint32_t target0 = 0, uint32_t sentinel = 0, int* pairs_written = nullptr);
 hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
                                     const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
                                     uint32_t* cnt, uint32_t* dslot, uint32_t* dpos, uint32_t* err);
@@ -152,6 +155,7 @@ extern "C" Epochs iock_epoch_bounds(uint32_t L, uint32_t n);
 
 // ---- index build without global atomics (ioc_build_sort.hip) ----
 struct IocBuildSort {
+    int pairs_done = 0;  // the queries' pairs are in pk_in / pv_in already (written by k_distinct_radix)
     int n;                        // queries
     uint32_t L;                   // left clusters: query j is target L + j
     const int64_t* doff;          // [n + 1] capacity offsets of the queries' distinct lists

@@ -205,7 +205,7 @@ k_distinct(int n, const int64_t* __restrict__ off_fwd, const uint32_t* __restric
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_distinct_radix(int n, const int64_t* __restrict__ off_fwd, const uint32_t* __restrict__ mins,
                  const int64_t* __restrict__ doff, uint32_t* __restrict__ dvals, uint32_t* __restrict__ dcount,
-                 uint32_t pmax, int passes)
+                 uint32_t pmax, int passes, uint32_t* __restrict__ pk, void* __restrict__ pv, int pv16, uint32_t target0, uint32_t sentinel)
 {
     extern __shared__ uint32_t s[];  // pmax words
     __shared__ uint32_t hist[IOC_WAVES][256];
@@ -290,15 +290,32 @@ k_distinct_radix(int n, const int64_t* __restrict__ off_fwd, const uint32_t* __r
     // 0xFFFFFFFF started behind every value and a stable sort leaves it behind the values it ties with)
     uint32_t base = 0;
     uint32_t* out = dvals + doff[j];
+    // (pk: the sorted index build's (value, target) pairs of this query, written here instead of by a kernel of their own; the
+    // unused tail of the query's stretch carries the sentinel key)
+    uint32_t* pko = pk ? pk + doff[j] : nullptr;
     for (uint32_t c = 0; c < m; c += IOC_BLOCK) {
         const uint32_t i = c + threadIdx.x;
         const uint32_t flag = (i < m) && (i == 0 || s[i] != s[i - 1]);
         uint32_t tot;
         const uint32_t ex = block_excl_scan(flag, tot, sh);
-        if (flag) out[base + ex] = s[i];
+        if (flag) {
+            out[base + ex] = s[i];
+            if (pko) pko[base + ex] = s[i];
+        }
         base += tot;
     }
     if (threadIdx.x == 0) dcount[j] = base;
+    if (pko) {
+        for (uint32_t d = base + threadIdx.x; d < m; d += IOC_BLOCK) pko[d] = sentinel;
+        const uint32_t t = target0 + uint32_t(j);
+        if (pv16) {
+            uint16_t* o = static_cast<uint16_t*>(pv) + doff[j];
+            for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) o[d] = uint16_t(t);
+        } else {
+            uint32_t* o = static_cast<uint32_t*>(pv) + doff[j];
+            for (uint32_t d = threadIdx.x; d < m; d += IOC_BLOCK) o[d] = t;
+        }
+    }
 }
 
 // =====================================================================================================
@@ -2383,8 +2400,10 @@ hipError_t iock_lds_oob_probe(hipStream_t st, uint32_t* d_result /* 2 words, zer
 
 
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
-                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits)
+                         uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits, uint32_t* pk, void* pv, int pv16, uint32_t target0,
+                         uint32_t sentinel, int* pairs_written)
 {
+    if (pairs_written) *pairs_written = 0;
     if (n <= 0) return hipSuccess;
     size_t lds = size_t(pmax) * 4;
     const bool radix = !(getenv("IOC_DISTINCT_BITONIC") && atoi(getenv("IOC_DISTINCT_BITONIC")) == 1);  // (=1: round 1's bitonic network, for comparison)
@@ -2393,7 +2412,9 @@ hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const ui
         lds = size_t(pm) * 4;
         const int bits = value_bits < 1 ? 32 : (value_bits > 32 ? 32 : value_bits);
         if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_distinct_radix, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        hipLaunchKernelGGL(k_distinct_radix, dim3(n), dim3(IOC_BLOCK), lds, st, n, off_fwd, mins, doff, dvals, dcount, pm, (bits + 7) / 8);
+        hipLaunchKernelGGL(k_distinct_radix, dim3(n), dim3(IOC_BLOCK), lds, st, n, off_fwd, mins, doff, dvals, dcount, pm, (bits + 7) / 8, pk, pv, pv16,
+                           target0, sentinel);
+        if (pairs_written && pk) *pairs_written = 1;
         return hipGetLastError();
     }
     if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_distinct, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
