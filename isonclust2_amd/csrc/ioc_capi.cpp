@@ -598,24 +598,24 @@ int ioc_index_build(ioc_ctx* c)
         uint32_t nslots = cap + 1;
         // (every pair + the padding of as many lists as the table is sized for; more lists than that: the slow way round below)
         const size_t post_ub = size_t(NP) + size_t(pmask) * std::min<size_t>(size_t(NP), size_t(cap) / 2 + 1) + 64;
-        auto table = [&](uint32_t slots) -> int {
+        // (the table, the counters, the per-key query info, the control words and the postings are cleared by ONE launch)
+        auto table = [&](uint32_t slots, size_t post_bytes) -> int {
             RESERVE(c, c->b_keys, size_t(slots) * 4);
             RESERVE(c, c->b_cnt, size_t(slots + 1) * 4);
             RESERVE(c, c->b_off, size_t(slots + 1) * 4);
             RESERVE(c, c->b_rows, size_t(slots) * 16);
             RESERVE(c, c->b_qinfo, size_t(slots) * 8);
-            HIPCHK(c, hipMemsetAsync(c->b_keys.p, 0xFF, size_t(slots) * 4, s));
-            HIPCHK(c, hipMemsetAsync(c->b_cnt.p, 0, size_t(slots + 1) * 4, s));
-            HIPCHK(c, hipMemsetAsync(c->b_qinfo.p, 0, size_t(slots) * 8, s));
-            HIPCHK(c, hipMemsetAsync(c->b_misc.p, 0, 256, s));
+            if (post_bytes) RESERVE(c, c->b_post, post_bytes);
+            void* ptrs[5] = {c->b_keys.p, c->b_cnt.p, c->b_qinfo.p, c->b_misc.p, c->b_post.p};
+            const size_t bytes[5] = {size_t(slots) * 4, size_t(slots + 1) * 4, size_t(slots) * 8, 256, post_bytes};
+            const uint32_t vals[5] = {0xFFFFFFFFu, 0u, 0u, 0u, 0xFFFFFFFFu};
+            HIPCHK(c, iock_fill_multi(s, post_bytes ? 5 : 4, ptrs, bytes, vals));
             return IOC_OK;
         };
         {
-            const int rt = table(nslots);
+            const int rt = table(nslots, (post_ub * psize + 256 + 3) & ~size_t(3));
             if (rt != IOC_OK) return rt;
         }
-        RESERVE(c, c->b_post, post_ub * psize + 256);
-        HIPCHK(c, hipMemsetAsync(c->b_post.p, 0xFF, post_ub * psize + 256, s));
         HIPCHK(c, iock_build_sort_phase1(s, &a));
         HIPCHK(c, hipMemcpyAsync(c->h_pin + 8, a.ctl, 8, hipMemcpyDeviceToHost, s));  // real pairs, runs = distinct keys
         HIPCHK(c, hipStreamSynchronize(s));
@@ -629,7 +629,7 @@ int ioc_index_build(ioc_ctx* c)
         if (2.0 * double(R) > double(cap)) {  // (more distinct keys than the k-mer space suggested: a larger table)
             cap = pow2_at_least(2.0 * double(R));
             nslots = cap + 1;
-            const int rt = table(nslots);
+            const int rt = table(nslots, 0);
             if (rt != IOC_OK) return rt;
         }
         uint32_t bits = 0;

@@ -79,6 +79,9 @@ hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, 
 hipError_t iock_hash_insert_left(hipStream_t st, int64_t nkeys, const uint32_t* lkeys, const int64_t* loffs,
                                  uint32_t* keys, uint32_t cap, uint32_t shift, uint32_t* cnt, uint32_t* lslot,
                                  uint32_t* err);
+// up to IOC_FILL_SEGS buffers (16-byte aligned, whole 32-bit words) filled with a 32-bit value each by one launch
+#define IOC_FILL_SEGS 6
+hipError_t iock_fill_multi(hipStream_t st, int nseg, void* const* ptrs, const size_t* bytes, const uint32_t* values);
 hipError_t iock_exclusive_scan(hipStream_t st, const uint32_t* in, int64_t n, uint32_t* out, uint32_t* scratch,
                                uint32_t round_mask);
 hipError_t iock_fill_left(hipStream_t st, int64_t nkeys, const int64_t* loffs, const uint32_t* lpost,

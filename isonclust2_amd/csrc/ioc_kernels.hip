@@ -2561,6 +2561,53 @@ hipError_t iock_gather_lists(hipStream_t st, uint32_t nlists, const int64_t* src
     return hipGetLastError();
 }
 
+// several buffers filled by ONE launch (the index build clears five: each memset is a launch of its own otherwise)
+struct FillSegs {
+    uint32_t* p[IOC_FILL_SEGS];
+    unsigned long long words[IOC_FILL_SEGS];  // 32-bit words
+    uint32_t value[IOC_FILL_SEGS];
+    unsigned long long first_block[IOC_FILL_SEGS + 1];  // blocks are dealt out in proportion to the segments' sizes
+};
+constexpr unsigned long long FILL_WORDS_PER_BLOCK = 256ull * 4ull * 8ull;  // 256 threads x uint4 x 8
+__global__ void __launch_bounds__(256) k_fill_multi(FillSegs f)
+{
+    int sgm = 0;
+#pragma unroll
+    for (int x = 1; x < IOC_FILL_SEGS; ++x)
+        if (blockIdx.x >= f.first_block[x]) sgm = x;
+    const unsigned long long b = blockIdx.x - f.first_block[sgm];
+    uint32_t* p = f.p[sgm];
+    const unsigned long long nw = f.words[sgm];
+    const uint32_t v = f.value[sgm];
+    const unsigned long long w0 = b * FILL_WORDS_PER_BLOCK, w1 = min(nw, w0 + FILL_WORDS_PER_BLOCK);
+    // (the buffers are 256-byte aligned device allocations: uint4 stores over whole quads, words behind them)
+    const unsigned long long q0 = w0 / 4, q1 = w1 / 4;
+    for (unsigned long long q = q0 + threadIdx.x; q < q1; q += 256) reinterpret_cast<uint4*>(p)[q] = uint4{v, v, v, v};
+    for (unsigned long long w = q1 * 4 + threadIdx.x; w < w1; w += 256) p[w] = v;
+}
+
+hipError_t iock_fill_multi(hipStream_t st, int nseg, void* const* ptrs, const size_t* bytes, const uint32_t* values)
+{
+    if (nseg < 1 || nseg > IOC_FILL_SEGS) return hipErrorInvalidValue;
+    FillSegs f{};
+    unsigned long long blocks = 0;
+    for (int x = 0; x < IOC_FILL_SEGS; ++x) {
+        f.first_block[x] = blocks;
+        if (x < nseg) {
+            if ((bytes[x] & 3u) || (reinterpret_cast<uintptr_t>(ptrs[x]) & 15u)) return hipErrorInvalidValue;
+            f.p[x] = static_cast<uint32_t*>(ptrs[x]);
+            f.words[x] = bytes[x] / 4;
+            f.value[x] = values[x];
+            blocks += (f.words[x] + FILL_WORDS_PER_BLOCK - 1) / FILL_WORDS_PER_BLOCK;
+        }
+    }
+    f.first_block[IOC_FILL_SEGS] = blocks;
+    if (blocks == 0) return hipSuccess;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fill_multi, dim3(unsigned(blocks)), dim3(256), 0, st, f);
+    return hipGetLastError();
+}
+
 hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys, const uint32_t* off,
                           const uint32_t* cnt, const uint32_t* qinfo, void* rows)
 {
