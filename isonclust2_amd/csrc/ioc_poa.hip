@@ -108,6 +108,7 @@ __global__ void k_poa_init(const PoaJob* __restrict__ jobs)
 }
 
 using GI32 = __attribute__((address_space(1))) int32_t;
+using LI32 = __attribute__((address_space(3))) int32_t;  // (LDS: a generic pointer would make the access a FLAT one)
 using GU32 = __attribute__((address_space(1))) uint32_t;
 using GU8 = __attribute__((address_space(1))) uint8_t;
 
@@ -150,12 +151,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __global__ void __launch_bounds__(POA_THREADS)
 k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
 {
-    __shared__ int sH[POA_RING][POA_CB], sF1[POA_RING][POA_CB], sF2[POA_RING][POA_CB];
+    __shared__ int sRing[3][POA_RING][POA_CB];  // H, F1, F2 (one array: one address register, the planes are immediate offsets)
+#define sH sRing[0]
+#define sF1 sRing[1]
+#define sF2 sRing[2]
     __shared__ int4 s_carry[POA_WAVES][POA_RB];  // [0]: from the tile on the left; [w]: from wave w - 1
     __shared__ int s_poff[POA_RB + 2];
     __shared__ int s_pred[POA_PRED_LDS], s_pslot[POA_PRED_LDS];
     __shared__ int s_base[POA_RB + 1], s_slot[POA_RB + 1];  // (one past the last row: read ahead, never used)
     __shared__ int s_red[3 * POA_WAVES];
+    __shared__ int s_done[POA_WAVES];  // rows of the tile wave w has finished
     const PoaJob J = jobs[blockIdx.y];
     const int R = J.R, L = J.L, nrb = J.nrb;
     const int cb_first = max(0, diag - nrb + 1), cb_last = min(J.ncb - 1, diag);
@@ -184,6 +189,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     // ---- the tile's rows: predecessor lists, bases, carries of the tile on the left ----
     const int nrows = r_hi - r_lo + 1;
     const int pb0 = pred_off[r_lo];
+    if (tid < POA_WAVES) s_done[tid] = 0;
     for (int t = tid; t <= nrows; t += POA_THREADS) s_poff[t] = pred_off[r_lo + t];
     if (tid == 0) s_poff[nrows + 1] = 0;
     for (int t = tid; t < nrows; t += POA_THREADS) {
@@ -212,9 +218,19 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
 #else
 #define POA_TICK(k)
 #endif
-    for (int s = 0; s < nrows + POA_WAVES - 1; ++s) {
-        const int t = s - wave;
-        if (t >= 0 && t < nrows) {  // (uniform in the wave)
+    // The waves are a pipeline, not a phalanx: wave w needs of row t only the carry wave w - 1 wrote when IT finished row t, so
+    // it waits for that (s_done[w - 1] > t: a counter in LDS next to the carries) instead of meeting all four waves at a barrier
+    // after every row — a third of a tile's time was spent at that barrier waiting for whichever wave the scheduler had served
+    // last.  Wave 0 never waits (its carries come from the tile on the left), so every wait ends.
+    for (int t = 0; t < nrows; ++t) {
+        if (wave > 0) {
+            // (plain LDS traffic: a wave's LDS operations are carried out in program order, a fence of the memory model would also
+            // wait for the row's global stores)
+            while (*(volatile LI32*)(LI32*)&s_done[wave - 1] <= t) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
+        POA_TICK(3)
+        {
             const int r = r_lo + t;
             const int4 cin = s_carry[wave][t];
             const int pe_nv = s_poff[t + 2];  // (made uniform at the end of the step: no wait for it up here)
@@ -235,20 +251,15 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     const int hu = sH[slp][tid], u1 = sF1[slp][tid], u2 = sF2[slp][tid];
                     const int edge = s_carry[wave][t - 1].w;
                     const int hl = __builtin_amdgcn_update_dpp(edge, hu, 0x138, 0xf, 0xf, false);  // wave_shr:1
-                    if (j > 0) {
-                        const int hd = hl + sc;
-                        if (hd > dg) dg = hd;
-                    }
-                    const int o1 = hu + S.g, x1 = u1 + S.e, v1 = max(o1, x1);
-                    if (v1 > f1) {
-                        f1 = v1;
-                        f1x = x1 > o1 ? 1u : 0u;
-                    }
-                    const int o2 = hu + S.q, x2 = u2 + S.c, v2 = max(o2, x2);
-                    if (v2 > f2) {
-                        f2 = v2;
-                        f2x = x2 > o2 ? 1u : 0u;
-                    }
+                    // (H of a row is >= 0: hl + sc, hu + g and hu + q are far above POA_NEG, the general loop's "is it better
+                    // than nothing" tests are true here)
+                    if (j > 0) dg = hl + sc;
+                    const int o1 = hu + S.g, x1 = u1 + S.e;
+                    f1 = max(o1, x1);
+                    f1x = x1 > o1 ? 1u : 0u;
+                    const int o2 = hu + S.q, x2 = u2 + S.c;
+                    f2 = max(o2, x2);
+                    f2x = x2 > o2 ? 1u : 0u;
                 } else {
                 // plane row of predecessor entry x (only the memory paths ask: a row read from memory is a kept one)
                 auto pslot_of = [&](int x) {
@@ -345,8 +356,9 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             int h = hn;
             uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
             if (j > 0) {
-                const int e1 = ex > POA_NEG / 2 ? ex + S.g + (j - 1) * S.e : POA_NEG;
-                const int e2 = ey > POA_NEG / 2 ? ey + S.q + (j - 1) * S.c : POA_NEG;
+                // (ex / ey are real prefix maxima here: the one POA_NEG, the left edge of the matrix, meets column 0 only)
+                const int e1 = ex + S.g + (j - 1) * S.e;
+                const int e2 = ey + S.q + (j - 1) * S.c;
                 const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
                 const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
                 if (e1 > h) {
@@ -395,14 +407,19 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             bs = bs_n;
             pr0 = pr0_n;
             my_slot = slot_n;
+            if (wave < POA_WAVES - 1) {  // the carry of row t is in LDS (this wave's LDS writes land in program order): say so
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *(volatile LI32*)(LI32*)&s_done[wave] = t + 1;
+            }
             POA_TICK(2)
         }
-        lds_barrier();  // the carries of this step's rows are in LDS before the waves on the right start them
-        POA_TICK(3)
     }
+#undef sH
+#undef sF1
+#undef sF2
 #ifdef POA_PROF
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && diag == 10)
-        printf("tile profile (wave 0, %d rows): predecessors %llu, scan + E %llu, stores %llu, barrier %llu cycles\n", nrows, tp[0], tp[1], tp[2], tp[3]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && diag == 10)
+        printf("tile profile (wave %d, %d rows): predecessors %llu, scan + E %llu, stores %llu, waiting for the wave on the left %llu cycles\n", wave, nrows, tp[0], tp[1], tp[2], tp[3]);
 #endif
     // ---- the tile's best cell: maximum score, ties to the smallest row, then the smallest column ----
     auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
