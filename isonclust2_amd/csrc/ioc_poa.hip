@@ -161,6 +161,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     __shared__ int s_base[POA_RB + 1], s_slot[POA_RB + 1];  // (one past the last row: read ahead, never used)
     __shared__ int s_red[3 * POA_WAVES];
     __shared__ int s_done[POA_WAVES];  // rows of the tile wave w has finished
+    __shared__ int4 s_rec[POA_RB + 1];  // per row: end of its predecessor list, base, plane row, first predecessor — what a wave fetches one row ahead
     const PoaJob J = jobs[blockIdx.y];
     const int R = J.R, L = J.L, nrb = J.nrb;
     const int cb_first = max(0, diag - nrb + 1), cb_last = min(J.ncb - 1, diag);
@@ -192,9 +193,11 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     if (tid < POA_WAVES) s_done[tid] = 0;
     for (int t = tid; t <= nrows; t += POA_THREADS) s_poff[t] = pred_off[r_lo + t];
     if (tid == 0) s_poff[nrows + 1] = 0;
+    if (tid == 0) s_rec[nrows] = int4{0, 0, 0, 0};  // (read ahead by the last row, never used)
     for (int t = tid; t < nrows; t += POA_THREADS) {
         s_base[t] = ((const GU8*)J.base)[r_lo + t];
         s_slot[t] = ((const GI32*)J.slot)[r_lo + t];
+        s_rec[t] = int4{pred_off[r_lo + t + 1], int(((const GU8*)J.base)[r_lo + t]), ((const GI32*)J.slot)[r_lo + t], pred[pred_off[r_lo + t]]};
         const GI32* ci = cin_row + int64_t(r_lo + t) * 4;
         s_carry[0][t] = cb > 0 ? int4{ci[0], ci[1], ci[2], ci[3]} : int4{POA_NEG, POA_NEG, 0, 0};
     }
@@ -210,8 +213,9 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     __syncthreads();
     int my_best = 0, my_r = 0, my_j = 0;
     // what the wave's next row starts with, fetched one step ahead: list bounds, base, first predecessor
-    int pb = __builtin_amdgcn_readfirstlane(s_poff[0]), pe = __builtin_amdgcn_readfirstlane(s_poff[1]), bs = s_base[0], pr0 = s_pred[0];
-    int my_slot = s_slot[0];
+    int pb = __builtin_amdgcn_readfirstlane(s_poff[0]), pe = __builtin_amdgcn_readfirstlane(s_poff[1]), bs = s_rec[0].y, pr0 = s_rec[0].w;
+    int my_slot = s_rec[0].z;
+    int edge_prev = 0;  // H of the column left of this wave's first, one row up (the previous row's carry)
 #ifdef POA_PROF
     unsigned long long tp[4] = {0, 0, 0, 0}, tp_t = __builtin_readcyclecounter();
 #define POA_TICK(k) { const unsigned long long t_ = __builtin_readcyclecounter(); tp[k] += t_ - tp_t; tp_t = t_; }
@@ -233,10 +237,8 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
         {
             const int r = r_lo + t;
             const int4 cin = s_carry[wave][t];
-            const int pe_nv = s_poff[t + 2];  // (made uniform at the end of the step: no wait for it up here)
-            const int bs_n = s_base[t + 1];
-            const int slot_n = s_slot[t + 1];
-            const int pr0_n = s_pred[min(pe - pb0, pred_lds - 1)];
+            const int4 nx = s_rec[t + 1];  // the next row (made uniform at the end of the step: no wait for it up here)
+            const int pe_nv = nx.x, bs_n = nx.y, slot_n = nx.z, pr0_n = nx.w;
             int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
             uint32_t d = SRC_STOP;
             {
@@ -249,8 +251,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     // loop below spends more time in its branches than in its arithmetic); same values bit for bit
                     const int slp = (r - 1) & (POA_RING - 1);
                     const int hu = sH[slp][tid], u1 = sF1[slp][tid], u2 = sF2[slp][tid];
-                    const int edge = s_carry[wave][t - 1].w;
-                    const int hl = __builtin_amdgcn_update_dpp(edge, hu, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    const int hl = __builtin_amdgcn_update_dpp(edge_prev, hu, 0x138, 0xf, 0xf, false);  // wave_shr:1
                     // (H of a row is >= 0: hl + sc, hu + g and hu + q are far above POA_NEG, the general loop's "is it better
                     // than nothing" tests are true here)
                     if (j > 0) dg = hl + sc;
@@ -402,6 +403,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     co[3] = h;
                 }
             }
+            edge_prev = cin.w;
             pb = pe;
             pe = __builtin_amdgcn_readfirstlane(pe_nv);
             bs = bs_n;
