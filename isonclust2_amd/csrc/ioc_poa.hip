@@ -131,6 +131,21 @@ __device__ __forceinline__ int wave_prefix_max(int v)
     v = max(v, dpp_or_self<0x143, 0xc>(v));
     return v;
 }
+__device__ __forceinline__ void wave_prefix_max2(int& a, int& b)
+{
+    a = max(a, dpp_or_self<0x111>(a));
+    b = max(b, dpp_or_self<0x111>(b));
+    a = max(a, dpp_or_self<0x112>(a));
+    b = max(b, dpp_or_self<0x112>(b));
+    a = max(a, dpp_or_self<0x114>(a));
+    b = max(b, dpp_or_self<0x114>(b));
+    a = max(a, dpp_or_self<0x118>(a));
+    b = max(b, dpp_or_self<0x118>(b));
+    a = max(a, dpp_or_self<0x142, 0xa>(a));
+    b = max(b, dpp_or_self<0x142, 0xa>(b));
+    a = max(a, dpp_or_self<0x143, 0xc>(a));
+    b = max(b, dpp_or_self<0x143, 0xc>(b));
+}
 // LDS traffic of this wave done, then the workgroup barrier: global stores stay in flight (a __syncthreads
 // would wait for the five stores of every row)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -242,7 +257,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
             uint32_t d = SRC_STOP;
             {
-                uint32_t dp = 0, f1p = 0, f2p = 0, f1x = 0, f2x = 0;
+                uint32_t pw = 0, f1x = 0, f2x = 0;  // pw: the predecessors the three moves came from (0 on a chain row)
                 int dg = POA_NEG;
                 const int sc = (bs == my_base) ? S.m : S.n;
                 const int pr0u = __builtin_amdgcn_readfirstlane(pr0);
@@ -262,6 +277,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     f2 = max(o2, x2);
                     f2x = x2 > o2 ? 1u : 0u;
                 } else {
+                uint32_t dp = 0, f1p = 0, f2p = 0;
                 // plane row of predecessor entry x (only the memory paths ask: a row read from memory is a kept one)
                 auto pslot_of = [&](int x) {
                     int v = s_pslot[min(x - pb0, pred_lds - 1)];
@@ -332,6 +348,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                         f2x = x2 > o2 ? 1u : 0u;
                     }
                 }
+                pw = (dp << 9) | (f1p << 16) | (f2p << 23);
                 }
                 if (dg > hn) {
                     hn = dg;
@@ -345,12 +362,15 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     hn = f2;
                     d = SRC_F2;
                 }
-                d |= (f1x << 7) | (f2x << 8) | (dp << 9) | (f1p << 16) | (f2p << 23);
+                d |= (f1x << 7) | (f2x << 8) | pw;
             }
             POA_TICK(0)
             // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
-            const int vx = max(wave_prefix_max(active ? hn - S.e * j : POA_NEG), cin.x);
-            const int vy = max(wave_prefix_max(active ? hn - S.c * j : POA_NEG), cin.y);
+            // (the two scans stage by stage side by side: a wave issues in order, and every stage waits for the one before it)
+            int sx = active ? hn - S.e * j : POA_NEG, sy = active ? hn - S.c * j : POA_NEG;
+            wave_prefix_max2(sx, sy);
+            const int vx = max(sx, cin.x);
+            const int vy = max(sy, cin.y);
             const int ex = __builtin_amdgcn_update_dpp(cin.x, vx, 0x138, 0xf, 0xf, false);  // wave_shr:1: the lane on the left
             const int ey = __builtin_amdgcn_update_dpp(cin.y, vy, 0x138, 0xf, 0xf, false);
             const int left = __builtin_amdgcn_update_dpp(cin.z, hn, 0x138, 0xf, 0xf, false);
