@@ -27,6 +27,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "cer.hpp"
@@ -216,17 +217,22 @@ static int main_sort(int argc, char** argv)
         unsigned long long seek = 0;
         for (auto& r : reads) {
             if (r.score < 0) continue;
-            tsv << r.name << "\t" << seek << endl;
+            tsv << r.name << "\t" << seek << "\n";  // (the same bytes as endl, without a write() per read)
             fq << "@" << r.name << "\n" << r.seq << "\n+\n" << r.qual << "\n";
             seek += r.name.size() + r.seq.size() + r.qual.size() + 6;
         }
         save_sorted_idx(sorted, a.BatchOutFolder + "/sorted_reads_idx.cer");
         create_file(a.BatchOutFolder + "/scores.tsv", sc);
-        for (auto& r : reads) sc << r.name << "\t" << r.score << endl;
+        for (auto& r : reads) sc << r.name << "\t" << r.score << "\n";
     }
 
     // ---- batches (main.cpp:149-199) ----
+    // The batches are independent once the reads are sorted: the extraction of a batch runs on the one context (a mutex around
+    // the three calls), the assembly of its records and its file are built by worker threads side by side (IOC_SORT_THREADS,
+    // default 6: the 64 batches of a 2 M-read file took 29 s one after the other).
+    std::mutex ctx_mu, log_mu;
     auto write_batch = [&](int start, int end, unsigned long bases, int nr) {
+        std::unique_lock<std::mutex> dev(ctx_mu);
         const int m = end - start + 1;
         std::vector<int64_t> bo(static_cast<size_t>(m) + 1, 0);
         for (int i = 0; i < m; ++i) bo[size_t(i) + 1] = bo[size_t(i)] + int64_t(reads[size_t(start + i)].seq.size());
@@ -246,6 +252,7 @@ static int main_sort(int argc, char** argv)
         check(c, ioc_extracted_download(c, mv.data(), mp.data(), tot + 1), "minimizer download");
         std::vector<char> hs(static_cast<size_t>(bo[size_t(m)]) + 1), hq(static_cast<size_t>(bo[size_t(m)]) + 1);
         check(c, ioc_extracted_hpc_download(c, hs.data(), hq.data(), int64_t(hs.size())), "hpc download");
+        dev.unlock();
         Batch b;
         b.Cls.resize(size_t(m));
         for (int i = 0; i < m; ++i) {
@@ -288,23 +295,47 @@ static int main_sort(int argc, char** argv)
         b.SortArgs = a;
         string err;
         if (!save_batch(b, batch_dir + "/isONbatch_" + std::to_string(nr) + ".cer", err)) die(err);
-        if (VERBOSE)
+        if (VERBOSE) {
+            std::lock_guard<std::mutex> lk(log_mu);
             cerr << "\tWritten batch " << nr << " with " << m << " sequences and " << int(double(bases) / 1000.0) << " kilobases." << endl;
+        }
     };
+    struct Range {
+        int start, end;
+        unsigned long bases;
+        int nr;
+    };
+    std::vector<Range> ranges;
     unsigned long batch_bases = 0;
     int batch_seqs = 0, nr_batches = 0, batch_start = 0;
     for (int i = 0; i < n; ++i) {
         batch_bases += reads[size_t(i)].seq.size();
         batch_seqs++;
         if (a.BatchSize > 0 && (batch_bases > (unsigned long)(a.BatchSize) * 1000ul || (a.BatchMaxSeq > 0 && batch_seqs >= a.BatchMaxSeq))) {
-            write_batch(batch_start, i, batch_bases, nr_batches);
+            ranges.push_back(Range{batch_start, i, batch_bases, nr_batches});
             batch_bases = 0;
             batch_seqs = 0;
             batch_start = i + 1;
             nr_batches++;
         }
     }
-    if (batch_start < n) write_batch(batch_start, n - 1, batch_bases, nr_batches);
+    if (batch_start < n) ranges.push_back(Range{batch_start, n - 1, batch_bases, nr_batches});
+    {
+        int nt = 6;
+        if (const char* e = getenv("IOC_SORT_THREADS")) nt = std::max(1, atoi(e));
+        nt = std::min<int>(nt, int(ranges.size()));
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t x = next.fetch_add(1); x < ranges.size(); x = next.fetch_add(1)) write_batch(ranges[x].start, ranges[x].end, ranges[x].bases, ranges[x].nr);
+        };
+        if (nt <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(work);
+            for (auto& t : th) t.join();
+        }
+    }
     ioc_ctx_destroy(c);
     return 0;
 }
@@ -850,7 +881,7 @@ static int main_dump(int argc, char** argv)
             s = revcomp(s);
             std::reverse(q.begin(), q.end());
         }
-        tsv << it->second.cls << "\t" << it->second.strand << "\t" << id << endl;
+        tsv << it->second.cls << "\t" << it->second.strand << "\t" << id << "\n";
         per_cluster[it->second.cls] += h + "\n" + s + "\n" + p + "\n" + q + "\n";
     }
     for (auto& kv : per_cluster) {

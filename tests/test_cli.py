@@ -169,3 +169,28 @@ def test_consensus_mode_sort_cluster_merge_dump(tmp_path):
     for g in (ga, gb, gm):
         g.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_sort_writes_the_same_batches_whatever_the_number_of_writer_threads(tmp_path):
+    """`sort` extracts batch by batch on the one context and lets worker threads assemble and write the batch files
+    (IOC_SORT_THREADS): one thread and four must leave the same files.  (A batch file records the output folder: the
+    same folder name for both runs.)"""
+    import filecmp
+    import shutil
+    rs = synth.generate(900, 40, 700, 9, 21, seed=77)
+    fq = tmp_path / "reads.fq"
+    _write_fastq(rs, fq)
+    out = tmp_path / "sorted"
+    kept = {}
+    for nt in ("1", "4"):
+        r = run("sort", "-B", "1000000", "-M", "128", "-o", str(out), str(fq), env=dict(os.environ, IOC_SORT_THREADS=nt))
+        assert r.returncode == 0, r.stderr
+        kept[nt] = tmp_path / ("run" + nt)
+        shutil.move(str(out), str(kept[nt]))
+    names = sorted(os.listdir(kept["1"] / "batches"))
+    assert len(names) == 8 and names == sorted(os.listdir(kept["4"] / "batches"))
+    for sub in [""] + ["batches"]:
+        cmp = filecmp.dircmp(kept["1"] / sub, kept["4"] / sub)
+        match, mismatch, errors = filecmp.cmpfiles(kept["1"] / sub, kept["4"] / sub, cmp.common_files, shallow=False)
+        assert not mismatch and not errors and len(match) == len(cmp.common_files) and not cmp.left_only and not cmp.right_only
