@@ -400,16 +400,26 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             if (lane == 63 && wave < POA_WAVES - 1) s_carry[wave + 1][t] = int4{vx, vy, hn, h};
             if (active) {
                 // (row bases are uniform: scalar arithmetic, the lane adds its 32-bit column offset)
+                // (the row's base stays in scalar registers — the empty asm keeps the compiler from folding it into a per-lane 64-bit
+                // pointer, which costs a 64-bit add or a multiply-add per store —, the lane adds a 32-bit offset: SADDR stores)
                 const int64_t ro = int64_t(r) * W;
                 const int ks = __builtin_amdgcn_readfirstlane(my_slot);
+                // (the lane's 32-bit offsets are made opaque where they are used: hoisted out of the loop their zero extension is a
+                // 64-bit pair in another block, and the store falls back to a 64-bit address per lane)
                 if (ks >= 0) {  // some later row reads this one from memory (it is above that row's tile or out of its ring)
                     const int64_t ko = int64_t(ks) * W;
-                    *(GI32*)((GU8*)(H + ko) + jb4) = h;
-                    *(GI32*)((GU8*)(F1 + ko) + jb4) = f1;
-                    *(GI32*)((GU8*)(F2 + ko) + jb4) = f2;
+                    uint64_t bh = uint64_t(H + ko), b1 = uint64_t(F1 + ko), b2 = uint64_t(F2 + ko);
+                    uint32_t oh = jb4, of1 = jb4, of2 = jb4;
+                    asm volatile("" : "+s"(bh), "+s"(b1), "+s"(b2), "+v"(oh), "+v"(of1), "+v"(of2));
+                    *(GI32*)((GU8*)bh + oh) = h;
+                    *(GI32*)((GU8*)b1 + of1) = f1;
+                    *(GI32*)((GU8*)b2 + of2) = f2;
                 }
-                *(GU32*)((GU8*)(dirs + ro) + jb4) = d;
-                *((ebits + ro) + uint32_t(j)) = uint8_t(eb);
+                uint64_t bd = uint64_t(dirs + ro), be = uint64_t(ebits + ro);
+                uint32_t o4 = jb4, o1 = uint32_t(j);
+                asm volatile("" : "+s"(bd), "+s"(be), "+v"(o4), "+v"(o1));
+                *(GU32*)((GU8*)bd + o4) = d;
+                *((GU8*)be + o1) = uint8_t(eb);
                 if (h > my_best) {  // rows ascend in time: the first row wins ties
                     my_best = h;
                     my_r = r;
