@@ -199,6 +199,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     const bool active = j < W;
     const int jj = min(j, W - 1);  // threads past the last column run along and store nothing
     const uint32_t jb4 = uint32_t(jj) * 4u;  // (W <= 2^20: fits)
+    const int ofs_e = active ? -S.e * j : POA_NEG, ofs_c = active ? -S.c * j : POA_NEG;  // (hn < 2^23: POA_NEG + hn stays an outsider)
     const int r_lo = rb * POA_RB + 1, r_hi = min(R, r_lo + POA_RB - 1);
     const GI32* cin_row = carry + int64_t(max(cb, 1) - 1) * (R + 1) * 4;
     GI32* cout_row = carry + int64_t(cb) * (R + 1) * 4;
@@ -367,8 +368,9 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             POA_TICK(0)
             // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
             // (the two scans stage by stage side by side: a wave issues in order, and every stage waits for the one before it)
-            int sx = active ? hn - S.e * j : POA_NEG, sy = active ? hn - S.c * j : POA_NEG;
+            int sx = hn + ofs_e, sy = hn + ofs_c;  // (hn - e j and hn - c j; far below everything for the lanes past the last column)
             wave_prefix_max2(sx, sy);
+            asm volatile("" : "+v"(sx), "+v"(sy));  // (keeps the last stage a v_max_i32_dpp: merged with the carry into a v_max3 it needs a move and a constant)
             const int vx = max(sx, cin.x);
             const int vy = max(sy, cin.y);
             const int ex = __builtin_amdgcn_update_dpp(cin.x, vx, 0x138, 0xf, 0xf, false);  // wave_shr:1: the lane on the left
@@ -420,10 +422,9 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 asm volatile("" : "+s"(bd), "+s"(be), "+v"(o4), "+v"(o1));
                 *(GU32*)((GU8*)bd + o4) = d;
                 *((GU8*)be + o1) = uint8_t(eb);
-                if (h > my_best) {  // rows ascend in time: the first row wins ties
+                if (h > my_best) {  // rows ascend in time: the first row wins ties (the column is the lane's own: set after the loop)
                     my_best = h;
                     my_r = r;
-                    my_j = j;
                 }
                 if (tid == POA_CB - 1 || j == W - 1) {
                     GI32* co = cout_row + int64_t(r) * 4;
@@ -453,6 +454,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && diag == 10)
         printf("tile profile (wave %d, %d rows): predecessors %llu, scan + E %llu, stores %llu, waiting for the wave on the left %llu cycles\n", wave, nrows, tp[0], tp[1], tp[2], tp[3]);
 #endif
+    if (my_best > 0) my_j = j;
     // ---- the tile's best cell: maximum score, ties to the smallest row, then the smallest column ----
     auto better = [](int s1, int r1, int c1, int s2, int r2, int c2) {
         return s1 > s2 || (s1 == s2 && (r1 < r2 || (r1 == r2 && c1 < c2)));
