@@ -465,6 +465,8 @@ int ioc_poa_last_alignment(ioc_poa* poa, int32_t cap, int32_t* nodes, int32_t* p
  * own): save returns the size (out == NULL to size), load replaces graph (side, idx). */
 int64_t ioc_poa_graph_save(ioc_poa* poa, int side, int idx, uint8_t* out, int64_t cap);
 int ioc_poa_graph_load(ioc_poa* poa, int side, int idx, const uint8_t* in, int64_t len);
+/* count graphs at once (idx[x] <- the blob in[x] of len[x] bytes), parsed on the host's cores; all or none. */
+int ioc_poa_graph_load_many(ioc_poa* poa, int side, int32_t count, const int32_t* idx, const uint8_t* const* in, const int64_t* len);
 
 /* The same pipeline on queries already resident on the device (bench: inputs in HBM). n entries
  * must all be clusterable.  Fast mode, or sahlin mode after ioc_resident_set_sequences. */

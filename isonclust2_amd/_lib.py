@@ -121,7 +121,7 @@ SYMBOLS = [
     "ioc_host_aln_ratio", "ioc_align_set_pool", "ioc_align_pairs", "ioc_set_aln_verdicts", "ioc_get_ties", "ioc_resident_set_sequences",
     "ioc_index_update", "ioc_left_export", "ioc_cluster_consensus",
     "ioc_poa_create", "ioc_poa_destroy", "ioc_poa_bind", "ioc_poa_graph_export", "ioc_poa_last_alignment",
-    "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_gather_records_device", "ioc_queries_generation", "ioc_scored_candidates",
+    "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_poa_graph_load_many", "ioc_gather_records_device", "ioc_queries_generation", "ioc_scored_candidates",
     "ioc_dist_unique_id", "ioc_dist_init", "ioc_dist_shutdown", "ioc_dist_info", "ioc_dist_allgather_device",
     "ioc_dist_allgatherv_device", "ioc_dist_allgather_i64", "ioc_dist_allgatherv_host", "ioc_dist_allreduce_max",
     "ioc_dist_barrier", "ioc_dist_merge", "ioc_set_shard", "ioc_shard_exchanges", "ioc_dist_exchange", "ioc_dist_set_shard", "ioc_align_set_verdict_threshold",
@@ -204,6 +204,7 @@ def load():
     L.ioc_poa_graph_save.argtypes = [vp, C.c_int, C.c_int, pu8, i64]
     L.ioc_poa_graph_save.restype = C.c_int64
     L.ioc_poa_graph_load.argtypes = [vp, C.c_int, C.c_int, pu8, i64]
+    L.ioc_poa_graph_load_many.argtypes = [vp, C.c_int, C.c_int32, C.POINTER(C.c_int32), C.POINTER(pu8), C.POINTER(i64)]
     L.ioc_host_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, i32, i32, C.c_char_p, i32, pi32]
     L.ioc_host_gap_open.argtypes = [C.c_double]
     L.ioc_host_aln_ratio.argtypes = [C.c_char_p, i32, C.c_double, C.c_uint32, C.c_uint32]

@@ -576,12 +576,20 @@ static int main_cluster(int argc, char** argv)
     if (cons_on) {
         if (mode == None) die("Invalid clustering mode: 3");
         check(c, ioc_poa_create(c, 4, -8, -8, -4, -20, -1, &poa), "consensus engine");  // src/main.cpp:285-290
-        for (size_t i = 0; i < left.ConsGs.size() && i < size_t(L); ++i)
-            if (!left.ConsGs[i].empty())
-                check(c, ioc_poa_graph_load(poa, 0, int(i), left.ConsGs[i].data(), int64_t(left.ConsGs[i].size())), "left consensus graph");
-        for (size_t i = 0; i < right.ConsGs.size() && i < size_t(n); ++i)
-            if (!right.ConsGs[i].empty())
-                check(c, ioc_poa_graph_load(poa, 1, int(i), right.ConsGs[i].data(), int64_t(right.ConsGs[i].size())), "right consensus graph");
+        auto load_side = [&](int side, const decltype(left.ConsGs)& gs, size_t limit, const char* what) {
+            std::vector<int32_t> ids;
+            std::vector<const uint8_t*> ptr;
+            std::vector<int64_t> len;
+            for (size_t i = 0; i < gs.size() && i < limit; ++i)
+                if (!gs[i].empty()) {
+                    ids.push_back(int32_t(i));
+                    ptr.push_back(gs[i].data());
+                    len.push_back(int64_t(gs[i].size()));
+                }
+            check(c, ioc_poa_graph_load_many(poa, side, int32_t(ids.size()), ids.data(), ptr.data(), len.data()), what);
+        };
+        load_side(0, left.ConsGs, size_t(L), "left consensus graph");
+        load_side(1, right.ConsGs, size_t(n), "right consensus graph");
         // left clusters without a stored graph (batches clustered without consensus): seeded with the representative
         for (int i = 0; i < L; ++i)
             if (size_t(i) >= left.ConsGs.size() || left.ConsGs[size_t(i)].empty()) {

@@ -1603,9 +1603,9 @@ int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t 
     return need;
 }
 
-int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t len)
+// blob -> graph (pure host code, no shared state: safe on worker threads); 0, or 1 foreign blob / 2 corrupt / 3 cyclic
+static int parse_graph_blob(const uint8_t* in, int64_t len, PGraph& G)
 {
-    if (!p || side < 0 || side > 1 || !in) return IOC_ERR_ARG;
     const uint8_t* q = in;
     const uint8_t* e = in + len;
     bool ok = true;
@@ -1625,12 +1625,11 @@ int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t
     };
     char magic[8];
     get(magic, 8);
-    if (!ok || memcmp(magic, "IOCPOA1", 8) != 0) return ioc_fail(p->ctx, IOC_ERR_INPUT, "not a graph written by this build");
-    PGraph G;
+    if (!ok || memcmp(magic, "IOCPOA1", 8) != 0) return 1;
     G.nseq = get32();
     const int32_t nn = get32(), ne = get32();
-    if (!ok || nn < 0 || ne < 0) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");
-    if (int64_t(nn) > len || int64_t(ne) > len) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");  // (a node takes 5 bytes at least)
+    if (!ok || nn < 0 || ne < 0) return 2;
+    if (int64_t(nn) > len || int64_t(ne) > len) return 2;  // (a node takes 5 bytes at least)
     for (int32_t i = 0; i < nn; ++i) G.add_node(0);
     for (int32_t i = 0; ok && i < nn; ++i) {
         get(&G.base[size_t(i)], 1);
@@ -1655,10 +1654,39 @@ int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t
         }
         G.link_edge(from, to, w);
     }
-    if (!ok) return ioc_fail(p->ctx, IOC_ERR_INPUT, "corrupt graph");
+    if (!ok) return 2;
     G.toposort();
-    if (G.rank.size() != G.n_nodes()) return ioc_fail(p->ctx, IOC_ERR_INPUT, "graph with a cycle");
+    if (G.rank.size() != G.n_nodes()) return 3;
+    return 0;
+}
+static int graph_blob_error(ioc_poa* p, int code)
+{
+    return ioc_fail(p->ctx, IOC_ERR_INPUT, code == 1 ? "not a graph written by this build" : code == 3 ? "graph with a cycle" : "corrupt graph");
+}
+
+int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t len)
+{
+    if (!p || side < 0 || side > 1 || !in) return IOC_ERR_ARG;
+    PGraph G;
+    const int code = parse_graph_blob(in, len, G);
+    if (code) return graph_blob_error(p, code);
     p->g[side][idx] = std::move(G);
+    return IOC_OK;
+}
+
+// many graphs at once: the blobs are parsed and ordered on the host's cores (a merge of two 1500-cluster batches loads 3000
+// graphs of thousands of nodes: 0.8 s one after the other).  Nothing is loaded when one of them is refused.
+int ioc_poa_graph_load_many(ioc_poa* p, int side, int32_t count, const int32_t* idx, const uint8_t* const* in, const int64_t* len)
+{
+    if (!p || side < 0 || side > 1 || count < 0 || (count > 0 && (!idx || !in || !len))) return IOC_ERR_ARG;
+    std::vector<PGraph> gs(static_cast<size_t>(count));
+    std::vector<int> code(static_cast<size_t>(count), 0);
+    for (int32_t x = 0; x < count; ++x)
+        if (!in[x]) return IOC_ERR_ARG;
+    ioc_parallel_for(size_t(count), [&](size_t x) { code[x] = parse_graph_blob(in[x], len[x], gs[x]); }, 8);
+    for (int32_t x = 0; x < count; ++x)
+        if (code[size_t(x)]) return graph_blob_error(p, code[size_t(x)]);
+    for (int32_t x = 0; x < count; ++x) p->g[side][idx[x]] = std::move(gs[size_t(x)]);
     return IOC_OK;
 }
 
