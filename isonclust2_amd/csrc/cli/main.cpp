@@ -44,7 +44,10 @@ static bool VERBOSE = false;
 [[noreturn]] static void die(const string& m)
 {
     cerr << m << endl;
-    exit(1);
+    // (no unwinding: `sort` calls this from a batch-writer thread while others still run, and the reference's own error exits
+    // leave through exit(1) with nothing left to flush)
+    fflush(nullptr);
+    _exit(1);
 }
 
 static string table_path()
