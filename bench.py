@@ -190,7 +190,8 @@ def cli_region(rs, mode, runs=3):
             res.append(j)
         best = min(res, key=lambda j: j["process_wall_ms"])
         out = {"process_wall_ms_min": best["process_wall_ms"], "process_wall_ms_all": [round(j["process_wall_ms"], 1) for j in res],
-               "phases_of_that_run": best, "runs": runs, "sort_process_s": t_sort, "batch_cer_MB": os.path.getsize(batch) / 1e6}
+               "phases_of_that_run": best, "runs": runs, "sort_process_s": t_sort, "batch_cer_MB": os.path.getsize(batch) / 1e6,
+               "phases_all_runs": [{k: round(j[k], 1) for k in ("process_wall_ms", "cli_ms", "core_ms", "load_ms", "ctx_ms", "save_ms") if k in j} for j in res]}
         if mode != "fast":
             out["note"] = ("a `cluster` process in an alignment mode allocates the aligner's checkpoint arena: 8 GB for this batch with "
                            "the default aligner (version 2, coarse checkpoints); round 2's 56 GB arena made a process started right "
