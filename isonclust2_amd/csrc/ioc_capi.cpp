@@ -501,6 +501,29 @@ static uint32_t env_u32(const char* name, uint32_t dflt)
     return x >= 0 ? uint32_t(x) : dflt;
 }
 
+// k_gap_bounds for the current queries, if the table is not there yet: a function of the queries, the gap limits and
+// the thresholds, kept across ioc_score calls on the same queries.  (Run on a stream of its own beside the index build it won
+// 20 us of its 125: both fill the chip.)
+static int gap_bounds_launch(ioc_ctx* c)
+{
+    const int n = c->n;
+    const bool aln_mode_s = c->params.mode == IOC_MODE_SAHLIN || c->params.mode == IOC_MODE_FURIOUS;
+    if (n <= 0 || env_u32("IOC_RESOLVE_BOUND", 1) != 1) return IOC_OK;
+    const bool cut_lists = !aln_mode_s && env_u32("IOC_SCORE_KEEPQ", 1) == 1;
+    if (c->gap_bound_gen == c->query_gen && c->gap_bound_cut == cut_lists) return IOC_OK;
+    {
+        const int rw = ioc_wait_uploads(c, 2);  // the positions
+        if (rw != IOC_OK) return rw;
+    }
+    RESERVE(c, c->b_gap_bound, size_t(n) * 2 * 15 * sizeof(uint2));
+    RESERVE(c, c->b_keep_q, size_t(n) * 4);
+    HIPCHK(c, iock_gap_bounds(c->stream, n, c->d_off_fwd, c->d_off_rev, c->d_pos, c->d_hpc_len, c->d_err_cell, P<int32_t>(c->b_glim),
+                              P<uint2>(c->b_gap_bound), c->d_min_total, uint32_t(c->keep), cut_lists ? P<uint32_t>(c->b_keep_q) : nullptr));
+    c->gap_bound_gen = c->query_gen;
+    c->gap_bound_cut = cut_lists;
+    return IOC_OK;
+}
+
 int ioc_index_build(ioc_ctx* c)
 {
     if (!c) return IOC_ERR_ARG;
@@ -755,21 +778,9 @@ int ioc_score(ioc_ctx* c)
     c->keep_q_on = false;
     c->h_keep_q.clear();
     if (n > 0 && env_u32("IOC_RESOLVE_BOUND", 1) == 1) {
-        {
-            const int rw = ioc_wait_uploads(c, 2);  // the positions
-            if (rw != IOC_OK) return rw;
-        }
-        RESERVE(c, c->b_gap_bound, size_t(n) * 2 * 15 * sizeof(uint2));
-        RESERVE(c, c->b_keep_q, size_t(n) * 4);
-        const bool cut_lists = !aln_mode_s && env_u32("IOC_SCORE_KEEPQ", 1) == 1;
-        // (a function of the queries, the gap limits and the thresholds: kept across calls on the same queries)
-        if (c->gap_bound_gen != c->query_gen || c->gap_bound_cut != cut_lists) {
-            HIPCHK(c, iock_gap_bounds(c->stream, n, c->d_off_fwd, c->d_off_rev, c->d_pos, c->d_hpc_len, c->d_err_cell, P<int32_t>(c->b_glim),
-                                      P<uint2>(c->b_gap_bound), c->d_min_total, uint32_t(c->keep), cut_lists ? P<uint32_t>(c->b_keep_q) : nullptr));
-            c->gap_bound_gen = c->query_gen;
-            c->gap_bound_cut = cut_lists;
-        }
-        c->keep_q_on = cut_lists;
+        const int rg = gap_bounds_launch(c);
+        if (rg != IOC_OK) return rg;
+        c->keep_q_on = c->gap_bound_cut;
     } else {
         c->gap_bound_gen = ~0ull;
     }

@@ -960,6 +960,9 @@ int ioc_cluster_resident(ioc_ctx* c, int32_t* out_cls, int8_t* out_strand, ioc_c
         c->h_min_total_gen = c->query_gen;
     }
     const std::vector<uint32_t>& need = c->h_min_total;
+    // every call is a pass over a batch of its own as far as the timings go: the table of the gap bounds (a function of the
+    // queries, kept per query set by ioc_score) is computed again, as it would be for a batch seen for the first time
+    c->gap_bound_gen = ~0ull;
     if (c->params.mode == IOC_MODE_FURIOUS || c->params.mode == IOC_MODE_NONE)
         return ioc_fail(c, IOC_ERR_STATE, "ioc_cluster_resident runs fast and sahlin mode: use ioc_cluster_batch for furious / none");
     if (c->params.mode == IOC_MODE_SAHLIN) {

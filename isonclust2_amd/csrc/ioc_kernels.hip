@@ -1346,6 +1346,23 @@ k_score_compact(int n, uint32_t L, const uint32_t* __restrict__ part, uint32_t k
 // its evaluation (IOC_MAPPED_REJECTED in the cache: "evaluated, fails").  Unrelated reads share ~M^2 / 4*3^(k-1) minimizers by
 // chance (90 of 4000 at k = 11): enough to be candidates of every query that opens a cluster, never enough to pass.
 #define IOC_MAPPED_REJECTED 0xFFFFFFFEu
+// maximum of an unsigned value over the 64 lanes of a wave, uniform result (0 is the identity the DPP moves fold away with)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
+{
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, dpp_or_zero<0x111>(v));
+    v = max(v, dpp_or_zero<0x112>(v));
+    v = max(v, dpp_or_zero<0x114>(v));
+    v = max(v, dpp_or_zero<0x118>(v));
+    v = max(v, dpp_or_zero<0x142, 0xa>(v));
+    v = max(v, dpp_or_zero<0x143, 0xc>(v));
+    return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
+
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev, const uint32_t* __restrict__ pos,
              const uint32_t* __restrict__ hpc_len, const uint8_t* __restrict__ err_cell, const int32_t* __restrict__ glim,
@@ -1391,18 +1408,29 @@ k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restri
                     s_pos[x] = v;
                     if (c0 + x + 1u < M && p[c0 + x + 1u] < v) s_nonmono = 1u;  // (a list that does not ascend: no bound for this query)
                 }
-                __syncthreads();
                 const uint32_t ce = (M - c0 < GB_CHUNK) ? M - c0 : GB_CHUNK;
                 const bool in_lds = lim[14] <= GB_HALO;
+                // (the list's end inside the staged stretch: the last position repeated behind it, so that "the minimizer lim
+                // places on, or the last one" is a plain read)
+                if (c0 + cn == M && in_lds)
+                    for (uint32_t x = cn + threadIdx.x; x < ce + GB_HALO; x += IOC_BLOCK) s_pos[x] = p[M - 1u];
+                __syncthreads();
                 for (uint32_t x = threadIdx.x; x < ce; x += IOC_BLOCK) {
                     const uint32_t a0 = s_pos[x];
                     const uint32_t left = M - 1u - (c0 + x);  // minimizers behind this one
 #pragma unroll
                     for (int e = 0; e < 15; ++e) {
                         if (e > 0 && lim[e] == lim[e - 1]) continue;  // (uniform)
-                        const uint32_t st = lim[e] < left ? lim[e] : left;
-                        const uint32_t a1 = in_lds ? s_pos[x + st] : p[c0 + x + st];
-                        const uint32_t span = a1 > a0 ? a1 - a0 : 0u;
+                        uint32_t a1;
+                        if (in_lds) {
+                            a1 = s_pos[x + lim[e]];
+                        } else {
+                            const uint32_t st = lim[e] < left ? lim[e] : left;
+                            a1 = p[c0 + x + st];
+                        }
+                        // (positions ascend; a list that does not is flagged above and gets no bound at all, so a wrapped
+                        // difference only ever makes a bound that is ignored)
+                        const uint32_t span = a1 - a0;
                         d[e] = span > d[e] ? span : d[e];
                     }
                 }
@@ -1424,15 +1452,11 @@ k_gap_bounds(int n, const int64_t* __restrict__ off_fwd, const int64_t* __restri
                     }
             }
         }
+        // (the wave's maxima by DPP — row_shr 1 2 4 8, row_bcast 15 / 31, the result in lane 63 —: 45 values through six
+        // ds_bpermute rounds each were as long as the pass over the positions)
 #pragma unroll
         for (int e = 0; e < 15; ++e) {
-            uint32_t x = d[e], y = hd[e], z = tl[e];
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t tx = __shfl_down(x, o), ty = __shfl_down(y, o), tz = __shfl_down(z, o);
-                x = tx > x ? tx : x;
-                y = ty > y ? ty : y;
-                z = tz > z ? tz : z;
-            }
+            const uint32_t x = wave_max_u32(d[e]), y = wave_max_u32(hd[e]), z = wave_max_u32(tl[e]);
             if (lane == 0) {
                 red[0][e][wave] = x;
                 red[1][e][wave] = y;

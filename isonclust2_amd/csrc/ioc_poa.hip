@@ -120,17 +120,7 @@ __device__ __forceinline__ int dpp_or_self(int v)
 {
     return __builtin_amdgcn_update_dpp(INT32_MIN, v, CTRL, ROW_MASK, 0xf, false);
 }
-// inclusive prefix maximum over the 64 lanes of a wave: row_shr 1 2 4 8, then row_bcast 15 and 31
-__device__ __forceinline__ int wave_prefix_max(int v)
-{
-    v = max(v, dpp_or_self<0x111>(v));
-    v = max(v, dpp_or_self<0x112>(v));
-    v = max(v, dpp_or_self<0x114>(v));
-    v = max(v, dpp_or_self<0x118>(v));
-    v = max(v, dpp_or_self<0x142, 0xa>(v));
-    v = max(v, dpp_or_self<0x143, 0xc>(v));
-    return v;
-}
+// inclusive prefix maxima over the 64 lanes of a wave, two values at once: row_shr 1 2 4 8, then row_bcast 15 and 31
 __device__ __forceinline__ void wave_prefix_max2(int& a, int& b)
 {
     a = max(a, dpp_or_self<0x111>(a));
@@ -146,9 +136,6 @@ __device__ __forceinline__ void wave_prefix_max2(int& a, int& b)
     a = max(a, dpp_or_self<0x143, 0xc>(a));
     b = max(b, dpp_or_self<0x143, 0xc>(b));
 }
-// LDS traffic of this wave done, then the workgroup barrier: global stores stay in flight (a __syncthreads
-// would wait for the five stores of every row)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // One anti-diagonal of tiles per launch (tile = POA_RB rows x POA_CB columns): the tiles of a diagonal are
 // independent, kernel boundaries are the only synchronisation between tiles (no flags, no cross-workgroup
