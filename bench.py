@@ -679,7 +679,8 @@ def main():
             "value": head["value"], "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "value_region": "resident: one pass of the hot path (ioc_cluster_resident) over a sorted batch already in HBM; "
+            "value_region": "resident: one pass of the hot path (ioc_cluster_resident: index build, gap-bound table, scoring, resolve, "
+                            "alignment rounds) over a sorted batch already in HBM, nothing kept from one step to the next; "
                             "`core` = host arrays -> host results incl. PCIe, `cli` = whole cluster process incl. .cer I/O",
             "config": {"workload": f"{a.config} = BASELINE.json configs[{2 if head_mode == 'sahlin' else 1}]: {rs.tag}; one sorted "
                                    "3000-read / 50 Mb batch per GPU, minimizer SoA and sequences resident in HBM",
