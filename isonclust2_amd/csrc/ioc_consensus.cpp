@@ -217,7 +217,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     // stands for it — the flag of an entry is overwritten whenever a later pass walks it again
     std::vector<int32_t> sub_tgt;
     std::vector<int8_t> sub_str;
-    std::vector<uint8_t> sub_flg, aln_flag(size_t(rb->n) + 1, 0);
+    std::vector<uint8_t> sub_flg, sub_dep, aln_flag(size_t(rb->n) + 1, 0);
     std::vector<int8_t> sub_strand;
     const int k = p->k, w = p->w;
     int pos = 0;
@@ -414,6 +414,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         sub_str.assign(size_t(m) + 1, 0);
         sub_flg.assign(size_t(m) + 1, 0);
         if (m > 0 && (r = ioc_get_decisions(c, sub_tgt.data(), sub_str.data(), sub_flg.data())) != IOC_OK) return r;
+        sub_dep.assign(size_t(m) + 1, 0);
+        for (int x = 0; x < m && size_t(x) < c->last_order_dep.size(); ++x) sub_dep[size_t(x)] = c->last_order_dep[size_t(x)];
         ph[1] += now() - t0;
         total.resolve_iters += st.resolve_iters;
         total.n_tie_replays += st.n_tie_replays;
@@ -445,8 +447,12 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             // stops at (int(top * MinFraction), ioc_get_cuts; without a walk: what would start one).
             if (dirty.nslots) {
                 const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
+                // (a decision that hangs on the reference's hit ORDER — a tie at the top Size, several candidates that align —
+                // depends on which (cluster, strand) keys the hit map holds at all and on their Sizes, down to Size 1: the
+                // iteration order of the unordered_map and the path of its std::sort change with them.  ONE value shared with a
+                // changed representative's old or new set can add, remove or resize such a key: the entry is decided again.)
                 if (dirty.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
-                                  rb->off_rev[i + 1] - rb->off_rev[i], thr)) {
+                                  rb->off_rev[i + 1] - rb->off_rev[i], sub_dep[size_t(x)] ? 1 : thr)) {
                     if (spec) {  // (it sees the OLD representative of a cluster with a pending event: the pass ends here)
                         stop_x = x;
                         break;
@@ -677,7 +683,7 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                         // (an entry with an event of its own is looked at again like any other, before its event counts)
                         const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
                         if (dirty_b.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
-                                            rb->off_rev[i + 1] - rb->off_rev[i], thr)) {
+                                            rb->off_rev[i + 1] - rb->off_rev[i], sub_dep[size_t(x)] ? 1 : thr)) {
                             violation = x;  // it can see a NEW representative: everything from here on is decided again
                             break;
                         }

@@ -304,6 +304,11 @@ static void order_from(const ioc_ctx* c, const RawCands& rc, const std::vector<i
         h.Mapped = x.mapped;
         h.Target = x.target;
     }
+    if (getenv("IOC_DEBUG_TIES")) {
+        fprintf(stderr, "[ioc] order_from: query %d, %zu minimizers, %zu buckets, %zu keys:", q, nm, res.bucket_count(), res.size());
+        for (auto& x : cs) fprintf(stderr, " (%d,%d size %u first %u tgt %d)", x.cls, int(x.strand), x.size, x.first, x.target);
+        fprintf(stderr, "\n");
+    }
     std::vector<std::unique_ptr<SortedHit>> order;
     order.reserve(res.size());
     for (auto& kv : res) {
@@ -341,6 +346,13 @@ static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint
     if (r != IOC_OK) return r;
     out_cls = -1;
     out_strand = 0;
+    if (getenv("IOC_DEBUG_TIES")) {
+        fprintf(stderr, "[ioc] tie replay of query %d (entry %lld, %d left clusters), need %u:", q,
+                (long long)(size_t(q) < c->aln_qid.size() ? c->aln_qid[size_t(q)] : 0), c->L, need);
+        for (size_t x = 0; x < order.size() && x < 6; ++x)
+            fprintf(stderr, " (%d,%d size %u mapped %u tgt %d)", order[x].cls, int(order[x].strand), order[x].size, order[x].mapped, order[x].target);
+        fprintf(stderr, "\n");
+    }
     if (order.empty()) return IOC_OK;
     const unsigned top = order[0].size;
     if (top < unsigned(c->params.min_shared)) return IOC_OK;
@@ -709,6 +721,16 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         int32_t t = tgt[size_t(i)];
         int8_t s = str[size_t(i)];
         int32_t cls = t < c->L ? t : cid[size_t(t - c->L)];
+        if (getenv("IOC_DEBUG_TIES") && size_t(i) < c->aln_qid.size() && (long long)c->aln_qid[size_t(i)] == atoll(getenv("IOC_DEBUG_TIES")))
+        {
+            fprintf(stderr, "[ioc] decision of query %d (entry %lld): target %d strand %d flags %u -> cluster %d, need %u;", i, (long long)c->aln_qid[size_t(i)], t, int(s),
+                    unsigned(flg[size_t(i)]), cls, need[size_t(i)]);
+            RawCands rc;
+            if (fetch_cands(c, i, rc) == IOC_OK)
+                for (size_t x = 0; x < rc.tg.size(); ++x)
+                    if (rc.sz[x] >= 100) fprintf(stderr, " (tgt %d strand %d size %u first %u mapped %u)", rc.tg[x], int(rc.st[x]), rc.sz[x], rc.fi[x], rc.tm[x]);
+            fprintf(stderr, "\n");
+        }
         if (flg[size_t(i)] & 1) {
             int32_t rt = -1;
             int8_t rs = 0;
@@ -741,6 +763,11 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         }
     }
     tr.mark("final ids + tie replays");
+    // (what a caller that re-uses decisions under a changed state — ioc_cluster_consensus — has to know: these decisions
+    // depend on which other (cluster, strand) keys exist at all, not only on the candidates they look at)
+    c->last_order_dep.assign(size_t(n), 0);
+    for (int i = 0; i < n; ++i)
+        c->last_order_dep[size_t(i)] = uint8_t(((flg[size_t(i)] & 1) ? 1 : 0) | ((!order_dep.empty() && order_dep[size_t(i)]) ? 1 : 0));
     if (stats) {
         stats->n_clusters = next;
         stats->n_joined = joined;

@@ -56,14 +56,18 @@ def test_cons_period_stops_the_updates_of_large_clusters():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,shape,seed,cmax,cmin,period", [
-    ("fast", (300, 6, 900), 3, 8, 3, 500),
-    ("fast", (400, 10, 700), 4, 6, 2, 25),
-    ("sahlin", (160, 5, 900), 6, 8, 3, 500),
+@pytest.mark.parametrize("mode,shape,seed,cmax,cmin,period,q", [
+    ("fast", (300, 6, 900), 3, 8, 3, 500, (12, 21)),
+    ("fast", (400, 10, 700), 4, 6, 2, 25, (12, 21)),
+    ("sahlin", (160, 5, 900), 6, 8, 3, 500, (11, 21)),
+    # found by tools/fuzz_consensus.py (seed 34, case 52): entry 82 meets two clusters tied at the top Size, both pass, and the
+    # reference's hit order between them hangs on a Size-1 key of a THIRD cluster whose representative changed one entry earlier
+    # (17 keys instead of 16: std::sort leaves its stable insertion sort) - a decision of that kind is taken again
+    ("fast", (162, 5, 1200), 163853082, 12, 2, 25, (11, 22)),
 ])
-def test_device_consensus_equals_oracle(mode, shape, seed, cmax, cmin, period):
+def test_device_consensus_equals_oracle(mode, shape, seed, cmax, cmin, period, q):
     from isonclust2_amd import _lib, api
-    rs = synth.generate(shape[0], shape[1], shape[2], 11 if mode == "sahlin" else 12, 21, seed=seed)
+    rs = synth.generate(shape[0], shape[1], shape[2], q[0], q[1], seed=seed)
     B, view, ost, og = _oracle_run(rs, cmax, cmin, period, mode=mode)   # (sahlin: the oracle's own scalar aligner)
     assert ost["cons_invoked"] > 3
     acl, ast = B.assignments(rs.n)
