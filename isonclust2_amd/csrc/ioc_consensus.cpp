@@ -23,6 +23,7 @@
 #include <map>
 #include <string>
 #include <unordered_map>
+#include <memory>
 #include <vector>
 
 #include "ioc_internal.h"
@@ -218,6 +219,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     std::vector<int32_t> sub_tgt;
     std::vector<int8_t> sub_str;
     std::vector<uint8_t> sub_flg, sub_dep, aln_flag(size_t(rb->n) + 1, 0);
+    std::vector<std::vector<std::pair<int32_t, int8_t>>> sub_depset;  // per window entry with sub_dep: the candidates its hit order chooses among
+    std::vector<int32_t> ncl_at;  // clusters that existed when the walk reached the window entry
     std::vector<int8_t> sub_strand;
     const int k = p->k, w = p->w;
     int pos = 0;
@@ -268,6 +271,45 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
     // representative — a rollback only repeats work, the result must not change
     const int force_rb = getenv("IOC_CONS_FORCE_ROLLBACK") ? std::max(0, atoi(getenv("IOC_CONS_FORCE_ROLLBACK"))) : 0;
     int64_t rb_counter = 0;
+    // The reference's hit order (GetMinimizerHits + SortMinimizerHits, minimizer.cpp:44-121) of entry i under the MinDB as it
+    // stands, clusters below `ncl` only: the same unordered_map (hash, initial bucket count, insertion sequence: forward
+    // minimizers in order, each posting list in order, then the reverse ones), the same std::sort.  The first candidate of `dep`
+    // in that order is what an order-dependent decision comes to (§3 of DESIGN.md): the candidates themselves — clusters
+    // whose representatives did not change — keep their Sizes and verdicts, only their order can move.
+    auto host_order_pick = [&](int i, int32_t ncl, const std::vector<std::pair<int32_t, int8_t>>& dep, int32_t& w_cls, int8_t& w_strand) -> bool {
+        typedef std::pair<int, int> SCl;
+        struct SClHash {
+            std::size_t operator()(const SCl& u) const { return size_t(int(u.first * u.second)); }
+        };
+        struct SHit {
+            unsigned Size, Cls;
+            int Strand;
+        };
+        const int64_t nf = rb->off_fwd[i + 1] - rb->off_fwd[i], nr = rb->off_rev[i + 1] - rb->off_rev[i];
+        std::unordered_map<SCl, unsigned, SClHash> res(size_t(20) * size_t(nf + nr), SClHash());
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t* v = rb->min_val + (pass ? rb->off_rev[i] : rb->off_fwd[i]);
+            const int64_t nv = pass ? nr : nf;
+            for (int64_t x = 0; x < nv; ++x) {
+                auto it = db.find(v[x]);
+                if (it == db.end()) continue;
+                for (uint32_t cid2 : it->second)
+                    if (int32_t(cid2) < ncl) res[std::make_pair(int(cid2), pass ? -1 : 1)]++;
+            }
+        }
+        std::vector<std::unique_ptr<SHit>> order;
+        order.reserve(res.size());
+        for (auto& kv : res) order.push_back(std::unique_ptr<SHit>(new SHit{kv.second, unsigned(kv.first.first), kv.first.second}));
+        std::sort(order.begin(), order.end(), [](const std::unique_ptr<SHit>& a, const std::unique_ptr<SHit>& b) { return a->Size > b->Size; });
+        for (auto& o : order)
+            for (auto& d : dep)
+                if (int32_t(o->Cls) == d.first && o->Strand == int(d.second)) {
+                    w_cls = d.first;
+                    w_strand = d.second;
+                    return true;
+                }
+        return false;
+    };
     while (pos < n) {
         const int m = std::min(n - pos, window);
         double t0 = now();
@@ -415,7 +457,12 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         sub_flg.assign(size_t(m) + 1, 0);
         if (m > 0 && (r = ioc_get_decisions(c, sub_tgt.data(), sub_str.data(), sub_flg.data())) != IOC_OK) return r;
         sub_dep.assign(size_t(m) + 1, 0);
-        for (int x = 0; x < m && size_t(x) < c->last_order_dep.size(); ++x) sub_dep[size_t(x)] = c->last_order_dep[size_t(x)];
+        sub_depset.assign(size_t(m) + 1, std::vector<std::pair<int32_t, int8_t>>());
+        for (int x = 0; x < m && size_t(x) < c->last_order_dep.size(); ++x) {
+            sub_dep[size_t(x)] = c->last_order_dep[size_t(x)];
+            if (sub_dep[size_t(x)] && size_t(x) < c->last_dep_set.size()) sub_depset[size_t(x)] = c->last_dep_set[size_t(x)];
+        }
+        ncl_at.assign(size_t(m) + 1, 0);
         ph[1] += now() - t0;
         total.resolve_iters += st.resolve_iters;
         total.n_tie_replays += st.n_tie_replays;
@@ -433,7 +480,8 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         int stop_x = m;  // (deferred mode) the walk stands up to here unless the verification says otherwise
         for (int x = 0; x < m; ++x) {
             const int i = pos + x;
-            const int32_t dc = sub_cls[size_t(x)];
+            int32_t dc = sub_cls[size_t(x)];
+            ncl_at[size_t(x)] = int32_t(cl.size());
             aln_flag[size_t(i)] = dc >= 0 && (sub_flg[size_t(x)] & 2) ? 1 : 0;
             if (dc < 0) {  // (gated by its quality: no cluster has a say)
                 out_cls[i] = -1;
@@ -450,9 +498,11 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 // (a decision that hangs on the reference's hit ORDER — a tie at the top Size, several candidates that align —
                 // depends on which (cluster, strand) keys the hit map holds at all and on their Sizes, down to Size 1: the
                 // iteration order of the unordered_map and the path of its std::sort change with them.  ONE value shared with a
-                // changed representative's old or new set can add, remove or resize such a key: the entry is decided again.)
+                // changed representative's old or new set can add, remove or resize such a key.  The candidates the order chooses
+                // among are known (sub_depset): the order itself is computed again on the host below — at once when every
+                // consensus so far has been taken, in the verification of the pass when they are deferred.)
                 if (dirty.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
-                                  rb->off_rev[i + 1] - rb->off_rev[i], sub_dep[size_t(x)] ? 1 : thr)) {
+                                  rb->off_rev[i + 1] - rb->off_rev[i], (sub_dep[size_t(x)] && sub_depset[size_t(x)].empty()) ? 1 : thr)) {
                     if (spec) {  // (it sees the OLD representative of a cluster with a pending event: the pass ends here)
                         stop_x = x;
                         break;
@@ -460,6 +510,14 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     pos = i;
                     restarted = true;
                     break;
+                }
+                if (!spec && sub_dep[size_t(x)] && !sub_depset[size_t(x)].empty() && dc < int32_t(cl.size())) {
+                    int32_t wc = -1;
+                    int8_t ws = 0;
+                    if (!host_order_pick(i, int32_t(cl.size()), sub_depset[size_t(x)], wc, ws))
+                        return ioc_fail(c, IOC_ERR_STATE, "consensus driver: none of an order-dependent decision's candidates is a hit any more");
+                    sub_cls[size_t(x)] = dc = wc;
+                    sub_strand[size_t(x)] = ws;
                 }
             }
             const char* rseq = rb->raw_seq + rb->raw_off[i];
@@ -683,9 +741,19 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                         // (an entry with an event of its own is looked at again like any other, before its event counts)
                         const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
                         if (dirty_b.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
-                                            rb->off_rev[i + 1] - rb->off_rev[i], sub_dep[size_t(x)] ? 1 : thr)) {
+                                            rb->off_rev[i + 1] - rb->off_rev[i], (sub_dep[size_t(x)] && sub_depset[size_t(x)].empty()) ? 1 : thr)) {
                             violation = x;  // it can see a NEW representative: everything from here on is decided again
                             break;
+                        }
+                        if (sub_dep[size_t(x)] && !sub_depset[size_t(x)].empty() && sub_cls[size_t(x)] < ncl_at[size_t(x)]) {
+                            // (an order-dependent decision: the order under the MinDB as the events before this entry leave it)
+                            int32_t wc = -1;
+                            int8_t ws = 0;
+                            if (!host_order_pick(i, ncl_at[size_t(x)], sub_depset[size_t(x)], wc, ws) || wc != sub_cls[size_t(x)] ||
+                                ws != sub_strand[size_t(x)]) {
+                                violation = x;
+                                break;
+                            }
                         }
                     }
                     if (e < ne && evs[e].x == x) {

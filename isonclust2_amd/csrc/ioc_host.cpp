@@ -339,7 +339,7 @@ static int build_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, std::
 // first passing candidate in the reference's order (cluster.cpp:381-403) — used for the queries whose
 // winner is order-dependent
 static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint32_t need, int32_t& out_cls,
-                        int8_t& out_strand)
+                        int8_t& out_strand, std::vector<std::pair<int32_t, int8_t>>* dep = nullptr)
 {
     std::vector<Ordered> order;
     int r = build_order(c, q, cid, order);
@@ -364,6 +364,11 @@ static int replay_order(ioc_ctx* c, int q, const std::vector<int32_t>& cid, uint
         if (o.mapped >= need) {
             out_cls = o.cls;
             out_strand = o.strand;
+            // (the candidates the order chooses among: every passing one of the winner's Size)
+            if (dep)
+                for (auto& o2 : order)
+                    if (o2.size == o.size && o2.mapped != 0xFFFFFFFEu && o2.mapped != 0xFFFFFFFFu && o2.mapped >= need)
+                        dep->emplace_back(o2.cls, o2.strand);
             return IOC_OK;
         }
     }
@@ -696,6 +701,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     }
     if (aln_mode && (r = ioc_set_aln_verdicts(c, nullptr, nullptr)) != IOC_OK) return r;
     // final cluster ids in creation order (newId = cls.size(), cluster.cpp:178)
+    c->last_dep_set.assign(size_t(n), std::vector<std::pair<int32_t, int8_t>>());
     std::fill(cid.begin(), cid.end(), -1);
     int32_t next = c->L;
     for (int i = 0; i < n; ++i)
@@ -736,7 +742,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
             int8_t rs = 0;
             const bool mine = !sharded || (i % c->shard_world) == c->shard_rank;
             if (mine) {
-                if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs)) != IOC_OK) return r;
+                if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs, &c->last_dep_set[size_t(i)])) != IOC_OK) return r;
                 if (rt < 0) return ioc_fail(c, IOC_ERR_STATE, "tie replay found no passing candidate");
             }
             if (sharded) {
@@ -766,8 +772,17 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     // (what a caller that re-uses decisions under a changed state — ioc_cluster_consensus — has to know: these decisions
     // depend on which other (cluster, strand) keys exist at all, not only on the candidates they look at)
     c->last_order_dep.assign(size_t(n), 0);
-    for (int i = 0; i < n; ++i)
-        c->last_order_dep[size_t(i)] = uint8_t(((flg[size_t(i)] & 1) ? 1 : 0) | ((!order_dep.empty() && order_dep[size_t(i)]) ? 1 : 0));
+    for (int i = 0; i < n; ++i) {
+        const bool aln_dep = !order_dep.empty() && order_dep[size_t(i)];
+        c->last_order_dep[size_t(i)] = uint8_t(((flg[size_t(i)] & 1) ? 1 : 0) | (aln_dep ? 1 : 0));
+        if (aln_dep && !(flg[size_t(i)] & 1))  // the tied candidates that align (cluster.cpp:481-511)
+            for (uint32_t t : v_ties[size_t(i)])
+                if (ad.cache[AlnDriver::key(i, t)] >= c->params.aligned_threshold) {
+                    const int32_t tg2 = int32_t(t >> 1);
+                    const int32_t id = tg2 < c->L ? tg2 : cid[size_t(tg2 - c->L)];
+                    if (id >= 0) c->last_dep_set[size_t(i)].emplace_back(id, int8_t((t & 1u) ? -1 : 1));
+                }
+    }
     if (stats) {
         stats->n_clusters = next;
         stats->n_joined = joined;
