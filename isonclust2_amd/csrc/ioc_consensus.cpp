@@ -474,11 +474,21 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         // ---- walk the decisions in the reference's order until a representative changes ----
         const int pass_from = pos;
         bool restarted = false;
+        // Deferred mode walks a device pass in SEGMENTS: a segment ends — flush, new representatives, verification — where a pass
+        // used to end, and also in front of an order-dependent entry met with consensus requests pending; in that case the walk
+        // goes on from that entry on the same device decisions (dirty_b keeps every representative changed since the device pass:
+        // an entry that can see one of them ends the device pass).
+        dirty_b.reset();
+        int x_begin = 0;
+        bool next_pass = false;
+        for (bool again = true; again;) {
+        again = false;
+        bool resume = false;
         dirty.reset();
         evs.clear();
         journal.clear();
         int stop_x = m;  // (deferred mode) the walk stands up to here unless the verification says otherwise
-        for (int x = 0; x < m; ++x) {
+        for (int x = x_begin; x < m; ++x) {
             const int i = pos + x;
             int32_t dc = sub_cls[size_t(x)];
             ncl_at[size_t(x)] = int32_t(cl.size());
@@ -493,6 +503,15 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             // Representatives changed earlier in this pass: the device's decision for this entry stands only if
             // the entry cannot see any of them — it shares fewer values with each than the Size its mapping walk
             // stops at (int(top * MinFraction), ioc_get_cuts; without a walk: what would start one).
+            if (spec && dirty_b.nslots) {  // (representatives replaced in an earlier segment of this device pass)
+                const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
+                if (dirty_b.full() ||
+                    dirty_b.touches(rb->min_val + rb->off_fwd[i], rb->off_fwd[i + 1] - rb->off_fwd[i], rb->min_val + rb->off_rev[i],
+                                    rb->off_rev[i + 1] - rb->off_rev[i], (sub_dep[size_t(x)] && sub_depset[size_t(x)].empty()) ? 1 : thr)) {
+                    stop_x = x;  // the device pass ends here
+                    break;
+                }
+            }
             if (dirty.nslots) {
                 const int thr = sub_cut[size_t(x)] == INT32_MAX ? dirty_thr : std::max(dirty_thr, int(sub_cut[size_t(x)]));
                 // (a decision that hangs on the reference's hit ORDER — a tie at the top Size, several candidates that align —
@@ -512,6 +531,21 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                     break;
                 }
                 if (!spec && sub_dep[size_t(x)] && !sub_depset[size_t(x)].empty() && dc < int32_t(cl.size())) {
+                    int32_t wc = -1;
+                    int8_t ws = 0;
+                    if (!host_order_pick(i, int32_t(cl.size()), sub_depset[size_t(x)], wc, ws))
+                        return ioc_fail(c, IOC_ERR_STATE, "consensus driver: none of an order-dependent decision's candidates is a hit any more");
+                    sub_cls[size_t(x)] = dc = wc;
+                    sub_strand[size_t(x)] = ws;
+                }
+            }
+            if (spec && sub_dep[size_t(x)] && !sub_depset[size_t(x)].empty() && dc < int32_t(cl.size())) {
+                if (!evs.empty()) {  // requests pending: the segment ends in front of this entry, the walk goes on from it afterwards
+                    stop_x = x;
+                    resume = true;
+                    break;
+                }
+                if (dirty_b.nslots) {  // nothing pending, the MinDB is exact: the order as it is now
                     int32_t wc = -1;
                     int8_t ws = 0;
                     if (!host_order_pick(i, int32_t(cl.size()), sub_depset[size_t(x)], wc, ws))
@@ -727,7 +761,6 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
                 ph[3] += now() - t1;
                 t1 = now();
                 // ---- in the reference's order: finalize event e, then look again at the entries walked after it ----
-                dirty_b.reset();
                 upd_keys.clear();
                 size_t e = 0;
                 int violation = -1;
@@ -856,6 +889,13 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             } else if (spec->commit(ops->user) < 0) {
                 return hook_fail(c, "commit");
             }
+            if (getenv("IOC_TRACE") && !evs.empty())
+                fprintf(stderr, "[ioc]   deferred: %zu events in the segment, entries [%d, %d) stand\n", evs.size(), pass_from + x_begin, pos0 + end_x);
+            if (resume && end_x == stop_x && !dirty_b.full()) {  // (no violation: on from the order-dependent entry)
+                x_begin = stop_x;
+                again = true;
+                continue;
+            }
             pos = pos0 + end_x;
             restarted = end_x < m;
             if (restarted) {
@@ -863,10 +903,10 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
             } else if (!fixed_window) {
                 window = std::min(n, std::max(64, 2 * window));
             }
-            if (getenv("IOC_TRACE") && !evs.empty())
-                fprintf(stderr, "[ioc]   deferred: %zu events in the pass, entries [%d, %d) stand\n", evs.size(), pass_from, pos);
-            continue;
+            next_pass = true;
         }
+        }  // segments
+        if (next_pass) continue;
         if (restarted) {
             // the next event is probably as far away as this one was
             if (!fixed_window) window = std::max(64, 4 * std::max(1, pos - pass_from));
