@@ -149,6 +149,11 @@ int ioc_cluster_consensus(ioc_ctx* c, const ioc_params* p, const char* table_pat
         explicit ShardOff(ioc_ctx* x) : c(x), world(x->shard_world) { c->shard_world = 1; }
         ~ShardOff() { c->shard_world = world; }
     } shard_off(c);
+    struct DepSets {  // (run_pipeline leaves the order-dependent queries and their candidate sets while this driver runs)
+        ioc_ctx* c;
+        explicit DepSets(ioc_ctx* x) : c(x) { c->want_dep_sets = true; }
+        ~DepSets() { c->want_dep_sets = false; }
+    } dep_sets(c);
     // ---- left state on the host: MinDB as an ordered map, one ClState per cluster ----
     // (hashed: UpdateMinDB looks up hundreds of keys per event, among half a million; where the reference's std::map order
     // matters — the flat view, the export — the keys are sorted)

@@ -701,7 +701,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     }
     if (aln_mode && (r = ioc_set_aln_verdicts(c, nullptr, nullptr)) != IOC_OK) return r;
     // final cluster ids in creation order (newId = cls.size(), cluster.cpp:178)
-    c->last_dep_set.assign(size_t(n), std::vector<std::pair<int32_t, int8_t>>());
+    if (c->want_dep_sets) c->last_dep_set.assign(size_t(n), std::vector<std::pair<int32_t, int8_t>>());
     std::fill(cid.begin(), cid.end(), -1);
     int32_t next = c->L;
     for (int i = 0; i < n; ++i)
@@ -742,7 +742,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
             int8_t rs = 0;
             const bool mine = !sharded || (i % c->shard_world) == c->shard_rank;
             if (mine) {
-                if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs, &c->last_dep_set[size_t(i)])) != IOC_OK) return r;
+                if ((r = replay_order(c, i, cid, need[size_t(i)], rt, rs, c->want_dep_sets ? &c->last_dep_set[size_t(i)] : nullptr)) != IOC_OK) return r;
                 if (rt < 0) return ioc_fail(c, IOC_ERR_STATE, "tie replay found no passing candidate");
             }
             if (sharded) {
@@ -771,8 +771,8 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     tr.mark("final ids + tie replays");
     // (what a caller that re-uses decisions under a changed state — ioc_cluster_consensus — has to know: these decisions
     // depend on which other (cluster, strand) keys exist at all, not only on the candidates they look at)
-    c->last_order_dep.assign(size_t(n), 0);
-    for (int i = 0; i < n; ++i) {
+    if (c->want_dep_sets) c->last_order_dep.assign(size_t(n), 0);
+    for (int i = 0; c->want_dep_sets && i < n; ++i) {
         const bool aln_dep = !order_dep.empty() && order_dep[size_t(i)];
         c->last_order_dep[size_t(i)] = uint8_t(((flg[size_t(i)] & 1) ? 1 : 0) | (aln_dep ? 1 : 0));
         if (aln_dep && !(flg[size_t(i)] & 1))  // the tied candidates that align (cluster.cpp:481-511)

@@ -93,6 +93,7 @@ struct ioc_ctx {
     std::vector<int8_t> h_forced_s;
     bool forced_dirty = false;
     std::vector<std::vector<std::pair<int32_t, int8_t>>> last_dep_set;  // ... and the (cluster, strand) candidates among which that order picks the first
+    bool want_dep_sets = false;  // (ioc_cluster_consensus: run_pipeline leaves last_order_dep / last_dep_set)
     std::vector<uint8_t> last_order_dep;  // per query of the last run_pipeline: its decision hangs on the reference's hit ORDER (a tie at the top Size, or several candidates that align)
     bool forced_host_clear = false, forced_dev_clear = false;  // nothing forced in the host arrays / in what the device holds (no upload then)
     std::vector<uint32_t> h_min_total;  // host copy of d_min_total for ioc_cluster_resident's tie replays, of queries `h_min_total_gen`
