@@ -363,3 +363,49 @@ def test_deferred_consensus_equals_immediate(ctx, monkeypatch, shape, mode, cons
         for x, y in zip(a[4], c[4]):
             assert np.array_equal(x, y)
         assert a[5] == c[5]
+
+
+@pytest.mark.gpu
+def test_graphs_travel_as_blobs_one_by_one_and_many_at_once(ctx):
+    """ioc_poa_graph_save -> ioc_poa_graph_load / ioc_poa_graph_load_many (the blobs of a merge's thousands of graphs are parsed on
+    the host's cores): the loaded graphs equal the saved ones — nodes, order, weighted edges, sequence count, consensus —, and a
+    batch with one refused blob loads nothing."""
+    rng = random.Random(21)
+    src = Poa(ctx)
+    L = src.L
+    blobs = []
+    for g in range(6):
+        truth = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([120, 300, 700])))
+        src.create(g, _mutate(rng, truth, 0.05))
+        for _ in range(rng.randint(0, 5)):
+            src.add(g, _mutate(rng, truth, 0.1))
+        sz = L.ioc_poa_graph_save(src.h, 0, g, None, 0)
+        assert sz > 0
+        buf = (C.c_uint8 * sz)()
+        assert L.ioc_poa_graph_save(src.h, 0, g, buf, sz) == sz
+        blobs.append(buf)
+
+    def same(dst, side, idx, g):
+        a, b = src.graph(g), dst.graph(idx, side)
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+        assert src.size(g) == dst.size(idx, side) and src.consensus(g) == dst.consensus(idx, side)
+
+    one = Poa(ctx)
+    for g, buf in enumerate(blobs):
+        assert L.ioc_poa_graph_load(one.h, 1, 10 + g, buf, len(buf)) == 0
+        same(one, 1, 10 + g, g)
+    many = Poa(ctx)
+    ids = (C.c_int32 * 6)(*[5 - g for g in range(6)])
+    ptrs = (C.POINTER(C.c_uint8) * 6)(*[C.cast(b, C.POINTER(C.c_uint8)) for b in blobs])
+    lens = (C.c_int64 * 6)(*[len(b) for b in blobs])
+    assert L.ioc_poa_graph_load_many(many.h, 0, 6, ids, ptrs, lens) == 0
+    for g in range(6):
+        same(many, 0, 5 - g, g)
+    # one blob cut short: refused, and none of the batch is there
+    none = Poa(ctx)
+    lens_bad = (C.c_int64 * 6)(*[len(b) if g != 3 else len(b) // 2 for g, b in enumerate(blobs)])
+    assert L.ioc_poa_graph_load_many(none.h, 0, 6, ids, ptrs, lens_bad) != 0
+    assert all(none.size(g) < 0 for g in range(6))
+    assert L.ioc_poa_graph_load_many(none.h, 0, 0, None, None, None) == 0
+    for p in (src, one, many, none):
+        p.close()
