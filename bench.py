@@ -321,6 +321,7 @@ def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode,
 
     def work():
         try:
+            torch.cuda.set_device(ctx.device)   # (a fresh thread starts on device 0: HIP's current device is per thread)
             p = api.default_params(k, w, mode)
             view = sb.view if mode != "fast" else {kk: vv for kk, vv in sb.view.items() if kk not in ("raw_seq", "raw_off")}
             cb2 = pipeline.cluster_single(ctx, p, pipeline.SortedBatch(view=view, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
@@ -341,17 +342,19 @@ def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode,
                 vf = {kk: vv for kk, vv in sb.view.items() if kk not in ("raw_seq", "raw_off")}
                 legs = {}
                 for tag, env in (("replicated", "0"), ("sharded", "1")):
-                    os.environ["IOC_DIST_SHARD"] = env
-                    cbf = pipeline.cluster_single(ctx, pf, pipeline.SortedBatch(view=vf, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
-                                                                                batch_start=sb.batch_start, batch_end=sb.batch_end))
+                    os.environ["IOC_DIST_SHARD"] = env      # (read by ioc_dist_merge at every call; this thread is the only one inside the library)
                     best = None
                     for _ in range(3):
+                        # re-clustered before EVERY repetition: a merge replaces the context's queries, and a second merge of the
+                        # same ClusteredBatch would silently take the host-array path (H2D) instead of the device gather
+                        cbf = pipeline.cluster_single(ctx, pf, pipeline.SortedBatch(view=vf, read_ids=sb.read_ids, batch_nr=sb.batch_nr,
+                                                                                    batch_start=sb.batch_start, batch_end=sb.batch_end))
                         tf = {}
                         mf = idist.merge_all_native(ctx, pf, cbf, torch, timing=tf)
                         t = ctx.timings()
                         rec = dict(merge_ms=tf["merge_ms"], score_ms=t["ms_score"], resolve_ms=t["ms_resolve"], sweeps=t["resolve_iters"],
                                    exchanges=tf["exchanges"], sharded=bool(tf["sharded"]), clusters_out=mf.n_clusters, fnv1a=fnv1a_reads(mf),
-                                   representatives=int(sum(tf["clusters_in"])))
+                                   representatives=int(sum(tf["clusters_in"])), lists_path=tf.get("lists_path"))
                         if best is None or rec["merge_ms"] < best["merge_ms"]:
                             best = rec
                     legs[tag] = best
@@ -391,14 +394,37 @@ def native_merge_leg(ctx, api, pipeline, idist, dist, torch, sb, cb, k, w, mode,
     return out
 
 
+def visible_gpus():
+    """Number of GPUs this process would see, WITHOUT touching HIP or torch: the kfd topology in sysfs (a node with
+    simd_count > 0 is a GPU), cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.
+    None = unknown (no kfd in sysfs, unreadable): the caller then skips its check and lets the ranks find out."""
+    import glob
+    n = 0
+    try:
+        nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+        if not nodes:
+            return None
+        for f in nodes:
+            for line in open(f):
+                if line.startswith("simd_count"):
+                    n += int(line.split()[1]) > 0
+                    break
+    except Exception:  # noqa: BLE001
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` on its own: start N ranks (one process per GPU, torch.distributed.run, RCCL) as CHILD
-    processes and pass their one JSON line through.  Nothing here touches a GPU (counting devices does not initialise
-    HIP), so no process that owns a GPU is ever replaced."""
+    processes and pass their one JSON line through.  This parent imports neither torch nor the library and makes no HIP
+    call (devices are counted in sysfs), so no process that has initialised a GPU is ever replaced or forked from."""
     import socket
-    import torch
-    ndev = torch.cuda.device_count()
-    if ndev < a.gpus and a.backend == "nccl":
+    ndev = visible_gpus()
+    if ndev is not None and ndev < a.gpus and a.backend == "nccl":
         print(json.dumps({"error": f"--gpus {a.gpus} but {ndev} GPU(s) are visible: RCCL needs one device per rank "
                                    "(--backend gloo lets ranks share a device: plumbing rehearsal only)", "n_gpus": a.gpus}), flush=True)
         return 2
@@ -700,8 +726,6 @@ def main():
             out["value_core"] = core[head_mode]["reads_per_s_job"]
             out["value_core_region"] = ("core: ioc_cluster_merge + ioc_index_export from host arrays, H2D of the minimizer SoA (+ sequences) and "
                                         "every D2H inside; min of 3 runs per rank, all ranks' reads / the slowest rank's time")
-            if head.get("cpu_baseline"):
-                out["value_core_vs_cpu_baseline"] = out["value_core"] / head["cpu_baseline"]["value"]
         if head_mode == "sahlin":
             out["alignment"] = sah["alignment"]
             out["config"]["aligner"] = ("IOC_ALIGN_ARENA=fat: version 1, fine checkpoints, arena kept resident" if a.aligner == "fat"

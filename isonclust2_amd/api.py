@@ -51,6 +51,7 @@ class Context:
         if rc != 0:
             raise IocError(rc, "ioc_ctx_create failed (no MI355X visible?)")
         self.h = h
+        self.device = int(device)   # (the HIP device is per THREAD: helpers that allocate through torch pass this explicitly)
         self._keep = []
 
     @property

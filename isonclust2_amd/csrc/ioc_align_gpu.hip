@@ -2001,7 +2001,16 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k_fwd2), 64 * V2_WAVES, 0) != hipSuccess) occ = 0;
     (void)hipGetLastError();
     if (occ < 1) occ = 3;
-    std::vector<hipEvent_t> evs(slices.size() * 3, nullptr);
+    struct EventSet {  // (destroyed on every way out, the ACHK returns included)
+        std::vector<hipEvent_t> v;
+        ~EventSet()
+        {
+            for (auto& e : v)
+                if (e) (void)hipEventDestroy(e);
+        }
+    } evset;
+    evset.v.assign(slices.size() * 3, nullptr);
+    std::vector<hipEvent_t>& evs = evset.v;
     for (auto& e : evs) ACHK(c, hipEventCreate(&e));
     size_t evi = 0;
     bool bad = false;
@@ -2101,7 +2110,6 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         if (hipEventElapsedTime(&a, evs[x], evs[x + 1]) == hipSuccess) c->tm.ms_align_fwd += a;
         if (hipEventElapsedTime(&b, evs[x + 1], evs[x + 2]) == hipSuccess) c->tm.ms_align_trace += b;
     }
-    for (auto& e : evs) (void)hipEventDestroy(e);
     if (getenv("IOC_TRACE"))
         fprintf(stderr, "[ioc]   aligner v2: forward %.3f ms, traceback %.3f ms (device, all slices so far)%s\n", c->tm.ms_align_fwd,
                 c->tm.ms_align_trace, bad ? " — a wait ran out: falling back to version 1" : "");

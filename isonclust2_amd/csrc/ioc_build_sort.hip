@@ -239,6 +239,8 @@ hipError_t iock_build_sort_phase2(hipStream_t st, const IocBuildSort* a, uint32_
                                   uint32_t* cnt, uint32_t* off, void* post, uint32_t* qinfo, uint32_t n_targets, uint32_t* err)
 {
     if (R == 0) return hipSuccess;
+    // (the scan's contract: ceil(n / 1024) + 1 words of scratch for n = cap + 1 slots; the caller sized it for the largest table)
+    if ((size_t(cap) + 1 + 1023) / 1024 + 1 > a->scan_words) return hipErrorInvalidValue;
     const Epochs E = iock_epoch_bounds(a->L, n_targets);
     const dim3 gr((R + BS_BLOCK - 1) / BS_BLOCK);
     if (a->post16)

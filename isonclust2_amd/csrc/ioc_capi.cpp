@@ -119,12 +119,12 @@ int ioc_ctx_create(int device, ioc_ctx** out)
             delete c;
             return IOC_ERR_HIP;
         }
-    // k_score_part's variant without a window test leans on the hardware dropping LDS atomics beyond the workgroup's
-    // allocation: probed here, on this device, before anything depends on it (IOC_SCORE_OOB=0 / 1 forces the variant)
+    // k_score_part has two builds.  The DEFAULT tests every posting against the workgroup's target window (defined behaviour).
+    // The other one has no window test and leans on gfx950 dropping LDS atomics beyond the workgroup's allocation; it bought
+    // 1.6 % of the kernel's time on config 2 (the kernel is LDS-bound, not VALU-bound), so it is opt-in: IOC_SCORE_OOB=1 asks
+    // for it, and even then only a passed probe on THIS device (k_lds_oob_probe) selects it.
     const char* force = getenv("IOC_SCORE_OOB");
-    if (force && *force) {
-        c->score_oob = atoi(force) != 0;
-    } else {
+    if (force && atoi(force) != 0) {
         uint32_t* d_res = nullptr;
         uint32_t h_res[2] = {~0u, 0u};
         if (hipMalloc(&d_res, 8) != hipSuccess || iock_lds_oob_probe(c->stream, d_res, h_res) != hipSuccess) {
@@ -589,7 +589,9 @@ int ioc_index_build(ioc_ctx* c)
         a.temp_bytes = iock_build_sort_temp_bytes(NP, c->post16, value_bits);
         // one arena: [pk_in][pk_out][rid][roff][run_start][lens][scan scratch][ctl][pv_in][pv_out][temp]
         const size_t w = size_t(NP) + 4;
-        const size_t words = 6 * w + (size_t(NP) / 1024 + 8) + 4;
+        // (the scan of phase 2 runs over the table's SLOTS, not over the pairs: up to cap_safe + 1 of them once the table has grown)
+        const size_t scan_words = (std::max<size_t>(size_t(NP), size_t(cap_safe)) + 1) / 1024 + 8;
+        const size_t words = 6 * w + scan_words + 4;
         const size_t pvb = (size_t(NP) * psize + 255) & ~size_t(255);
         RESERVE(c, c->b_bsort, words * 4 + 2 * pvb + a.temp_bytes + 1024);
         uint32_t* wp = P<uint32_t>(c->b_bsort);
@@ -599,7 +601,8 @@ int ioc_index_build(ioc_ctx* c)
         a.run_slot = wp + 3 * w;
         a.run_start = wp + 4 * w;
         a.scan_scratch = wp + 6 * w;
-        a.ctl = a.scan_scratch + (size_t(NP) / 1024 + 8);
+        a.scan_words = scan_words;
+        a.ctl = a.scan_scratch + scan_words;
         uint8_t* bp = reinterpret_cast<uint8_t*>(wp) + ((words * 4 + 255) & ~size_t(255));
         a.pv_in = bp;
         a.pv_out = bp + pvb;
@@ -784,6 +787,14 @@ int ioc_score(ioc_ctx* c)
     } else {
         c->gap_bound_gen = ~0ull;
     }
+    // (the launcher's per-thread settings are taken back on EVERY way out of this function, the error returns included)
+    struct ScoreSettings {
+        ~ScoreSettings()
+        {
+            iock_set_score_shard(1, 0);
+            iock_set_score_keep(nullptr);
+        }
+    } score_settings_guard;
     iock_set_score_keep(c->keep_q_on ? P<uint32_t>(c->b_keep_q) : nullptr);
     c->scored_sharded = c->shard_world > 1 && c->shard_fn && !aln_mode_s;
     iock_set_score_shard(c->scored_sharded ? c->shard_world : 1, c->shard_rank);

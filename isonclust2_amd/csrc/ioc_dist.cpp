@@ -21,12 +21,21 @@ struct ioc_dist_state {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     DevBuf stage;  // host records on their way through HBM
+    // status agreement (see agree()): a device word pair and its pinned mirror; `informed` = this rank has already learnt
+    // through an agreement that some rank failed, so it owes its peers no further announcement
+    int32_t* d_status = nullptr;
+    int32_t* h_status = nullptr;
+    bool informed = false;
+    hipStream_t stream = nullptr;
 };
 
 #define NCK(c, x)                                                                                   \
     do {                                                                                            \
         ncclResult_t r_ = (x);                                                                      \
-        if (r_ != ncclSuccess) return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ") + ncclGetErrorString(r_) + " (" #x ")"); \
+        if (r_ != ncclSuccess) {                                                                    \
+            dist_abort((c)->dist);                                                                  \
+            return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ") + ncclGetErrorString(r_) + " (" #x "); communicator aborted"); \
+        }                                                                                           \
     } while (0)
 #define HCK(c, x)                                                                                  \
     do {                                                                                           \
@@ -38,7 +47,46 @@ static int need_dist(ioc_ctx* c)
 {
     if (!c) return IOC_ERR_ARG;
     if (!c->dist) return ioc_fail(c, IOC_ERR_STATE, "ioc_dist_init has not been called on this context");
+    if (!c->dist->comm) return ioc_fail(c, IOC_ERR_STATE, "the communicator of this context was aborted after an RCCL error");
     return IOC_OK;
+}
+
+// An RCCL call failed on this rank: abort the communicator, so that this rank's queued collectives are torn down and every
+// later ioc_dist_* call fails at once instead of entering a collective the peers will never complete.
+static void dist_abort(ioc_dist_state* d)
+{
+    if (d && d->comm) {
+        (void)ncclCommAbort(d->comm);
+        d->comm = nullptr;
+    }
+}
+
+// STATUS AGREEMENT.  A rank that fails locally (an allocation, a size check, a replay that finds nothing) must not simply
+// return: its peers are inside, or about to enter, the next collective and would wait for ever.  Protocol: every collective
+// stage that can be preceded by a local failure starts with agree(local status) — one all-reduce (max) of one word, read back
+// by the host.  All ranks leave it with the same answer; when it is non-zero every rank gives up at that point.  A rank that
+// fails BETWEEN two agreements jumps straight to its next agree() with status 1 — that call pairs with whatever agreement the
+// peers reach next (they are all the same collective: 1 x int32, max), the peers learn of the failure there and stop.  A rank
+// that has been told of a failure this way (`informed`) skips its own closing announcement: everybody has left already.
+static int agree(ioc_dist_state* d, int local_status)
+{
+    if (!d || !d->comm) return 1;
+    if (d->informed) return 1;
+    if (d->world == 1) return local_status != 0;
+    d->h_status[0] = local_status != 0 ? 1 : 0;
+    if (hipMemcpyAsync(d->d_status, d->h_status, 4, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
+        ncclAllReduce(d->d_status, d->d_status + 1, 1, ncclInt32, ncclMax, d->comm, d->stream) != ncclSuccess) {
+        dist_abort(d);
+        return 1;
+    }
+    if (hipMemcpyAsync(d->h_status + 1, d->d_status + 1, 4, hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+        hipStreamSynchronize(d->stream) != hipSuccess) {
+        dist_abort(d);
+        return 1;
+    }
+    const int worst = static_cast<volatile int32_t*>(d->h_status)[1];
+    if (worst != 0 && local_status == 0) d->informed = true;  // (somebody else failed: nothing left to announce)
+    return worst;
 }
 
 static int reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
@@ -60,10 +108,17 @@ static int rccl_exchange(void* user, void* d_buf, int64_t count, int32_t kind, v
 {
     ioc_dist_state* d = static_cast<ioc_dist_state*>(user);
     if (!d || !d->comm || count < 0) return 1;
+    // (every exchange of the sharded resolve is a point where the ranks agree that all of them are still in: a rank that
+    // failed since the last one announces it here, through ioc_dist_merge's closing agree())
+    if (agree(d, 0) != 0) return 1;
     if (count == 0) return 0;
     ncclDataType_t t = kind == IOC_XCHG_MAX_U8 ? ncclUint8 : kind == IOC_XCHG_MIN_U32 ? ncclUint32 : ncclInt32;
     ncclRedOp_t op = kind == IOC_XCHG_MAX_U8 ? ncclMax : kind == IOC_XCHG_MIN_U32 ? ncclMin : ncclSum;
-    return ncclAllReduce(d_buf, d_buf, size_t(count), t, op, d->comm, static_cast<hipStream_t>(hip_stream)) == ncclSuccess ? 0 : 1;
+    if (ncclAllReduce(d_buf, d_buf, size_t(count), t, op, d->comm, static_cast<hipStream_t>(hip_stream)) != ncclSuccess) {
+        dist_abort(d);
+        return 1;
+    }
+    return 0;
 }
 
 extern "C" {
@@ -93,6 +148,14 @@ int ioc_dist_init(ioc_ctx* c, const uint8_t* id, int32_t rank, int32_t world)
         delete d;
         return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ncclCommInitRank: ") + ncclGetErrorString(r));
     }
+    d->stream = c->stream;
+    if (hipMalloc(reinterpret_cast<void**>(&d->d_status), 16) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&d->h_status), 16, hipHostMallocDefault) != hipSuccess) {
+        if (d->d_status) (void)hipFree(d->d_status);
+        (void)ncclCommAbort(d->comm);
+        delete d;
+        return ioc_fail(c, IOC_ERR_HIP, "ioc_dist_init: no memory for the status words");
+    }
     c->dist = d;
     return IOC_OK;
 }
@@ -105,6 +168,8 @@ int ioc_dist_shutdown(ioc_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     if (c->dist->comm) (void)ncclCommDestroy(c->dist->comm);
     if (c->dist->stage.p) (void)hipFree(c->dist->stage.p);
+    if (c->dist->d_status) (void)hipFree(c->dist->d_status);
+    if (c->dist->h_status) (void)hipHostFree(c->dist->h_status);
     delete c->dist;
     c->dist = nullptr;
     return IOC_OK;
@@ -272,12 +337,17 @@ int ioc_dist_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, cons
         if (sbs[size_t(r)] < 0) all_seq = false; else SB += sbs[size_t(r)];
     }
     if (!out_cls || !out_strand) return IOC_OK;  // sizing call
-    if (out_cap < N) return ioc_fail(c, IOC_ERR_ARG, "ioc_dist_merge: out_cap is smaller than the number of representatives of all ranks");
-    if (N > INT32_MAX) return ioc_fail(c, IOC_ERR_CAPACITY, "too many representatives");
+    d->informed = false;
+    // (local checks first, then the ranks agree: a rank that cannot go on must not leave the others inside the list exchange)
+    int local = IOC_OK;
+    if (out_cap < N) local = ioc_fail(c, IOC_ERR_ARG, "ioc_dist_merge: out_cap is smaller than the number of representatives of all ranks");
+    else if (N > INT32_MAX) local = ioc_fail(c, IOC_ERR_CAPACITY, "too many representatives");
     // 2. the minimizer lists, HBM to HBM, into [all forward lists][all reverse lists]
+    if (local == IOC_OK) local = reserve(c, c->b_dist_min, size_t(FW + RW) * 4 + 256);
+    if (local == IOC_OK) local = reserve(c, c->b_dist_pos, size_t(FW + RW) * 4 + 256);
+    if (agree(d, local) != 0)
+        return local != IOC_OK ? local : ioc_fail(c, IOC_ERR_STATE, "ioc_dist_merge: another rank could not start the exchange (its own error says why)");
     HCK(c, hipEventRecord(e0, c->stream));
-    if (int rc = reserve(c, c->b_dist_min, size_t(FW + RW) * 4 + 256)) return rc;
-    if (int rc = reserve(c, c->b_dist_pos, size_t(FW + RW) * 4 + 256)) return rc;
     uint32_t* gmin = static_cast<uint32_t*>(c->b_dist_min.p);
     uint32_t* gpos = static_cast<uint32_t*>(c->b_dist_pos.p);
     std::vector<int64_t> dF(static_cast<size_t>(W)), dR(static_cast<size_t>(W));
@@ -383,10 +453,16 @@ int ioc_dist_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, cons
     // fast mode: score + resolve sharded over the ranks (query j on rank j % W), `valid` all-reduced after every sweep
     const char* es = getenv("IOC_DIST_SHARD");
     const bool shard = W > 1 && p->mode == IOC_MODE_FAST && !(es && es[0] == '0');
-    if (shard && ioc_dist_set_shard(c, 1) != IOC_OK) return IOC_ERR_STATE;
-    const int rc = ioc_cluster_merge(c, p, table_path, nullptr, &v, out_cls, out_strand, stats);
+    int rc = IOC_OK;
+    if (shard && ioc_dist_set_shard(c, 1) != IOC_OK) rc = IOC_ERR_STATE;
+    if (rc == IOC_OK) rc = ioc_cluster_merge(c, p, table_path, nullptr, &v, out_cls, out_strand, stats);
     const int exchanges = ioc_shard_exchanges(c);
     if (shard) (void)ioc_dist_set_shard(c, 0);
+    // the closing agreement: a rank that failed since the last exchange (or in a merge without exchanges: the alignment modes)
+    // says so here; it pairs with the agreement in front of the peers' next exchange or with their closing one
+    const bool told = d->informed;
+    if (!told && agree(d, rc) != 0 && rc == IOC_OK)
+        rc = ioc_fail(c, IOC_ERR_STATE, "ioc_dist_merge: another rank failed inside the merge (its own error says why)");
     if (times) {
         times->sharded = shard ? 1 : 0;
         times->exchanges = exchanges;

@@ -175,7 +175,8 @@ struct IocBuildSort {
     void *pv_in, *pv_out;         // [P] postings (u16 / u32)
     uint32_t *rid, *run_slot;     // [P + 1]: run number of every pair (exclusive scan of the flags); hash slot of every run
     uint32_t *run_start;          // [P + 1]
-    uint32_t *scan_scratch;       // [P / 1024 + 4]
+    uint32_t *scan_scratch;       // [scan_words]: what an exclusive scan over the table's slots needs (ceil((cap + 1) / 1024) + 1)
+    size_t scan_words;
     uint32_t* ctl;                // 4 words
     void* temp;
     size_t temp_bytes;

@@ -2337,8 +2337,10 @@ static int g_score_variant = 0;
 static int g_part32 = 0;
 static int g_score_oob = 0;  // k_score_part without a window test (ioc_ctx_create's probe passed, or IOC_SCORE_OOB=1)
 // sharded merge: this rank scores the queries j with j % stride == offset 
-static int g_own_stride = 1, g_own_offset = 0;
-static const uint32_t* g_keep_q = nullptr;  // per-query compaction threshold (fast mode; null: the uniform `keep`)
+// (per calling thread: two contexts driven from two threads do not see each other's setting; ioc_score resets both through a
+// scope guard on every way out)
+static thread_local int g_own_stride = 1, g_own_offset = 0;
+static thread_local const uint32_t* g_keep_q = nullptr;  // per-query compaction threshold (fast mode; null: the uniform `keep`)
 
 namespace {
 // ---- MinDB export (ioc_index_export): the posting lists restricted to the targets that ARE clusters, with final ids ----

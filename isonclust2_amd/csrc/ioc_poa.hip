@@ -1593,6 +1593,7 @@ int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t 
 // blob -> graph (pure host code, no shared state: safe on worker threads); 0, or 1 foreign blob / 2 corrupt / 3 cyclic
 static int parse_graph_blob(const uint8_t* in, int64_t len, PGraph& G)
 {
+    if (!in || len < 20) return 2;  // (magic + three counts; a negative length would put `e` in front of `q`)
     const uint8_t* q = in;
     const uint8_t* e = in + len;
     bool ok = true;
@@ -1653,7 +1654,7 @@ static int graph_blob_error(ioc_poa* p, int code)
 
 int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t len)
 {
-    if (!p || side < 0 || side > 1 || !in) return IOC_ERR_ARG;
+    if (!p || side < 0 || side > 1 || !in || idx < 0 || len < 0) return IOC_ERR_ARG;
     PGraph G;
     const int code = parse_graph_blob(in, len, G);
     if (code) return graph_blob_error(p, code);
@@ -1669,7 +1670,7 @@ int ioc_poa_graph_load_many(ioc_poa* p, int side, int32_t count, const int32_t* 
     std::vector<PGraph> gs(static_cast<size_t>(count));
     std::vector<int> code(static_cast<size_t>(count), 0);
     for (int32_t x = 0; x < count; ++x)
-        if (!in[x]) return IOC_ERR_ARG;
+        if (!in[x] || idx[x] < 0 || len[x] < 0) return IOC_ERR_ARG;
     ioc_parallel_for(size_t(count), [&](size_t x) { code[x] = parse_graph_blob(in[x], len[x], gs[x]); }, 8);
     for (int32_t x = 0; x < count; ++x)
         if (code[size_t(x)]) return graph_blob_error(p, code[size_t(x)]);

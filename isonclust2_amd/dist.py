@@ -297,12 +297,20 @@ def merge_gathered(ctx, params, metas, recv_min, recv_pos, cap, min_cls_size=3, 
     return _assemble(metas, cls, strand, st, mindb=mindb)
 
 
+def _ctx_device(ctx, torch):
+    """The context's OWN card as a torch device, and torch's current device of the calling thread set to it: HIP's current device
+    is per thread (a fresh worker thread starts on device 0), so nothing here may rely on torch.cuda.current_device()."""
+    idx = int(getattr(ctx, "device", 0))
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
 def merge_all_device(ctx, params, cb: ClusteredBatch, dist, torch, min_cls_size=3, export_mindb=False, timing=None):
     """The merge of all ranks' freshly clustered batches with device-resident representative records (module
     docstring, steps 1-3).  Every rank returns the merged clustering (membership + counts; the merged clusters'
     records stay in HBM)."""
     import time
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _ctx_device(ctx, torch)
     t0 = time.perf_counter()
     mins, poss = gather_local(ctx, cb, torch, dev)                       # step 1: HBM -> HBM
     meta = pack_clustered(cb, with_minimizers=False)
@@ -350,7 +358,7 @@ def torch_exchange(ctx, dist, torch):
     with gloo it is reduced on the host.  The context's stream is drained before and torch's after, so the order the C ABI
     asks for (after the work already on the stream, before what follows) holds."""
     from . import _lib
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _ctx_device(ctx, torch)
     on_host = _device(dist).type != "cuda"
 
     class Wrap:
@@ -429,11 +437,13 @@ def merge_all_native(ctx, params, cb: ClusteredBatch, torch=None, min_cls_size=3
     W = world.value
     rv = dict(cb.rep_view)
     keep = None
+    path = "host arrays (H2D inside ioc_dist_merge)"
     if torch is not None and cb.rep_entry is not None and cb.ctx_serial == ctx.serial:
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = _ctx_device(ctx, torch)
         mins, poss = gather_local(ctx, cb, torch, dev)                   # the lists never visit the host
         rv.update(min_val=mins.data_ptr(), min_pos=poss.data_ptr(), total=int(mins.numel()), minimizers_on_device=True)
         keep = (mins, poss)
+        path = "device gather (lists HBM to HBM)"
     if cb.rep_seq is not None:
         rv.update(raw_seq=cb.rep_seq, raw_off=cb.rep_off)
     view, n, alive = ctx._make_view(rv)
@@ -474,5 +484,5 @@ def merge_all_native(ctx, params, cb: ClusteredBatch, torch=None, min_cls_size=3
     if timing is not None:
         timing.update(sizing_ms=(t1 - t0) * 1e3, call_ms=(t2 - t1) * 1e3, exchange_lists_ms=float(tms.ms_exchange_lists),
                       merge_ms=float(tms.ms_merge), bytes_lists=int(tms.bytes_lists), bytes_records=int(tms.bytes_records),
-                      clusters_in=[int(x) for x in counts], sharded=int(tms.sharded), exchanges=int(tms.exchanges))
+                      clusters_in=[int(x) for x in counts], sharded=int(tms.sharded), exchanges=int(tms.exchanges), lists_path=path)
     return merged

@@ -15,23 +15,7 @@ from oracle import pyoracle as po
 from tests.helpers import ToyGraphs
 
 
-def _oracle_run(rs, cons_max, cons_min, period, mode="fast", k=11, w=15, graphs=None):
-    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
-    R.score_sort(k, w)
-    p = po.default_params(k, w)
-    p.cons_max_size = cons_max
-    B = po.Batch(R, 0, rs.n - 1, p)
-    info, off_f, off_r, mn, ps = B.minimizer_soa()
-    view = dict(off_fwd=off_f, off_rev=off_r, min_val=mn, min_pos=ps, raw_len=info["raw_len"], hpc_len=info["hpc_len"],
-                score=info["score"], raw_err=info["raw_err"], hpc_err=info["hpc_err"], state=info["state"].astype(np.uint8),
-                min_qual=p.min_qual, orig=info["orig"])
-    g = graphs or ToyGraphs()
-    po.lib().orc_set_consensus(C.cast(C.pointer(g.ops), C.c_void_p), cons_min, period)
-    try:
-        st = B.cluster(mode=mode)
-    finally:
-        po.lib().orc_set_consensus(None, 50, 500)
-    return B, view, st, g
+from tests.fuzz_cases import oracle_consensus_run as _oracle_run  # noqa: E402  (one definition for tests and soaks)
 
 
 def test_oracle_consensus_branch_runs_and_updates_the_index():

@@ -1,0 +1,126 @@
+"""Bounded slices of the randomised differential battery (tools/fuzz_*.py) inside the driver-run `-m gpu` suite
+(VERDICT r3 "what's missing" 4: the one real parity bug of round 3 — a Size-1 key reordering two tied clusters,
+src/cluster.cpp:622-636 — was found by a fuzz seed the driver never ran).
+
+Every slice = FIXED cases first (every case that ever failed, and tie-heavy shapes), then cases drawn from a seed that ROTATES
+with the build: the sha of the library's sources (the .git directory does not travel to the GPU box), so that every code
+change is met by cases no earlier build saw.  A slice stops drawing new cases when its share of the time is spent
+(IOC_FUZZ_SECONDS, default 12 s per slice; the fixed cases always run).  A failure prints the reproducer: the case's full
+parameter dict, `python tools/fuzz_parity.py --case '<dict>'` (or fuzz_consensus.py) replays it."""
+import glob
+import hashlib
+import os
+import random
+import time
+
+import numpy as np
+import pytest
+
+from isonclust2_amd import api
+from tests import fuzz_cases as fz
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUDGET = float(os.environ.get("IOC_FUZZ_SECONDS", "12"))
+
+
+def _build_seed():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "isonclust2_amd", "csrc", "*.*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if f.endswith((".hip", ".cpp", ".h", ".inc")):
+            h.update(open(f, "rb").read())
+    return int.from_bytes(h.digest()[:4], "little")
+
+
+SEED = _build_seed()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _slice(run, fixed, draw, min_random=4):
+    """fixed cases, then random ones until the budget is spent (at least min_random); returns the failures."""
+    bad, t0, n = [], time.time(), 0
+    for c in fixed:
+        ok, why = run(c)
+        if not ok:
+            bad.append((c, why))
+    while n < min_random or time.time() - t0 < BUDGET:
+        c = draw()
+        ok, why = run(c)
+        n += 1
+        if not ok:
+            bad.append((c, why))
+        if n >= 400:
+            break
+    return bad, n
+
+
+# tie-heavy fixed shapes: short duplicated transcripts (many clusters tied at the top Size: the libstdc++ order decides)
+_PARITY_FIXED = [
+    dict(n=200, g=12, ln=200, qlo=11.0, qhi=19.0, dup=2, jit=0.0, k=11, w=15, seed=101, mode="fast"),
+    dict(n=259, g=23, ln=120, qlo=9.0, qhi=21.0, dup=3, jit=0.3, k=10, w=14, seed=202, mode="fast"),
+    dict(n=150, g=6, ln=350, qlo=7.0, qhi=11.0, dup=2, jit=0.0, k=13, w=20, seed=303, mode="fast"),
+    dict(n=1, g=1, ln=120, qlo=14.0, qhi=18.0, dup=0, jit=0.0, k=15, w=22, seed=404, mode="fast"),
+]
+
+
+@pytest.mark.parametrize("mode", ["fast", "sahlin", "furious"])
+def test_fuzz_parity(ctx, mode):
+    rng = np.random.default_rng([SEED, {"fast": 1, "sahlin": 2, "furious": 3}[mode]])
+    fixed = [dict(c, mode=mode, n=min(c["n"], 70 if mode != "fast" else c["n"]), ln=min(c["ln"], 350 if mode != "fast" else c["ln"])) for c in _PARITY_FIXED]
+    count = [0]
+
+    def run(c):
+        count[0] += 1
+        return fz.run_parity(ctx, c, merge=(count[0] % 4 == 0))
+
+    bad, n = _slice(run, fixed, lambda: fz.draw_parity(rng, None if mode == "fast" else mode))
+    assert not bad, f"{len(bad)} of {n + len(fixed)} cases differ from the oracle; first: python tools/fuzz_parity.py --case \"{bad[0][0]}\"  ({bad[0][1]})"
+
+
+_CONS_FIXED = [
+    # tools/fuzz_consensus.py seed 34, case 52 (round 3): entry 82 meets two clusters tied at the top Size, both pass, and the
+    # reference's hit order between them hangs on a Size-1 key of a THIRD cluster whose representative changed one entry earlier
+    dict(n=162, g=5, ln=1200, cmax=12, cmin=2, period=25, seed=163853082, dup=0, mode="fast", qlo=11, qhi=22),
+    # tie-heavy: duplicated transcripts, short reads, consensus at every second member
+    dict(n=200, g=8, ln=300, cmax=3, cmin=2, period=500, seed=77, dup=2, mode="fast", qlo=11, qhi=22),
+    dict(n=219, g=11, ln=500, cmax=6, cmin=2, period=5, seed=78, dup=2, mode="fast", qlo=11, qhi=22),
+]
+
+
+@pytest.mark.parametrize("mode,speculate", [("fast", None), ("fast", False), ("sahlin", None)])
+def test_fuzz_consensus(ctx, mode, speculate):
+    rng = np.random.default_rng([SEED, 10 + (0 if mode == "fast" else 1) + (2 if speculate is False else 0)])
+    fixed = [dict(c, mode=mode, n=min(c["n"], 120 if mode != "fast" else c["n"]), ln=min(c["ln"], 800 if mode != "fast" else c["ln"])) for c in _CONS_FIXED]
+    bad, n = _slice(lambda c: fz.run_consensus(ctx, c, speculate=speculate), fixed, lambda: fz.draw_consensus(rng, mode))
+    env = "IOC_CONS_SPECULATE=0 " if speculate is False else ""
+    assert not bad, f"{len(bad)} of {n + len(fixed)} cases differ from the oracle; first: {env}python tools/fuzz_consensus.py --case \"{bad[0][0]}\"  ({bad[0][1]})"
+
+
+def test_fuzz_align(ctx):
+    bad, t0, n = [], time.time(), 0
+    for s in [31, SEED & 0xFFFF] + [((SEED >> 8) + i) & 0xFFFFFF for i in range(200)]:
+        ok, why = fz.align_batch(ctx, random.Random(s))
+        n += 1
+        if not ok:
+            bad.append((s, why))
+        if n >= 3 and time.time() - t0 > BUDGET:
+            break
+    assert not bad, f"{len(bad)} of {n} batches differ from the host aligner; first: python tools/fuzz_align.py --seed {bad[0][0]}  ({bad[0][1]})"
+
+
+def test_fuzz_verdict(ctx):
+    bad, t0, n = [], time.time(), 0
+    for s in [32, SEED & 0xFFFF] + [((SEED >> 12) + i) & 0xFFFFFF for i in range(200)]:
+        ok, why = fz.verdict_batch(ctx, random.Random(s))
+        n += 1
+        if not ok:
+            bad.append((s, why))
+        if n >= 2 and time.time() - t0 > BUDGET:
+            break
+    assert not bad, f"{len(bad)} of {n} batches: verdict mode differs from the exact mode; first: python tools/fuzz_verdict.py --seed {bad[0][0]}  ({bad[0][1]})"
