@@ -42,8 +42,8 @@ def default_params(k=11, w=15, mode="fast"):
 
 def build(force=False):
     so = os.path.join(HERE, "liboracle.so")
-    src = os.path.join(HERE, "oracle.cpp")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, "oracle.cpp"), os.path.join(HERE, "poa_oracle.cpp")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs if os.path.exists(x)):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     return so
 
@@ -115,6 +115,15 @@ def lib():
     L.orc_batch_update_mindb.argtypes = [vp, C.c_int, u32p, C.c_int64, u32p, C.c_int64, C.c_int]
     L.orc_set_consensus.argtypes = [vp, C.c_int, C.c_int]
     L.orc_set_consensus.restype = None
+    # the scalar partial-order alignment (poa_oracle.cpp)
+    L.orp_create.argtypes = [i32] * 6
+    L.orp_create.restype = vp
+    L.orp_destroy.argtypes = [vp]
+    L.orp_destroy.restype = None
+    L.orp_bind.argtypes = [vp, vp]
+    L.orp_bind.restype = None
+    L.orp_graph_export.argtypes = [vp, i32, i32, i32p, i32p, i32p, cp, i32p, i32p, i32p, i64p, i32p, i32p]
+    L.orp_last_alignment.argtypes = [vp, i32, i32p, i32p, i32p]
     _lib = L
     return L
 
@@ -397,3 +406,78 @@ def ref():
     R.ref_pmin_lookup.restype = C.c_double
     _ref = R
     return R
+
+
+# ---- the scalar POA behind the consensus' graph operations (poa_oracle.cpp) -----------------------------------------------
+class PoaOps(C.Structure):
+    """orc_cons_ops (oracle.h) = the first six members of ioc_consensus_ops."""
+    _fields_ = [("user", C.c_void_p), ("create", C.c_void_p), ("size", C.c_void_p), ("add", C.c_void_p),
+                ("consensus", C.c_void_p), ("purge", C.c_void_p)]
+
+
+class OraclePoa:
+    """One store of partial-order graphs {(side, idx)} with spoa 4.0's operations restated (poa_oracle.cpp): create / add /
+    size / consensus / purge, plus inspection of a graph and of the last alignment."""
+    SC = dict(m=4, n=-8, g=-8, e=-4, q=-20, c=-1)   # src/main.cpp:285-290
+
+    def __init__(self, **sc):
+        sc = dict(self.SC, **sc)
+        self.L = lib()
+        self.h = self.L.orp_create(sc["m"], sc["n"], sc["g"], sc["e"], sc["q"], sc["c"])
+        self.ops = PoaOps()
+        self.L.orp_bind(self.h, C.addressof(self.ops))
+        proto = lambda *a: C.CFUNCTYPE(C.c_int, C.c_void_p, *a)
+        self._create = proto(C.c_int, C.c_int, C.c_char_p, C.c_int)(self.ops.create)
+        self._size = proto(C.c_int, C.c_int)(self.ops.size)
+        self._add = proto(C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_uint)(self.ops.add)
+        self._cons = proto(C.c_int, C.c_int, C.c_char_p, C.c_int)(self.ops.consensus)
+        self._purge = proto(C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_uint)(self.ops.purge)
+
+    def ops_pointer(self):
+        """for orc_set_consensus / a struct that starts like ioc_consensus_ops"""
+        return C.cast(C.pointer(self.ops), C.c_void_p)
+
+    def create(self, idx, s, side=0):
+        assert self._create(self.ops.user, side, idx, s, len(s)) == 0
+
+    def add(self, idx, s, w=1, side=0):
+        assert self._add(self.ops.user, side, idx, s, len(s), w) == 0
+
+    def purge(self, idx, s, w=1, side=0):
+        assert self._purge(self.ops.user, side, idx, s, len(s), w) == 0
+
+    def size(self, idx, side=0):
+        return self._size(self.ops.user, side, idx)
+
+    def consensus(self, idx, side=0):
+        buf = C.create_string_buffer(1 << 20)
+        n = self._cons(self.ops.user, side, idx, buf, len(buf))
+        assert n >= 0
+        return buf.raw[:n]
+
+    def graph(self, idx, side=0, aligned=False):
+        nn, ne, na = C.c_int32(), C.c_int32(), C.c_int32()
+        assert self.L.orp_graph_export(self.h, side, idx, C.byref(nn), C.byref(ne), C.byref(na), None, None, None, None, None, None, None) == 0
+        bases = C.create_string_buffer(nn.value + 1)
+        rank = np.zeros(max(1, nn.value), np.int32)
+        ef, et = np.zeros(max(1, ne.value), np.int32), np.zeros(max(1, ne.value), np.int32)
+        ew = np.zeros(max(1, ne.value), np.int64)
+        ao, al = np.zeros(nn.value + 1, np.int32), np.zeros(max(1, na.value), np.int32)
+        assert self.L.orp_graph_export(self.h, side, idx, C.byref(nn), C.byref(ne), C.byref(na), bases, _p(rank, C.c_int32), _p(ef, C.c_int32),
+                                       _p(et, C.c_int32), _p(ew, C.c_int64), _p(ao, C.c_int32), _p(al, C.c_int32)) == 0
+        out = (bases.raw[:nn.value], rank[:nn.value], ef[:ne.value], et[:ne.value], ew[:ne.value])
+        if aligned:
+            out += ([al[ao[v]:ao[v + 1]].tolist() for v in range(nn.value)],)
+        return out
+
+    def last_alignment(self):
+        sc = C.c_int32()
+        n = self.L.orp_last_alignment(self.h, 0, None, None, C.byref(sc))
+        nodes, pos = np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.int32)
+        assert self.L.orp_last_alignment(self.h, n, _p(nodes, C.c_int32), _p(pos, C.c_int32), C.byref(sc)) == n
+        return nodes[:n], pos[:n], sc.value
+
+    def close(self):
+        if self.h:
+            self.L.orp_destroy(self.h)
+            self.h = None
