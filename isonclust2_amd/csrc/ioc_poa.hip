@@ -47,7 +47,10 @@ constexpr int POA_MAX_COLS = 1 << 20;
 constexpr int POA_MAX_PREDS = 127;
 
 // direction word: [1:0] source of Hn (0 stop, 1 diagonal, 2 F1, 3 F2)  [7] F1 extended  [8] F2 extended
-// (a horizontal gap winning H is in the cell's E byte: [2:0] 4 E1 / 5 E2 / 0, [3] E1 extended, [4] E2 extended)
+// [2] / [3]: extending and opening F1 / F2 score the same (the traceback's rule for that tie differs between the step that
+// ENTERS a vertical gap from H — extension first — and the steps that follow the gap up — opening first: DESIGN.md 5.7)
+// (a horizontal gap winning H is in the cell's E byte: [2:0] 4 E1 / 5 E2 / 0, [3] E1 extended, [4] E2 extended; a tie
+// between extending and opening a horizontal gap counts as extended)
 // [15:9] / [22:16] / [29:23] predecessor (index into the row's predecessor list) of the diagonal / F1 / F2 move
 enum : uint32_t { SRC_STOP = 0, SRC_DIAG = 1, SRC_F1 = 2, SRC_F2 = 3, SRC_E1 = 4, SRC_E2 = 5 };
 
@@ -245,7 +248,8 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
             uint32_t d = SRC_STOP;
             {
-                uint32_t pw = 0, f1x = 0, f2x = 0;  // pw: the predecessors the three moves came from (0 on a chain row)
+                uint32_t pw = 0, f1x = 0, f2x = 0, ft = 0;  // pw: the predecessors the three moves came from (0 on a chain row); ft: the tie bits
+                uint32_t f1p = 0, f2p = 0;
                 int dg = POA_NEG;
                 const int sc = (bs == my_base) ? S.m : S.n;
                 const int pr0u = __builtin_amdgcn_readfirstlane(pr0);
@@ -264,8 +268,9 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     const int o2 = hu + S.q, x2 = u2 + S.c;
                     f2 = max(o2, x2);
                     f2x = x2 > o2 ? 1u : 0u;
+                    ft = (x1 == o1 ? 4u : 0u) | (x2 == o2 ? 8u : 0u);
                 } else {
-                uint32_t dp = 0, f1p = 0, f2p = 0;
+                uint32_t dp = 0;
                 // plane row of predecessor entry x (only the memory paths ask: a row read from memory is a kept one)
                 auto pslot_of = [&](int x) {
                     int v = s_pslot[min(x - pb0, pred_lds - 1)];
@@ -327,6 +332,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                         f1 = v1;
                         f1p = uint32_t(x - pb);
                         f1x = x1 > o1 ? 1u : 0u;
+                        ft = (ft & ~4u) | (x1 == o1 ? 4u : 0u);
                     }
                     const int o2 = hu + S.q, x2 = u2 + S.c;
                     const int v2 = max(o2, x2);
@@ -334,6 +340,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                         f2 = v2;
                         f2p = uint32_t(x - pb);
                         f2x = x2 > o2 ? 1u : 0u;
+                        ft = (ft & ~8u) | (x2 == o2 ? 8u : 0u);
                     }
                 }
                 pw = (dp << 9) | (f1p << 16) | (f2p << 23);
@@ -346,11 +353,13 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     hn = f1;
                     d = SRC_F1;
                 }
-                if (f2 > hn) {
+                // (the two pieces score the same: the traceback takes the predecessor that comes first in the node's edge list,
+                // whichever piece it offers; on a chain row both are predecessor 0 and the first piece stands)
+                if (f2 > hn || (f2 == hn && d == SRC_F1 && f2p < f1p)) {
                     hn = f2;
                     d = SRC_F2;
                 }
-                d |= (f1x << 7) | (f2x << 8) | pw;
+                d |= (f1x << 7) | (f2x << 8) | ft | pw;
             }
             POA_TICK(0)
             // ---- prefix maxima of Hn[x] - e x and Hn[x] - c x over the columns left of j ----
@@ -362,15 +371,19 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             const int vy = max(sy, cin.y);
             const int ex = __builtin_amdgcn_update_dpp(cin.x, vx, 0x138, 0xf, 0xf, false);  // wave_shr:1: the lane on the left
             const int ey = __builtin_amdgcn_update_dpp(cin.y, vy, 0x138, 0xf, 0xf, false);
-            const int left = __builtin_amdgcn_update_dpp(cin.z, hn, 0x138, 0xf, 0xf, false);
+            // Is this column a STRICT new prefix maximum (per piece)?  The gap that ends one column to the right was opened here —
+            // rather than extended — exactly then: a tie between extending and opening counts as extended (the traceback follows a
+            // horizontal gap for as long as it can have been extended).  The flags travel right like the other carries.
+            const int snm = ((hn + ofs_e) > ex ? 1 : 0) | ((hn + ofs_c) > ey ? 2 : 0);
+            const int fl = __builtin_amdgcn_update_dpp(cin.z, snm, 0x138, 0xf, 0xf, false);
             int h = hn;
             uint32_t eb = 0;  // [2:0] E1 / E2 if a horizontal gap wins H, [3] E1 extended, [4] E2 extended
             if (j > 0) {
                 // (ex / ey are real prefix maxima here: the one POA_NEG, the left edge of the matrix, meets column 0 only)
                 const int e1 = ex + S.g + (j - 1) * S.e;
                 const int e2 = ey + S.q + (j - 1) * S.c;
-                const uint32_t e1x = e1 > left + S.g ? 1u : 0u;  // opened iff the maximum sits at column j - 1
-                const uint32_t e2x = e2 > left + S.q ? 1u : 0u;
+                const uint32_t e1x = (fl & 1) ? 0u : 1u;  // opened iff column j - 1 alone holds the maximum
+                const uint32_t e2x = (fl & 2) ? 0u : 1u;
                 if (e1 > h) {
                     h = e1;
                     eb = SRC_E1;
@@ -386,7 +399,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             sH[sl][tid] = h;
             sF1[sl][tid] = f1;
             sF2[sl][tid] = f2;
-            if (lane == 63 && wave < POA_WAVES - 1) s_carry[wave + 1][t] = int4{vx, vy, hn, h};
+            if (lane == 63 && wave < POA_WAVES - 1) s_carry[wave + 1][t] = int4{vx, vy, snm, h};
             if (active) {
                 // (row bases are uniform: scalar arithmetic, the lane adds its 32-bit column offset)
                 // (the row's base stays in scalar registers — the empty asm keeps the compiler from folding it into a per-lane 64-bit
@@ -417,7 +430,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     GI32* co = cout_row + int64_t(r) * 4;
                     co[0] = vx;
                     co[1] = vy;
-                    co[2] = hn;
+                    co[2] = snm;
                     co[3] = h;
                 }
             }
@@ -525,6 +538,7 @@ __global__ void __launch_bounds__(64) k_poa_trace(const PoaJob* __restrict__ job
     const int lane = threadIdx.x;
     int r = best[1], j = best[2], n = 0;
     int state = 0;  // 0 H, 1 Hn (H without the horizontal sources), 2 F1, 3 F2, 4 E1, 5 E2
+    bool entered = false;  // the vertical gap was entered from H by the step before: its extension / opening tie goes to the extension
     while (r > 0 && n < cap) {
         if (state == 0) {
             const int rr = r - lane, jl = j - lane;
@@ -568,6 +582,7 @@ __global__ void __launch_bounds__(64) k_poa_trace(const PoaJob* __restrict__ job
                 state = 0;
             } else {
                 state = int(src);  // F1 / F2 / E1 / E2: same cell, other matrix
+                entered = true;
             }
         } else if (state == 2 || state == 3) {
             if (lane == 0) {
@@ -575,7 +590,9 @@ __global__ void __launch_bounds__(64) k_poa_trace(const PoaJob* __restrict__ job
                 out_pos[n] = -1;
             }
             ++n;
-            const bool ext = state == 2 ? (d >> 7) & 1u : (d >> 8) & 1u;
+            bool ext = state == 2 ? (d >> 7) & 1u : (d >> 8) & 1u;
+            if (entered && (state == 2 ? (d >> 2) & 1u : (d >> 3) & 1u)) ext = true;
+            entered = false;
             r = pred[pb + int(state == 2 ? (d >> 16) & 127u : (d >> 23) & 127u)];
             if (!ext) state = 0;
         } else {
@@ -685,44 +702,68 @@ struct PGraph {
             }
         link_edge(u, v, w);
     }
-    int add_chain(const char* s, int a, int b, int64_t w)  // nodes for s[a..b), returns the first
+    // nodes for s[a..b), returns the first.  An edge between two consecutive bases of a sequence carries the weights of BOTH
+    // (spoa: weights[i - 1] + weights[i]; every base of a sequence has the same weight here, src/consensus.cpp:15-32)
+    int add_chain(const char* s, int a, int b, int64_t w)
     {
         int first = -1, prev = -1;
         for (int i = a; i < b; ++i) {
             const int v = add_node(s[i]);
             if (first < 0) first = v;
-            if (prev >= 0) link_edge(prev, v, w);  // (both nodes are new: no such edge yet)
+            if (prev >= 0) link_edge(prev, v, 2 * w);  // (both nodes are new: no such edge yet)
             prev = v;
         }
         return first;
     }
+    // Topological order as spoa's graph keeps it (the order of the DP's rows decides which of several best cells is the first
+    // one, and the consensus walks it): depth-first from every node in id order, a node after all its predecessors, the nodes
+    // of one aligned column next to each other (the column is emitted when its first-reached member is complete).
     void toposort()
     {
-        // Kahn, smallest node id first: deterministic, independent of edge insertion order
         const size_t n = n_nodes();
-        std::vector<int> indeg(in_deg);
-        std::vector<int> heap;
-        auto cmp = [](int a, int b) { return a > b; };
-        for (size_t i = 0; i < n; ++i)
-            if (!indeg[i]) heap.push_back(int(i));
-        std::make_heap(heap.begin(), heap.end(), cmp);
         rank.clear();
         rank.reserve(n);
-        while (!heap.empty()) {
-            std::pop_heap(heap.begin(), heap.end(), cmp);
-            const int u = heap.back();
-            heap.pop_back();
-            rank.push_back(u);
-            for (int e = out_head[size_t(u)]; e >= 0; e = e_out_next[size_t(e)]) {
-                const int v = e_to[size_t(e)];
-                if (--indeg[size_t(v)] == 0) {
-                    heap.push_back(v);
-                    std::push_heap(heap.begin(), heap.end(), cmp);
+        std::vector<uint8_t> mark(n, 0), ignored(n, 0);
+        std::vector<int> stack;
+        for (size_t start = 0; start < n; ++start) {
+            if (mark[start]) continue;
+            stack.push_back(int(start));
+            while (!stack.empty()) {
+                const int cur = stack.back();
+                bool valid = true;
+                if (mark[size_t(cur)] != 2) {
+                    for (int e = in_head[size_t(cur)]; e >= 0; e = e_in_next[size_t(e)]) {
+                        const int t = e_from[size_t(e)];
+                        if (mark[size_t(t)] != 2) {
+                            stack.push_back(t);
+                            valid = false;
+                        }
+                    }
+                    if (!ignored[size_t(cur)])
+                        for (int q = al_head[size_t(cur)]; q >= 0; q = al_next[size_t(q)]) {
+                            const int a = al_val[size_t(q)];
+                            if (mark[size_t(a)] != 2) {
+                                stack.push_back(a);
+                                ignored[size_t(a)] = 1;
+                                valid = false;
+                            }
+                        }
+                    if (valid) {
+                        mark[size_t(cur)] = 2;
+                        if (!ignored[size_t(cur)]) {
+                            rank.push_back(cur);
+                            for (int q = al_head[size_t(cur)]; q >= 0; q = al_next[size_t(q)]) rank.push_back(al_val[size_t(q)]);
+                        }
+                    } else {
+                        mark[size_t(cur)] = 1;
+                    }
                 }
+                if (valid) stack.pop_back();
             }
         }
     }
-    // AddAlignment: aln = (node id or -1, position or -1) in forward order; an empty alignment adds a chain
+    // AddAlignment: aln = (node id or -1, position or -1) in forward order; an empty alignment adds a chain.  Node ids follow
+    // spoa's creation order: the unaligned head of the read, its unaligned tail, then the aligned part base by base.
     void add_alignment(const std::vector<std::pair<int, int>>& aln, const char* s, int len, int64_t w)
     {
         if (len <= 0) return;
@@ -744,6 +785,7 @@ struct PGraph {
             add_chain(s, 0, first_pos, w);
             head = int(n_nodes()) - 1;
         }
+        const int tail = last_pos + 1 < len ? add_chain(s, last_pos + 1, len, w) : -1;
         std::vector<int> grp;
         for (auto& a : aln) {
             if (a.second < 0) continue;
@@ -771,13 +813,10 @@ struct PGraph {
                     }
                 }
             }
-            if (head >= 0) add_edge(head, cur, w);
+            if (head >= 0) add_edge(head, cur, 2 * w);
             head = cur;
         }
-        if (last_pos + 1 < len) {
-            const int f = add_chain(s, last_pos + 1, len, w);
-            if (head >= 0) add_edge(head, f, w);
-        }
+        if (tail >= 0 && head >= 0) add_edge(head, tail, 2 * w);
         ++nseq;
         toposort();
     }
@@ -841,41 +880,62 @@ struct PGraph {
         for (size_t y = 0; y < p_pred.size(); ++y) p_pslot[y] = p_slot[size_t(p_pred[y])];
         planned = true;
     }
-    // heaviest bundle: per node the heaviest in-edge (ties: the predecessor with the higher score), the best
-    // end node, then forward along the heaviest out-edges to a sink
-    std::string consensus() const
+    // Heaviest bundle with branch completion (Lee 2003, as spoa's graph does it): in topological order every node takes its
+    // heaviest in-edge — on equal weights the LATER edge wins unless its tail scores lower —, a node without in-edges scores -1;
+    // the best-scoring node ends the bundle; if it is not a sink, the rest of the graph is scored again with the competitors of
+    // its successors switched off, until a sink is reached.
+    int branch_completion(size_t rk, std::vector<int64_t>& score, std::vector<int>& from) const
     {
-        const size_t n = n_nodes();
-        if (n == 0) return std::string();
-        std::vector<int64_t> score(n, 0);
-        std::vector<int> from(n, -1);
-        int best = rank.empty() ? 0 : rank[0];
-        for (int u : rank) {
-            int64_t bw = -1;
+        const int start = rank[rk];
+        for (int e = out_head[size_t(start)]; e >= 0; e = e_out_next[size_t(e)])
+            for (int f = in_head[size_t(e_to[size_t(e)])]; f >= 0; f = e_in_next[size_t(f)])
+                if (e_from[size_t(f)] != start) score[size_t(e_from[size_t(f)])] = -1;
+        int best = -1;
+        for (size_t i = rk + 1; i < rank.size(); ++i) {
+            const int u = rank[i];
+            score[size_t(u)] = -1;
+            from[size_t(u)] = -1;
             for (int e = in_head[size_t(u)]; e >= 0; e = e_in_next[size_t(e)]) {
                 const int f = e_from[size_t(e)];
+                if (score[size_t(f)] == -1) continue;
                 const int64_t w = e_w[size_t(e)];
-                if (from[size_t(u)] < 0 || w > bw || (w == bw && score[size_t(f)] > score[size_t(from[size_t(u)])])) {
-                    bw = w;
+                if (score[size_t(u)] < w || (score[size_t(u)] == w && score[size_t(from[size_t(u)])] <= score[size_t(f)])) {
+                    score[size_t(u)] = w;
                     from[size_t(u)] = f;
                 }
             }
-            if (from[size_t(u)] >= 0) score[size_t(u)] = bw + score[size_t(from[size_t(u)])];
-            if (score[size_t(u)] > score[size_t(best)]) best = u;
+            if (from[size_t(u)] >= 0) score[size_t(u)] += score[size_t(from[size_t(u)])];
+            if (best < 0 || score[size_t(best)] < score[size_t(u)]) best = u;
         }
-        std::vector<int> path;
-        for (int u = best; u >= 0; u = from[size_t(u)]) path.push_back(u);
-        std::reverse(path.begin(), path.end());
-        for (int u = best; out_head[size_t(u)] >= 0;) {
-            int be = out_head[size_t(u)];
-            for (int e = be; e >= 0; e = e_out_next[size_t(e)])
-                if (e_w[size_t(e)] > e_w[size_t(be)]) be = e;
-            u = e_to[size_t(be)];
-            path.push_back(u);
+        return best;
+    }
+    std::string consensus() const
+    {
+        const size_t n = n_nodes();
+        if (n == 0 || rank.empty()) return std::string();
+        std::vector<int64_t> score(n, -1);
+        std::vector<int> from(n, -1);
+        int best = -1;
+        for (int u : rank) {
+            for (int e = in_head[size_t(u)]; e >= 0; e = e_in_next[size_t(e)]) {
+                const int f = e_from[size_t(e)];
+                const int64_t w = e_w[size_t(e)];
+                if (score[size_t(u)] < w || (score[size_t(u)] == w && score[size_t(from[size_t(u)])] <= score[size_t(f)])) {
+                    score[size_t(u)] = w;
+                    from[size_t(u)] = f;
+                }
+            }
+            if (from[size_t(u)] >= 0) score[size_t(u)] += score[size_t(from[size_t(u)])];
+            if (best < 0 || score[size_t(best)] < score[size_t(u)]) best = u;
+        }
+        if (out_head[size_t(best)] >= 0) {
+            std::vector<size_t> row_of(n, 0);
+            for (size_t i = 0; i < rank.size(); ++i) row_of[size_t(rank[i])] = i;
+            while (out_head[size_t(best)] >= 0) best = branch_completion(row_of[size_t(best)], score, from);
         }
         std::string s;
-        s.reserve(path.size());
-        for (int u : path) s.push_back(base[size_t(u)]);
+        for (int u = best; u >= 0; u = from[size_t(u)]) s.push_back(base[size_t(u)]);
+        std::reverse(s.begin(), s.end());
         return s;
     }
 };

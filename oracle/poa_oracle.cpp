@@ -520,6 +520,18 @@ int orp_graph_export(void* s, int side, int idx, int32_t* n_nodes, int32_t* n_ed
     }
     return 0;
 }
+// a copy of graph (side, idx) of store `from` becomes graph (to_side, to_idx) of store `to` (the merge of two clustered batches
+// takes the left batch's graphs as side 0 and the right batch's as side 1, src/cluster.cpp:273-278); 0, -1 if there is none
+int orp_graph_copy(void* from, int side, int idx, void* to, int to_side, int to_idx)
+{
+    Store* A = static_cast<Store*>(from);
+    Store* B = static_cast<Store*>(to);
+    if (side < 0 || side > 1 || to_side < 0 || to_side > 1) return -1;
+    auto it = A->g[side].find(idx);
+    if (it == A->g[side].end()) return -1;
+    B->g[to_side][to_idx] = std::unique_ptr<Graph>(new Graph(*it->second));
+    return 0;
+}
 // the alignment of the last create / add / purge: pairs in read order; returns their number
 int orp_last_alignment(void* s, int32_t cap, int32_t* nodes, int32_t* pos, int32_t* score)
 {

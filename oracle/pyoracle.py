@@ -124,6 +124,7 @@ def lib():
     L.orp_bind.restype = None
     L.orp_graph_export.argtypes = [vp, i32, i32, i32p, i32p, i32p, cp, i32p, i32p, i32p, i64p, i32p, i32p]
     L.orp_last_alignment.argtypes = [vp, i32, i32p, i32p, i32p]
+    L.orp_graph_copy.argtypes = [vp, i32, i32, vp, i32, i32]
     _lib = L
     return L
 
@@ -469,6 +470,9 @@ class OraclePoa:
         if aligned:
             out += ([al[ao[v]:ao[v + 1]].tolist() for v in range(nn.value)],)
         return out
+
+    def copy_graph_to(self, idx, other, to_side, to_idx, side=0):
+        assert self.L.orp_graph_copy(self.h, side, idx, other.h, to_side, to_idx) == 0
 
     def last_alignment(self):
         sc = C.c_int32()

@@ -98,7 +98,7 @@ def draw_consensus(rng, mode="fast"):
     return dict(n=n, g=g, ln=ln, cmax=cmax, cmin=cmin, period=period, seed=seed, dup=dup, mode=mode, qlo=11, qhi=22)
 
 
-def oracle_consensus_run(rs, cons_max, cons_min, period, mode="fast", k=11, w=15, graphs=None):
+def oracle_consensus_run(rs, cons_max, cons_min, period, mode="fast", k=11, w=15, graphs=None, ops_pointer=None):
     R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
     R.score_sort(k, w)
     p = po.default_params(k, w)
@@ -109,7 +109,7 @@ def oracle_consensus_run(rs, cons_max, cons_min, period, mode="fast", k=11, w=15
                 score=info["score"], raw_err=info["raw_err"], hpc_err=info["hpc_err"], state=info["state"].astype(np.uint8),
                 min_qual=p.min_qual, orig=info["orig"])
     g = graphs or ToyGraphs()
-    po.lib().orc_set_consensus(C.cast(C.pointer(g.ops), C.c_void_p), cons_min, period)
+    po.lib().orc_set_consensus(ops_pointer or C.cast(C.pointer(g.ops), C.c_void_p), cons_min, period)
     try:
         st = B.cluster(mode=mode)
     finally:
@@ -149,6 +149,48 @@ def run_consensus(ctx, c, speculate=None):
         what.append(f"events {st['n_cons_invoked']} vs {ost['cons_invoked']}")
     if not (np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)):
         what.append("MinDB")
+    return not what, ", ".join(what)
+
+
+def run_consensus_poa(ctx, c):
+    """Consensus mode with REAL partial-order graphs on both sides: the product's engine (ioc_poa.hip) behind
+    ioc_cluster_consensus, the oracle's scalar POA (oracle/poa_oracle.cpp) behind the oracle's hook.  Compared: assignments,
+    the event count, the MinDB, and every cluster's graph (letters, weighted edges, order) and consensus."""
+    from tests.test_gpu_poa import Poa
+    rs = synth.generate(c["n"], c["g"], c["ln"], c["qlo"], c["qhi"], seed=c["seed"], dup_every=c["dup"])
+    mode = c["mode"]
+    o_poa = po.OraclePoa()
+    B, view, ost, _ = oracle_consensus_run(rs, c["cmax"], c["cmin"], c["period"], mode=mode, graphs=o_poa, ops_pointer=o_poa.ops_pointer())
+    acl, ast = B.assignments(rs.n)
+    ocl, ostr = acl[view["orig"]], ast[view["orig"]]
+    v = _with_sequences(rs, view)
+    p_poa = Poa(ctx)
+    what = []
+    try:
+        cargs = _lib.ConsensusArgs(cons_min_size=c["cmin"], cons_max_size=c["cmax"], cons_period=c["period"], left_depth=-1, left_sizes=None)
+        cls, strand, st = ctx.cluster_consensus(api.default_params(11, 15, mode), None, v, cargs, p_poa.ops)
+        keys, offs, post = ctx.index_export()
+        okeys, ooffs, opost = B.index()
+        if not (np.array_equal(cls, ocl) and np.array_equal(strand, ostr)):
+            what.append("assignments")
+        if st["n_cons_invoked"] != ost["cons_invoked"]:
+            what.append(f"events {st['n_cons_invoked']} vs {ost['cons_invoked']}")
+        if not (np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)):
+            what.append("MinDB")
+        if not what:
+            for c_id in range(B.n_clusters()):
+                db, dr, def_, det, dew = p_poa.graph(c_id)
+                ob, orr, oef, oet, oew = o_poa.graph(c_id)
+                if not (db == ob and dr.tolist() == orr.tolist() and
+                        sorted(zip(def_.tolist(), det.tolist(), dew.tolist())) == sorted(zip(oef.tolist(), oet.tolist(), oew.tolist()))):
+                    what.append(f"graph of cluster {c_id}")
+                    break
+                if p_poa.consensus(c_id) != o_poa.consensus(c_id):
+                    what.append(f"consensus of cluster {c_id}")
+                    break
+    finally:
+        p_poa.close()
+        o_poa.close()
     return not what, ", ".join(what)
 
 

@@ -95,13 +95,12 @@ def test_sort_cluster_merge_dump_matches_oracle(tmp_path, mode):
 def test_consensus_mode_sort_cluster_merge_dump(tmp_path):
     """`sort -g 3 -c 8 -P 400` freezes the consensus parameters; `cluster` then keeps one POA graph per cluster
     (this build's engine, graphs carried in the .cer files), replaces representatives by consensus sequences
-    and updates the MinDB; the merge runs with the Depth != -1 rules.  The oracle runs the same three steps with
-    a second instance of the engine behind its consensus hook (the graphs of step 2 serve as the right batch's in
-    the merge)."""
+    and updates the MinDB; the merge runs with the Depth != -1 rules.  The oracle runs the same three steps with ITS OWN
+    scalar POA (oracle/poa_oracle.cpp) behind its consensus hook — nothing of the product on that side —, the graphs of
+    step 2 serving as the right batch's in the merge.  Parity with the oracle's POA; spoa itself is unpinned."""
     import ctypes as C
     from isonclust2_amd import api
     from oracle import pyoracle as po
-    from tests.test_gpu_poa import Poa
     rs = synth.generate(200, 6, 800, 12, 21, seed=31)
     half = rs.n // 2
     fq = tmp_path / "reads.fq"
@@ -119,34 +118,27 @@ def test_consensus_mode_sort_cluster_merge_dump(tmp_path):
     r = run("dump", "-i", str(out / "sorted_reads_idx.cer"), "-o", str(tmp_path / "dump"), str(tmp_path / "m.cer"))
     assert r.returncode == 0, r.stderr
 
-    # ---- oracle with the same engine behind its hook ----
-    ctx = api.Context(0)
+    # ---- the oracle, its own POA behind its hook ----
     R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
     R.score_sort(11, 15)
     p = po.default_params(11, 15)
     p.cons_max_size = 8
     A, B = po.Batch(R, 0, half - 1, p, 0), po.Batch(R, half, rs.n - 1, p, 1)
-    ga, gb = Poa(ctx), Poa(ctx)
+    ga, gb = po.OraclePoa(), po.OraclePoa()
     events = 0
     for Bo, g in ((A, ga), (B, gb)):
-        po.lib().orc_set_consensus(C.cast(C.pointer(g.ops), C.c_void_p), 3, 400)
+        po.lib().orc_set_consensus(g.ops_pointer(), 3, 400)
         try:
             events += Bo.cluster(mode="fast")["cons_invoked"]
         finally:
             po.lib().orc_set_consensus(None, 50, 500)
     assert events > 5
     # merge: left graphs = ga's side 0, right graphs = gb's side 0 presented as side 1
-    gm = Poa(ctx)
-    L = gm.L
+    gm = po.OraclePoa()
     for src, dst_side in ((ga, 0), (gb, 1)):
-        ncl = (A if src is ga else B).n_clusters()
-        for c_id in range(ncl):
-            sz = L.ioc_poa_graph_save(src.h, 0, c_id, None, 0)
-            assert sz > 0
-            buf = (C.c_uint8 * sz)()
-            assert L.ioc_poa_graph_save(src.h, 0, c_id, buf, sz) == sz
-            assert L.ioc_poa_graph_load(gm.h, dst_side, c_id, buf, sz) == 0
-    po.lib().orc_set_consensus(C.cast(C.pointer(gm.ops), C.c_void_p), 3, 400)
+        for c_id in range((A if src is ga else B).n_clusters()):
+            src.copy_graph_to(c_id, gm, dst_side, c_id)
+    po.lib().orc_set_consensus(gm.ops_pointer(), 3, 400)
     try:
         A.cluster(right=B, mode="fast")
     finally:
@@ -168,7 +160,6 @@ def test_consensus_mode_sort_cluster_merge_dump(tmp_path):
     assert "cons_" in cons
     for g in (ga, gb, gm):
         g.close()
-    ctx.close()
 
 
 @pytest.mark.gpu

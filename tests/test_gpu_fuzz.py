@@ -102,6 +102,20 @@ def test_fuzz_consensus(ctx, mode, speculate):
     assert not bad, f"{len(bad)} of {n + len(fixed)} cases differ from the oracle; first: {env}python tools/fuzz_consensus.py --case \"{bad[0][0]}\"  ({bad[0][1]})"
 
 
+def test_fuzz_consensus_with_real_graphs(ctx):
+    """the POA engine behind the product, the oracle's scalar POA behind the oracle (spoa itself: unpinned)"""
+    rng = np.random.default_rng([SEED, 20])
+
+    def draw():
+        c = fz.draw_consensus(rng, "fast")
+        c.update(n=min(c["n"], 150), ln=min(c["ln"], 500))
+        return c
+
+    fixed = [dict(c, n=min(c["n"], 150), ln=min(c["ln"], 500)) for c in _CONS_FIXED[1:]]
+    bad, n = _slice(lambda c: fz.run_consensus_poa(ctx, c), fixed, draw, min_random=3)
+    assert not bad, f"{len(bad)} of {n + len(fixed)} cases differ from the oracle; first: {bad[0][0]}  ({bad[0][1]})"
+
+
 def test_fuzz_align(ctx):
     bad, t0, n = [], time.time(), 0
     for s in [31, SEED & 0xFFFF] + [((SEED >> 8) + i) & 0xFFFFFF for i in range(200)]:

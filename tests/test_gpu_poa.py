@@ -146,8 +146,8 @@ def test_consensus_recovers_the_source_sequence(ctx):
 
 
 def test_consensus_mode_pipeline_with_the_poa_engine(ctx):
-    """ioc_cluster_consensus with this engine against the oracle's consensus branch driving a second instance of
-    the same engine: assignments, event counts and the final MinDB."""
+    """ioc_cluster_consensus with this engine against the oracle's consensus branch driving the ORACLE's scalar POA
+    (oracle/poa_oracle.cpp): assignments, event counts, the final MinDB and every final graph."""
     from isonclust2_amd import synth
     from oracle import pyoracle as po
     rs = synth.generate(120, 4, 700, 12, 21, seed=2)
@@ -160,8 +160,8 @@ def test_consensus_mode_pipeline_with_the_poa_engine(ctx):
     view = dict(off_fwd=off_f, off_rev=off_r, min_val=mn, min_pos=ps, raw_len=info["raw_len"], hpc_len=info["hpc_len"],
                 score=info["score"], raw_err=info["raw_err"], hpc_err=info["hpc_err"], state=info["state"].astype(np.uint8),
                 min_qual=p.min_qual, orig=info["orig"])
-    o_poa = Poa(ctx)
-    po.lib().orc_set_consensus(C.cast(C.pointer(o_poa.ops), C.c_void_p), 3, 500)
+    o_poa = po.OraclePoa()
+    po.lib().orc_set_consensus(o_poa.ops_pointer(), 3, 500)
     try:
         ost = B.cluster(mode="fast")
     finally:
@@ -182,6 +182,12 @@ def test_consensus_mode_pipeline_with_the_poa_engine(ctx):
     keys, offs, post = ctx.index_export()
     okeys, ooffs, opost = B.index()
     assert np.array_equal(keys, okeys) and np.array_equal(offs, ooffs) and np.array_equal(post, opost)
+    for c_id in range(B.n_clusters()):      # the graphs themselves: letters, edges with their weights, order, consensus
+        db, dr, def_, det, dew = p_poa.graph(c_id)
+        ob, orr, oef, oet, oew = o_poa.graph(c_id)
+        assert db == ob and dr.tolist() == orr.tolist(), c_id
+        assert sorted(zip(def_.tolist(), det.tolist(), dew.tolist())) == sorted(zip(oef.tolist(), oet.tolist(), oew.tolist())), c_id
+        assert p_poa.consensus(c_id) == o_poa.consensus(c_id), c_id
     o_poa.close()
     p_poa.close()
 
