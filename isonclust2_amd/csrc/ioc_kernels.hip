@@ -24,9 +24,14 @@
 #define IOC_BLOCK 256
 #define IOC_WAVES (IOC_BLOCK / 64)
 #define IOC_EMPTY 0xFFFFFFFFu
+#ifndef IOC_FLAT_UNROLL
 #define IOC_FLAT_UNROLL 8
+#endif
 #ifndef IOC_FLAT_TAIL
-#define IOC_FLAT_TAIL 2  // steps per group in the tail of a chunk (flat_traverse_u16)
+#ifndef IOC_FLAT_TAIL
+#define IOC_FLAT_TAIL 2
+#endif
+// IOC_FLAT_TAIL: steps per group in the tail of a chunk (flat_traverse_u16)
 #endif
 #define IOC_SHORT_LIST 192
 #ifndef IOC_SCORE_OOB
@@ -819,6 +824,17 @@ __device__ __forceinline__ void count_word_u16(uint32_t w, uint32_t T, uint32_t 
     }
 }
 
+// (tuning, round 4 — profiles/r04_score_variants.txt: groups of 4 steps instead of 8, a tail of single steps, the next chunk's
+// hash probes in flight while the current chunk is traversed and a register budget of 64 (8 waves per SIMD, a handful of
+// spilled registers) took the scoring phase of config 2 from 0.774 to 0.696 ms: the kernel waits more than it issues, and what
+// it waits for — index rows, posting units, the LDS atomic pipe — is covered by more resident waves, not by a longer group)
+#ifndef IOC_FLAT_UNROLL16
+#define IOC_FLAT_UNROLL16 4
+#endif
+#ifndef IOC_FLAT_TAIL16
+#define IOC_FLAT_TAIL16 1
+#endif
+static_assert(IOC_FLAT_UNROLL16 <= IOC_FLAT_UNROLL, "the bitmap's slack words are sized by IOC_FLAT_UNROLL");
 template <bool OOB>
 __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ post, uint32_t o, uint32_t len,
                                                   uint32_t* __restrict__ wb, unsigned long long* __restrict__ bm,
@@ -839,8 +855,8 @@ __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ p
         return;
     }
     const uint4* __restrict__ post4 = reinterpret_cast<const uint4*>(post);
-    trav += IOC_SCORE_TRAV_CAPACITY ? 512ull * (nwords / IOC_FLAT_UNROLL * IOC_FLAT_UNROLL + (nwords % IOC_FLAT_UNROLL + IOC_FLAT_TAIL - 1) / IOC_FLAT_TAIL * IOC_FLAT_TAIL) : 8ull * total;
-    for (uint32_t w = lane; w < nwords + IOC_FLAT_UNROLL; w += 64) bm[w] = 0ull;
+    trav += IOC_SCORE_TRAV_CAPACITY ? 512ull * (nwords / IOC_FLAT_UNROLL16 * IOC_FLAT_UNROLL16 + (nwords % IOC_FLAT_UNROLL16 + IOC_FLAT_TAIL16 - 1) / IOC_FLAT_TAIL16 * IOC_FLAT_TAIL16) : 8ull * total;
+    for (uint32_t w = lane; w < nwords + IOC_FLAT_UNROLL16; w += 64) bm[w] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lenU) {
@@ -885,11 +901,11 @@ __device__ __forceinline__ void flat_traverse_u16(const uint16_t* __restrict__ p
             count_word_u16<OOB>(tg[u].w, Tl, hb, one);
         }
     };
-    // whole groups of IOC_FLAT_UNROLL steps, then the rest two steps at a time: with one loop of 8 the steps past the end of
+    // whole groups of IOC_FLAT_UNROLL16 steps, then the rest two steps at a time: with one loop of 8 the steps past the end of
     // a chunk (9.8 steps on average on config 2) were 31 % of all the posting slots the kernel issued
     uint32_t w0 = 0;
-    for (; w0 + IOC_FLAT_UNROLL <= nwords; w0 += IOC_FLAT_UNROLL) group(std::integral_constant<int, IOC_FLAT_UNROLL>{}, w0);
-    for (; w0 < nwords; w0 += IOC_FLAT_TAIL) group(std::integral_constant<int, IOC_FLAT_TAIL>{}, w0);
+    for (; w0 + IOC_FLAT_UNROLL16 <= nwords; w0 += IOC_FLAT_UNROLL16) group(std::integral_constant<int, IOC_FLAT_UNROLL16>{}, w0);
+    for (; w0 < nwords; w0 += IOC_FLAT_TAIL16) group(std::integral_constant<int, IOC_FLAT_TAIL16>{}, w0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the atomics above are invisible to the compiler's counters)
     __builtin_amdgcn_wave_barrier();
 }
@@ -1106,8 +1122,14 @@ k_partition_mins(int n, const int64_t* __restrict__ off_fwd, const int64_t* __re
     }
 }
 
+#ifndef IOC_SCORE_PART_MINWAVES
+#define IOC_SCORE_PART_MINWAVES 8  // minimum waves per SIMD the register allocation must allow: 64 registers
+#endif
+#ifndef IOC_SCORE_PREFETCH
+#define IOC_SCORE_PREFETCH 1       // 1: the hash probe of a wave's NEXT chunk of minimizers is issued before the current chunk is traversed
+#endif
 template <typename PT, bool OOB>
-__global__ void __launch_bounds__(IOC_BLOCK)
+__global__ void __launch_bounds__(IOC_BLOCK, IOC_SCORE_PART_MINWAVES)
 k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64_t* __restrict__ off_rev,
              const uint32_t* __restrict__ pmins, const uint32_t* __restrict__ pbnd, const uint4* __restrict__ rows,
              uint32_t cap, uint32_t shift, const PT* __restrict__ post, uint32_t* __restrict__ part, Epochs E,
@@ -1145,11 +1167,31 @@ k_score_part(int n, uint32_t L, const int64_t* __restrict__ off_fwd, const int64
         const uint32_t* bnd = pbnd + (size_t(j) * 2 + s) * (IOC_PARTS + 1);
         const int64_t b = b0 + bnd[x], e = b0 + bnd[x + 1];  // this partition's bucket
         uint32_t* h = hist;
+#if IOC_SCORE_PREFETCH
+        uint32_t o_nx = 0, c_nx = 0;
+        uint2 q_nx = make_uint2(0u, 0u);
+        {
+            const int64_t t = b + wave * 64 + lane;
+            if (t < e) index_lookup(rows, cap, shift, pmins[t], o_nx, c_nx, q_nx);
+        }
+#endif
         for (int64_t c0 = b + wave * 64; c0 < e; c0 += IOC_WAVES * 64) {
+#if IOC_SCORE_PREFETCH
+            uint32_t o = o_nx, len = c_nx;
+            const uint2 qi = q_nx;
+            {
+                const int64_t t = c0 + IOC_WAVES * 64 + lane;
+                o_nx = 0;
+                c_nx = 0;
+                q_nx = make_uint2(0u, 0u);
+                if (t < e) index_lookup(rows, cap, shift, pmins[t], o_nx, c_nx, q_nx);
+            }
+#else
             const int64_t t = c0 + lane;
             uint32_t o = 0, len = 0;
             uint2 qi = make_uint2(0u, 0u);
             if (t < e) index_lookup(rows, cap, shift, pmins[t], o, len, qi);
+#endif
             if (len) {
                 if (!(qi.y & 0x80000000u))
                     len = epoch_cut(qi, len, eword, eshift);
