@@ -1060,7 +1060,7 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     a.q_count = P<uint32_t>(c->b_misc) + 9;
     a.q_cap = q_cap;
     a.incomplete = P<uint32_t>(c->b_misc) + 10;
-    const int eval_blocks = int(env_u32("IOC_EVAL_BLOCKS", 256 * 5));
+    const int eval_blocks = int(env_u32("IOC_EVAL_BLOCKS", 256 * 4));  // (what the chip holds: 4 workgroups of k_eval per CU)
     const bool diag = getenv("IOC_EVAL_DIAG") != nullptr;
     a.diag = nullptr;
     if (diag) {

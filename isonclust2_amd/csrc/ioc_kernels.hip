@@ -25,11 +25,11 @@
 #define IOC_WAVES (IOC_BLOCK / 64)
 #define IOC_EMPTY 0xFFFFFFFFu
 #ifndef IOC_FLAT_UNROLL
-#define IOC_FLAT_UNROLL 8
+#define IOC_FLAT_UNROLL 4   // (8 until round 4: the long-chunk path inlined into k_score_part then costs 18 more spilled registers under its 64-register budget)
 #endif
 #ifndef IOC_FLAT_TAIL
 #ifndef IOC_FLAT_TAIL
-#define IOC_FLAT_TAIL 2
+#define IOC_FLAT_TAIL 1
 #endif
 // IOC_FLAT_TAIL: steps per group in the tail of a chunk (flat_traverse_u16)
 #endif
@@ -1796,30 +1796,32 @@ __device__ __forceinline__ uint32_t eval_total_mapped(const uint32_t* __restrict
 // Fast path of one evaluation (target set <= 4096 values, the common case).
 //   * every global load is issued up front and coalesced (16 set values per thread; 16 query values per
 //     thread and pass, kept in registers across consecutive items of the same (query, strand));
-//   * membership = a 64 Kbit filter in LDS (one ds_or per set value, one ds_read per query value, all
-//     batched, no probe chains) followed by an exact binary search in an LDS copy of the sorted set for
-//     the few positives, which are first compacted across the wave so that the search runs on full
-//     waves;
-//   * hit bitmap -> previous-hit table -> gap scan; the hits are spread over the threads when sparse.
+//   * membership = an open-addressed hash table of the target's set in LDS (8192 slots for <= 4096 values: one
+//     ds_cmpst per set value, 1.3 ds_read per query value on average, all batched).  Round 3 had a 64 Kbit filter in front
+//     of a binary search in an LDS copy of the sorted set: the candidates that get evaluated are the RELATED ones — three
+//     query values in four are members —, so the filter filtered little and the 12 dependent reads of the search per
+//     positive were 21 of an evaluation's 47 us (IOC_EVAL_DIAG);
+//   * hit bitmap -> previous-hit table -> gap scan, a thread per 16 indices: the positions of its hits are requested
+//     together (one latency instead of one per hit: 16 of the 47 us).
 #define IOC_EV_PER 16                              // indices per thread per pass
 #define IOC_EV_PASS (IOC_EV_PER * IOC_BLOCK)       // 4096 query minimizers per pass
-#define IOC_EV_FILTER_WORDS 2048                   // 65536-bit membership filter
+#define IOC_EV_HBITS 13
+#define IOC_EV_HSLOTS (1u << IOC_EV_HBITS)         // 8192 slots: load <= 0.5
 struct EvQuery {
     uint32_t qv[IOC_EV_PER];
     uint32_t pend0;  // valid-index mask of the cached pass
 };
 struct EvLds {
-    uint32_t sset[IOC_EV_PASS];             // sorted copy of the target set
-    uint32_t filt[IOC_EV_FILTER_WORDS];
+    __attribute__((aligned(16))) uint32_t htab[IOC_EV_HSLOTS];  // the target's set (IOC_EMPTY: free slot)
     unsigned long long bits[64];            // hit bitmap of the pass
     uint32_t prevlast[65];
-    uint32_t wq[IOC_WAVES][256];            // per-wave ring of (value, index): filter positives awaiting the exact test
     uint32_t red[IOC_WAVES + 1];
     uint32_t carry[4];
     uint32_t nhits;
+    uint32_t has_empty;                     // the set holds the value IOC_EMPTY itself (k = 16: sixteen T)
 };
 
-__device__ __forceinline__ uint32_t ev_filter_hash(uint32_t v) { return (v * 0x9E3779B1u) >> 16; }
+__device__ __forceinline__ uint32_t ev_hash(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - IOC_EV_HBITS); }
 
 __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin, const uint32_t* __restrict__ qpos,
                                               uint32_t M, const uint32_t* __restrict__ set, uint32_t setN,
@@ -1829,7 +1831,6 @@ __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin,
     long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
     if (diag) s0 = clock64();
     const int lane = lane_id(), wave = wave_id();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t sv[IOC_EV_PER];
 #pragma unroll
     for (int u = 0; u < IOC_EV_PER; ++u) {
@@ -1847,33 +1848,45 @@ __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin,
             if (in) Q.pend0 |= 1u << u;
         }
     }
-    for (uint32_t i = threadIdx.x; i < IOC_EV_FILTER_WORDS; i += IOC_BLOCK) S.filt[i] = 0;
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(S.htab);
+        const uint4 e4 = make_uint4(IOC_EMPTY, IOC_EMPTY, IOC_EMPTY, IOC_EMPTY);
+#pragma unroll
+        for (uint32_t i = 0; i < IOC_EV_HSLOTS / 4 / IOC_BLOCK; ++i) h4[i * IOC_BLOCK + threadIdx.x] = e4;
+    }
     if (threadIdx.x == 0) {
         S.carry[0] = 0;  // any hit so far
         S.carry[1] = 0;  // index of the last hit so far
+        S.has_empty = 0;
     }
     __syncthreads();
     if (diag) s1 = clock64();
+    {   // insert: the first slot of all 16 values at once, then the (few) values whose slot was taken walk on
+        uint32_t hs[IOC_EV_PER], old[IOC_EV_PER];
 #pragma unroll
-    for (int u = 0; u < IOC_EV_PER; ++u) {
-        const uint32_t i = uint32_t(u) * IOC_BLOCK + threadIdx.x;
-        S.sset[i] = sv[u];  // entries >= setN hold 0xFFFFFFFF (never searched beyond setN)
-        if (i < setN) {
-            const uint32_t h = ev_filter_hash(sv[u]);
-            atomicOr(&S.filt[h >> 5], 1u << (h & 31u));
+        for (int u = 0; u < IOC_EV_PER; ++u) {
+            hs[u] = ev_hash(sv[u]);
+            old[u] = sv[u] != IOC_EMPTY ? atomicCAS(&S.htab[hs[u]], IOC_EMPTY, sv[u]) : IOC_EMPTY;
         }
+#pragma unroll
+        for (int u = 0; u < IOC_EV_PER; ++u) {
+            uint32_t h = hs[u], o = old[u];
+            while (o != IOC_EMPTY) {  // (set values are distinct: a taken slot holds another value)
+                h = (h + 1u) & (IOC_EV_HSLOTS - 1u);
+                o = atomicCAS(&S.htab[h], IOC_EMPTY, sv[u]);
+            }
+        }
+        // (IOC_EMPTY as a VALUE of the set — the sorted set's last entry — cannot live in the table)
+        if (setN && threadIdx.x == ((setN - 1u) & (IOC_BLOCK - 1u)) && sv[(setN - 1u) / IOC_BLOCK] == IOC_EMPTY) S.has_empty = 1u;
     }
     __syncthreads();
     if (diag) s2 = clock64();
-    uint32_t hp2 = 1;
-    while ((hp2 << 1) <= setN) hp2 <<= 1;
-    if (setN == 0) hp2 = 0;
-    uint32_t* const q = S.wq[wave];
+    const uint32_t has_empty = S.has_empty;
     uint32_t total = 0;
     for (uint32_t pbase = 0; pbase < M; pbase += IOC_EV_PASS) {
         const uint32_t Mp = (M - pbase < IOC_EV_PASS) ? (M - pbase) : IOC_EV_PASS;
-        // thread owns local indices (u * IOC_WAVES + wave) * 64 + lane: word u*IOC_WAVES+wave of the pass
-        uint32_t qv[IOC_EV_PER], fw[IOC_EV_PER];
+        // thread owns local indices (u * IOC_WAVES + wave) * 64 + lane: bit `lane` of word u * IOC_WAVES + wave of the pass
+        uint32_t qv[IOC_EV_PER];
         uint32_t pend = 0;
         if (pbase == 0) {
             pend = Q.pend0;
@@ -1888,50 +1901,32 @@ __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin,
                 if (in) pend |= 1u << u;
             }
         }
-        if (threadIdx.x < 64) S.bits[threadIdx.x] = 0ull;
-        // filter: 16 independent LDS reads
-#pragma unroll
-        for (int u = 0; u < IOC_EV_PER; ++u) fw[u] = S.filt[ev_filter_hash(qv[u]) >> 5];
-        uint32_t pos_mask = 0;
+        // membership: the first slot of all 16 values at once; a value is decided by its own slot's content unless another
+        // value sits there
+        uint32_t hs[IOC_EV_PER], x[IOC_EV_PER];
 #pragma unroll
         for (int u = 0; u < IOC_EV_PER; ++u) {
-            const uint32_t h = ev_filter_hash(qv[u]);
-            pos_mask |= (((fw[u] >> (h & 31u)) & (pend >> u)) & 1u) << u;
+            hs[u] = ev_hash(qv[u]);
+            x[u] = S.htab[hs[u]];
         }
-        __syncthreads();  // bits cleared
-        // exact test of the positives, compacted through a per-wave ring so that each search step runs
-        // on a full wave: ring entry = local index (the value is re-read from the register file copy
-        // kept in LDS-free form: we push value and index as two words)
-        uint32_t qhead = 0, qn = 0;
-        for (int u = 0; u <= IOC_EV_PER; ++u) {
-            if (u < IOC_EV_PER) {
-                const bool f = (pos_mask >> u) & 1u;
-                const unsigned long long bm = __ballot(f);
-                if (f) {
-                    const uint32_t slot = (qhead + qn + uint32_t(__popcll(bm & lt_mask))) & 127u;
-                    q[slot] = qv[u];
-                    q[128 + slot] = (uint32_t(u) * IOC_WAVES + wave) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < IOC_EV_PER; ++u) {
+            uint32_t h = hs[u], y = x[u];
+            const uint32_t v = qv[u];
+            bool member = false;
+            if ((pend >> u) & 1u) {
+                if (v == IOC_EMPTY) {
+                    member = has_empty != 0u;
+                } else {
+                    while (y != v && y != IOC_EMPTY) {
+                        h = (h + 1u) & (IOC_EV_HSLOTS - 1u);
+                        y = S.htab[h];
+                    }
+                    member = y == v;
                 }
-                qn += uint32_t(__popcll(bm));
             }
-            // ring of 128 (value, index) pairs: full waves while filling, the remainder at the end
-            while (qn >= 64 || (u == IOC_EV_PER && qn > 0)) {
-                const uint32_t take = qn < 64 ? qn : 64;
-                __builtin_amdgcn_wave_barrier();
-                const bool act = uint32_t(lane) < take;
-                const uint32_t v = act ? q[(qhead + lane) & 127u] : 0u;
-                const uint32_t li = act ? q[128 + ((qhead + lane) & 127u)] : 0u;
-                uint32_t pos = 0;
-                for (uint32_t h = hp2; h > 0; h >>= 1) {
-                    const uint32_t t = pos + h;
-                    if (t <= setN && S.sset[t - 1] < v) pos = t;
-                }
-                const bool member = act && pos < setN && S.sset[pos] == v;
-                if (member) atomicOr(&S.bits[li >> 6], 1ull << (li & 63u));
-                qhead = (qhead + take) & 127u;
-                qn -= take;
-                __builtin_amdgcn_wave_barrier();
-            }
+            const unsigned long long m = __ballot(member);
+            if (lane == 0) S.bits[uint32_t(u) * IOC_WAVES + uint32_t(wave)] = m;
         }
         __syncthreads();
         if (diag) s3 = clock64();
@@ -1961,7 +1956,7 @@ __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin,
             const uint32_t wd = threadIdx.x >> 2;        // 64 words
             const uint32_t qtr = threadIdx.x & 3u;       // 16 bits each
             const unsigned long long m = S.bits[wd];
-            uint32_t part = uint32_t(m >> (16 * qtr)) & 0xFFFFu;
+            const uint32_t part = uint32_t(m >> (16 * qtr)) & 0xFFFFu;
             // previous hit before this quarter
             bool pany = false;
             uint32_t pidx = 0;
@@ -1979,20 +1974,26 @@ __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin,
                     pidx = had_last;
                 }
             }
-            uint32_t ppos = (part && pany) ? qpos[pidx] : 0u;
-            while (part) {
-                const uint32_t bit = uint32_t(__builtin_ctz(part));
-                part &= part - 1;
-                const uint32_t i = pbase + wd * 64 + 16 * qtr + bit;
-                const uint32_t ipos = qpos[i];
-                if (!pany) {
-                    if (i < limEx) local += ipos;  // pow(pError, hits[0].Index) >= p0
-                } else if (i - pidx - 1 < limEx) {
-                    local += ipos - ppos;
+            if (part) {
+                // the positions of this quarter's hits and of the hit before it: requested together
+                const uint32_t i0 = pbase + wd * 64 + 16 * qtr;
+                uint32_t pp[16];
+#pragma unroll
+                for (int bq = 0; bq < 16; ++bq) pp[bq] = ((part >> bq) & 1u) ? qpos[i0 + uint32_t(bq)] : 0u;
+                uint32_t ppos = pany ? qpos[pidx] : 0u;
+#pragma unroll
+                for (int bq = 0; bq < 16; ++bq) {
+                    if (!((part >> bq) & 1u)) continue;
+                    const uint32_t i = i0 + uint32_t(bq);
+                    if (!pany) {
+                        if (i < limEx) local += pp[bq];  // pow(pError, hits[0].Index) >= p0
+                    } else if (i - pidx - 1 < limEx) {
+                        local += pp[bq] - ppos;
+                    }
+                    pany = true;
+                    pidx = i;
+                    ppos = pp[bq];
                 }
-                pany = true;
-                pidx = i;
-                ppos = ipos;
             }
         }
         for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
@@ -2017,15 +2018,22 @@ __device__ __forceinline__ uint32_t eval_fast(const uint32_t* __restrict__ qmin,
     __syncthreads();
     if (diag && threadIdx.x == 0) {
         s4 = clock64();
-        atomicAdd(&diag[5], (unsigned long long)(s1 - s0));  // issue loads + clear filter
-        atomicAdd(&diag[6], (unsigned long long)(s2 - s1));  // set copy + filter build (waits for the loads)
-        atomicAdd(&diag[7], (unsigned long long)(s3 - s2));  // filter + exact tests
+        atomicAdd(&diag[5], (unsigned long long)(s1 - s0));  // issue loads + clear the table
+        atomicAdd(&diag[6], (unsigned long long)(s2 - s1));  // table build (waits for the loads)
+        atomicAdd(&diag[7], (unsigned long long)(s3 - s2));  // membership
         atomicAdd(&diag[0], (unsigned long long)(s4 - s3));  // gap scan + reduce
     }
     return total;
 }
 
-__global__ void __launch_bounds__(IOC_BLOCK)
+// (Round 4 tried the opposite layout — every entry's values hashed ONCE per index build into a table in global memory, one WAVE
+// per evaluation probing it, no LDS, 64 registers, 8192 evaluations in flight — and measured it at 691 us of k_eval per fast
+// step against 366: 3000 tables of 32 KB are 98 MB, probed 4 bytes at a time at random, each by one or two evaluations only;
+// what the workgroup version reads once and coalesced (48 KB per evaluation) became 6000 cache-line requests.  Taken out.)
+#ifndef IOC_EVAL_MINWAVES
+#define IOC_EVAL_MINWAVES 4  // 128 registers (5 spilled): four workgroups per CU instead of three
+#endif
+__global__ void __launch_bounds__(IOC_BLOCK, IOC_EVAL_MINWAVES)
 k_eval(DecideArgs a)
 {
     __shared__ unsigned long long bits[IOC_BITWORDS];  // slow path only
