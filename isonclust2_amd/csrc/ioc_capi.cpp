@@ -1052,10 +1052,14 @@ int ioc_resolve(ioc_ctx* c, int32_t* n_iter)
     // misc layout (uint32 words): [8] first_changed, [9] q_count (phase 1), [10] incomplete, [11] q_count (phase 2)
     const uint32_t q_cap = env_u32("IOC_QUEUE_CAP", 1u << 20);
     RESERVE(c, c->b_queue, size_t(q_cap) * 8);
-    RESERVE(c, c->b_cut, size_t(n) * 9 + 64);
+    // [cut][top][done (bytes)][walk_n][walk_c]: per query
+    const size_t walk_at = 2 * size_t(n) + (size_t(n) + 3) / 4 + 16;  // (words)
+    RESERVE(c, c->b_cut, (walk_at + size_t(n) * (1 + IOC_WALK_SLOTS)) * 4 + 64);
     a.cut = P<int32_t>(c->b_cut);
     a.top = P<uint32_t>(c->b_cut) + n;
     a.done = reinterpret_cast<uint8_t*>(P<uint32_t>(c->b_cut) + 2 * size_t(n));
+    a.walk_n = P<uint32_t>(c->b_cut) + walk_at;
+    a.walk_c = a.walk_n + n;
     a.q_items = P<uint32_t>(c->b_queue);
     a.q_count = P<uint32_t>(c->b_misc) + 9;
     a.q_cap = q_cap;

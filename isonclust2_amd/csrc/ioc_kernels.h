@@ -62,7 +62,13 @@ struct DecideArgs {
     const int8_t* aln_s;
     uint32_t* tie_count;    // per query: number of top-Size candidates that are clusters
     uint32_t* tie_keys;     // per query: up to IOC_TIE_SLOTS of their keys (target << 1 | strand bit), any order
+    // the walk of a query as k_decide_scan found it (the candidates that are clusters and pass the Size rule of the phase), for
+    // k_decide_pick of the same phase: walk_n[j] entries of walk_c[j * IOC_WALK_SLOTS ...], or IOC_WALK_OVERFLOW (pick scans the list)
+    uint32_t* walk_n;
+    uint32_t* walk_c;
 };
+#define IOC_WALK_SLOTS 32
+#define IOC_WALK_OVERFLOW 0xFFFFFFFFu
 #ifndef IOC_TIE_SLOTS
 #define IOC_TIE_SLOTS 16  // (include/isonclust2_hip.h)
 #endif

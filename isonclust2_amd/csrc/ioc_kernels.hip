@@ -1554,11 +1554,19 @@ __device__ __forceinline__ bool bound_rejects(const DecideArgs& a, int j, uint32
 #define IOC_BITWORDS 256    // 16384 minimizers per strand per pass (slow path)
 #define IOC_EVAL_ILP 8
 
+// (round 4) ONE pass over a query's candidate list per phase: the candidates of the first 2048 entries stay in registers between
+// the maximum and the selection, the selected ones — a handful: the list's median length is 12, its mean 900, and what passes
+// the Size rule is 1 - 3 — are staged in LDS, queued with one atomic, and left as the query's WALK for k_decide_pick, which then
+// reads those instead of the list.  Before: three passes here and one in k_decide_pick over (key, Size, cached totalMapped) of
+// 2.7 M candidates per sweep, 0.33 of the fast step's 0.77 ms of resolve.
+#define IOC_SCAN_CACHE 8      // candidates per thread kept in registers (phase 1)
+#define IOC_SCAN_ITEMS 256    // items staged per query before they go to the queue one by one
 __global__ void __launch_bounds__(IOC_BLOCK)
 k_decide_scan(DecideArgs a)
 {
     __shared__ uint32_t red[IOC_WAVES];
-    __shared__ uint32_t s_top;
+    __shared__ uint32_t s_top, s_base, s_nw, s_ni;
+    __shared__ uint32_t s_walk[IOC_WALK_SLOTS], s_item[IOC_SCAN_ITEMS];
     const int j = owned_from(a.first, int(blockIdx.x), a.own_stride, a.own_offset);  // (sharded merge: this rank's queries)
     if (j >= a.n) return;
     const int lane = lane_id(), wave = wave_id();
@@ -1567,22 +1575,39 @@ k_decide_scan(DecideArgs a)
     const uint32_t C = a.cand_count[j];
     int cut;
     uint32_t top;
+    uint32_t csz[IOC_SCAN_CACHE];  // phase 1: Size of candidate k * IOC_BLOCK + threadIdx.x if it is a cluster, else 0
+    if (threadIdx.x == 0) {
+        s_nw = 0;
+        s_ni = 0;
+    }
     if (a.phase == 1) {
         if (a.forced_t[j] != INT32_MIN) {
-            if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
+            if (threadIdx.x == 0) {
+                a.cut[j] = IOC_CUT_NEG;
+                a.walk_n[j] = 0;
+            }
             return;
         }
         top = 0;
-        for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
-            uint32_t tg = a.cand_key[cbase + c] >> 1;
-            bool ok = (tg < L) || a.valid_in[tg - L];
-            uint32_t sz = a.cand_size[cbase + c];
+#pragma unroll
+        for (int k = 0; k < IOC_SCAN_CACHE; ++k) {
+            const uint32_t c = uint32_t(k) * IOC_BLOCK + threadIdx.x;
+            uint32_t v = 0;
+            if (c < C) {
+                const uint32_t tg = a.cand_key[cbase + c] >> 1;
+                const bool ok = (tg < L) || a.valid_in[tg - L];
+                v = ok ? a.cand_size[cbase + c] : 0u;
+            }
+            csz[k] = v;
+            top = v > top ? v : top;
+        }
+        for (uint32_t c = IOC_SCAN_CACHE * IOC_BLOCK + threadIdx.x; c < C; c += IOC_BLOCK) {
+            const uint32_t tg = a.cand_key[cbase + c] >> 1;
+            const bool ok = (tg < L) || a.valid_in[tg - L];
+            const uint32_t sz = a.cand_size[cbase + c];
             if (ok && sz > top) top = sz;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            uint32_t t = __shfl_down(top, o);
-            top = t > top ? t : top;
-        }
+        top = wave_max_u32(top);
         if (lane == 0) red[wave] = top;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1593,7 +1618,10 @@ k_decide_scan(DecideArgs a)
         __syncthreads();
         top = s_top;
         if (top < uint32_t(a.min_shared)) {
-            if (threadIdx.x == 0) a.cut[j] = IOC_CUT_NEG;
+            if (threadIdx.x == 0) {
+                a.cut[j] = IOC_CUT_NEG;
+                a.walk_n[j] = 0;
+            }
             return;
         }
         cut = int(double(top) * a.min_fraction);
@@ -1606,67 +1634,65 @@ k_decide_scan(DecideArgs a)
         cut = a.cut[j];
         top = a.top[j];
         if (cut == IOC_CUT_NEG) return;
+        __syncthreads();  // (s_nw / s_ni are zero)
     }
-    // phase 1 queues only the candidates of maximal Size (the first ones the reference walks): most
-    // queries are decided by them; phase 2 queues the rest of the walk for the undecided queries.
-    // A query's items occupy one contiguous range of the queue (k_eval reuses the query's minimizers
-    // across consecutive items): count, reserve with one atomicAdd, write in candidate order.
-    __shared__ uint32_t s_base;
-    __shared__ uint32_t wtot[IOC_WAVES];
-    uint32_t mine = 0;
-    for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
-        const uint32_t c = c0 + threadIdx.x;
-        bool f = false;
-        if (c < C) {
-            uint32_t tg = a.cand_key[cbase + c] >> 1;
-            bool ok = (tg < L) || a.valid_in[tg - L];
-            const uint32_t sz = a.cand_size[cbase + c];
-            f = ok && (a.phase == 1 ? sz == top : int(sz) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
-            if (f && a.gap_bound && bound_rejects(a, j, a.cand_key[cbase + c], sz, a.min_total[j])) {
-                a.cand_mapped[cbase + c] = IOC_MAPPED_REJECTED;  // (the second loop below reads it back: same thread, same entry)
-                f = false;
-            }
+    // phase 1 walks only the candidates of maximal Size (the first ones the reference walks): most queries are decided by them;
+    // phase 2 the rest of the walk for the undecided queries.  A walk candidate whose totalMapped is not cached yet — and that its
+    // upper bound does not reject — is an item for k_eval.
+    const uint32_t need = a.min_total[j];
+    auto take = [&](uint32_t c, uint32_t sz) {  // candidate c is a cluster and passes the Size rule of the phase
+        const uint32_t pw = atomicAdd(&s_nw, 1u);
+        if (pw < IOC_WALK_SLOTS) s_walk[pw] = c;
+        if (a.cand_mapped[cbase + c] != 0xFFFFFFFFu) return;
+        if (a.gap_bound && bound_rejects(a, j, a.cand_key[cbase + c], sz, need)) {
+            a.cand_mapped[cbase + c] = IOC_MAPPED_REJECTED;
+            return;
         }
-        mine += uint32_t(__popcll(__ballot(f)));
-    }
-    // every lane of a wave holds the wave's count; per slice the waves interleave, so positions are
-    // computed per slice below from running per-slice prefix sums
-    if (lane == 0) wtot[wave] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t all = 0;
-        for (int w = 0; w < IOC_WAVES; ++w) all += wtot[w];
-        s_base = all ? atomicAdd(a.q_count, all) : 0u;
-    }
-    __syncthreads();
-    uint32_t run = s_base;
-    __shared__ uint32_t slice[IOC_WAVES];
-    for (uint32_t c0 = 0; c0 < C; c0 += IOC_BLOCK) {
-        const uint32_t c = c0 + threadIdx.x;
-        bool f = false;
-        if (c < C) {
-            uint32_t tg = a.cand_key[cbase + c] >> 1;
-            bool ok = (tg < L) || a.valid_in[tg - L];
-            const uint32_t sz = a.cand_size[cbase + c];
-            f = ok && (a.phase == 1 ? sz == top : int(sz) >= cut) && (a.cand_mapped[cbase + c] == 0xFFFFFFFFu);
-        }
-        const unsigned long long bm = __ballot(f);
-        if (lane == 0) slice[wave] = uint32_t(__popcll(bm));
-        __syncthreads();
-        uint32_t wb = run, all = 0;
-        for (int w = 0; w < IOC_WAVES; ++w) {
-            if (w < wave) wb += slice[w];
-            all += slice[w];
-        }
-        if (f) {
-            const uint32_t slot = wb + uint32_t(__popcll(bm & ((1ull << lane) - 1ull)));
+        const uint32_t pi = atomicAdd(&s_ni, 1u);
+        if (pi < IOC_SCAN_ITEMS) {
+            s_item[pi] = c;
+        } else {  // (a query with hundreds of unevaluated candidates: its further items go to the queue one by one)
+            const uint32_t slot = atomicAdd(a.q_count, 1u);
             if (slot < a.q_cap) {
                 a.q_items[2 * size_t(slot)] = uint32_t(j);
                 a.q_items[2 * size_t(slot) + 1] = c;
             }
         }
-        run += all;
-        __syncthreads();
+    };
+    if (a.phase == 1) {
+#pragma unroll
+        for (int k = 0; k < IOC_SCAN_CACHE; ++k)
+            if (csz[k] == top) take(uint32_t(k) * IOC_BLOCK + threadIdx.x, top);  // (top >= MinShared > 0: never an empty slot)
+        for (uint32_t c = IOC_SCAN_CACHE * IOC_BLOCK + threadIdx.x; c < C; c += IOC_BLOCK) {
+            const uint32_t sz = a.cand_size[cbase + c];
+            if (sz != top) continue;
+            const uint32_t tg = a.cand_key[cbase + c] >> 1;
+            if ((tg < L) || a.valid_in[tg - L]) take(c, sz);
+        }
+    } else {
+        for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
+            const uint32_t sz = a.cand_size[cbase + c];
+            if (int(sz) < cut) continue;
+            const uint32_t tg = a.cand_key[cbase + c] >> 1;
+            if ((tg < L) || a.valid_in[tg - L]) take(c, sz);
+        }
+    }
+    __syncthreads();
+    const uint32_t nw = s_nw, ni = s_ni < IOC_SCAN_ITEMS ? s_ni : IOC_SCAN_ITEMS;
+    if (threadIdx.x == 0) {
+        a.walk_n[j] = nw <= IOC_WALK_SLOTS ? nw : IOC_WALK_OVERFLOW;
+        s_base = ni ? atomicAdd(a.q_count, ni) : 0u;
+    }
+    if (threadIdx.x < nw && threadIdx.x < IOC_WALK_SLOTS) a.walk_c[size_t(j) * IOC_WALK_SLOTS + threadIdx.x] = s_walk[threadIdx.x];
+    __syncthreads();
+    // a query's staged items occupy one contiguous range of the queue (k_eval reuses the query's minimizers across consecutive
+    // items)
+    for (uint32_t x = threadIdx.x; x < ni; x += IOC_BLOCK) {
+        const uint32_t slot = s_base + x;
+        if (slot < a.q_cap) {
+            a.q_items[2 * size_t(slot)] = uint32_t(j);
+            a.q_items[2 * size_t(slot) + 1] = s_item[x];
+        }
     }
 }
 
@@ -2140,7 +2166,13 @@ k_decide_pick(DecideArgs a)
         const uint32_t need = a.min_total[j];
         const uint32_t top = a.top[j];
         uint32_t bs = 0, be = 0xFFFFFFFFu, bc = 0, miss = 0;
-        for (uint32_t c = threadIdx.x; c < C; c += IOC_BLOCK) {
+        // the walk as k_decide_scan of this phase left it (a handful of candidates), or — more than IOC_WALK_SLOTS of them — the list
+        const uint32_t wn = a.walk_n[j];
+        const bool listed = wn != IOC_WALK_OVERFLOW;
+        const uint32_t* wl = a.walk_c + size_t(j) * IOC_WALK_SLOTS;
+        const uint32_t n_iter = listed ? wn : C;
+        for (uint32_t x = threadIdx.x; x < n_iter; x += IOC_BLOCK) {
+            const uint32_t c = listed ? wl[x] : x;
             const uint32_t key = a.cand_key[cbase + c];
             const uint32_t tg = key >> 1;
             const bool ok = (tg < L) || a.valid_in[tg - L];
