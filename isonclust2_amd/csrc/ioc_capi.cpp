@@ -102,23 +102,44 @@ int ioc_ctx_create(int device, ioc_ctx** out)
 {
     if (!out) return IOC_ERR_ARG;
     *out = nullptr;
+    // (IOC_TRACE: where a context's creation spends its time — the runtime's own start-up is most of it)
+    const bool trace = getenv("IOC_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ioc] ctx_create: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IOC_ERR_NO_DEVICE;
+    lap("hipGetDeviceCount (hipInit)");
     if (device < 0 || device >= ndev) return IOC_ERR_ARG;
     ioc_ctx* c = new (std::nothrow) ioc_ctx;
     if (!c) return IOC_ERR_CAPACITY;
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), 256, hipHostMallocDefault) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess) {
         delete c;
         return IOC_ERR_HIP;
     }
+    lap("hipSetDevice");
+    if (hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        return IOC_ERR_HIP;
+    }
+    lap("hipStreamCreate");
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_pin), 256, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return IOC_ERR_HIP;
+    }
+    lap("hipHostMalloc");
     c->stream = c->own_stream;
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) {
             delete c;
             return IOC_ERR_HIP;
         }
+    lap("hipEventCreate x n");
     // k_score_part has two builds.  The DEFAULT tests every posting against the workgroup's target window (defined behaviour).
     // The other one has no window test and leans on gfx950 dropping LDS atomics beyond the workgroup's allocation; it bought
     // 1.6 % of the kernel's time on config 2 (the kernel is LDS-bound, not VALU-bound), so it is opt-in: IOC_SCORE_OOB=1 asks

@@ -6,8 +6,9 @@
 // representatives' records: their minimizer lists HBM to HBM (ragged: one broadcast per rank inside one RCCL group, straight
 // into the [all forward lists][all reverse lists] layout ioc_batch_view takes — no padding, no re-layout copy), and a small
 // per-representative host record (lengths, error rates, raw sequences in sahlin / furious mode) staged through HBM.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // (types and prototypes only: the library itself is opened on first use, see rccl())
 
 #include <chrono>
 #include <cstdlib>
@@ -16,6 +17,70 @@
 #include <vector>
 
 #include "ioc_internal.h"
+
+// librccl.so is 573 MB of device code for every collective, data type and architecture: linked the ordinary way it is mapped,
+// relocated and registered with the HIP runtime at EVERY start of every process that loads this library — the one-GPU `cluster`
+// command included, which never communicates (0.1 - 0.2 s of a 0.5 s process, round 3's VERDICT item 7).  So it is opened when a
+// context first asks for a communicator, and the ten entry points used here are looked up by name.
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+// the library, opened once per process (thread-safe: a function-local static); nullptr + RcclApi::error if it cannot be had
+const RcclApi* rccl(std::string* why = nullptr)
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) {
+            const char* e = dlerror();
+            a.error = std::string("librccl.so.1 cannot be opened: ") + (e ? e : "?");
+            return a;
+        }
+        bool ok = true;
+        auto sym = [&](const char* nm) {
+            void* p = dlsym(a.handle, nm);
+            if (!p) {
+                ok = false;
+                a.error = std::string("librccl.so.1 lacks ") + nm;
+            }
+            return p;
+        };
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(sym("ncclBroadcast"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) a.handle = nullptr;
+        return a;
+    }();
+    if (!api.handle) {
+        if (why) *why = api.error;
+        return nullptr;
+    }
+    return &api;
+}
+}  // namespace
 
 struct ioc_dist_state {
     ncclComm_t comm = nullptr;
@@ -34,7 +99,7 @@ struct ioc_dist_state {
         ncclResult_t r_ = (x);                                                                      \
         if (r_ != ncclSuccess) {                                                                    \
             dist_abort((c)->dist);                                                                  \
-            return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ") + ncclGetErrorString(r_) + " (" #x "); communicator aborted"); \
+            return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ") + rccl()->GetErrorString(r_) + " (" #x "); communicator aborted"); \
         }                                                                                           \
     } while (0)
 #define HCK(c, x)                                                                                  \
@@ -56,7 +121,7 @@ static int need_dist(ioc_ctx* c)
 static void dist_abort(ioc_dist_state* d)
 {
     if (d && d->comm) {
-        (void)ncclCommAbort(d->comm);
+        (void)rccl()->CommAbort(d->comm);
         d->comm = nullptr;
     }
 }
@@ -75,7 +140,7 @@ static int agree(ioc_dist_state* d, int local_status)
     if (d->world == 1) return local_status != 0;
     d->h_status[0] = local_status != 0 ? 1 : 0;
     if (hipMemcpyAsync(d->d_status, d->h_status, 4, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
-        ncclAllReduce(d->d_status, d->d_status + 1, 1, ncclInt32, ncclMax, d->comm, d->stream) != ncclSuccess) {
+        rccl()->AllReduce(d->d_status, d->d_status + 1, 1, ncclInt32, ncclMax, d->comm, d->stream) != ncclSuccess) {
         dist_abort(d);
         return 1;
     }
@@ -114,7 +179,7 @@ static int rccl_exchange(void* user, void* d_buf, int64_t count, int32_t kind, v
     if (count == 0) return 0;
     ncclDataType_t t = kind == IOC_XCHG_MAX_U8 ? ncclUint8 : kind == IOC_XCHG_MIN_U32 ? ncclUint32 : ncclInt32;
     ncclRedOp_t op = kind == IOC_XCHG_MAX_U8 ? ncclMax : kind == IOC_XCHG_MIN_U32 ? ncclMin : ncclSum;
-    if (ncclAllReduce(d_buf, d_buf, size_t(count), t, op, d->comm, static_cast<hipStream_t>(hip_stream)) != ncclSuccess) {
+    if (rccl()->AllReduce(d_buf, d_buf, size_t(count), t, op, d->comm, static_cast<hipStream_t>(hip_stream)) != ncclSuccess) {
         dist_abort(d);
         return 1;
     }
@@ -128,7 +193,8 @@ int ioc_dist_unique_id(uint8_t* id)
     if (!id) return IOC_ERR_ARG;
     static_assert(IOC_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return IOC_ERR_HIP;
+    const RcclApi* R = rccl();
+    if (!R || R->GetUniqueId(&u) != ncclSuccess) return IOC_ERR_HIP;
     std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return IOC_OK;
 }
@@ -143,16 +209,22 @@ int ioc_dist_init(ioc_ctx* c, const uint8_t* id, int32_t rank, int32_t world)
     ioc_dist_state* d = new ioc_dist_state;
     d->rank = rank;
     d->world = world;
-    ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
+    std::string why;
+    const RcclApi* R = rccl(&why);
+    if (!R) {
+        delete d;
+        return ioc_fail(c, IOC_ERR_HIP, "RCCL: " + why);
+    }
+    ncclResult_t r = R->CommInitRank(&d->comm, world, u, rank);
     if (r != ncclSuccess) {
         delete d;
-        return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ncclCommInitRank: ") + ncclGetErrorString(r));
+        return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ncclCommInitRank: ") + rccl()->GetErrorString(r));
     }
     d->stream = c->stream;
     if (hipMalloc(reinterpret_cast<void**>(&d->d_status), 16) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&d->h_status), 16, hipHostMallocDefault) != hipSuccess) {
         if (d->d_status) (void)hipFree(d->d_status);
-        (void)ncclCommAbort(d->comm);
+        (void)rccl()->CommAbort(d->comm);
         delete d;
         return ioc_fail(c, IOC_ERR_HIP, "ioc_dist_init: no memory for the status words");
     }
@@ -166,7 +238,7 @@ int ioc_dist_shutdown(ioc_ctx* c)
     if (!c->dist) return IOC_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->dist->comm) (void)ncclCommDestroy(c->dist->comm);
+    if (c->dist->comm) (void)rccl()->CommDestroy(c->dist->comm);
     if (c->dist->stage.p) (void)hipFree(c->dist->stage.p);
     if (c->dist->d_status) (void)hipFree(c->dist->d_status);
     if (c->dist->h_status) (void)hipHostFree(c->dist->h_status);
@@ -189,7 +261,7 @@ int ioc_dist_allgather_device(ioc_ctx* c, const void* d_send, void* d_recv, int6
     if (int rc = need_dist(c)) return rc;
     if (bytes < 0 || (bytes && (!d_send || !d_recv))) return IOC_ERR_ARG;
     HCK(c, hipSetDevice(c->device));
-    if (bytes) NCK(c, ncclAllGather(d_send, d_recv, size_t(bytes), ncclUint8, c->dist->comm, c->stream));
+    if (bytes) NCK(c, rccl()->AllGather(d_send, d_recv, size_t(bytes), ncclUint8, c->dist->comm, c->stream));
     return IOC_OK;
 }
 
@@ -202,18 +274,18 @@ int ioc_dist_allgatherv_device(ioc_ctx* c, const void* d_send, void* d_recv, con
     if (!counts || !displs || esize <= 0) return IOC_ERR_ARG;
     HCK(c, hipSetDevice(c->device));
     ioc_dist_state* d = c->dist;
-    NCK(c, ncclGroupStart());
+    NCK(c, rccl()->GroupStart());
     for (int r = 0; r < d->world; ++r) {
         if (counts[r] <= 0) continue;
         char* dst = static_cast<char*>(d_recv) + displs[r] * esize;
         // (the root's send buffer may be its own slot of d_recv: in place)
-        ncclResult_t e = ncclBroadcast(r == d->rank ? d_send : dst, dst, size_t(counts[r]) * size_t(esize), ncclUint8, r, d->comm, c->stream);
+        ncclResult_t e = rccl()->Broadcast(r == d->rank ? d_send : dst, dst, size_t(counts[r]) * size_t(esize), ncclUint8, r, d->comm, c->stream);
         if (e != ncclSuccess) {
-            (void)ncclGroupEnd();
-            return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ncclBroadcast: ") + ncclGetErrorString(e));
+            (void)rccl()->GroupEnd();
+            return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ncclBroadcast: ") + rccl()->GetErrorString(e));
         }
     }
-    NCK(c, ncclGroupEnd());
+    NCK(c, rccl()->GroupEnd());
     return IOC_OK;
 }
 
@@ -226,7 +298,7 @@ int ioc_dist_allgather_i64(ioc_ctx* c, int64_t mine, int64_t* all)
     if (int rc = reserve(c, d->stage, size_t(d->world + 1) * 8)) return rc;
     int64_t* dv = static_cast<int64_t*>(d->stage.p);
     HCK(c, hipMemcpyAsync(dv + d->world, &mine, 8, hipMemcpyHostToDevice, c->stream));
-    NCK(c, ncclAllGather(dv + d->world, dv, 1, ncclInt64, d->comm, c->stream));
+    NCK(c, rccl()->AllGather(dv + d->world, dv, 1, ncclInt64, d->comm, c->stream));
     HCK(c, hipMemcpyAsync(all, dv, size_t(d->world) * 8, hipMemcpyDeviceToHost, c->stream));
     HCK(c, hipStreamSynchronize(c->stream));
     return IOC_OK;
@@ -263,7 +335,7 @@ int ioc_dist_allreduce_max(ioc_ctx* c, double* x)
     if (int rc = reserve(c, d->stage, 16)) return rc;
     double* dv = static_cast<double*>(d->stage.p);
     HCK(c, hipMemcpyAsync(dv, x, 8, hipMemcpyHostToDevice, c->stream));
-    NCK(c, ncclAllReduce(dv, dv + 1, 1, ncclDouble, ncclMax, d->comm, c->stream));
+    NCK(c, rccl()->AllReduce(dv, dv + 1, 1, ncclDouble, ncclMax, d->comm, c->stream));
     HCK(c, hipMemcpyAsync(x, dv + 1, 8, hipMemcpyDeviceToHost, c->stream));
     HCK(c, hipStreamSynchronize(c->stream));
     return IOC_OK;
