@@ -523,6 +523,11 @@ typedef int (*ioc_exchange_fn)(void* user, void* d_buf, int64_t count, int32_t k
 int ioc_set_shard(ioc_ctx* ctx, int32_t world, int32_t rank, ioc_exchange_fn fn, void* user);
 /* all-reduces issued by the last ioc_resolve (0: it was not sharded) */
 int32_t ioc_shard_exchanges(const ioc_ctx* ctx);
+/* sahlin / furious: scoring and resolve stay replicated under ioc_set_shard (their tie sets read every query's candidates), the
+ * ALIGNMENT rounds are shared out by owner of the query (a pair's result is a function of its two sequences, cluster.cpp:408-459);
+ * the verdicts of a round travel as one summed word array through the same hook.  Pairs this rank has aligned since
+ * ioc_set_shard: */
+int64_t ioc_shard_aligned_pairs(const ioc_ctx* ctx);
 /* The RCCL form of that exchange over the context's communicator (ioc_dist_init), on the context's stream: directly, and
  * installed as the context's shard setting with the communicator's world and rank (on = 0 removes it). */
 int ioc_dist_exchange(ioc_ctx* ctx, void* d_buf, int64_t count, int32_t kind);

@@ -124,7 +124,7 @@ SYMBOLS = [
     "ioc_poa_graph_save", "ioc_poa_graph_load", "ioc_poa_graph_load_many", "ioc_gather_records_device", "ioc_queries_generation", "ioc_scored_candidates",
     "ioc_dist_unique_id", "ioc_dist_init", "ioc_dist_shutdown", "ioc_dist_info", "ioc_dist_allgather_device",
     "ioc_dist_allgatherv_device", "ioc_dist_allgather_i64", "ioc_dist_allgatherv_host", "ioc_dist_allreduce_max",
-    "ioc_dist_barrier", "ioc_dist_merge", "ioc_set_shard", "ioc_shard_exchanges", "ioc_dist_exchange", "ioc_dist_set_shard", "ioc_align_set_verdict_threshold",
+    "ioc_dist_barrier", "ioc_dist_merge", "ioc_set_shard", "ioc_shard_exchanges", "ioc_shard_aligned_pairs", "ioc_dist_exchange", "ioc_dist_set_shard", "ioc_align_set_verdict_threshold",
 ]
 
 _lib = None
@@ -230,6 +230,8 @@ def load():
                                  C.POINTER(ClusterStats), C.POINTER(DistMergeTimes)]
     L.ioc_set_shard.argtypes = [vp, i32, i32, EXCHANGE_FN, vp]
     L.ioc_shard_exchanges.argtypes = [vp]
+    L.ioc_shard_aligned_pairs.argtypes = [vp]
+    L.ioc_shard_aligned_pairs.restype = C.c_int64
     L.ioc_dist_exchange.argtypes = [vp, vp, i64, i32]
     L.ioc_dist_set_shard.argtypes = [vp, i32]
     L.ioc_align_set_verdict_threshold.argtypes = [vp, C.c_double]

@@ -174,6 +174,11 @@ class Context:
     def shard_exchanges(self):
         return int(self.L.ioc_shard_exchanges(self.h))
 
+    @property
+    def shard_aligned_pairs(self):
+        """pairs THIS rank aligned in the sharded alignment rounds since set_shard (sahlin / furious)"""
+        return int(self.L.ioc_shard_aligned_pairs(self.h))
+
     def scored_candidates(self, q, cap=1 << 16):
         """(key, size) the scoring kernels wrote for query q: key = target << 1 | strand."""
         key, size = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)

@@ -930,6 +930,7 @@ int ioc_set_shard(ioc_ctx* c, int32_t world, int32_t rank, ioc_exchange_fn fn, v
         c->shard_rank = rank;
         c->shard_fn = fn;
         c->shard_user = user;
+        c->shard_aln_pairs = 0;
     } else {
         c->shard_world = 1;
         c->shard_rank = 0;
@@ -942,6 +943,7 @@ int ioc_set_shard(ioc_ctx* c, int32_t world, int32_t rank, ioc_exchange_fn fn, v
 }
 
 int32_t ioc_shard_exchanges(const ioc_ctx* c) { return c ? c->shard_exchanges : 0; }
+int64_t ioc_shard_aligned_pairs(const ioc_ctx* c) { return c ? c->shard_aln_pairs : 0; }
 
 }  // extern "C"
 

@@ -522,9 +522,10 @@ int ioc_dist_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, cons
     v.minimizers_on_device = 1;
     HCK(c, hipStreamSynchronize(c->stream));
     const auto t0 = std::chrono::steady_clock::now();
-    // fast mode: score + resolve sharded over the ranks (query j on rank j % W), `valid` all-reduced after every sweep
+    // fast mode: score + resolve sharded over the ranks (query j on rank j % W), `valid` all-reduced after every sweep;
+    // sahlin / furious: the alignment rounds sharded by owner of the query, their verdicts summed over the ranks (ioc_host.cpp)
     const char* es = getenv("IOC_DIST_SHARD");
-    const bool shard = W > 1 && p->mode == IOC_MODE_FAST && !(es && es[0] == '0');
+    const bool shard = W > 1 && !(es && es[0] == '0');
     int rc = IOC_OK;
     if (shard && ioc_dist_set_shard(c, 1) != IOC_OK) rc = IOC_ERR_STATE;
     if (rc == IOC_OK) rc = ioc_cluster_merge(c, p, table_path, nullptr, &v, out_cls, out_strand, stats);

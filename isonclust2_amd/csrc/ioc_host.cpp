@@ -487,22 +487,49 @@ struct AlnDriver {
             }
             return IOC_OK;
         }
-        std::vector<ioc_aln_pair> pairs(todo.size());
-        for (size_t i = 0; i < todo.size(); ++i) {
+        // Sharded merge (ioc_set_shard): the alignment rounds of sahlin / furious mode are shared out by owner of the QUERY — a pair's
+        // result depends on the two sequences only (cluster.cpp:408-459, 498-507), every rank holds the same decisions and hence
+        // the same list of pairs —, rank r aligns the pairs of the queries q with q % world == r, and the verdicts travel as one
+        // summed word array (1 = aligned, below the threshold; 2 = at or above it; 0 = not mine).  Scoring and resolve stay
+        // replicated in these modes: their tie sets read every query's candidates.
+        const bool shard = c->shard_world > 1 && c->shard_fn != nullptr;
+        std::vector<size_t> mine;
+        for (size_t i = 0; i < todo.size(); ++i)
+            if (!shard || todo[i].first % c->shard_world == c->shard_rank) mine.push_back(i);
+        std::vector<ioc_aln_pair> pairs(mine.size());
+        for (size_t x = 0; x < mine.size(); ++x) {
+            const size_t i = mine[x];
             const int32_t target = int32_t(todo[i].second >> 1);
-            pairs[i].query = todo[i].first;
-            pairs[i].ref = target < c->L ? n + target : target - c->L;
-            pairs[i].ref_revcomp = int32_t(todo[i].second & 1u);
-            pairs[i].reserved = 0;
-            pairs[i].e = sa->r_err[todo[i].first] + err_of(target);
+            pairs[x].query = todo[i].first;
+            pairs[x].ref = target < c->L ? n + target : target - c->L;
+            pairs[x].ref_revcomp = int32_t(todo[i].second & 1u);
+            pairs[x].reserved = 0;
+            pairs[x].e = sa->r_err[todo[i].first] + err_of(target);
         }
-        std::vector<double> ratio(todo.size());
+        std::vector<double> ratio(mine.size());
         // (the ratios are only ever compared with AlignedThreshold: the tracebacks may stop once that comparison is decided)
         const double saved_thr = c->aln_verdict_thr;
         const char* ev = getenv("IOC_ALIGN_VERDICT");
         if (!(ev && ev[0] == '0')) (void)ioc_align_set_verdict_threshold(c, c->params.aligned_threshold);
-        int r = ioc_align_pairs(c, int32_t(pairs.size()), pairs.data(), c->params.k, 2, -2, 1, nullptr, nullptr, ratio.data());
+        int r = mine.empty() ? IOC_OK : ioc_align_pairs(c, int32_t(pairs.size()), pairs.data(), c->params.k, 2, -2, 1, nullptr, nullptr, ratio.data());
         c->aln_verdict_thr = saved_thr;
+        if (shard) {
+            // (a rank whose alignment failed still joins the exchange — its peers are on their way into it — with nothing to say;
+            // the pairs it owed come back as 0 and every rank fails on them together)
+            std::vector<int32_t> words(todo.size(), 0);
+            if (r == IOC_OK)
+                for (size_t x = 0; x < mine.size(); ++x) words[mine[x]] = ratio[x] >= c->params.aligned_threshold ? 2 : 1;
+            const int rx = ioc_shard_sum_host(c, words.data(), int64_t(words.size()));
+            if (r != IOC_OK) return r;
+            if (rx != IOC_OK) return rx;
+            c->shard_aln_pairs += int64_t(mine.size());
+            for (size_t i = 0; i < todo.size(); ++i) {
+                if (words[i] != 1 && words[i] != 2) return ioc_fail(c, IOC_ERR_STATE, "sharded alignment round: a pair came back from no rank (or from two)");
+                // (only the comparison with AlignedThreshold is ever read: the owner's verdict stands in for the ratio)
+                cache[key(todo[i].first, todo[i].second)] = words[i] == 2 ? std::max(1.0, c->params.aligned_threshold) : -1.0;
+            }
+            return IOC_OK;
+        }
         if (r != IOC_OK) return r;
         for (size_t i = 0; i < todo.size(); ++i) {
             cache[key(todo[i].first, todo[i].second)] = ratio[i];

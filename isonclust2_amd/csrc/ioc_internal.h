@@ -157,6 +157,7 @@ struct ioc_ctx {
     void* shard_user = nullptr;
     bool scored_sharded = false;  // the candidate tables hold the owned queries only
     int shard_exchanges = 0;
+    int64_t shard_aln_pairs = 0;  // pairs THIS rank aligned in sharded alignment rounds since ioc_set_shard
     DevBuf b_shard_stage;
     double aln_verdict_thr = -1.0;  // ioc_align_set_verdict_threshold (<= 0: exact counts)
     uint32_t* h_pin = nullptr;     // 256 bytes of pinned host memory: the read-backs of the resolve's sweeps

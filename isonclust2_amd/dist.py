@@ -329,11 +329,23 @@ def merge_all_device(ctx, params, cb: ClusteredBatch, dist, torch, min_cls_size=
             recv_min, recv_pos = recv_min.to(dev), recv_pos.to(dev)
         torch.cuda.synchronize()
     t2 = time.perf_counter()
-    merged = merge_gathered(ctx, params, metas, recv_min, recv_pos, cap, min_cls_size, export_mindb)   # step 3
+    # step 3 with the work of the pass shared out over the ranks (ioc_set_shard, the exchange over this process group): fast mode
+    # shards scoring and resolve by query, sahlin / furious shard their alignment rounds by query; IOC_DIST_SHARD=0: replicated
+    import os
+    world = dist.get_world_size() if dist is not None else 1
+    shard = world > 1 and os.environ.get("IOC_DIST_SHARD", "1") != "0"
+    if shard:
+        ctx.set_shard(world, dist.get_rank(), torch_exchange(ctx, dist, torch))
+    try:
+        merged = merge_gathered(ctx, params, metas, recv_min, recv_pos, cap, min_cls_size, export_mindb)
+        info = dict(sharded=shard, exchanges=ctx.shard_exchanges, aligned_pairs_this_rank=ctx.shard_aligned_pairs)
+    finally:
+        if shard:
+            ctx.set_shard(1, 0, None)
     t3 = time.perf_counter()
     if timing is not None:
         timing.update(gather_ms=(t1 - t0) * 1e3, allgather_ms=(t2 - t1) * 1e3, merge_ms=(t3 - t2) * 1e3, payload_bytes_per_rank=nbytes,
-                      clusters_in=[m.n_clusters for m in metas])
+                      clusters_in=[m.n_clusters for m in metas], **info)
     return merged
 
 
@@ -347,8 +359,12 @@ def timed_merge(ctx, params, cb: ClusteredBatch, dist, torch=None, dev=None):
             "reads_assigned": int(len(merged.member_read)), "gather_ms": max_over_ranks(tm["gather_ms"], dist),
             "allgather_ms": max_over_ranks(tm["allgather_ms"], dist), "merge_ms": max_over_ranks(tm["merge_ms"], dist),
             "payload_bytes_per_rank": tm["payload_bytes_per_rank"], "fnv1a": fnv1a_reads(merged),
-            "merged_on": "every rank (device-resident representative records, replicated one-pass merge)",
-            "replicated": True,
+            "merged_on": "every rank holds the gathered representatives; the pass's work is shared out by query (fast: scoring + "
+                         "resolve, `valid` all-reduced per sweep; sahlin / furious: the alignment rounds, verdicts summed)" if tm.get("sharded")
+                         else "every rank (device-resident representative records, replicated one-pass merge)",
+            "replicated": not tm.get("sharded"), "exchanges_last_resolve": tm.get("exchanges"),
+            "aligned_pairs_per_rank_max": max_over_ranks(tm.get("aligned_pairs_this_rank") or 0, dist),
+            "aln_pairs_total": merged.stats.get("n_aln_pairs"),
             "aln_invoked": merged.stats.get("n_aln_invoked")}
 
 

@@ -185,13 +185,29 @@ def _worker_shard(rank, world, port, q):
             w1, m1, it1, x1 = run(p, sb)
             ok = same(w0, w1) and same(m0, m1) and x0 == 0 and x1 >= 2 * it1 + 4 and it1 == it0
             out.append((name, ok, w0.n_clusters, w1.n_clusters, m0.n_clusters, m1.n_clusters, it0, it1, x0, x1))
-            if name == "tiny" and not rng:      # sahlin ignores the setting: no exchange, same result
-                ps = api.default_params(11, 15, "sahlin")
-                s1 = pipeline.cluster_single(ctx, ps, sb)
-                xs = ctx.shard_exchanges
+            if name in ("tiny", "short_dup") and not rng:
+                # sahlin / furious: scoring and resolve stay replicated, the ALIGNMENT rounds are shared out by owner of the query
+                # and their verdicts summed over the ranks: same clustering, and this rank aligned only its share of the pairs
+                for mode in ("sahlin", "furious"):
+                    ps = api.default_params(11, 15, mode)
+                    ctx.set_shard(1, 0, None)
+                    s0 = pipeline.cluster_single(ctx, ps, sb)
+                    pairs0 = ctx.timings()["n_align_pairs"]
+                    half = len(sb.read_ids) // 2
+                    a0 = pipeline.cluster_single(ctx, ps, pipeline.slice_sorted(sb, 0, half, batch_nr=0))
+                    b0 = pipeline.cluster_single(ctx, ps, pipeline.slice_sorted(sb, half, len(sb.read_ids), batch_nr=1))
+                    m0s = pipeline.cluster_merge(ctx, ps, a0, b0)
+                    ctx.set_shard(world, rank, d.torch_exchange(ctx, dist, torch))
+                    s1 = pipeline.cluster_single(ctx, ps, sb)
+                    mine = ctx.shard_aligned_pairs
+                    m1s = pipeline.cluster_merge(ctx, ps, a0, b0)       # (the merge's alignment rounds: queries against left representatives)
+                    tot = torch.tensor([mine], dtype=torch.int64)
+                    dist.all_reduce(tot)
+                    st_pairs = s0.stats.get("n_aln_pairs", -1)
+                    ok_s = same(s0, s1) and same(m0s, m1s) and int(tot.item()) == st_pairs and (st_pairs < 4 or 0 < mine < st_pairs)
+                    print(f"  {mode}: pairs {st_pairs} (device count {pairs0}), this rank {mine}, all ranks {int(tot.item())}", file=log)
+                    out.append((f"{name}/{mode}", ok_s, s0.n_clusters, s1.n_clusters, m0s.n_clusters, m1s.n_clusters, st_pairs, mine, int(tot.item()), 0))
                 ctx.set_shard(1, 0, None)
-                s0 = pipeline.cluster_single(ctx, ps, sb)
-                out.append(("tiny/sahlin", same(s0, s1) and xs == 0, s0.n_clusters, s1.n_clusters, 0, 0, 0, 0, 0, xs))
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
