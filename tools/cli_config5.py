@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Runs the isONclust2-hip CLI end to end on BASELINE.json configs[4]'s shape ("config 5" in SURVEY.md §8(d): 2 M reads /
 4 Gb in 64 batches of 31 250 reads x 2 kb, sahlin mode, consensus on), or a slice of it: sort -> cluster each batch ->
-merge -> dump, through the files, ONE GPU.  The way the reference's external pipeline runs the steps (README.md:105-117):
-the `cluster` jobs of the leaves are independent processes, the merges form a binary tree whose levels are independent
-processes again; `--jobs J` of them run at a time and share the GPU (J = 1 and `--fold` give round 2's first form: one
-process at a time, merges folded left to right).  Prints wall times and what the domain offers as size-independent
+merge -> dump, through the files, on `--gpus N` GPUs of one node (default 1).  The way the reference's external pipeline runs the
+steps (README.md:105-117, main.cpp:262-275: batch b -> worker b mod N): the `cluster` jobs of the leaves are independent
+processes, the merges form a binary tree whose levels are independent processes again; job j of a stage runs on GPU j mod N
+(ISONCLUST2_DEVICE, read by the command line), `--jobs J` processes at a time PER GPU share a card (J = 1 and `--fold` give
+round 2's first form: one process at a time, merges folded left to right).  With more GPUs asked for than the node shows, the
+jobs are mapped onto the visible ones (a rehearsal of the scheduling: the output says so).  Prints wall times and what the domain offers as size-independent
 checks (every read assigned exactly once, clusters ~ the generator's transcripts).
-    tools/cli_config5.py NB [--per 31250] [--mode sahlin] [--cons 20,100,400] [--jobs 4] [--fold] [--gen-procs 12]"""
+    tools/cli_config5.py NB [--per 31250] [--mode sahlin] [--cons 20,100,400] [--gpus 8] [--jobs 4] [--fold] [--gen-procs 12]"""
 import argparse
 import json
 import multiprocessing
@@ -26,13 +28,37 @@ ap.add_argument("nb", type=int, nargs="?", default=2)
 ap.add_argument("--per", type=int, default=31250)
 ap.add_argument("--mode", default="sahlin")
 ap.add_argument("--cons", default=None, help="ConsMinSize,ConsMaxSize,ConsPeriod: consensus mode")
-ap.add_argument("--jobs", type=int, default=4, help="cluster / merge processes at a time (they share the GPU; keep <= 5)")
+ap.add_argument("--jobs", type=int, default=4, help="cluster / merge processes at a time PER GPU (they share the card; keep <= 5)")
+ap.add_argument("--gpus", type=int, default=1, help="GPUs of the node: job j of a stage runs on GPU j mod N (ISONCLUST2_DEVICE)")
+ap.add_argument("--visible", type=int, default=0, help="GPUs this node really has, where sysfs does not say (rehearsals of --gpus N on fewer cards)")
 ap.add_argument("--fold", action="store_true", help="merge left to right instead of as a binary tree")
 ap.add_argument("--gen-procs", type=int, default=min(12, os.cpu_count() or 1))
 ap.add_argument("--progress", default=None, help="file that receives the results so far after every stage")
 ap.add_argument("--keep", action="store_true", help="keep the intermediate files of consumed steps")
 a = ap.parse_args()
 assert 1 <= a.jobs <= 5, "the GPU box allows 6 processes on the card at once"
+assert a.gpus >= 1
+
+
+def visible_gpus():
+    """GPUs of this node without touching HIP: the kfd topology in sysfs (None: unknown)"""
+    import glob
+    n, nodes = 0, glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    try:
+        for f in nodes:
+            for line in open(f):
+                if line.startswith("simd_count"):
+                    n += int(line.split()[1]) > 0
+                    break
+    except OSError:          # (an ordinary user may not read the topology)
+        return None
+    return n
+
+
+VIS = a.visible if a.visible else visible_gpus()
+MAPPED = VIS is not None and 0 < VIS < a.gpus       # fewer cards than asked for: the schedule is rehearsed on what is there
 CLI = os.environ.get("IOC_CLI", os.path.join("isonclust2_amd", "bin", "isONclust2-hip"))
 G, LEN, TR_SEED = 1500, 2000, 11
 d = tempfile.mkdtemp(prefix="ioc_cli5_")
@@ -66,7 +92,8 @@ with open(fq, "wb") as f:
         os.unlink(p)
 n_reads = a.nb * a.per
 out = {"workload": f"{a.nb} x {a.per} reads of 2 kb, {a.mode}; {G} transcripts, chunk seeds 1000.., transcript seed {TR_SEED}",
-       "fastq_MB": os.path.getsize(fq) / 1e6, "generate_s": time.time() - t, "jobs": a.jobs,
+       "fastq_MB": os.path.getsize(fq) / 1e6, "generate_s": time.time() - t, "jobs_per_gpu": a.jobs, "gpus": a.gpus,
+       "gpus_visible": VIS, "devices_mapped_onto_visible": bool(MAPPED),
        "merge_shape": "left fold" if a.fold else "binary tree"}
 log(f"reads written ({out['fastq_MB']:.0f} MB)")
 
@@ -79,12 +106,15 @@ def checkpoint():
             json.dump(out, f)
 
 
-def run(args, tag=""):
+def run(args, tag="", slot=0):
     t0 = time.time()
-    r = subprocess.run([CLI] + args, capture_output=True, text=True, env=env)
+    dev = slot % a.gpus
+    if MAPPED:
+        dev %= VIS
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, env=dict(env, ISONCLUST2_DEVICE=str(dev)))
     assert r.returncode == 0, (args, r.stderr[-2000:])
     dt = time.time() - t0
-    log(f"{args[0]} {tag}: {dt:.1f} s")
+    log(f"{args[0]} {tag} [gpu {dev}]: {dt:.1f} s")
     if args[0] == "cluster":
         js = [ln for ln in r.stderr.splitlines() if ln.startswith("{")]
         if js:
@@ -93,10 +123,19 @@ def run(args, tag=""):
 
 
 def run_many(jobs):
-    """jobs: (args, tag) of independent processes; a.jobs at a time.  Returns (per-process seconds, wall seconds)."""
+    """jobs: (args, tag) of independent processes; job j on GPU j mod N, a.jobs at a time per GPU (one worker pool per GPU, so
+    that a slow job holds up its own card only).  Returns (per-process seconds in job order, wall seconds)."""
     t0 = time.time()
-    with ThreadPoolExecutor(a.jobs) as ex:
-        secs = list(ex.map(lambda j: run(*j), jobs))
+    secs = [0.0] * len(jobs)
+    per_gpu = [[j for j in range(len(jobs)) if j % a.gpus == g] for g in range(a.gpus)]
+
+    def drain(g):
+        with ThreadPoolExecutor(a.jobs) as ex:
+            for j, dt in zip(per_gpu[g], ex.map(lambda j: run(jobs[j][0], jobs[j][1], slot=j), per_gpu[g])):
+                secs[j] = dt
+
+    with ThreadPoolExecutor(a.gpus) as outer:
+        list(outer.map(drain, range(a.gpus)))
     return secs, time.time() - t0
 
 
