@@ -1831,7 +1831,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     std::vector<V2PairEnd> pend(np);
     std::vector<uint64_t> cwords(ncouples);  // arena words of a couple
     auto up4 = [](uint64_t x) { return (x + 3u) & ~uint64_t(3); };
-    uint32_t lrow_total = 0, best_total = 0;
+    uint32_t lrow_total = 0, best_total = 0, max_strips = 1;
+    uint64_t prof_total = 0;
     for (uint32_t k2 = 0; k2 < ncouples; ++k2) {
         V2Couple& cp = cps[k2];
         cp.pid[0] = order[2u * k2];
@@ -1895,6 +1896,9 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         cp.cbase = w;
         w += up4(ncc * uint64_t(cp.nq) * 2u);
         cwords[k2] = w;
+        cp.prof = prof_total;  // (uint4 entries)
+        prof_total += uint64_t(cp.nstrips) * 2u * 5u * 64u;
+        max_strips = std::max(max_strips, cp.nstrips);
         for (int h = 0; h < 2; ++h) {
             cp.lrow0[h] = lrow_total;
             cp.best0[h] = best_total;
@@ -1974,6 +1978,11 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     ACHK(c, hipMemcpyAsync(d_cps, cps.data(), size_t(ncouples) * sizeof(V2Couple), hipMemcpyHostToDevice, s));
     ACHK(c, hipMemcpyAsync(d_pck, pck.data(), size_t(np) * sizeof(V2PairCk), hipMemcpyHostToDevice, s));
     ACHK(c, hipMemcpyAsync(d_pend, pend.data(), size_t(np) * sizeof(V2PairEnd), hipMemcpyHostToDevice, s));
+    // the query profiles of every (couple, strip), once per batch
+    if ((r = reserve(c, c->a_prof, size_t(prof_total) * sizeof(uint4) + 256)) != IOC_OK) return r;
+    hipLaunchKernelGGL(k_fwd2_prof, dim3(ncouples, max_strips), dim3(128), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps,
+                       static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint4*>(c->a_prof.p));
+    ACHK(c, hipGetLastError());
     if ((r = reserve(c, c->a_ends2, size_t(np) * sizeof(int4))) != IOC_OK) return r;
     if ((r = reserve(c, c->a_lrow, (size_t(lrow_total) + best_total + 16) * sizeof(int2))) != IOC_OK) return r;
     int2* d_lrow = static_cast<int2*>(c->a_lrow.p);
@@ -2029,7 +2038,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_items + V2_WAVES - 1) / V2_WAVES));
         hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_items,
                            d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                           d_best, d_ctl + 16 + max_flags, guard);
+                           d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
         ACHK(c, hipGetLastError());
         hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
                            d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p));

@@ -112,7 +112,7 @@ struct ioc_ctx {
     std::vector<uint8_t> x_keep;
 
     // ---- GPU alignment fallback (ioc_align_gpu.hip) ----
-    DevBuf a_pool, a_pairs, a_order, a_out, a_bnd, a_lrow, a_ck, a_cko, a_ends, a_ends2, a_xflags;
+    DevBuf a_pool, a_pairs, a_order, a_out, a_bnd, a_lrow, a_ck, a_cko, a_ends, a_ends2, a_xflags, a_prof;
     std::vector<uint8_t> aln_other;  // per pool sequence: holds a byte other than A C G T
     std::vector<int64_t> aln_offs;
     DevBuf b_aln_t, b_aln_s, b_tie_count, b_tie_keys;
