@@ -1105,12 +1105,12 @@ int main(int argc, char** argv)
     const string cmd = argv[1];
     // The GPU commands leave through _exit once their files are closed and the streams flushed: the HIP runtime's exit handlers
     // (code objects unloaded, every allocation returned one by one) cost a one-shot process 50 - 100 ms for nothing — the driver
-    // takes the process's memory back either way.  IOC_CLI_ORDERLY_EXIT=1: the ordinary way out (sanitizer runs).
+    // takes the process's memory back either way.  IOC_CLI_CLEAN_EXIT=1: the ordinary way out (profilers and sanitizers write their results from exit handlers).
     auto leave = [](int rc) {
         std::cout.flush();
         std::cerr.flush();
         fflush(nullptr);
-        if (getenv("IOC_CLI_ORDERLY_EXIT")) return rc;
+        if (getenv("IOC_CLI_CLEAN_EXIT")) return rc;
         _exit(rc);
     };
     if (cmd == "sort") return leave(main_sort(argc - 1, argv + 1));
