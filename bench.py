@@ -48,9 +48,9 @@ ALIGN_VALU_PER_CELL = 5  # fwd_cells: add with byte select, max3, sub, max, max 
 
 
 def valu_rates():
-    """The JSON line of the issue-rate microbenchmark (tools/micro/valu_rate.hip -> profiles/r03_valu_rate.txt): T lane-op/s per
-    instruction, launches of 50 - 100 ms, best over 1-8 waves per SIMD."""
-    for name in ("r03_valu_rate.txt", "r02_valu_rate.txt"):
+    """The JSON line of the issue-rate microbenchmark (tools/micro/valu_rate.hip -> profiles/r04_valu_rate.txt): T lane-op/s per
+    instruction, every wave at work for the same 40 ms of wall clock, best over 1-8 waves per SIMD."""
+    for name in ("r04_valu_rate.txt", "r03_valu_rate.txt", "r02_valu_rate.txt"):
         try:
             for line in open(os.path.join(ROOT, "profiles", name)):
                 if line.startswith("JSON "):

@@ -5,6 +5,11 @@
 // so every SIMD holds exactly `wps` waves for the whole launch.  Launches run >= 50 ms after a burn-in (the clock under an
 // all-VALU load settles well below the 2.4 GHz nominal); the shader clock during the launch is read as
 // s_memtime ticks per s_memrealtime tick (100 MHz) by one wave per workgroup.
+// Round 4: every wave works for a fixed stretch of WALL time (the 100 MHz clock, read every 256 x 16 instructions) and counts what it
+// got done, instead of a fixed number of iterations: with equal work per wave the waves of a SIMD do not finish together — the
+// issue arbiter serves the oldest wave first, the first workgroups of a launch left after a third of it and the last one ran
+// alone at the end (round 3's "workgroups alive 52 - 86 % of the launch") — so the tail of every launch ran at the rate of fewer
+// waves than the row claims.  Now all `wps` waves of every SIMD are at work for the whole measured stretch.
 // Round 3: the launches are 50 - 100 ms (were 1 - 5: the launch tail was a third of the timed region), the rate and the
 // "cycles of a SIMD per wave-instruction" both come from the EVENT time of the launch (the per-wave cycle counts of round 2
 // under-counted when waves did not all start together: the sub-2-cycle v_add_u32 reading), and the line says how much of
@@ -22,7 +27,7 @@ static const char* NAMES[N_MODES] = {"v_fma_f32", "v_add_u32", "v_max_i32", "v_m
 static const int OPS[N_MODES] = {1, 1, 1, 1, 1, 1, 1, 1, 5, 1, 1, 7};
 
 template <int MODE>
-__global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters, uint32_t seed)
+__global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters, uint32_t seed, uint64_t budget)
 {
     extern __shared__ uint32_t pad[];
     uint32_t a[16];
@@ -31,7 +36,13 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters
     uint32_t b = seed * 3 + 1, c = seed ^ 0x1234;
     float fb = 1.0001f, fc = 0.5f;
     const uint64_t t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
-    for (int it = 0; it < iters; ++it) {
+    uint64_t chunks = 0;
+    // (budget == 0: `iters` iterations, the burn-in; otherwise chunks of 256 iterations until the wall-clock budget is spent)
+    for (;;) {
+    if (budget ? wall_clock64() - w0 >= budget : chunks > 0) break;
+    const int n_it = budget ? 256 : iters;
+    ++chunks;
+    for (int it = 0; it < n_it; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (MODE == FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(fb), "v"(fc));
@@ -64,58 +75,61 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint64_t* cyc, int iters
             }
         }
     }
+    }
     const uint64_t t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s ^= a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + pad[0] * 0;
-    if (threadIdx.x == 0) {
-        cyc[2 * blockIdx.x] = t1 - t0;
-        cyc[2 * blockIdx.x + 1] = w1 - w0;
+    if ((threadIdx.x & 63) == 0) {  // per wave: cycles, wall ticks, chunks done, start
+        uint64_t* o = cyc + 4 * (size_t(blockIdx.x) * 4 + (threadIdx.x >> 6));
+        o[0] = t1 - t0;
+        o[1] = w1 - w0;
+        o[2] = chunks;
+        o[3] = w0;
     }
 }
 
 template <int MODE>
 void run(int n_cu, int wps, double* out_rate)
 {
-    const int grid = n_cu * wps, iters = 2400000 / wps / OPS[MODE];   // 50 - 100 ms per launch
+    const int grid = n_cu * wps;
+    const uint64_t budget = 4000000;  // 40 ms of the 100 MHz clock
     uint32_t* d;
     uint64_t* dc;
     hipMalloc(&d, size_t(grid) * 256 * 4);
-    hipMalloc(&dc, size_t(grid) * 16);
+    hipMalloc(&dc, size_t(grid) * 4 * 32);
     // at most `wps` workgroups per CU: each takes just over 160 KB / (wps + 1) of LDS (64 KB is the default cap per block)
     size_t lds = wps >= 8 ? 0 : (size_t(160) * 1024 / (wps + 1) + 1024) & ~size_t(255);
     if (lds > 64 * 1024) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     }
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, iters / 4, 1u);  // burn-in
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, iters, 1u);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    uint64_t* hc = new uint64_t[2 * grid];
-    hipMemcpy(hc, dc, size_t(grid) * 16, hipMemcpyDeviceToHost);
-    double cavg = 0, wavg = 0;
-    for (int i = 0; i < grid; ++i) {
-        cavg += double(hc[2 * i]);
-        wavg += double(hc[2 * i + 1]);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, 200000 / wps / OPS[MODE], 1u, uint64_t(0));  // burn-in
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), lds, 0, d, dc, 0, 1u, budget);
+    hipDeviceSynchronize();
+    const int nw = grid * 4;
+    uint64_t* hc = new uint64_t[4 * size_t(nw)];
+    hipMemcpy(hc, dc, size_t(nw) * 32, hipMemcpyDeviceToHost);
+    double cyc = 0, ticks = 0, chunks = 0;
+    uint64_t first_start = ~0ull, last_start = 0, cmin = ~0ull, cmax = 0;
+    for (int i = 0; i < nw; ++i) {
+        cyc += double(hc[4 * i]);
+        ticks += double(hc[4 * i + 1]);
+        chunks += double(hc[4 * i + 2]);
+        cmin = hc[4 * i + 2] < cmin ? hc[4 * i + 2] : cmin;
+        cmax = hc[4 * i + 2] > cmax ? hc[4 * i + 2] : cmax;
+        first_start = hc[4 * i + 3] < first_start ? hc[4 * i + 3] : first_start;
+        last_start = hc[4 * i + 3] > last_start ? hc[4 * i + 3] : last_start;
     }
-    cavg /= grid;
-    wavg /= grid;
     delete[] hc;
-    const double ghz = cavg / wavg * 0.1;  // s_memtime ticks per 10 ns
-    const double winstr = double(iters) * 16 * OPS[MODE];           // wave-instructions per wave
-    const double lane_ops = winstr * 64 * 4 * double(grid);         // lane-operations of the launch
-    const double rate = lane_ops / (ms * 1e-3) / 1e12;
-    // cycles of a SIMD per wave-instruction it issued: the launch's event time x the clock read inside it / (instructions of
-    // a wave x waves sharing the SIMD)
-    printf("  %-56s wps %d: %8.3f ms  %6.2f T lane-op/s  %5.2f cycles of a SIMD per wave-instr  (clock %.2f GHz; workgroups alive %.0f %% of the launch)\n",
-           NAMES[MODE], wps, ms, rate, ms * 1e-3 * ghz * 1e9 / (winstr * wps), ghz, wavg * 1e-5 / ms * 100);
+    const double ghz = cyc / ticks * 0.1;            // s_memtime ticks per 10 ns
+    const double secs = ticks / nw * 1e-8;           // the stretch a wave was at work (the budget + its last chunk)
+    const double winstr = chunks * 256.0 * 16 * OPS[MODE];      // wave-instructions of the launch
+    const double rate = winstr * 64 / secs / 1e12;
+    // cycles of a SIMD per wave-instruction it issued = SIMD-cycles of the stretch / instructions of the SIMD's waves
+    const double cpi = secs * ghz * 1e9 * double(n_cu) * 4 / winstr;
+    printf("  %-56s wps %d: %6.2f T lane-op/s  %5.2f cycles of a SIMD per wave-instr  (clock %.2f GHz; %.1f ms per wave, all started within %.3f ms; slowest / fastest wave got %.2f of the mean work: %.2f / %.2f)\n",
+           NAMES[MODE], wps, rate, cpi, ghz, secs * 1e3, double(last_start - first_start) * 1e-5, double(cmin) / (chunks / nw), double(cmin) / (chunks / nw), double(cmax) / (chunks / nw));
     if (out_rate) *out_rate = rate;
     hipFree(d);
     hipFree(dc);
