@@ -222,6 +222,28 @@ def cpu_baseline_fast(rs, order, cls, strand, k, w, max_runs, budget_s):
     return min(times), times, st, mism, pin.core
 
 
+def cpu_simd_score_pass(rs, order, n_pairs=24):
+    """What the reference's alignment calls cost at least on this host: a 16-bit SSE2 striped score pass of the semi-global alignment
+    (oracle/sg_striped.cpp, Farrar 2007 — parasail, which the reference calls, is absent from its tree; its sg_trace_scan_16 also
+    writes a traceback table and re-runs saturated pairs in 32 bits) on pairs of neighbouring reads of the sorted batch, one pinned
+    core.  Returns G cell updates per second."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    L = po.lib()
+    cells, t_all, sat = 0, 0.0, 0
+    with pinned():
+        for x in range(n_pairs):
+            a, _ = rs.read(int(order[2 * x]))
+            b, _ = rs.read(int(order[2 * x + 1]))
+            f = C.c_int32()
+            t0 = time.perf_counter()
+            L.orc_sg_striped16(a, len(a), b, len(b), 2, -2, 3, 1, C.byref(f))
+            t_all += time.perf_counter() - t0
+            cells += len(a) * len(b)
+            sat += f.value
+    return {"gcups": cells / t_all / 1e9, "pairs": n_pairs, "seconds": t_all, "saturated_pairs": sat}
+
+
 def cpu_baseline_sahlin(ctx_factory, api, pipeline, rs, order, k, w, sample, max_runs, budget_s):
     """Sahlin mode on one host core is dominated by 16.7 kb x 16.7 kb alignments: the oracle (with its OWN scalar
     aligner — not parasail's SIMD scan, not the product's) runs on the first `sample` reads of the sorted batch; the
@@ -653,10 +675,17 @@ def main():
                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg_bytes,
                         "kernel_ms": ms_score, "counts": {"M": M, "H": H, "C_s": Cs, "H_source": h_source}}
+                # `traffic` = HBM bytes per launch from the PMC passes of tools/collect_profile.sh (FETCH_SIZE / WRITE_SIZE need their own
+                # rocprofv3 runs: they cannot be read inside this process); the file says which build it was measured on
                 tfile = os.path.join(ROOT, "profiles", "k_score_traffic.json")
                 if os.path.exists(tfile):
                     try:
-                        roof["traffic"] = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                        from isonclust2_amd.digest import source_stamp
+                        tj = json.load(open(tfile))
+                        roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                        st_ = (tj.get("stamp") or {}).get("sources_sha12")
+                        roof["traffic_source"] = {"file": "profiles/k_score_traffic.json", "measured_on_sources": st_, "these_sources": source_stamp(),
+                                                  "same_build": st_ == source_stamp()}
                     except Exception:
                         pass
         # ---- sahlin mode (configs[2]): the step is dominated by the alignment fallback's forward DP, an
@@ -689,6 +718,20 @@ def main():
                                        "sample": f"first {ns} reads of the sorted {a.config} batch, sahlin mode, oracle -O3 -DNDEBUG "
                                                  f"-msse3, min of {len(times)} run(s), 1 pinned core; {ost['aln_invoked']} reads reach the fallback"}
                 sah["parity"] = {"entries": ns, "mismatches": mism, "oracle_aln_invoked": ost["aln_invoked"]}
+                # the same batch if its alignments cost a SIMD score pass each instead of the scalar aligner: a LOWER bound of the CPU's
+                # time (no traceback table, no 32-bit second pass), hence an upper bound of what one core could reach
+                try:
+                    sp = cpu_simd_score_pass(rs, order)
+                    fast_s = rs.n / fast["cpu_baseline"]["value"] if fast and fast.get("cpu_baseline") else None
+                    aln_s = sah["alignment"]["cells"] / (sp["gcups"] * 1e9)
+                    sah["cpu_baseline_simd_bound"] = {
+                        "value": rs.n / (aln_s + (fast_s or 0.0)), "unit": "reads/s", "cores": 1, "kind": "port",
+                        "score_pass_gcups": sp["gcups"], "pairs_timed": sp["pairs"], "seconds_timed": sp["seconds"],
+                        "sample": f"upper bound for one core: the batch's {sah['alignment']['pairs']} alignments ({sah['alignment']['cells']:.3g} cells) at the rate of a "
+                                  "16-bit SSE2 striped SCORE pass (oracle/sg_striped.cpp; no traceback table, no 32-bit re-run of saturated pairs: "
+                                  "parasail's sg_trace_scan_16 does both)" + (f" + the fast-mode oracle time of the batch ({fast_s:.1f} s)" if fast_s else "")}
+                except Exception as e:  # noqa: BLE001
+                    sah["cpu_baseline_simd_bound"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         cpu_node = None
         if single and not a.no_cpu_node:
             cpu_node = cpu_baseline_node(a.config, k, w)
@@ -716,7 +759,7 @@ def main():
                        "identical_batches": bool(a.same_seed) and world > 1},
             "phase_ms": head["phase_ms"],
             "roofline": roof if roof is not None else roof_aln,
-            "cpu_baseline": head.get("cpu_baseline"), "parity": head.get("parity"),
+            "cpu_baseline": head.get("cpu_baseline"), "cpu_baseline_simd_bound": head.get("cpu_baseline_simd_bound"), "parity": head.get("parity"),
             "core": core or None, "cli": cli, "merge": merge, "golden_parity": rank_parity or None,
             "cpu_baseline_node": cpu_node,
         }

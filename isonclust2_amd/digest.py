@@ -19,3 +19,20 @@ def fnv1a_reads(cb, n_reads=None):
         n_reads = max(n_reads, int(cb.batch_end) + 1)
     cls, strand = cb.assignments(n_reads)
     return f"{fnv1a(cls, strand):016x}"
+
+
+def source_stamp():
+    """sha256 (first 12 hex digits) over the library's sources (csrc/*.{hip,cpp,h,inc}, cli/, the public header): identifies the build a
+    profile was taken on where git is not available (the GPU box gets a snapshot without .git)."""
+    import glob
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "isonclust2_amd", "csrc", "*.*")) + glob.glob(os.path.join(root, "isonclust2_amd", "csrc", "cli", "*.*")) +
+                   glob.glob(os.path.join(root, "include", "*.h")))
+    for f in files:
+        if f.endswith((".hip", ".cpp", ".h", ".hpp", ".inc")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]

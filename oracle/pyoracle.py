@@ -42,7 +42,7 @@ def default_params(k=11, w=15, mode="fast"):
 
 def build(force=False):
     so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, "oracle.cpp"), os.path.join(HERE, "poa_oracle.cpp")]
+    srcs = [os.path.join(HERE, "oracle.cpp"), os.path.join(HERE, "poa_oracle.cpp"), os.path.join(HERE, "sg_striped.cpp")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs if os.path.exists(x)):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     return so
@@ -125,6 +125,8 @@ def lib():
     L.orp_graph_export.argtypes = [vp, i32, i32, i32p, i32p, i32p, cp, i32p, i32p, i32p, i64p, i32p, i32p]
     L.orp_last_alignment.argtypes = [vp, i32, i32p, i32p, i32p]
     L.orp_graph_copy.argtypes = [vp, i32, i32, vp, i32, i32]
+    L.orc_sg_striped16.argtypes = [cp, i32, cp, i32, i32, i32, i32, i32, i32p]
+    L.orc_sg_striped16.restype = C.c_int32
     _lib = L
     return L
 

@@ -50,7 +50,7 @@ for sub in ("fetch", "write", "sq", "tcc"):
         for cn, val in v.items():
             d[cn + "_per_launch"] = val / max(1, len(calls[k]))
 # the scoring launch = k_score_part (+ k_score_compact) in the XCD-partitioned path, k_score_t otherwise
-names = [k for k in summary["kernels"] if k.startswith("k_score")]
+names = [k for k in summary["kernels"] if k.startswith("k_score") or k.startswith("k_partition_mins")]
 fetch_kb = sum(summary["kernels"][k].get("FETCH_SIZE_per_launch", 0.0) for k in names)
 write_kb = sum(summary["kernels"][k].get("WRITE_SIZE_per_launch", 0.0) for k in names)
 if names and (fetch_kb or write_kb):
@@ -60,6 +60,11 @@ if names and (fetch_kb or write_kb):
                "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
                "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes; gather access widths are "
                        "uncalibrated per the guide, Infinity-Cache hits are counted in FETCH_SIZE"}
+    # stamped with the build it was measured on: the sha of the library's sources (bench.py prints it beside `traffic` and says
+    # when the sources have changed since)
+    sys.path.insert(0, ".")
+    from isonclust2_amd.digest import source_stamp
+    traffic["stamp"] = {"sources_sha12": source_stamp(), "tag": tag, "collected_with": "tools/collect_profile.sh"}
     json.dump(traffic, open("profiles/k_score_traffic.json", "w"), indent=1)
     summary["k_score_traffic"] = traffic
 json.dump(summary, open(f"profiles/{tag}_summary.json", "w"), indent=1, sort_keys=True)
