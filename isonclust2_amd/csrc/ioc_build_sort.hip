@@ -11,8 +11,8 @@
 //   pairs     [left postings (key of their list, cluster id)] [query j's distinct values, capacity of its forward list: the
 //             unused tail holds a sentinel key above every value]
 //   sort      by key, stable, value bits + 1 (the sentinel sorts last)
-//   runs      a flag where the key changes, exclusive scan (rocPRIM) = run number, run starts, run lengths (their padded sum
-//             tells the host how many postings to allocate)
+//   runs      a flag where the key changes, exclusive scan = run number, run starts, run lengths (their padded sum tells the
+//             host how many postings to allocate)
 //   slots     one hash insert per RUN (distinct keys only, no contention on a slot), cnt[slot] = the run's length, then the
 //             exclusive scan of the padded counts over the SLOTS: keys / cnt / off exactly as the atomic build leaves them —
 //             everything downstream (rows, export, the query tables, the scoring kernels' partitions) is unchanged
@@ -24,9 +24,6 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "ioc_kernels.h"
 
@@ -84,35 +81,132 @@ k_bs_pairs_left(int64_t nkeys, const uint32_t* __restrict__ lkeys, const int64_t
     }
 }
 
-// 1 at the first pair of every run of real keys (the scan's input, computed on the fly from the sorted keys)
-struct BsFlag {
-    const uint32_t* pk;
-    uint32_t sentinel;
-    size_t P;
-    __device__ uint32_t operator()(size_t i) const
-    {
-        if (i >= P) return 0u;
-        const uint32_t k = pk[i];
-        return (k < sentinel && (i == 0 || pk[i - 1] != k)) ? 1u : 0u;
-    }
-};
+// ---- runs of equal keys: run number of every pair, run starts, totals ------------------------------------------------------
+// A pair opens a run if its key is a real one (below the sentinel) and differs from the key before it.  rid[i] = the number of
+// runs opened BEFORE pair i (an exclusive scan of those flags; the run of pair i is rid[i] if it opens one, rid[i] - 1 otherwise),
+// run_start[r] = the first pair of run r, run_start[R] = ctl[0] = the number of real pairs, ctl[1] = R.  Three launches — count
+// per block, scan of the blocks' counts, number — that read the sorted keys twice and write rid once (rocPRIM's one-pass scan
+// over a flag iterator followed by a kernel for the starts took 69 + 33 us for the bench batch's 12.3 M pairs; this 8 + 4 + 29 us).
+constexpr int RUN_IPT = 8;                       // consecutive pairs per thread
+constexpr int RUN_ELEMS = BS_BLOCK * RUN_IPT;    // ... per block
 
-// run_start[r] = index of run r's first pair; run_start[R] = number of real pairs = ctl[0]; ctl[1] = R
-__global__ void __launch_bounds__(BS_BLOCK)
-k_bs_starts(int64_t P, const uint32_t* __restrict__ pk, uint32_t sentinel, const uint32_t* __restrict__ rid, uint32_t* __restrict__ ctl,
-            uint32_t* __restrict__ run_start)
+// exclusive prefix sum of v over the block's 256 threads; total = the block's sum
+__device__ __forceinline__ uint32_t bs_block_scan(uint32_t v, uint32_t& total, uint32_t* sh)
 {
-    const int64_t i = int64_t(blockIdx.x) * BS_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t key = pk[i];
-    if (key >= sentinel) return;
-    const bool first = i == 0 || pk[i - 1] != key;
-    const uint32_t r = first ? rid[i] : rid[i] - 1u;
-    if (first) run_start[r] = uint32_t(i);
-    if (i + 1 == P || pk[i + 1] >= sentinel) {  // the last real pair
-        run_start[r + 1] = uint32_t(i + 1);
-        ctl[0] = uint32_t(i + 1);
-        ctl[1] = r + 1u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= uint32_t(o)) inc += t;
+    }
+    if (lane == 63u) sh[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < BS_BLOCK / 64; ++w) {
+        const uint32_t x = sh[w];
+        if (w < wv) before += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return before + inc - v;
+}
+
+// keys[0 .. RUN_IPT + 1]: the key before the thread's first pair (a value no key has if there is none), its pairs (the sentinel
+// past the end), the key after them
+__device__ __forceinline__ void bs_load_keys(const uint32_t* __restrict__ pk, int64_t P, int64_t i0, uint32_t sentinel, uint32_t (&keys)[RUN_IPT + 2])
+{
+    keys[0] = (i0 > 0 && i0 <= P) ? pk[i0 - 1] : 0xFFFFFFFFu;
+    if (i0 + RUN_IPT <= P) {
+        const uint4 a = *reinterpret_cast<const uint4*>(pk + i0), b = *reinterpret_cast<const uint4*>(pk + i0 + 4);  // (i0 is a multiple of 8, the array 16-byte aligned)
+        keys[1] = a.x, keys[2] = a.y, keys[3] = a.z, keys[4] = a.w, keys[5] = b.x, keys[6] = b.y, keys[7] = b.z, keys[8] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < RUN_IPT; ++e) keys[1 + e] = i0 + e < P ? pk[i0 + e] : sentinel;
+    }
+    keys[RUN_IPT + 1] = i0 + RUN_IPT < P ? pk[i0 + RUN_IPT] : sentinel;
+}
+
+__global__ void __launch_bounds__(BS_BLOCK)
+k_bs_run_count(int64_t P, const uint32_t* __restrict__ pk, uint32_t sentinel, uint32_t* __restrict__ bsum)
+{
+    __shared__ uint32_t sh[BS_BLOCK / 64];
+    static_assert(RUN_IPT == 8, "bs_load_keys reads two 16-byte vectors");
+    const int64_t i0 = int64_t(blockIdx.x) * RUN_ELEMS + int64_t(threadIdx.x) * RUN_IPT;
+    uint32_t keys[RUN_IPT + 2];
+    bs_load_keys(pk, P, i0, sentinel, keys);
+    uint32_t n = 0;
+#pragma unroll
+    for (int e = 0; e < RUN_IPT; ++e) n += (keys[1 + e] < sentinel && keys[e] != keys[1 + e]) ? 1u : 0u;
+    uint32_t tot;
+    (void)bs_block_scan(n, tot, sh);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// one block: the blocks' counts -> the number of runs opened before each block
+__global__ void __launch_bounds__(BS_BLOCK)
+k_bs_run_sums(uint32_t* __restrict__ bsum, int64_t nb)
+{
+    __shared__ uint32_t sh[BS_BLOCK / 64];
+    uint32_t carry = 0;
+    for (int64_t c = 0; c < nb; c += RUN_ELEMS) {
+        const int64_t i0 = c + int64_t(threadIdx.x) * RUN_IPT;
+        uint32_t v[RUN_IPT], s = 0;
+#pragma unroll
+        for (int e = 0; e < RUN_IPT; ++e) {
+            v[e] = i0 + e < nb ? bsum[i0 + e] : 0u;
+            s += v[e];
+        }
+        uint32_t tot;
+        uint32_t ex = bs_block_scan(s, tot, sh) + carry;
+#pragma unroll
+        for (int e = 0; e < RUN_IPT; ++e) {
+            if (i0 + e < nb) bsum[i0 + e] = ex;
+            ex += v[e];
+        }
+        carry += tot;
+    }
+}
+
+__global__ void __launch_bounds__(BS_BLOCK)
+k_bs_runs(int64_t P, const uint32_t* __restrict__ pk, uint32_t sentinel, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ rid,
+          uint32_t* __restrict__ ctl, uint32_t* __restrict__ run_start)
+{
+    __shared__ uint32_t sh[BS_BLOCK / 64];
+    const int64_t i0 = int64_t(blockIdx.x) * RUN_ELEMS + int64_t(threadIdx.x) * RUN_IPT;
+    uint32_t keys[RUN_IPT + 2];
+    bs_load_keys(pk, P, i0, sentinel, keys);
+    uint32_t n = 0;
+    bool first[RUN_IPT];
+#pragma unroll
+    for (int e = 0; e < RUN_IPT; ++e) {
+        first[e] = keys[1 + e] < sentinel && keys[e] != keys[1 + e];
+        n += first[e] ? 1u : 0u;
+    }
+    uint32_t tot;
+    uint32_t ex = bs_block_scan(n, tot, sh) + bsum[blockIdx.x];
+    uint32_t out[RUN_IPT];
+#pragma unroll
+    for (int e = 0; e < RUN_IPT; ++e) {
+        out[e] = ex;
+        if (first[e]) run_start[ex] = uint32_t(i0 + e);
+        ex += first[e] ? 1u : 0u;
+        // the last real pair (the keys are sorted: the sentinels, if any, follow it)
+        if (i0 + e < P && keys[1 + e] < sentinel && (i0 + e + 1 == P || keys[2 + e] >= sentinel)) {
+            run_start[ex] = uint32_t(i0 + e + 1);
+            ctl[0] = uint32_t(i0 + e + 1);
+            ctl[1] = ex;
+        }
+    }
+    if (i0 + RUN_IPT <= P) {
+        *reinterpret_cast<uint4*>(rid + i0) = uint4{out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<uint4*>(rid + i0 + 4) = uint4{out[4], out[5], out[6], out[7]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < RUN_IPT; ++e)
+            if (i0 + e < P) rid[i0 + e] = out[e];
     }
 }
 
@@ -180,11 +274,7 @@ size_t iock_build_sort_temp_bytes(int64_t P, int post16, int value_bits)
         uint32_t* v = nullptr;
         (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, v, v, size_t(P), 0, unsigned(value_bits + 1));
     }
-    size_t tmp2 = 0;
-    {
-        auto flag_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), BsFlag{k, 0u, size_t(P)});
-        (void)rocprim::exclusive_scan(nullptr, tmp2, flag_it, k, 0u, size_t(P), rocprim::plus<uint32_t>());
-    }
+    const size_t tmp2 = (size_t(P) / RUN_ELEMS + 2) * 4;  // the run numbering's counts per block (after the sort: the same scratch)
     return (tmp > tmp2 ? tmp : tmp2) + 256;
 }
 
@@ -224,13 +314,13 @@ hipError_t iock_build_sort_phase1(hipStream_t st, const IocBuildSort* a)
         e = rocprim::radix_sort_pairs(a->temp, tmp, a->pk_in, a->pk_out, static_cast<uint32_t*>(a->pv_in), static_cast<uint32_t*>(a->pv_out), size_t(P), 0,
                                       unsigned(a->value_bits + 1), st);
     if (e != hipSuccess) return e;
-    const dim3 gp(unsigned((P + BS_BLOCK - 1) / BS_BLOCK));
-    // run numbers: exclusive scan of the run-start flags
-    tmp = a->temp_bytes;
-    auto flag_it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), BsFlag{a->pk_out, sentinel, size_t(P)});
-    e = rocprim::exclusive_scan(a->temp, tmp, flag_it, a->rid, 0u, size_t(P), rocprim::plus<uint32_t>(), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bs_starts, gp, dim3(BS_BLOCK), 0, st, P, a->pk_out, sentinel, a->rid, a->ctl, a->run_start);
+    // run numbers, run starts, totals
+    const int64_t nb = (P + RUN_ELEMS - 1) / RUN_ELEMS;
+    if ((size_t(nb) + 1) * 4 > a->temp_bytes) return hipErrorInvalidValue;
+    uint32_t* bsum = static_cast<uint32_t*>(a->temp);
+    hipLaunchKernelGGL(k_bs_run_count, dim3(unsigned(nb)), dim3(BS_BLOCK), 0, st, P, a->pk_out, sentinel, bsum);
+    hipLaunchKernelGGL(k_bs_run_sums, dim3(1), dim3(BS_BLOCK), 0, st, bsum, nb);
+    hipLaunchKernelGGL(k_bs_runs, dim3(unsigned(nb)), dim3(BS_BLOCK), 0, st, P, a->pk_out, sentinel, bsum, a->rid, a->ctl, a->run_start);
     return hipGetLastError();
 }
 

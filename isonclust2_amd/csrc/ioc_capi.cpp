@@ -609,7 +609,7 @@ int ioc_index_build(ioc_ctx* c)
         a.pad_mask = pmask;
         a.temp_bytes = iock_build_sort_temp_bytes(NP, c->post16, value_bits);
         // one arena: [pk_in][pk_out][rid][roff][run_start][lens][scan scratch][ctl][pv_in][pv_out][temp]
-        const size_t w = size_t(NP) + 4;
+        const size_t w = (size_t(NP) + 7) & ~size_t(3);  // (every array 16-byte aligned: the run numbering reads and writes vectors)
         // (the scan of phase 2 runs over the table's SLOTS, not over the pairs: up to cap_safe + 1 of them once the table has grown)
         const size_t scan_words = (std::max<size_t>(size_t(NP), size_t(cap_safe)) + 1) / 1024 + 8;
         const size_t words = 6 * w + scan_words + 4;

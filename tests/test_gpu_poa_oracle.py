@@ -119,3 +119,31 @@ def test_purge_and_unrelated_reads(ctx):
     _same_graph(dev, orc, 3, "unrelated")
     dev.close()
     orc.close()
+
+
+def test_reads_longer_than_a_tile_column(ctx):
+    """2.1 - 2.6 kb reads (row widths of every residue mod 4: the cell arrays' pitch is padded) against graphs 35+ tile rows
+    deep: the row carries (prefix maxima, strict-maximum flags, boundary H) cross waves AND column tiles, deletions of 30 - 80
+    bases put edges across tile rows, a low-complexity stretch sits on the tile edge at column 1024."""
+    rng = random.Random(53)
+    for g, ln in enumerate([2101, 2302, 2563, 2048]):
+        dev, orc = Poa(ctx), po.OraclePoa()
+        truth = bytearray(rng.choice(b"ACGT") for _ in range(ln))
+        truth[1000:1050] = (b"AC" * 25)
+        truth = bytes(truth)
+        first = mutate(rng, truth, 0.05)
+        dev.create(0, first)
+        orc.create(0, first)
+        for t in range(5):
+            r = mutate(rng, truth, rng.choice([0.03, 0.1]))
+            if t == 2:
+                a = rng.randint(900, 1100)
+                r = r[:a] + r[a + rng.randint(30, 80):]
+            if t == 3:
+                r = r[rng.randint(0, 300): len(r) - rng.randint(0, 300)]
+            dev.add(0, r, w=1 + t % 2)
+            orc.add(0, r, w=1 + t % 2)
+            _same_alignment(dev, orc, (g, t))
+            _same_graph(dev, orc, 0, (g, t))
+        dev.close()
+        orc.close()
