@@ -160,12 +160,15 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
 #define sH sRing[0]
 #define sF1 sRing[1]
 #define sF2 sRing[2]
-    __shared__ int4 s_carry[POA_WAVES][POA_RB];  // [0]: from the tile on the left; [w]: from wave w - 1
+    // a row's carry into a wave — [0]: from the tile on the left; [w]: from wave w - 1 — as two 8-byte halves: (prefix maxima of the
+    // two pieces) and (H of the last column, the strict-maximum flags | (row of the tile + 1) << 2).  The second half is written
+    // AFTER the first and read BEFORE it (a wave's LDS operations are carried out in program order): a reader that finds the row's
+    // tag has the whole carry — no separate "rows done" counter, one LDS round trip per row instead of two
+    __shared__ __attribute__((aligned(16))) int4 s_carry[POA_WAVES][POA_RB];
     __shared__ int s_poff[POA_RB + 2];
     __shared__ int s_pred[POA_PRED_LDS], s_pslot[POA_PRED_LDS];
     __shared__ int s_base[POA_RB + 1], s_slot[POA_RB + 1];  // (one past the last row: read ahead, never used)
     __shared__ int s_red[3 * POA_WAVES];
-    __shared__ int s_done[POA_WAVES];  // rows of the tile wave w has finished
     __shared__ int4 s_rec[POA_RB + 1];  // per row: end of its predecessor list, base, plane row, first predecessor — what a wave fetches one row ahead
     const PoaJob J = jobs[blockIdx.y];
     const int R = J.R, L = J.L, nrb = J.nrb;
@@ -196,7 +199,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
     // ---- the tile's rows: predecessor lists, bases, carries of the tile on the left ----
     const int nrows = r_hi - r_lo + 1;
     const int pb0 = pred_off[r_lo];
-    if (tid < POA_WAVES) s_done[tid] = 0;
+    for (int t = tid; t < (POA_WAVES - 1) * POA_RB; t += POA_THREADS) s_carry[1 + t / POA_RB][t % POA_RB] = int4{0, 0, 0, 0};  // (no row's tag)
     for (int t = tid; t <= nrows; t += POA_THREADS) s_poff[t] = pred_off[r_lo + t];
     if (tid == 0) s_poff[nrows + 1] = 0;
     if (tid == 0) s_rec[nrows] = int4{0, 0, 0, 0};  // (read ahead by the last row, never used)
@@ -205,7 +208,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
         s_slot[t] = ((const GI32*)J.slot)[r_lo + t];
         s_rec[t] = int4{pred_off[r_lo + t + 1], int(((const GU8*)J.base)[r_lo + t]), ((const GI32*)J.slot)[r_lo + t], pred[pred_off[r_lo + t]]};
         const GI32* ci = cin_row + int64_t(r_lo + t) * 4;
-        s_carry[0][t] = cb > 0 ? int4{ci[0], ci[1], ci[2], ci[3]} : int4{POA_NEG, POA_NEG, 0, 0};
+        s_carry[0][t] = cb > 0 ? int4{ci[0], ci[1], ci[3], ci[2] | ((t + 1) << 2)} : int4{POA_NEG, POA_NEG, 0, (t + 1) << 2};
     }
     {
         const int np = min(pred_off[r_hi + 1] - pb0, pred_lds);
@@ -229,20 +232,16 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
 #define POA_TICK(k)
 #endif
     // The waves are a pipeline, not a phalanx: wave w needs of row t only the carry wave w - 1 wrote when IT finished row t, so
-    // it waits for that (s_done[w - 1] > t: a counter in LDS next to the carries) instead of meeting all four waves at a barrier
-    // after every row — a third of a tile's time was spent at that barrier waiting for whichever wave the scheduler had served
-    // last.  Wave 0 never waits (its carries come from the tile on the left), so every wait ends.
+    // it waits for that (the row's tag in the carry itself) instead of meeting all four waves at a barrier after every row — a
+    // third of a tile's time was spent at that barrier waiting for whichever wave the scheduler had served last — and only where
+    // the carry is first needed: the row's vertical moves and its own prefix scan do not depend on the wave on the left.
+    // Wave 0 never waits (its carries come from the tile on the left, tagged when they were staged), so every wait ends.
+    const uint32_t carry_in = uint32_t(reinterpret_cast<uintptr_t>(&s_carry[wave][0]));  // LDS byte addresses
+    const uint32_t carry_out = uint32_t(reinterpret_cast<uintptr_t>(&s_carry[min(wave + 1, POA_WAVES - 1)][0]));
+    int ph = 0, p1 = POA_NEG, p2 = POA_NEG;  // this lane's H, F1, F2 of the row before (what a chain row reads: no LDS round trip)
     for (int t = 0; t < nrows; ++t) {
-        if (wave > 0) {
-            // (plain LDS traffic: a wave's LDS operations are carried out in program order, a fence of the memory model would also
-            // wait for the row's global stores)
-            while (*(volatile LI32*)(LI32*)&s_done[wave - 1] <= t) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-        }
-        POA_TICK(3)
         {
             const int r = r_lo + t;
-            const int4 cin = s_carry[wave][t];
             const int4 nx = s_rec[t + 1];  // the next row (made uniform at the end of the step: no wait for it up here)
             const int pe_nv = nx.x, bs_n = nx.y, slot_n = nx.z, pr0_n = nx.w;
             int hn = 0, f1 = POA_NEG, f2 = POA_NEG;
@@ -256,8 +255,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 if (pe - pb == 1 && t > 0 && pr0u == r - 1) {
                     // the common row: ONE predecessor, the row above, in this tile — straight-line code (the general
                     // loop below spends more time in its branches than in its arithmetic); same values bit for bit
-                    const int slp = (r - 1) & (POA_RING - 1);
-                    const int hu = sH[slp][tid], u1 = sF1[slp][tid], u2 = sF2[slp][tid];
+                    const int hu = ph, u1 = p1, u2 = p2;
                     const int hl = __builtin_amdgcn_update_dpp(edge_prev, hu, 0x138, 0xf, 0xf, false);  // wave_shr:1
                     // (H of a row is >= 0: hl + sc, hu + g and hu + q are far above POA_NEG, the general loop's "is it better
                     // than nothing" tests are true here)
@@ -292,7 +290,7 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                     const int pr = __builtin_amdgcn_readfirstlane(prv);
                     int hu, u1, u2, hl;
                     if (pr >= r_lo) {
-                        const int edge = s_carry[wave][pr - r_lo].w;  // H of the column left of this wave's first
+                        const int edge = s_carry[wave][pr - r_lo].z;  // H of the column left of this wave's first
                         if (r - pr <= POA_RING) {
                             const int sl = pr & (POA_RING - 1);
                             hu = sH[sl][tid];
@@ -367,6 +365,19 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             int sx = hn + ofs_e, sy = hn + ofs_c;  // (hn - e j and hn - c j; far below everything for the lanes past the last column)
             wave_prefix_max2(sx, sy);
             asm volatile("" : "+v"(sx), "+v"(sy));  // (keeps the last stage a v_max_i32_dpp: merged with the carry into a v_max3 it needs a move and a constant)
+            POA_TICK(3)
+            // ---- the carry of the wave on the left (or of the tile on the left): second half first, until it holds this row's tag ----
+            int4 cin;
+            {
+                const uint32_t ca = carry_in + uint32_t(t) * 16u;
+                for (;;) {
+                    uint64_t hb, ha;
+                    asm volatile("ds_read_b64 %0, %2 offset:8\n\tds_read_b64 %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(hb), "=&v"(ha) : "v"(ca) : "memory");
+                    cin = int4{int(uint32_t(ha)), int(uint32_t(ha >> 32)), int(uint32_t(hb >> 32)) & 3, int(uint32_t(hb))};  // (prefix maxima, flags, H: the order the code below grew up with)
+                    if (__builtin_amdgcn_readfirstlane(int(uint32_t(hb >> 32)) >> 2) == t + 1) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
             const int vx = max(sx, cin.x);
             const int vy = max(sy, cin.y);
             const int ex = __builtin_amdgcn_update_dpp(cin.x, vx, 0x138, 0xf, 0xf, false);  // wave_shr:1: the lane on the left
@@ -399,7 +410,12 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
             sH[sl][tid] = h;
             sF1[sl][tid] = f1;
             sF2[sl][tid] = f2;
-            if (lane == 63 && wave < POA_WAVES - 1) s_carry[wave + 1][t] = int4{vx, vy, snm, h};
+            if (lane == 63 && wave < POA_WAVES - 1) {  // first half, then the half with the tag (in this order: see s_carry)
+                const uint64_t ha = uint64_t(uint32_t(vx)) | (uint64_t(uint32_t(vy)) << 32);
+                const uint64_t hb = uint64_t(uint32_t(h)) | (uint64_t(uint32_t(snm) | (uint32_t(t + 1) << 2)) << 32);
+                const uint32_t ca = carry_out + uint32_t(t) * 16u;
+                asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(ca), "v"(ha), "v"(hb) : "memory");
+            }
             if (active) {
                 // (row bases are uniform: scalar arithmetic, the lane adds its 32-bit column offset)
                 // (the row's base stays in scalar registers — the empty asm keeps the compiler from folding it into a per-lane 64-bit
@@ -435,15 +451,14 @@ k_poa_tile(const PoaJob* __restrict__ jobs, int diag, PoaScores S, int pred_lds)
                 }
             }
             edge_prev = cin.w;
+            ph = h;
+            p1 = f1;
+            p2 = f2;
             pb = pe;
             pe = __builtin_amdgcn_readfirstlane(pe_nv);
             bs = bs_n;
             pr0 = pr0_n;
             my_slot = slot_n;
-            if (wave < POA_WAVES - 1) {  // the carry of row t is in LDS (this wave's LDS writes land in program order): say so
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) *(volatile LI32*)(LI32*)&s_done[wave] = t + 1;
-            }
             POA_TICK(2)
         }
     }
