@@ -2001,11 +2001,22 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     // (the helper buffers belong to the second launch's WORKGROUPS — one per compute unit — not to the pairs: 0.66 MB each)
     const uint32_t help_wgs = deadline ? std::min<uint32_t>(max_pairs, uint32_t(n_cu)) : 0u;
     const size_t n_scratch = size_t(max_pairs) + size_t(help_wgs) * V2_NHELP * V2_HBUF;
-    if ((r = reserve(c, c->a_bnd, n_scratch * sizeof(V2Scratch) + (size_t(np) * V2_RESUME_WORDS + size_t(max_pairs) + 1u) * 4)) != IOC_OK) return r;
+    const size_t resume_words = size_t(np) * V2_RESUME_WORDS + 2u * (size_t(max_pairs) + 1u) + 4u;  // (parked state, the two lists of walks for the helper launches)
+    if ((r = reserve(c, c->a_bnd, n_scratch * sizeof(V2Scratch) + resume_words * 4)) != IOC_OK) return r;
     V2Scratch* d_scratch = static_cast<V2Scratch*>(c->a_bnd.p);
     V2Scratch* d_hscratch = d_scratch + max_pairs;
     uint32_t* d_resume = reinterpret_cast<uint32_t*>(d_scratch + n_scratch);
-    uint32_t* d_park = d_resume + size_t(np) * V2_RESUME_WORDS;  // [count][pair slots of the slice]
+    uint32_t* d_park = d_resume + size_t(np) * V2_RESUME_WORDS;  // [count][pair slots of the slice]: parked by the first traceback launch
+    uint32_t* d_early = d_park + size_t(max_pairs) + 1u;         // ... and sent to the helper launch by k_fwd2_ends (wrong candidates, by their score)
+    uint32_t* d_gate = d_early + size_t(max_pairs) + 1u;         // workgroups of that launch that have started
+    // The helper launch for those runs on a side stream BESIDE the first traceback launch (IOC_TRACE2_EARLY=0: everything goes
+    // through the first launch, as before): the walks of the wrong candidates are the longest of the batch, and the first launch —
+    // one pair's latency long, with the chip half empty — no longer waits for them to reach their deadline first.
+    const bool route = deadline && !(getenv("IOC_TRACE2_EARLY") && atoi(getenv("IOC_TRACE2_EARLY")) == 0);
+    if (route && !c->side_stream) {
+        ACHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        for (auto& e : c->ev_side) ACHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(k_fwd2), 64 * V2_WAVES, 0) != hipSuccess) occ = 0;
     (void)hipGetLastError();
@@ -2029,6 +2040,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         ACHK(c, hipMemcpyAsync(d_items, items[si].data(), size_t(n_items) * sizeof(V2Item), hipMemcpyHostToDevice, s));
         ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
         ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
+        ACHK(c, hipMemsetAsync(d_resume, 0, resume_words * 4, s));  // (parked state and the two lists of walks; k_fwd2_ends writes into them)
         if (getenv("IOC_ALIGN_V2_FAKE_TIMEOUT")) {  // (tests: as if a bounded wait had run out — every later wait gives up at once,
             const uint32_t one = 1;                 // tiles run on whatever is there, the host must fall back to version 1)
             ACHK(c, hipMemcpyAsync(d_ctl + 1, &one, 4, hipMemcpyHostToDevice, s));
@@ -2041,19 +2053,32 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                                d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
         ACHK(c, hipGetLastError());
         hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
-                           d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p));
+                           d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p), d_resume, d_early, route ? int(P.match) : 0,
+                           std::min<uint32_t>(n_pairs, help_wgs));
         ACHK(c, hipGetLastError());
         ACHK(c, hipEventRecord(evs[evi++], s));
-        ACHK(c, hipMemsetAsync(d_resume, 0, (size_t(np) * V2_RESUME_WORDS + size_t(max_pairs) + 1u) * 4, s));  // (parked state and the list of parked walks)
+        if (route) {  // (issued before the first launch: its workgroups — a walker and ten helpers each — take their places first)
+            ACHK(c, hipEventRecord(c->ev_side[0], s));
+            ACHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
+            hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, help_wgs)), dim3(64 * V2_HWAVES), 0, c->side_stream,
+                               static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P,
+                               static_cast<const uint32_t*>(c->a_ck.p), d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
+                               d_early, d_score, d_count, n_pairs, 2u, d_gate);
+            ACHK(c, hipGetLastError());
+            ACHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
+            hipLaunchKernelGGL(k_trace2_gate, dim3(1), dim3(1), 0, s, d_early, d_gate, std::min<uint32_t>(n_pairs, help_wgs));
+            ACHK(c, hipGetLastError());
+        }
         hipLaunchKernelGGL(k_trace2, dim3((n_pairs + TR_WAVES - 1) / TR_WAVES), dim3(64 * TR_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p),
                            d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const uint32_t*>(c->a_ck.p), d_pck,
                            static_cast<const int4*>(c->a_ends2.p), d_scratch, d_resume, d_park, d_score, d_count, n_pairs, deadline, deadline_cycles);
         ACHK(c, hipGetLastError());
+        if (route) ACHK(c, hipStreamWaitEvent(s, c->ev_side[1], 0));  // (the two helper launches share the helpers' buffers)
         if (deadline) {  // (one workgroup per compute unit: a walker and its helpers fill one; more parked walks than that take turns)
             hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, help_wgs)), dim3(64 * V2_HWAVES), 0, s,
                                static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P,
                                static_cast<const uint32_t*>(c->a_ck.p), d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
-                               d_park, d_score, d_count, n_pairs);
+                               d_park, d_score, d_count, n_pairs, 1u, nullptr);
             ACHK(c, hipGetLastError());
         }
         ACHK(c, hipEventRecord(evs[evi++], s));
@@ -2109,6 +2134,29 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                         double(rec(pid, 8)) * 256.0, double(rec(pid, 12)) * 256.0, d.n, d.m, rec(pid, 9) & 0xFFFFu, rec(pid, 9) >> 16, rec(pid, 13) & 0xFFFFu, rec(pid, 13) >> 16,
                         rec(pid, 10), rec(pid, 14), rec(pid, 11), rec(pid, 15));
             };
+            {   // how well does the forward score tell the walks that get parked (wrong candidates) from the others?  score / shorter length
+                std::vector<int4> he(np);
+                ACHK(c, hipMemcpy(he.data(), c->a_ends2.p, size_t(np) * sizeof(int4), hipMemcpyDeviceToHost));
+                double pk_max = -1e9, un_min = 1e9, pk_sum = 0, un_sum = 0;
+                uint32_t npk = 0, nun = 0;
+                std::vector<double> pks, uns;
+                for (uint32_t pid : ids) {
+                    const AlnPairDev& d = dp[pid];
+                    const double q = double(he[pid].x) / double(std::max(1u, std::min(d.n, d.m)));
+                    if (rec(pid, 6)) {
+                        pk_max = std::max(pk_max, q), pk_sum += q, ++npk;
+                        pks.push_back(q);
+                    } else {
+                        un_min = std::min(un_min, q), un_sum += q, ++nun;
+                        uns.push_back(q);
+                    }
+                }
+                std::sort(pks.begin(), pks.end());
+                std::sort(uns.begin(), uns.end());
+                auto qt = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[std::min(v.size() - 1, size_t(f * double(v.size())))]; };
+                fprintf(stderr, "[ioc]   forward score / shorter length: parked walks (%u) mean %.3f, 50 %% %.3f, 90 %% %.3f, 99 %% %.3f, max %.3f | others (%u) min %.3f, 1 %% %.3f, 10 %% %.3f, mean %.3f\n", npk,
+                        npk ? pk_sum / npk : 0.0, qt(pks, 0.5), qt(pks, 0.9), qt(pks, 0.99), pk_max, nun, un_min, qt(uns, 0.01), qt(uns, 0.1), nun ? un_sum / nun : 0.0);
+            }
             for (uint32_t x = 0; x < std::min(n_pairs, 10u); ++x) line("", ids[x]);
             for (uint32_t qx : {n_pairs / 4u, n_pairs / 2u, 3u * n_pairs / 4u}) line("rank", ids[qx]);
         }

@@ -171,6 +171,9 @@ void ioc_ctx_destroy(ioc_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     (void)ioc_dist_shutdown(c);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    for (auto& e : c->ev_side)
+        if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->b_off_fwd, &c->b_off_rev, &c->b_min, &c->b_pos, &c->b_hpc_len, &c->b_err_cell,
                       &c->b_min_total, &c->b_doff, &c->b_left_err, &c->b_lkeys, &c->b_loffs, &c->b_lpost,
                       &c->b_lslot, &c->b_lset_off, &c->b_lset_val, &c->b_keys, &c->b_cnt, &c->b_off, &c->b_fill,

@@ -61,6 +61,8 @@ struct ioc_ctx {
     uint64_t query_gen = 0;  // bumped whenever the context's queries are replaced (ioc_queries_generation)
     std::string up_err;
     hipStream_t copy_stream = nullptr;
+    hipStream_t side_stream = nullptr;  // the aligner's helper launch for the wrong candidates, beside the first traceback launch
+    hipEvent_t ev_side[2]{};
 
     // ---- left state ----
     int32_t L = 0;

@@ -367,10 +367,14 @@ def test_verdict_mode_decides_every_comparison_like_the_full_count(ctx):
     assert np.array_equal(w2, w0) and np.array_equal(r2, r0)
 
 
-def test_second_traceback_launch_takes_turns_when_many_walks_park(ctx):
+@pytest.mark.parametrize("early", ["1", "0"])
+def test_second_traceback_launch_takes_turns_when_many_walks_park(ctx, monkeypatch, early):
     """More undecided walks than the second launch has workgroups (one per compute unit): 700 pairs of unrelated 5 kb sequences
     in verdict mode all park after a few blocks and go on with helper waves, two or three per workgroup one after the other;
-    among them a few related pairs that are decided in the first launch.  Scores exact, every comparison as with the full count."""
+    among them a few related pairs that are decided in the first launch.  Scores exact, every comparison as with the full count.
+    early = 1 (the default): k_fwd2_ends sends the first 256 of the wrong candidates — by their forward score — to a helper
+    launch that runs beside the first traceback launch; the rest park as before and go on in the helper launch after it."""
+    monkeypatch.setenv("IOC_TRACE2_EARLY", early)
     rng = random.Random(47)
     seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(4500, 5500))) for _ in range(60)]
     seqs += [_mutate(rng, seqs[i], 0.08) for i in range(5)]
