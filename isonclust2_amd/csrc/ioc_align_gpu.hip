@@ -1794,6 +1794,9 @@ int reserve(ioc_ctx* c, DevBuf& b, size_t bytes)
 // the pairs order[0 .. cnt) (all of the query-profile kind, heaviest first) through k_fwd2 / k_fwd2_ends / k_trace2.
 // Returns IOC_OK with *fell_back = true when a bounded wait of the forward pass ran out (the caller then runs the same
 // pairs through version 1).
+// set while pairs the corridor could not vouch for are re-run: every tile of their grids
+thread_local bool g_no_corridor = false;
+
 int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* order, uint32_t cnt, const uint32_t* d_order,
                  const AlnParams& P, int32_t* d_score, uint32_t* d_count, bool* fell_back)
 {
@@ -1813,6 +1816,13 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if (const char* e = getenv("IOC_ALIGN_V2_GUARD")) guard = std::max(1, std::min(P16_GUARD, atoi(e)));
     const uint32_t np = uint32_t(dp.size());
     const uint32_t ncouples = (cnt + 1u) / 2u;
+    // The corridor's half width as a fraction of the longer sequence (V2Couple; IOC_ALIGN_CORRIDOR=0: every tile; a pair whose
+    // result the corridor cannot vouch for is run again with g_no_corridor set).  0.2: a pair of one transcript scores 1.62 - 1.8
+    // per base at match 2 — it passes if 2 (1 - B / len) < 1.62 — and the tile grid of a 16.7 kb pair shrinks to about half.
+    double corridor_frac = g_no_corridor ? 0.0 : 0.2;
+    if (const char* e = getenv("IOC_ALIGN_CORRIDOR")) corridor_frac = g_no_corridor ? 0.0 : std::max(0.0, std::min(1.0, atof(e)));
+    std::vector<int32_t> pend_cert(np, INT32_MIN);
+    uint64_t tiles_skipped = 0, tiles_all = 0;
     // Bands per couple.  A full batch (config 3: 811 couples) is bound by throughput: 11 bands of 1536 rows (66.8 ms; 7 of 2560:
     // 69.2; 17 of 1024: worse again).  A small one (a merge aligns a few hundred representatives) is bound by ONE couple's
     // critical path, (bands + strips - 1) tiles of rows / (4 bands) + 63 steps: more, shorter bands shorten it as long as the
@@ -1883,6 +1893,61 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                 if (b < cp.nbands) acc += hts[b];
             }
         }
+        {   // the corridor (V2Couple): tiles that meet |row - column| <= B, if that leaves out a fifth of the grid or more
+            cp.corridor = 0;
+            for (uint32_t b = 0; b < uint32_t(V2_MAX_BANDS); ++b) {
+                cp.plo[b] = 0;
+                cp.phi[b] = uint8_t(std::min<uint32_t>(255u, cp.nstrips - 1u));
+            }
+            const uint32_t strip_cols = 64u * FW_C;
+            const uint32_t B = uint32_t(corridor_frac * double(std::max(nmax, mmax)));
+            int64_t beff = INT64_MAX;
+            uint32_t skipped = 0;
+            uint8_t lo[V2_MAX_BANDS], hi[V2_MAX_BANDS];
+            bool fits = corridor_frac > 0.0 && B >= strip_cols && cp.nstrips <= 255u && cp.nbands <= uint32_t(V2_MAX_BANDS);
+            for (uint32_t b = 0; fits && b < cp.nbands; ++b) {
+                const uint32_t r0 = uint32_t(cp.bstart[b]) * uint32_t(CK2), r1 = std::min(nmax, uint32_t(cp.bstart[b + 1u]) * uint32_t(CK2));
+                const uint32_t c_lo = r0 > B ? r0 - B : 0u, c_hi = std::min<uint64_t>(mmax, uint64_t(r1) + B);
+                if (c_hi <= c_lo) {  // (a band wholly below the last column's corridor: rows the longer query has alone)
+                    fits = false;
+                    break;
+                }
+                lo[b] = uint8_t(c_lo / strip_cols);
+                hi[b] = uint8_t((c_hi - 1u) / strip_cols);
+                skipped += lo[b] + (cp.nstrips - 1u - hi[b]);
+                if (lo[b] > 0) beff = std::min<int64_t>(beff, int64_t(r0) - int64_t(lo[b]) * strip_cols);
+                if ((uint64_t(hi[b]) + 1u) * strip_cols < mmax) beff = std::min<int64_t>(beff, int64_t(hi[b] + 1u) * strip_cols - int64_t(r1));
+            }
+            // the probe (V2Couple): the first band that ends at row 3072 or below, the strip its last diagonal cell is in; every tile
+            // above and to the left of it must be inside the corridor with nothing missing around it, both pairs must reach it
+            uint32_t pb = 0, ps = 0;
+            if (fits) {
+                while (pb + 1u < cp.nbands && uint32_t(cp.bstart[pb + 1u]) * uint32_t(CK2) < 3072u) ++pb;
+                const uint32_t R = uint32_t(cp.bstart[pb + 1u]) * uint32_t(CK2);
+                ps = (R - 1u) / strip_cols;
+                fits = pb + 1u < cp.nbands && R >= 2048u;
+                for (uint32_t b = 0; fits && b <= pb; ++b) fits = lo[b] == 0 && hi[b] >= ps;
+                for (int h = 0; fits && h < 2; ++h)
+                    if (cp.pid[h] != 0xFFFFFFFFu) fits = dp[cp.pid[h]].n >= R && dp[cp.pid[h]].m > ps * strip_cols;
+            }
+            cp.probe_band = uint16_t(pb);
+            cp.probe_strip = uint16_t(ps);
+            if (fits && skipped * 5u >= cp.nbands * cp.nstrips && beff > 0 && beff < INT64_MAX) {
+                cp.corridor = 1;
+                for (uint32_t b = 0; b < cp.nbands; ++b) {
+                    cp.plo[b] = lo[b];
+                    cp.phi[b] = hi[b];
+                }
+                tiles_skipped += skipped;
+            }
+            tiles_all += uint64_t(cp.nbands) * cp.nstrips;
+            for (int h = 0; h < 2; ++h)
+                if (cp.pid[h] != 0xFFFFFFFFu) {
+                    const AlnPairDev& d = dp[cp.pid[h]];
+                    // (a path through a skipped cell has at most max(n, m) - Beff - 1 diagonal steps, each worth `match` at most)
+                    pend_cert[cp.pid[h]] = cp.corridor ? int32_t(std::min<int64_t>(INT32_MAX, int64_t(P.match) * std::max<int64_t>(0, int64_t(std::max(d.n, d.m)) - beff - 1))) : INT32_MIN;
+                }
+        }
         cp.mpad = uint32_t((uint64_t(mmax) + 15u) & ~uint64_t(15));
         cp.nq = (nmax + 3u) / 4u;
         const uint64_t ncr = (nmax - 1u) / CK2, ncc = (mmax - 1u) / CK2;
@@ -1905,7 +1970,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             if (cp.pid[h] == 0xFFFFFFFFu) continue;
             const AlnPairDev& d = dp[cp.pid[h]];
             const uint32_t nstr = (d.m + 64u * FW_C - 1) / (64u * FW_C);
-            pend[cp.pid[h]] = V2PairEnd{lrow_total, best_total, cp.nbands, k2};
+            pend[cp.pid[h]] = V2PairEnd{lrow_total, best_total, cp.nbands, k2, pend_cert[cp.pid[h]]};
             lrow_total += nstr * 64u;
             best_total += cp.nbands;
         }
@@ -1923,7 +1988,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             cp.cdat += used;
             cp.cbase += used;
             for (int h = 0; h < 2; ++h)
-                if (cp.pid[h] != 0xFFFFFFFFu) pck[cp.pid[h]] = V2PairCk{cp.rdat, cp.rbase, cp.cdat, cp.cbase, cp.mpad, cp.nq, uint32_t(h), 0u};
+                if (cp.pid[h] != 0xFFFFFFFFu) pck[cp.pid[h]] = V2PairCk{cp.rdat, cp.rbase, cp.cdat, cp.cbase, cp.mpad, cp.nq, uint32_t(h), k2};
             used += cwords[k2];
             ++k2;
         }
@@ -1937,11 +2002,13 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     c->tm.align_slices = int32_t(slices.size());
     c->tm.align_version = 2;
     if (getenv("IOC_TRACE"))
-        fprintf(stderr, "[ioc]   aligner v2: %u couples, checkpoint arena %.1f MB (%zu slice(s)) reserved in %.3f ms\n", ncouples,
-                double(arena_words) * 4e-6, slices.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_res0).count());
+        fprintf(stderr, "[ioc]   aligner v2: %u couples, checkpoint arena %.1f MB (%zu slice(s)) reserved in %.3f ms; corridor: %llu of %llu tiles skipped\n", ncouples,
+                double(arena_words) * 4e-6, slices.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_res0).count(),
+                (unsigned long long)tiles_skipped, (unsigned long long)tiles_all);
     // flags and items per slice; the static tables once
     uint32_t max_items = 0, max_flags = 0, max_pairs = 0;
     std::vector<std::vector<V2Item>> items(slices.size());
+    std::vector<uint32_t> n_probe(slices.size(), 0);  // (the probe launch's tiles come first in a slice's list)
     for (size_t si = 0; si < slices.size(); ++si) {
         uint32_t nf = 0;
         auto& it = items[si];
@@ -1956,7 +2023,20 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         }
         // anti-diagonal by anti-diagonal, couples side by side: every tile comes after the tile above it and the tile to its left
         // (generated in that order: sorting 150 000 items cost 4 ms of host time per call)
-        it.reserve(total_items);
+        it.reserve(total_items + 64u * slices[si].second);
+        // first the probe's tiles (couples with a corridor: the top left corner of the grid, V2Couple), in the same order
+        for (uint32_t dg = 0; dg <= maxdiag; ++dg) {
+            bool any = false;
+            for (uint32_t k2 = slices[si].first; k2 < slices[si].first + slices[si].second; ++k2) {
+                const V2Couple& cp = cps[k2];
+                if (!cp.corridor || dg > uint32_t(cp.probe_band) + cp.probe_strip) continue;
+                any = true;
+                const uint32_t b_lo = dg >= uint32_t(cp.probe_strip) + 1u ? dg - cp.probe_strip : 0u, b_hi = std::min<uint32_t>(dg, cp.probe_band);
+                for (uint32_t b = b_lo; b <= b_hi; ++b) it.push_back(V2Item{k2, uint16_t(b), uint16_t(dg - b)});
+            }
+            if (!any && dg > 64u) break;
+        }
+        n_probe[si] = uint32_t(it.size());
         for (uint32_t dg = 0; dg <= maxdiag; ++dg)
             for (uint32_t k2 = slices[si].first; k2 < slices[si].first + slices[si].second; ++k2) {
                 const V2Couple& cp = cps[k2];
@@ -2041,14 +2121,28 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
         ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
         ACHK(c, hipMemsetAsync(d_resume, 0, resume_words * 4, s));  // (parked state and the two lists of walks; k_fwd2_ends writes into them)
+        if (tiles_skipped)  // (the bests of the last row and the last column that a skipped tile does not write: far below any score)
+            ACHK(c, hipMemsetAsync(d_lrow, 0x80, (size_t(lrow_total) + best_total) * sizeof(int2), s));
         if (getenv("IOC_ALIGN_V2_FAKE_TIMEOUT")) {  // (tests: as if a bounded wait had run out — every later wait gives up at once,
             const uint32_t one = 1;                 // tiles run on whatever is there, the host must fall back to version 1)
             ACHK(c, hipMemcpyAsync(d_ctl + 1, &one, 4, hipMemcpyHostToDevice, s));
         }
         ACHK(c, hipEventRecord(evs[evi++], s));
         // persistent waves: as many workgroups as the chip holds, but no more waves than tiles
-        const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_items + V2_WAVES - 1) / V2_WAVES));
-        hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_items,
+        if (n_probe[si]) {  // the probe launch and its verdicts (V2Couple): all on the device, nothing comes back to the host
+            const uint32_t n_wg0 = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_probe[si] + V2_WAVES - 1) / V2_WAVES));
+            hipLaunchKernelGGL(k_fwd2, dim3(n_wg0), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_probe[si],
+                               d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
+                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
+            ACHK(c, hipGetLastError());
+            hipLaunchKernelGGL(k_fwd2_probe, dim3(slices[si].second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first, d_pend,
+                               static_cast<const uint32_t*>(c->a_ck.p), P);
+            ACHK(c, hipGetLastError());
+            ACHK(c, hipMemsetAsync(d_ctl, 0, 4, s));  // (the queue's counter; the flags of the probe's tiles stay)
+        }
+        const uint32_t n_main = n_items - n_probe[si];
+        const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_main + V2_WAVES - 1) / V2_WAVES));
+        hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items + n_probe[si], n_main,
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
                                d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
         ACHK(c, hipGetLastError());
@@ -2062,7 +2156,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             ACHK(c, hipStreamWaitEvent(c->side_stream, c->ev_side[0], 0));
             hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, help_wgs)), dim3(64 * V2_HWAVES), 0, c->side_stream,
                                static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P,
-                               static_cast<const uint32_t*>(c->a_ck.p), d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
+                               static_cast<const uint32_t*>(c->a_ck.p), d_cps, d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
                                d_early, d_score, d_count, n_pairs, 2u, d_gate);
             ACHK(c, hipGetLastError());
             ACHK(c, hipEventRecord(c->ev_side[1], c->side_stream));
@@ -2070,14 +2164,14 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             ACHK(c, hipGetLastError());
         }
         hipLaunchKernelGGL(k_trace2, dim3((n_pairs + TR_WAVES - 1) / TR_WAVES), dim3(64 * TR_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p),
-                           d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const uint32_t*>(c->a_ck.p), d_pck,
+                           d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<const uint32_t*>(c->a_ck.p), d_cps, d_pck,
                            static_cast<const int4*>(c->a_ends2.p), d_scratch, d_resume, d_park, d_score, d_count, n_pairs, deadline, deadline_cycles);
         ACHK(c, hipGetLastError());
         if (route) ACHK(c, hipStreamWaitEvent(s, c->ev_side[1], 0));  // (the two helper launches share the helpers' buffers)
         if (deadline) {  // (one workgroup per compute unit: a walker and its helpers fill one; more parked walks than that take turns)
             hipLaunchKernelGGL(k_trace2_help, dim3(std::min<uint32_t>(n_pairs, help_wgs)), dim3(64 * V2_HWAVES), 0, s,
                                static_cast<const AlnPairDev*>(c->a_pairs.p), d_order + first_pair, static_cast<const uint8_t*>(c->a_pool.p), P,
-                               static_cast<const uint32_t*>(c->a_ck.p), d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
+                               static_cast<const uint32_t*>(c->a_ck.p), d_cps, d_pck, static_cast<const int4*>(c->a_ends2.p), d_scratch, d_hscratch, d_resume,
                                d_park, d_score, d_count, n_pairs, 1u, nullptr);
             ACHK(c, hipGetLastError());
         }
@@ -2618,15 +2712,40 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     ACHK(c, hipMemcpyAsync(hc.data(), d_count, size_t(np) * 4, hipMemcpyDeviceToHost, s));
     ACHK(c, hipStreamSynchronize(s));
     std::vector<int32_t> again;  // pairs the packed kernel flagged: scores outside its 16-bit window
+    std::vector<int32_t> again_full;  // pairs whose result the corridor cannot vouch for (V2Couple): every tile this time
     for (uint32_t x = 0; x < np; ++x) {
         const uint32_t i = back[x];
         if ((packed || v2) && hc[x] == 0xFFFFFFFFu && hs[x] == INT32_MIN) {
             again.push_back(int32_t(i));
             continue;
         }
+        if (v2 && hc[x] == 0xFFFFFFFFu && hs[x] == INT32_MIN + 1) {
+            again_full.push_back(int32_t(i));
+            continue;
+        }
         if (out_score) out_score[i] = hs[x];
         if (out_windows) out_windows[i] = int64_t(hc[x]);
         if (out_ratio) out_ratio[i] = double(hc[x]) / double(dp[x].n);  // getAlnRatio: aligned / slen
+    }
+    if (!again_full.empty()) {
+        std::vector<ioc_aln_pair> sub(again_full.size());
+        std::vector<int32_t> sc(again_full.size());
+        std::vector<int64_t> sw(again_full.size());
+        std::vector<double> sr(again_full.size());
+        for (size_t x = 0; x < again_full.size(); ++x) sub[x] = pairs[again_full[x]];
+        const int64_t pairs_so_far = c->tm.n_align_pairs, cells_so_far = c->tm.n_align_cells;  // (a pair counts once)
+        g_no_corridor = true;
+        const int rr = ioc_align_pairs(c, int32_t(sub.size()), sub.data(), k, match, mismatch, gap_extend, sc.data(), sw.data(), sr.data());
+        g_no_corridor = false;
+        if (rr != IOC_OK) return rr;
+        c->tm.n_align_pairs = pairs_so_far;
+        c->tm.n_align_cells = cells_so_far;
+        if (getenv("IOC_TRACE")) fprintf(stderr, "[ioc]   aligner v2: %zu of %u pairs run again without a corridor\n", again_full.size(), np);
+        for (size_t x = 0; x < again_full.size(); ++x) {
+            if (out_score) out_score[again_full[x]] = sc[x];
+            if (out_windows) out_windows[again_full[x]] = sw[x];
+            if (out_ratio) out_ratio[again_full[x]] = sr[x];
+        }
     }
     if (!again.empty()) {
         std::vector<ioc_aln_pair> sub(again.size());
