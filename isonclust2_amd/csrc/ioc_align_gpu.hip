@@ -1904,7 +1904,11 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             int64_t beff = INT64_MAX;
             uint32_t skipped = 0;
             uint8_t lo[V2_MAX_BANDS], hi[V2_MAX_BANDS];
-            bool fits = corridor_frac > 0.0 && B >= strip_cols && cp.nstrips <= 255u && cp.nbands <= uint32_t(V2_MAX_BANDS);
+            // (the bound behind the certificate: a column of an alignment scores `match` at most — no reward for mismatches or gaps)
+            bool fits = corridor_frac > 0.0 && B >= strip_cols && cp.nstrips <= 255u && cp.nbands <= uint32_t(V2_MAX_BANDS) && P.match > 0 && P.mismatch <= P.match &&
+                        P.gap_extend >= 0;
+            for (int h = 0; fits && h < 2; ++h)
+                if (cp.pid[h] != 0xFFFFFFFFu) fits = dp[cp.pid[h]].gap_open >= 0;
             for (uint32_t b = 0; fits && b < cp.nbands; ++b) {
                 const uint32_t r0 = uint32_t(cp.bstart[b]) * uint32_t(CK2), r1 = std::min(nmax, uint32_t(cp.bstart[b + 1u]) * uint32_t(CK2));
                 const uint32_t c_lo = r0 > B ? r0 - B : 0u, c_hi = std::min<uint64_t>(mmax, uint64_t(r1) + B);
@@ -2136,7 +2140,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                                d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
             ACHK(c, hipGetLastError());
             hipLaunchKernelGGL(k_fwd2_probe, dim3(slices[si].second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first, d_pend,
-                               static_cast<const uint32_t*>(c->a_ck.p), P);
+                               static_cast<const uint32_t*>(c->a_ck.p), P, float(corridor_frac));
             ACHK(c, hipGetLastError());
             ACHK(c, hipMemsetAsync(d_ctl, 0, 4, s));  // (the queue's counter; the flags of the probe's tiles stay)
         }

@@ -9,6 +9,7 @@ What is compared (reference behaviour behind it):
   consensus_case   consensus on (src/consensus.cpp:34-126): assignments, the log of graph operations, the event count, the MinDB
   align_batch      the GPU aligner against the host aligner (score + window ratio of getAlnRatio, src/cluster.cpp:408-459)
   verdict_batch    the aligner's verdict mode against its own exact mode
+  corridor_batch   long pairs: the forward pass's corridor (probe, certificate, second pass) against every tile and the host aligner
 """
 import ctypes as C
 import os
@@ -273,3 +274,72 @@ def verdict_batch(ctx, rng, lmax=3000, npairs=60):
     finally:
         ctx.align_set_verdict_threshold(0.0)
     return not bad, f"k={k} {bad[:2]}"
+
+
+def corridor_batch(ctx, rng, lmin=5200, lmax=11000, npairs=14, host_checks=2):
+    """rng: random.Random.  Long pairs (the corridor of the aligner's forward pass only exists from ~5 kb on): related ones at several
+    divergences, with a long insertion / deletion (the path leaves the main diagonal), a fragment against the whole (the path is
+    far off the diagonal: the probe or the certificate must send the pair through every tile), half related, unrelated, low
+    complexity, unequal lengths.  The default build (corridor, probe launch, certificate, second pass for the refuted) against
+    IOC_ALIGN_CORRIDOR=0 (every tile) in exact mode and in verdict mode; `host_checks` of the pairs also against the host aligner."""
+    from tests.test_gpu_align import _host, _mutate as mut
+    L = _lib.load()
+    seqs, pairs = [], []
+    for t in range(npairs):
+        n = rng.randint(lmin, lmax)
+        base = bytes(rng.choice(b"ACGT") for _ in range(n + 200))
+        kind = rng.random()
+        if kind < 0.35:
+            q, r = mut(rng, base, rng.choice([0.03, 0.08, 0.15]))[:n], mut(rng, base[rng.randint(0, 60):], rng.choice([0.03, 0.1]))
+        elif kind < 0.5:      # a long deletion or insertion in the middle
+            a, d = rng.randint(n // 4, n // 2), rng.choice([300, 1200, 2500, 4000])
+            q, r = mut(rng, base, 0.05), mut(rng, base[:a] + base[a + d:], 0.05)
+            if rng.random() < 0.5:
+                q, r = r, q
+        elif kind < 0.62:     # a fragment against the whole
+            a = rng.randint(n // 4, n // 2)
+            q, r = mut(rng, base[a:], 0.05), mut(rng, base, 0.05)
+            if rng.random() < 0.5:
+                q, r = r, q
+        elif kind < 0.72:     # related in the first half only
+            q, r = mut(rng, base, 0.05), mut(rng, base[: n // 2], 0.05) + bytes(rng.choice(b"ACGT") for _ in range(n // 2))
+        elif kind < 0.9:
+            q, r = bytes(rng.choice(b"ACGT") for _ in range(n)), bytes(rng.choice(b"ACGT") for _ in range(rng.randint(lmin, lmax)))
+        else:
+            q, r = bytes(rng.choice(b"AC") for _ in range(n)), bytes(rng.choice(b"AC") for _ in range(n + rng.randint(-300, 300)))
+        seqs += [q, r]
+        pairs.append((2 * t, 2 * t + 1, 0, rng.choice([0.02, 0.05, 0.12])))
+    k = rng.choice([11, 15])
+    thr = rng.choice([0.1, 0.4])
+    ctx.align_set_pool(seqs)
+    old = os.environ.get("IOC_ALIGN_CORRIDOR")
+    res = {}
+    try:
+        for frac in ("0", None):
+            if frac is None:
+                os.environ.pop("IOC_ALIGN_CORRIDOR", None) if old is None else os.environ.__setitem__("IOC_ALIGN_CORRIDOR", old)
+            else:
+                os.environ["IOC_ALIGN_CORRIDOR"] = frac
+            ctx.align_set_verdict_threshold(0.0)
+            exact = ctx.align_pairs(pairs, k)
+            ctx.align_set_verdict_threshold(thr)
+            verdict = ctx.align_pairs(pairs, k)
+            res[frac] = (exact, verdict)
+    finally:
+        ctx.align_set_verdict_threshold(0.0)
+        if old is None:
+            os.environ.pop("IOC_ALIGN_CORRIDOR", None)
+        else:
+            os.environ["IOC_ALIGN_CORRIDOR"] = old
+    bad = []
+    (e0, v0), (e1, v1) = res["0"], res[None]
+    for i in range(npairs):
+        if e0[0][i] != e1[0][i] or e0[1][i] != e1[1][i] or e0[2][i] != e1[2][i]:
+            bad.append(("exact", i, len(seqs[2 * i]), len(seqs[2 * i + 1]), int(e0[0][i]), int(e1[0][i]), int(e0[1][i]), int(e1[1][i])))
+        if v0[0][i] != v1[0][i] or (v0[2][i] >= thr) != (v1[2][i] >= thr) or (e0[2][i] >= thr) != (v1[2][i] >= thr):
+            bad.append(("verdict", i, len(seqs[2 * i]), len(seqs[2 * i + 1]), int(v0[0][i]), int(v1[0][i]), float(v0[2][i]), float(v1[2][i])))
+    for i in rng.sample(range(npairs), min(host_checks, npairs)):
+        hs, hr = _host(L, seqs[2 * i], seqs[2 * i + 1], 0, pairs[i][3], k)
+        if e1[0][i] != hs or e1[2][i] != hr:
+            bad.append(("host", i, len(seqs[2 * i]), len(seqs[2 * i + 1]), int(e1[0][i]), hs, float(e1[2][i]), hr))
+    return not bad, f"k={k} thr={thr} {bad[:3]}"

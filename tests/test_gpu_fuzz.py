@@ -138,3 +138,16 @@ def test_fuzz_verdict(ctx):
         if n >= 2 and time.time() - t0 > BUDGET:
             break
     assert not bad, f"{len(bad)} of {n} batches: verdict mode differs from the exact mode; first: python tools/fuzz_verdict.py --seed {bad[0][0]}  ({bad[0][1]})"
+
+
+def test_fuzz_corridor(ctx):
+    """long pairs: the aligner's corridor (probe launch, certificate, second pass) against every tile, and the host aligner"""
+    bad, t0, n = [], time.time(), 0
+    for s in [33, 34, SEED & 0xFFFF] + [((SEED >> 4) + i) & 0xFFFFFF for i in range(200)]:
+        ok, why = fz.corridor_batch(ctx, random.Random(s))
+        n += 1
+        if not ok:
+            bad.append((s, why))
+        if n >= 3 and time.time() - t0 > BUDGET:
+            break
+    assert not bad, f"{len(bad)} of {n} batches: the corridor's results differ; first: python tools/fuzz_corridor.py --seed {bad[0][0]}  ({bad[0][1]})"
