@@ -1816,13 +1816,13 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if (const char* e = getenv("IOC_ALIGN_V2_GUARD")) guard = std::max(1, std::min(P16_GUARD, atoi(e)));
     const uint32_t np = uint32_t(dp.size());
     const uint32_t ncouples = (cnt + 1u) / 2u;
+    std::vector<int32_t> pend_cert(np, INT32_MIN);
+    uint64_t tiles_skipped = 0, tiles_all = 0;
     // The corridor's half width as a fraction of the longer sequence (V2Couple; IOC_ALIGN_CORRIDOR=0: every tile; a pair whose
     // result the corridor cannot vouch for is run again with g_no_corridor set).  0.2: a pair of one transcript scores 1.62 - 1.8
     // per base at match 2 — it passes if 2 (1 - B / len) < 1.62 — and the tile grid of a 16.7 kb pair shrinks to about half.
     double corridor_frac = g_no_corridor ? 0.0 : 0.2;
     if (const char* e = getenv("IOC_ALIGN_CORRIDOR")) corridor_frac = g_no_corridor ? 0.0 : std::max(0.0, std::min(1.0, atof(e)));
-    std::vector<int32_t> pend_cert(np, INT32_MIN);
-    uint64_t tiles_skipped = 0, tiles_all = 0;
     // Bands per couple.  A full batch (config 3: 811 couples) is bound by throughput: 11 bands of 1536 rows (66.8 ms; 7 of 2560:
     // 69.2; 17 of 1024: worse again).  A small one (a merge aligns a few hundred representatives) is bound by ONE couple's
     // critical path, (bands + strips - 1) tiles of rows / (4 bands) + 63 steps: more, shorter bands shorten it as long as the
@@ -1859,7 +1859,10 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         // enough (>= 1024 rows = 256 steps) for the 63 steps of pipeline fill to stay small — except the first and the last
         // ones, which CAN be short (V2Couple::bstart; IOC_ALIGN_V2_RAMP=1): 1, 2, 4 coarse rows, then the regular height, then 4, 2, 1
         {
-            const uint32_t reg = std::max<uint32_t>(want_bands > 16u ? 1u : 2u, (ncoarse + want_bands - 1) / want_bands);  // (coarse rows per band)
+            // (a pair long enough for a corridor: shorter bands follow the diagonal more closely — config 3 with the corridor: 17 bands
+            // of 1024 rows 45.9 ms, 11 of 1536 47.6, 22 of 1024 / 512 46.1)
+            const uint32_t wb = (corridor_frac > 0.0 && ncoarse >= 16u && !getenv("IOC_ALIGN_V2_BANDS")) ? std::max(want_bands, 17u) : want_bands;
+            const uint32_t reg = std::max<uint32_t>(want_bands > 16u ? 1u : 2u, (ncoarse + wb - 1) / wb);  // (coarse rows per band)
             std::vector<uint32_t> hts;
             uint32_t left = ncoarse;
             auto take = [&](uint32_t hgt) {
