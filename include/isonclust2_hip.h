@@ -228,6 +228,9 @@ typedef struct {
     int64_t align_arena_bytes;
     int32_t align_slices;
     int32_t align_version;
+    /* cells of the DP matrices the forward pass really computed (version 2 leaves out the tiles outside its certified corridor;
+     * n_align_cells stays the reference's figure: every pair's whole matrix) */
+    int64_t n_align_cells_computed;
 } ioc_timings;
 int ioc_get_timings(ioc_ctx* ctx, ioc_timings* out);
 /* Instrumentation (one extra scoring launch, outside any timed region): the number of postings the

@@ -103,7 +103,8 @@ class Timings(C.Structure):
                 ("ms_align_fwd", C.c_float), ("ms_align_trace", C.c_float), ("n_align_pairs", C.c_int64),
                 ("n_align_cells", C.c_int64),
                 ("n_align_refused", C.c_int64), ("score_oob", C.c_int32), ("score_oob_probe", C.c_int32),
-                ("align_arena_bytes", C.c_int64), ("align_slices", C.c_int32), ("align_version", C.c_int32)]
+                ("align_arena_bytes", C.c_int64), ("align_slices", C.c_int32), ("align_version", C.c_int32),
+                ("n_align_cells_computed", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

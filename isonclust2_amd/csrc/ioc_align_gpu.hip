@@ -1816,6 +1816,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if (const char* e = getenv("IOC_ALIGN_V2_GUARD")) guard = std::max(1, std::min(P16_GUARD, atoi(e)));
     const uint32_t np = uint32_t(dp.size());
     const uint32_t ncouples = (cnt + 1u) / 2u;
+    uint32_t probe_rows = 1024;
+    if (const char* e = getenv("IOC_ALIGN_PROBE_ROWS")) probe_rows = uint32_t(std::max(512, atoi(e)));
     std::vector<int32_t> pend_cert(np, INT32_MIN);
     uint64_t tiles_skipped = 0, tiles_all = 0;
     // The corridor's half width as a fraction of the longer sequence (V2Couple; IOC_ALIGN_CORRIDOR=0: every tile; a pair whose
@@ -1925,14 +1927,14 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                 if (lo[b] > 0) beff = std::min<int64_t>(beff, int64_t(r0) - int64_t(lo[b]) * strip_cols);
                 if ((uint64_t(hi[b]) + 1u) * strip_cols < mmax) beff = std::min<int64_t>(beff, int64_t(hi[b] + 1u) * strip_cols - int64_t(r1));
             }
-            // the probe (V2Couple): the first band that ends at row 3072 or below, the strip its last diagonal cell is in; every tile
+            // the probe (V2Couple): the first band that ends at row 2048 or below, the strip its last diagonal cell is in; every tile
             // above and to the left of it must be inside the corridor with nothing missing around it, both pairs must reach it
             uint32_t pb = 0, ps = 0;
             if (fits) {
-                while (pb + 1u < cp.nbands && uint32_t(cp.bstart[pb + 1u]) * uint32_t(CK2) < 3072u) ++pb;
+                while (pb + 1u < cp.nbands && uint32_t(cp.bstart[pb + 1u]) * uint32_t(CK2) < probe_rows) ++pb;  // (3072 rows: a probe launch of 4.2 ms; 2048: 2.3)
                 const uint32_t R = uint32_t(cp.bstart[pb + 1u]) * uint32_t(CK2);
                 ps = (R - 1u) / strip_cols;
-                fits = pb + 1u < cp.nbands && R >= 2048u;
+                fits = pb + 1u < cp.nbands && R >= probe_rows;
                 for (uint32_t b = 0; fits && b <= pb; ++b) fits = lo[b] == 0 && hi[b] >= ps;
                 for (int h = 0; fits && h < 2; ++h)
                     if (cp.pid[h] != 0xFFFFFFFFu) fits = dp[cp.pid[h]].n >= R && dp[cp.pid[h]].m > ps * strip_cols;
@@ -2075,7 +2077,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     int2* d_lrow = static_cast<int2*>(c->a_lrow.p);
     int2* d_best = d_lrow + lrow_total;
     // [queue][err][pad ...][flags][ovf per pair]
-    const size_t ctl_words = 16 + size_t(max_flags) + np;
+    const size_t ctl_words = ((16 + size_t(max_flags) + np + 1) & ~size_t(1)) + 2;  // (... and, 8-byte aligned, the count of computed cells)
     if ((r = reserve(c, c->a_xflags, ctl_words * 4)) != IOC_OK) return r;
     uint32_t* d_ctl = static_cast<uint32_t*>(c->a_xflags.p);
     // the traceback in two launches: walks that need more than `deadline` blocks go on in the second one, with helper waves
@@ -2140,7 +2142,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             const uint32_t n_wg0 = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_probe[si] + V2_WAVES - 1) / V2_WAVES));
             hipLaunchKernelGGL(k_fwd2, dim3(n_wg0), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_probe[si],
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
+                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2));
             ACHK(c, hipGetLastError());
             hipLaunchKernelGGL(k_fwd2_probe, dim3(slices[si].second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first, d_pend,
                                static_cast<const uint32_t*>(c->a_ck.p), P, float(corridor_frac));
@@ -2151,7 +2153,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_main + V2_WAVES - 1) / V2_WAVES));
         hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items + n_probe[si], n_main,
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p));
+                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2));
         ACHK(c, hipGetLastError());
         hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
                            d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p), d_resume, d_early, route ? int(P.match) : 0,
@@ -2200,8 +2202,11 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             }
         }
         uint32_t xe = 0;
+        unsigned long long cells_done = 0;
         ACHK(c, hipMemcpyAsync(&xe, d_ctl + 1, 4, hipMemcpyDeviceToHost, s));
+        ACHK(c, hipMemcpyAsync(&cells_done, d_ctl + ctl_words - 2, 8, hipMemcpyDeviceToHost, s));
         ACHK(c, hipStreamSynchronize(s));
+        c->tm.n_align_cells_computed += int64_t(cells_done);
         if (getenv("IOC_V2_PROGRESS")) {  // (marks build: cycles the waves spent waiting for tiles / alive / the longest-lived wave)
             unsigned long long t[3] = {0, 0, 0};
             uint32_t pg[16] = {0};
@@ -2713,6 +2718,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     }
     c->tm.n_align_pairs += np;
     for (auto& d : dp) c->tm.n_align_cells += int64_t(d.n) * int64_t(d.m);
+    for (uint32_t x = n_v2; x < np; ++x) c->tm.n_align_cells_computed += int64_t(dp[order[x]].n) * int64_t(dp[order[x]].m);  // (version 1: every cell; version 2 counts its tiles)
     std::vector<int32_t> hs(np);
     std::vector<uint32_t> hc(np);
     ACHK(c, hipMemcpyAsync(hs.data(), d_score, size_t(np) * 4, hipMemcpyDeviceToHost, s));

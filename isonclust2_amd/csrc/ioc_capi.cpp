@@ -564,7 +564,7 @@ int ioc_index_build(ioc_ctx* c)
     if (pmax > 32768) return ioc_fail(c, IOC_ERR_CAPACITY, "a query has more than 32768 forward minimizers");
     hipStream_t s = c->stream;
     c->tm.ms_align_fwd = c->tm.ms_align_trace = 0.f;
-    c->tm.n_align_pairs = c->tm.n_align_cells = c->tm.n_align_refused = 0;
+    c->tm.n_align_pairs = c->tm.n_align_cells = c->tm.n_align_refused = c->tm.n_align_cells_computed = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], s));
     // 16-bit postings when every target id fits (the padding value 0xFFFF must stay above every id)
     c->post16 = (uint64_t(c->L) + uint64_t(n) <= 65535ull && env_u32("IOC_POST16", 1) == 1) ? 1 : 0;

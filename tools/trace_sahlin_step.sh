@@ -13,7 +13,7 @@ fw = [i for i, r in enumerate(rows) if "k_fwd2(" in r["Kernel_Name"] or r["Kerne
 a = fw[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 out = open("$OUT/step.txt", "w")
-for r in rows[a:a + 12]:
+for r in rows[max(0, a - 4):a + 12]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print(f'{(s - t0) / 1e3:10.1f} us .. {(e - t0) / 1e3:10.1f} us  {(e - s) / 1e3:9.1f} us  {r["Kernel_Name"][:60]}', file=out)
 PY
