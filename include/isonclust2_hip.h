@@ -272,7 +272,10 @@ typedef struct {
     int32_t query;
     int32_t ref;
     int32_t ref_revcomp;
-    int32_t reserved;
+    int32_t reserved;   /* 0, or a HINT > 0: any measure of how much alike the caller expects the two sequences to be that can be
+                         * compared across the pairs of one call (the cluster drivers pass the query's cut, i.e. its top count of
+                         * shared minimizers).  The aligner schedules pairs hinted far below the call's median together; no result
+                         * depends on it. */
     double e;
 } ioc_aln_pair;
 /* Upload the sequence pool (concatenated raw sequences, offs[n_seqs + 1], offs[0] == 0). */

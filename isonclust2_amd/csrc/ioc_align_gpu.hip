@@ -2396,6 +2396,23 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return uint64_t(dp[x].n) * dp[x].m > uint64_t(dp[y].n) * dp[y].m;
     });
+    // The caller's similarity hints (ioc_aln_pair::reserved, 0 = none): pairs hinted far below the batch's median — a quarter of
+    // it — are taken for unrelated and sorted behind the others, so that version 2 couples them with each other: a couple with
+    // an unrelated pair gets no corridor, and a pair of one transcript coupled with it pays for every tile too (config 3: 19 %
+    // of the couples hold a wrong candidate when they are coupled by size alone, 10 % of the pairs are one).  Order only.
+    {
+        std::vector<int32_t> hp;
+        for (uint32_t x = 0; x < np; ++x)
+            if (pairs[back[x]].reserved > 0) hp.push_back(pairs[back[x]].reserved);
+        if (hp.size() >= 8 && !getenv("IOC_ALIGN_NO_HINTS")) {
+            std::nth_element(hp.begin(), hp.begin() + long(hp.size() / 2), hp.end());
+            const int64_t med = hp[hp.size() / 2];
+            std::stable_partition(order.begin(), order.end(), [&](uint32_t x) {
+                const int64_t h = pairs[back[x]].reserved;
+                return !(h > 0 && h * 4 < med);
+            });
+        }
+    }
     // trace variant: the pairs of the query-profile kernel first, the comparing kernel's after them
     std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return dp[x].pad != 0; });
     const char* ev = getenv("IOC_ALIGN_VARIANT");

@@ -400,6 +400,7 @@ struct AlnDriver {
     const SeqAccess* sa = nullptr;
     int n = 0;
     bool host_only = false;
+    const int32_t* cuts = nullptr;  // per query: ioc_get_cuts of the current decisions (a scheduling hint for the aligner, ioc_aln_pair::reserved)
     std::unordered_map<uint64_t, double> cache;  // (query, tie key) -> getAlnRatio
 
     static uint64_t key(int q, uint32_t tie) { return (uint64_t(uint32_t(q)) << 32) | tie; }
@@ -503,7 +504,9 @@ struct AlnDriver {
             pairs[x].query = todo[i].first;
             pairs[x].ref = target < c->L ? n + target : target - c->L;
             pairs[x].ref_revcomp = int32_t(todo[i].second & 1u);
-            pairs[x].reserved = 0;
+            // (the query's cut = int(top Size x MinFraction): the candidates aligned are the ones tied at that top Size — a few dozen
+            // shared minimizers for a chance candidate, thousands for a read of the same transcript)
+            pairs[x].reserved = (cuts && cuts[todo[i].first] > 0 && cuts[todo[i].first] < INT32_MAX) ? cuts[todo[i].first] : 0;
             pairs[x].e = sa->r_err[todo[i].first] + err_of(target);
         }
         std::vector<double> ratio(mine.size());
@@ -608,6 +611,7 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
     std::vector<std::vector<uint32_t>> v_ties;
     std::vector<uint8_t> order_dep;
     std::vector<uint32_t> tcount, tkeys;
+    std::vector<int32_t> cuts;
     if (aln_mode) {
         ad.c = c;
         ad.sa = sa;
@@ -630,6 +634,11 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
         if (!aln_mode) break;
         if (round > 2 * n + 8) return ioc_fail(c, IOC_ERR_STATE, "alignment fallback did not converge");
         if ((r = ioc_get_ties(c, tcount.data(), tkeys.data())) != IOC_OK) return r;
+        if (!ad.host_only) {
+            cuts.resize(size_t(n) + 1);
+            if ((r = ioc_get_cuts(c, cuts.data())) != IOC_OK) return r;
+            ad.cuts = cuts.data();
+        }
         int32_t next_id = c->L;
         for (int i = 0; i < n; ++i) cid[size_t(i)] = (!gated[size_t(i)] && tgt[size_t(i)] < 0) ? next_id++ : -1;
         // queries that reach the alignment and whose verdict is missing, stale or order-dependent
