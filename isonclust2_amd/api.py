@@ -216,12 +216,14 @@ class Context:
         self._chk(self.L.ioc_align_set_verdict_threshold(self.h, float(thr)))
 
     def align_pairs(self, pairs, k, match=2, mismatch=-2, gap_extend=1):
-        """ParasailAlign + getAlnRatio (src/cluster.cpp:408-459) for (query, ref, ref_revcomp, e) tuples:
+        """ParasailAlign + getAlnRatio (src/cluster.cpp:408-459) for (query, ref, ref_revcomp, e[, hint]) tuples:
         returns (score, qualifying windows, ratio) arrays."""
         n = len(pairs)
         arr = (_lib.AlnPair * max(n, 1))()
-        for i, (qi, ri, rc, e) in enumerate(pairs):
+        for i, pr in enumerate(pairs):        # (a fifth element: the similarity hint, ioc_aln_pair::reserved)
+            qi, ri, rc, e = pr[:4]
             arr[i].query, arr[i].ref, arr[i].ref_revcomp, arr[i].e = int(qi), int(ri), int(bool(rc)), float(e)
+            arr[i].reserved = int(pr[4]) if len(pr) > 4 else 0
         score, win, ratio = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.float64)
         self._chk(self.L.ioc_align_pairs(self.h, n, arr, k, match, mismatch, gap_extend, _p(score, C.c_int32),
                                          _p(win, C.c_int64), _p(ratio, C.c_double)))

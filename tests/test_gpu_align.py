@@ -390,3 +390,25 @@ def test_second_traceback_launch_takes_turns_when_many_walks_park(ctx, monkeypat
         ctx.align_set_verdict_threshold(0.0)
     assert np.array_equal(s0, s1) and np.array_equal(r0 >= 0.2, r1 >= 0.2) and np.all(w1 <= w0)
     assert int(np.count_nonzero(r0 >= 0.2)) >= 5 and int(np.count_nonzero(r0 < 0.2)) >= 600
+
+
+def test_similarity_hints_change_the_order_only(ctx):
+    """ioc_aln_pair::reserved: pairs hinted far below the call's median are coupled with each other (a couple with an unrelated
+    pair gets every tile of its grid, V2Couple).  Right hints, no hints, wrong hints: the same scores, windows and ratios."""
+    rng = random.Random(53)
+    base = [bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(7000, 9000))) for _ in range(3)]
+    seqs, plain, kind = [], [], []
+    for t in range(12):
+        if t % 3 == 2:
+            q, r = base[t % 3], bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(7000, 9000)))
+        else:
+            q, r = _mutate(rng, base[t % 3], 0.05), _mutate(rng, base[t % 3], 0.08)
+        seqs += [q, r]
+        plain.append((2 * t, 2 * t + 1, 0, 0.12))
+        kind.append(t % 3 == 2)
+    ctx.align_set_pool(seqs)
+    ref = ctx.align_pairs(plain, 11)
+    assert sum(1 for i in range(12) if ref[2][i] < 0.1) == 4               # the unrelated ones
+    for hints in ([60 if u else 2500 for u in kind], [2500 if u else 60 for u in kind], [rng.randrange(1, 5000) for _ in kind]):
+        got = ctx.align_pairs([p + (h,) for p, h in zip(plain, hints)], 11)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got)), hints
