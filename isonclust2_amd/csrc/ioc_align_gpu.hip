@@ -1804,6 +1804,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if (cnt == 0) return IOC_OK;
     hipStream_t s = c->stream;
     int r;
+    const auto t_plan0 = std::chrono::steady_clock::now();  // (IOC_TRACE: host time of the planning up to the first launch)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
     if (n_cu < 1) n_cu = 256;
@@ -2123,6 +2124,9 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     for (auto& e : evs) ACHK(c, hipEventCreate(&e));
     size_t evi = 0;
     bool bad = false;
+    if (getenv("IOC_TRACE"))
+        fprintf(stderr, "[ioc]   aligner v2: planning (couples, corridors, tile lists, tables) took the host %.3f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count());
     for (size_t si = 0; si < slices.size() && !bad; ++si) {
         const uint32_t first_pair = 2u * slices[si].first, n_pairs = std::min(cnt, 2u * (slices[si].first + slices[si].second)) - first_pair;
         const uint32_t n_items = uint32_t(items[si].size());
