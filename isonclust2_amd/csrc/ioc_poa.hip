@@ -1317,7 +1317,21 @@ int poa_flush(ioc_poa* p, bool only_marked = false, int safe_tag = INT32_MIN)
         size_t largest = 0;
         for (const HostJob& j : cand)
             if (j.G->n_nodes() && !j.item->seq.empty()) largest = std::max(largest, j.bytes());
-        size_t budget = std::min(std::min((free_b + have) / 2, size_t(48) << 30), std::max(size_t(10) << 30, 32 * largest));
+        // ... but device memory is not free: hipMalloc costs ~0.07 ms per MB (a `cluster` process that merges two leaves — 1 600
+        // alignments — spent 0.70 of its 2.4 s allocating the 10 GB), while a batch of a quarter the size only runs less efficiently
+        // (bound by the rows' dependent chain instead of the VALU).  So the 10 GB are for a flush with enough work to pay for them:
+        // a 24th of what is queued, between 2 and 10 GB, and never less than what the engine holds already.
+        size_t queued = 0;
+        for (int side = 0; side < 2; ++side)
+            for (auto& kv : p->pending[side]) {
+                auto it = p->g[side].find(kv.first);
+                if (it == p->g[side].end()) continue;
+                const size_t rows = it->second.n_nodes() + 1;
+                for (auto& item : kv.second)
+                    if (!item.marker) queued += rows * (item.seq.size() + 1) * 5;
+            }
+        const size_t base = std::max(have, std::min(size_t(10) << 30, std::max(size_t(2) << 30, queued / 24)));
+        size_t budget = std::min(std::min((free_b + have) / 2, size_t(48) << 30), std::max(base, 32 * largest));
         if (const char* e = getenv("IOC_POA_BUDGET_MB")) budget = size_t(atoll(e)) << 20;
         p->reserve_hint = budget + budget / 16;  // (the cells' direction words are 4/5 of it, their E bytes 1/5)
         for (size_t x = 0; x < cand.size(); ++x) {

@@ -1,25 +1,41 @@
 #!/bin/bash
-# Developer aid, runs on the GPU box: ONE merge of the configs[4] tree (two 31 250-read leaves, sahlin, consensus 20,100,400) through the
-# command line with IOC_TRACE=1: where its seconds go.   tools/merge_profile.sh TAG
+# Developer aid, runs on the GPU box: ONE merge of configs[4] (two clustered 31 250-read x 2 kb leaves, sahlin, consensus
+# 20,100,400) through the command line with IOC_TRACE=1, then under rocprofv3 --kernel-trace --stats.   tools/merge_profile.sh TAG [per]
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
-TAG=$1
+export TMPDIR=/tmp
+TAG=$1; PER=${2:-31250}
 D=/tmp/ioc_mergeprof; rm -rf $D; mkdir -p $D gpurun_out/merge_$TAG
-python3 - "$D" <<'PY'
+python3 - "$PER" "$D" <<'PY'
 import sys
 sys.path.insert(0, ".")
 from isonclust2_amd import synth
-d = sys.argv[1]
+per, d = int(sys.argv[1]), sys.argv[2]
 with open(d + "/r.fq", "wb") as f:
-    for c in range(2):
-        rs = synth.generate(31250, 1500, 2000, 10, 21, seed=1000 + c, tr_seed=11)
+    for b in range(2):
+        rs = synth.generate(per, 1500, 2000, 10, 21, seed=1000 + b, tr_seed=11)
         for i in range(rs.n):
             s, q = rs.read(i)
-            f.write(b"@r%d\n" % (c * 31250 + i) + s + b"\n+\n" + q + b"\n")
+            f.write(b"@r%d_%d\n" % (b, i) + s + b"\n+\n" + q + b"\n")
 PY
 CLI=isonclust2_amd/bin/isONclust2-hip
-$CLI sort -B 1000000 -M 31250 -g 20 -c 100 -P 400 -o $D/s $D/r.fq > /dev/null 2>&1 || exit 1
-for b in 0 1; do $CLI cluster -l $D/s/batches/isONbatch_$b.cer -o $D/c$b.cer -x sahlin > /dev/null 2>&1 || exit 1; done
+$CLI sort -B 1000000 -M $PER -g 20 -c 100 -P 400 -o $D/s $D/r.fq > /dev/null 2>&1 || exit 1
+$CLI cluster -l $D/s/batches/isONbatch_0.cer -o $D/c0.cer -x sahlin > /dev/null 2>&1 || exit 1
+$CLI cluster -l $D/s/batches/isONbatch_1.cer -o $D/c1.cer -x sahlin > /dev/null 2>&1 || exit 1
 ( time IOC_TRACE=1 ISONCLUST2_STATS_JSON=1 $CLI cluster -l $D/c0.cer -r $D/c1.cer -o $D/m.cer -x sahlin ) 2> gpurun_out/merge_$TAG/trace.err || exit 1
-grep "consensus phases\|POA\|^{\|real\|deferred consensus" gpurun_out/merge_$TAG/trace.err | cut -c1-330
-grep "^\[ioc\]" gpurun_out/merge_$TAG/trace.err | grep " ms" | grep -v "consensus phases\|POA\|aligner v2\|candidate tables:" | sed -E 's/\([0-9]+ candidate tables\)//' | awk '{v=$(NF-1); $NF=""; $(NF-1)=""; k=$0; s[k]+=v; n[k]++} END {for (k in s) printf "%10.1f ms %6d  %s\n", s[k], n[k], k}' | sort -rn | head -12
+python3 - gpurun_out/merge_$TAG/trace.err <<'PY'
+import re, collections, sys
+tot, cnt = collections.Counter(), collections.Counter()
+for line in open(sys.argv[1]):
+    m = re.match(r'\[ioc\] (.*?)\s+([0-9.]+) ms$', line.rstrip())
+    if m:
+        tot[m.group(1).strip()] += float(m.group(2)); cnt[m.group(1).strip()] += 1
+for k, v in tot.most_common(14):
+    print(f"{v:10.1f} ms  x{cnt[k]:5d}  {k}")
+PY
+grep "consensus phases\|POA: \|^{\|real" gpurun_out/merge_$TAG/trace.err | cut -c1-260
+[ -n "${NOPROF:-}" ] && exit 0
+IOC_CLI_CLEAN_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/merge_$TAG/prof -- $CLI cluster -l $D/c0.cer -r $D/c1.cer -o $D/m2.cer -x sahlin > gpurun_out/merge_$TAG/prof.log 2>&1
+F=$(find gpurun_out/merge_$TAG/prof -name "*kernel_stats.csv" | head -1)
+cp "$F" gpurun_out/merge_$TAG/kernel_stats.csv && head -12 gpurun_out/merge_$TAG/kernel_stats.csv | cut -c1-140
+find gpurun_out/merge_$TAG/prof -name "*kernel_trace.csv" -size +40M -delete
