@@ -1903,15 +1903,15 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             cp.corridor = 0;
             for (uint32_t b = 0; b < uint32_t(V2_MAX_BANDS); ++b) {
                 cp.plo[b] = 0;
-                cp.phi[b] = uint8_t(std::min<uint32_t>(255u, cp.nstrips - 1u));
+                cp.phi[b] = uint16_t(std::min<uint32_t>(65535u, cp.nstrips - 1u));  // (V2Item::strip is 16 bits wide)
             }
             const uint32_t strip_cols = 64u * FW_C;
             const uint32_t B = uint32_t(corridor_frac * double(std::max(nmax, mmax)));
             int64_t beff = INT64_MAX;
             uint32_t skipped = 0;
-            uint8_t lo[V2_MAX_BANDS], hi[V2_MAX_BANDS];
+            uint16_t lo[V2_MAX_BANDS], hi[V2_MAX_BANDS];
             // (the bound behind the certificate: a column of an alignment scores `match` at most — no reward for mismatches or gaps)
-            bool fits = corridor_frac > 0.0 && B >= strip_cols && cp.nstrips <= 255u && cp.nbands <= uint32_t(V2_MAX_BANDS) && P.match > 0 && P.mismatch <= P.match &&
+            bool fits = corridor_frac > 0.0 && B >= strip_cols && cp.nstrips <= 65535u && cp.nbands <= uint32_t(V2_MAX_BANDS) && P.match > 0 && P.mismatch <= P.match &&
                         P.gap_extend >= 0;
             for (int h = 0; fits && h < 2; ++h)
                 if (cp.pid[h] != 0xFFFFFFFFu) fits = dp[cp.pid[h]].gap_open >= 0;
@@ -1922,8 +1922,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                     fits = false;
                     break;
                 }
-                lo[b] = uint8_t(c_lo / strip_cols);
-                hi[b] = uint8_t((c_hi - 1u) / strip_cols);
+                lo[b] = uint16_t(c_lo / strip_cols);
+                hi[b] = uint16_t((c_hi - 1u) / strip_cols);
                 skipped += lo[b] + (cp.nstrips - 1u - hi[b]);
                 if (lo[b] > 0) beff = std::min<int64_t>(beff, int64_t(r0) - int64_t(lo[b]) * strip_cols);
                 if ((uint64_t(hi[b]) + 1u) * strip_cols < mmax) beff = std::min<int64_t>(beff, int64_t(hi[b] + 1u) * strip_cols - int64_t(r1));

@@ -412,3 +412,17 @@ def test_similarity_hints_change_the_order_only(ctx):
     for hints in ([60 if u else 2500 for u in kind], [2500 if u else 60 for u in kind], [rng.randrange(1, 5000) for _ in kind]):
         got = ctx.align_pairs([p + (h,) for p, h in zip(plain, hints)], 11)
         assert all(np.array_equal(a, b) for a, b in zip(ref, got)), hints
+
+
+def test_corridor_on_sequences_with_more_than_256_strips(ctx, monkeypatch):
+    """A 265 kb pair: 259 strips of 1024 columns (the corridor's strip bounds are 16 bits wide, as V2Item::strip is), 30 bands.
+    The corridor's result against every tile."""
+    rng = random.Random(59)
+    base = bytes(rng.choice(b"ACGT") for _ in range(265000))
+    seqs = [_mutate(rng, base, 0.04), _mutate(rng, base, 0.05)]
+    ctx.align_set_pool(seqs)
+    got = ctx.align_pairs([(0, 1, 0, 0.12)], 11)
+    monkeypatch.setenv("IOC_ALIGN_CORRIDOR", "0")
+    ref = ctx.align_pairs([(0, 1, 0, 0.12)], 11)
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    assert got[0][0] > 400000 and got[2][0] > 0.9
