@@ -5,7 +5,7 @@
 # .cer reader / writer (round trip, every truncation, flipped bytes, crafted counts: `isONclust2-hip selftest`).
 # GPU ASan is not available on this pool: the kernels themselves are covered by the parity tests on the MI355X.
 # Two passes, because the two ASan runtimes (gcc's for the oracle, clang's for the HIP library) cannot share a process.
-#   tools/run_sanitizers.sh            -> log in profiles/r03_sanitizers.log
+#   tools/run_sanitizers.sh            -> log in profiles/r04_sanitizers.log
 # Exit 0 only when every build and every pass ran to its end AND nothing was reported: the braces below run in a pipeline
 # subshell, so their `exit 1` is read back through PIPESTATUS, the '== done' marker is required, and a pytest summary with
 # anything but passes (failed, error) counts as a finding.
@@ -13,7 +13,7 @@ set -u -o pipefail
 cd "$(dirname "$0")/.."
 OUT=build/asan
 mkdir -p "$OUT"
-LOG=profiles/r03_sanitizers.log
+LOG=profiles/${SAN_LOG:-r04_sanitizers.log}
 CLANG_RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 GCC_RT=$(gcc -print-file-name=libasan.so)
 # (libstdc++ next to the runtime: preloaded into python, ASan's __cxa_throw interceptor otherwise finds no real one)
@@ -22,7 +22,7 @@ SRC=isonclust2_amd/csrc
 {
 echo "== sanitizer pass $(date -u +%Y-%m-%dT%H:%MZ) =="
 echo "-- build: oracle with g++ -fsanitize=address,undefined"
-g++ -std=c++14 -O1 -g -DNDEBUG -msse3 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $OUT/liboracle_asan.so oracle/oracle.cpp || exit 1
+g++ -std=c++14 -O1 -g -DNDEBUG -msse3 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $OUT/liboracle_asan.so oracle/oracle.cpp oracle/poa_oracle.cpp oracle/sg_striped.cpp || exit 1
 echo "-- build: libisonclust2_hip.so host code with clang -fsanitize=address,undefined (device code unchanged)"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -pthread -ffp-contract=off -Wno-unused-result -Wno-option-ignored \
     -fsanitize=address,undefined -fno-omit-frame-pointer -shared-libsan -Iinclude -I$SRC -shared -o $OUT/libisonclust2_hip.so \
