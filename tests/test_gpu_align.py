@@ -426,3 +426,20 @@ def test_corridor_on_sequences_with_more_than_256_strips(ctx, monkeypatch):
     ref = ctx.align_pairs([(0, 1, 0, 0.12)], 11)
     assert all(np.array_equal(a, b) for a, b in zip(ref, got))
     assert got[0][0] > 400000 and got[2][0] > 0.9
+
+
+def test_corridor_with_several_slices(ctx, monkeypatch):
+    """Long pairs under a small checkpoint budget: several launches (slices), each with its own probe launch, corridor tiles,
+    certificates — and two unrelated pairs among them whose couples get every tile.  Against every tile in one slice."""
+    rng = random.Random(61)
+    base = bytes(rng.choice(b"ACGT") for _ in range(9000))
+    seqs = [_mutate(rng, base, 0.05) for _ in range(10)] + [bytes(rng.choice(b"ACGT") for _ in range(8800)) for _ in range(2)]
+    pairs = [(i, (i + 1) % 10, 0, 0.12) for i in range(10)] + [(0, 10, 0, 0.12), (11, 3, 0, 0.12)]
+    ctx.align_set_pool(seqs)
+    monkeypatch.setenv("IOC_ALIGN_CORRIDOR", "0")
+    ref = ctx.align_pairs(pairs, 11)
+    monkeypatch.delenv("IOC_ALIGN_CORRIDOR")
+    monkeypatch.setenv("IOC_ALIGN_CK_BUDGET_MB", "12")
+    got = ctx.align_pairs(pairs, 11)
+    assert ctx.timings()["align_slices"] > 1
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
