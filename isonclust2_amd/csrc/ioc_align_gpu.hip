@@ -1830,6 +1830,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     // 69.2; 17 of 1024: worse again).  A small one (a merge aligns a few hundred representatives) is bound by ONE couple's
     // critical path, (bands + strips - 1) tiles of rows / (4 bands) + 63 steps: more, shorter bands shorten it as long as the
     // waves the chip holds outnumber the tiles in flight.
+    uint32_t few_limit = 128;  // couples in a launch up to which its tiles wait for rows instead of tiles (IOC_ALIGN_V2_FEW; 0: never)
+    if (const char* e = getenv("IOC_ALIGN_V2_FEW")) few_limit = uint32_t(std::max(0, atoi(e)));
     uint32_t want_bands = 12;
     {
         int occ0 = 3;
@@ -1837,6 +1839,10 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         (void)hipGetLastError();
         const uint32_t waves = uint32_t(occ0) * uint32_t(n_cu) * uint32_t(V2_WAVES);
         want_bands = std::max(12u, std::min(uint32_t(V2_MAX_BANDS), (waves + ncouples - 1u) / std::max(1u, ncouples)));
+        // (with tiles that follow their left neighbours row by row — v2_wait_rows — a strip starts ~120 steps after the one on its
+        // left whatever the band's height: fewer, taller bands win again.  A second round of 31 couples of 16.7 kb: 33 bands of 512
+        // rows 16.6 ms, 17 of 1024 rows 14.9, 11 of 1536 rows 16.2; without: 16.9 / 19.4 / 23.5)
+        if (few_limit && ncouples <= few_limit) want_bands = std::min(want_bands, 17u);
     }
     if (const char* e = getenv("IOC_ALIGN_V2_BANDS")) want_bands = uint32_t(std::max(1, std::min(64, atoi(e))));
     std::vector<V2Couple> cps(ncouples);
@@ -2077,8 +2083,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     if ((r = reserve(c, c->a_lrow, (size_t(lrow_total) + best_total + 16) * sizeof(int2))) != IOC_OK) return r;
     int2* d_lrow = static_cast<int2*>(c->a_lrow.p);
     int2* d_best = d_lrow + lrow_total;
-    // [queue][err][pad ...][flags][ovf per pair]
-    const size_t ctl_words = ((16 + size_t(max_flags) + np + 1) & ~size_t(1)) + 2;  // (... and, 8-byte aligned, the count of computed cells)
+    // [queue][err][pad ...][flags][rows of a tile's right edge that are out (v2_wait_rows)][ovf per pair][computed cells, 8-byte aligned]
+    const size_t ctl_words = ((16 + 2 * size_t(max_flags) + np + 1) & ~size_t(1)) + 2;
     if ((r = reserve(c, c->a_xflags, ctl_words * 4)) != IOC_OK) return r;
     uint32_t* d_ctl = static_cast<uint32_t*>(c->a_xflags.p);
     // the traceback in two launches: walks that need more than `deadline` blocks go on in the second one, with helper waves
@@ -2130,6 +2136,8 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     for (size_t si = 0; si < slices.size() && !bad; ++si) {
         const uint32_t first_pair = 2u * slices[si].first, n_pairs = std::min(cnt, 2u * (slices[si].first + slices[si].second)) - first_pair;
         const uint32_t n_items = uint32_t(items[si].size());
+        // (few couples: bound by ONE grid's critical path — tiles follow their left neighbours row by row, v2_wait_rows)
+        const bool few_couples = slices[si].second <= few_limit;
         ACHK(c, hipMemcpyAsync(d_items, items[si].data(), size_t(n_items) * sizeof(V2Item), hipMemcpyHostToDevice, s));
         ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
         ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
@@ -2146,7 +2154,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             const uint32_t n_wg0 = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_probe[si] + V2_WAVES - 1) / V2_WAVES));
             hipLaunchKernelGGL(k_fwd2, dim3(n_wg0), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_probe[si],
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2));
+                               d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), few_couples ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr));
             ACHK(c, hipGetLastError());
             hipLaunchKernelGGL(k_fwd2_probe, dim3(slices[si].second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first, d_pend,
                                static_cast<const uint32_t*>(c->a_ck.p), P, float(corridor_frac));
@@ -2157,10 +2165,10 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_main + V2_WAVES - 1) / V2_WAVES));
         hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items + n_probe[si], n_main,
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                               d_best, d_ctl + 16 + max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2));
+                               d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), few_couples ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr));
         ACHK(c, hipGetLastError());
         hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
-                           d_pend, d_lrow, d_best, d_ctl + 16 + max_flags, static_cast<int4*>(c->a_ends2.p), d_resume, d_early, route ? int(P.match) : 0,
+                           d_pend, d_lrow, d_best, d_ctl + 16 + 2 * max_flags, static_cast<int4*>(c->a_ends2.p), d_resume, d_early, route ? int(P.match) : 0,
                            std::min<uint32_t>(n_pairs, help_wgs));
         ACHK(c, hipGetLastError());
         ACHK(c, hipEventRecord(evs[evi++], s));
