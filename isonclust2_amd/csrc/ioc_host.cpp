@@ -662,9 +662,56 @@ static int run_pipeline(ioc_ctx* c, const std::vector<uint8_t>& gated, const std
             cur.push_back(std::move(ties));
             if (ad.host_only && v_t[size_t(i)] == INT32_MIN) break;  // host aligner: no speculation beyond the first
         }
+        // Speculation: a tie that is itself a query waiting for its verdict in THIS round stops being a representative if one of its
+        // own ties aligns — and the query's tie set then falls back, usually to that very cluster (a read whose closest earlier read
+        // is another read of its transcript that is about to join the transcript's cluster).  Such pairs used to make a second
+        // alignment round of a few dozen pairs, which costs as much as its longest alignment's critical path (~17 ms for 16.7 kb
+        // reads) whatever its size; aligned now, in the batch that runs anyway, they are in the driver's cache when the next
+        // resolve asks for them.  Results only ever come out of the cache under the exact (query, tie key) they were aligned for.
+        size_t n_spec = 0;
+        if (!ad.host_only && !bad.empty() && !(getenv("IOC_ALIGN_SPECULATE") && atoi(getenv("IOC_ALIGN_SPECULATE")) == 0)) {
+            std::unordered_map<int, size_t> waiting;
+            for (size_t b = 0; b < bad.size(); ++b) waiting[bad[b]] = b;
+            const size_t asked = want.size();
+            // (only where both steps look like reads of one transcript — their cuts, the top counts of shared minimizers, are not far
+            // below the round's median: a chance candidate of a chance candidate is nobody's fallback)
+            int64_t med = 0;
+            if (ad.cuts) {
+                std::vector<int32_t> hp;
+                for (int q : bad)
+                    if (ad.cuts[q] > 0 && ad.cuts[q] < INT32_MAX) hp.push_back(ad.cuts[q]);
+                if (!hp.empty()) {
+                    std::nth_element(hp.begin(), hp.begin() + long(hp.size() / 2), hp.end());
+                    med = hp[hp.size() / 2];
+                }
+            }
+            auto alike = [&](int q) { return ad.cuts && ad.cuts[q] > 0 && ad.cuts[q] < INT32_MAX && int64_t(ad.cuts[q]) * 4 >= med; };
+            for (size_t b = 0; b < bad.size() && n_spec * 4 < asked + 64; ++b)
+                for (uint32_t t : cur[b]) {
+                    const int32_t target = int32_t(t >> 1);
+                    if (target < c->L || !alike(bad[b])) continue;
+                    auto it = waiting.find(target - c->L);
+                    if (it == waiting.end() || !alike(target - c->L)) continue;
+                    for (uint32_t t2 : cur[it->second]) {
+                        want.emplace_back(bad[b], (t2 & ~1u) | ((t ^ t2) & 1u));  // (the strands compose)
+                        ++n_spec;
+                    }
+                }
+        }
+        if (getenv("IOC_DEBUG_ROUND2") && round > 0) {
+            for (size_t b = 0; b < bad.size() && b < 12; ++b) {
+                const int i = bad[b];
+                fprintf(stderr, "[round %d] query %d: verdict so far %d, old ties [", round, i, v_t[size_t(i)]);
+                for (uint32_t t : v_ties[size_t(i)]) fprintf(stderr, " %u%s(v %d)", t >> 1, (t & 1) ? "-" : "+", int32_t(t >> 1) >= c->L ? v_t[size_t(int32_t(t >> 1) - c->L)] : -9);
+                fprintf(stderr, " ] new ties [");
+                for (uint32_t t : cur[b]) fprintf(stderr, " %u%s", t >> 1, (t & 1) ? "-" : "+");
+                fprintf(stderr, " ] order_dep %d\n", int(order_dep[size_t(i)]));
+            }
+        }
         tr.mark("tie sets");
         if (bad.empty()) break;
         aln_rounds++;
+        if (getenv("IOC_TRACE") && n_spec) fprintf(stderr, "[ioc] alignment round %d: %zu pairs asked for, %zu more on speculation\n", aln_rounds, want.size() - n_spec, n_spec);
         if ((r = ad.ensure(want)) != IOC_OK) return r;
         tr.mark("alignment batch");
         bool changed = false;
