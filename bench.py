@@ -160,12 +160,17 @@ def core_region(ctx, api, pipeline, sb, k, w, mode, runs):
             "d2h_bytes": int(sum(a.nbytes for a in cb.mindb) + 5 * len(sb.read_ids))}, cb
 
 
-def cli_region(rs, mode, runs=3):
-    """SURVEY §8(d) *cli*: the whole `isONclust2-hip cluster -l batch.cer -o out.cer -x mode` process."""
+def cli_region(rs, modes, runs=3):
+    """SURVEY §8(d) *cli*: the whole `isONclust2-hip cluster -l batch.cer -o out.cer -x mode` process, `runs` processes back to
+    back per mode — `one_shot`: the job runs in the process the caller started (ISONCLUST2_SERVE=0: runtime start, first-use
+    costs and the driver taking the context back are part of every call); `served`: the command's default, the job is handed to
+    the resident worker that the first `cluster` of a pipeline starts (csrc/cli/main.cpp "serve"; its first call is reported
+    apart).  A fresh output path per run, as a pipeline's are."""
     cli = os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
     if not os.path.exists(cli):
         return None
     d = tempfile.mkdtemp(prefix="ioc_bench_")
+    keys = ("process_wall_ms", "cli_ms", "core_ms", "load_ms", "ctx_ms", "bookkeeping_ms", "save_ms", "before_main_ms", "after_exit_ms")
     try:
         fq = os.path.join(d, "reads.fq")
         with open(fq, "wb") as f:
@@ -177,25 +182,44 @@ def cli_region(rs, mode, runs=3):
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         t_sort = time.perf_counter() - t
         batch = os.path.join(d, "sorted", "batches", "isONbatch_0.cer")
-        res = []
-        for _ in range(runs):
-            t = time.perf_counter()
-            r = subprocess.run([cli, "cluster", "-l", batch, "-o", os.path.join(d, "out.cer"), "-x", mode], capture_output=True,
-                               text=True, env=dict(os.environ, ISONCLUST2_STATS_JSON="1"))
-            wall = (time.perf_counter() - t) * 1e3
+        out = {"sort_process_s": t_sort, "batch_cer_MB": os.path.getsize(batch) / 1e6}
+        nr = 0
+
+        def one(mode, env):
+            nonlocal nr
+            nr += 1
+            o = os.path.join(d, f"out{nr}.cer")
+            t0, m0 = time.perf_counter(), time.monotonic() * 1e3
+            r = subprocess.run([cli, "cluster", "-l", batch, "-o", o, "-x", mode], capture_output=True, text=True, env=env)
+            wall, m1 = (time.perf_counter() - t0) * 1e3, time.monotonic() * 1e3
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
             j = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
             j["process_wall_ms"] = wall
-            res.append(j)
-        best = min(res, key=lambda j: j["process_wall_ms"])
-        out = {"process_wall_ms_min": best["process_wall_ms"], "process_wall_ms_all": [round(j["process_wall_ms"], 1) for j in res],
-               "phases_of_that_run": best, "runs": runs, "sort_process_s": t_sort, "batch_cer_MB": os.path.getsize(batch) / 1e6,
-               "phases_all_runs": [{k: round(j[k], 1) for k in ("process_wall_ms", "cli_ms", "core_ms", "load_ms", "ctx_ms", "save_ms") if k in j} for j in res]}
-        if mode != "fast":
-            out["note"] = ("a `cluster` process in an alignment mode allocates the aligner's checkpoint arena: 8 GB for this batch with "
-                           "the default aligner (version 2, coarse checkpoints); round 2's 56 GB arena made a process started right "
-                           "after another one wait ~2 s for the driver to wipe the released VRAM")
+            if "t_begin_mono_ms" in j:   # (one-shot: time before main and after _exit; served: before the worker had the job / after it answered)
+                j["before_main_ms"], j["after_exit_ms"] = j["t_begin_mono_ms"] - m0, m1 - j["t_end_mono_ms"]
+            os.unlink(o)
+            return j
+
+        for mode in modes:
+            res = {}
+            for kind, env in (("one_shot", dict(os.environ, ISONCLUST2_STATS_JSON="1", ISONCLUST2_SERVE="0")),
+                              ("served", dict(os.environ, ISONCLUST2_STATS_JSON="1", ISONCLUST2_SERVE_DIR=os.path.join(d, "srv")))):
+                first = one(mode, env) if kind == "served" else None     # (starts the worker: a pipeline pays this once)
+                rr = [one(mode, env) for _ in range(runs)]
+                bad = [j for j in rr + ([first] if first else []) if "error" in j]
+                if bad:
+                    res[kind] = bad[0]
+                    continue
+                best = min(rr, key=lambda j: j["process_wall_ms"])
+                res[kind] = {"process_wall_ms_min": best["process_wall_ms"], "process_wall_ms_all": [round(j["process_wall_ms"], 1) for j in rr],
+                             "phases_of_that_run": {k: v for k, v in best.items() if not k.startswith("t_")}, "runs": runs,
+                             "phases_all_runs": [{k: round(j[k], 1) for k in keys if k in j} for j in rr]}
+                if first:
+                    res[kind]["first_call_starting_the_worker"] = {k: round(first[k], 1) for k in keys if k in first}
+                    subprocess.run([cli, "serve", "stop"], capture_output=True, env=env)
+            # (the keys of earlier rounds' lines: the one-shot process)
+            out[mode] = dict(res.get("one_shot", {}), served=res.get("served"))
         return out
     finally:
         subprocess.call(["rm", "-rf", d])
@@ -741,11 +765,7 @@ def main():
             cpu_node = cpu_baseline_node(a.config, k, w)
         cli = None
         if world == 1 and not a.no_cli:
-            cli = {}
-            if want_sahlin:
-                cli["sahlin"] = cli_region(rs, "sahlin")
-            if want_fast:
-                cli["fast"] = cli_region(rs, "fast")
+            cli = cli_region(rs, [m for m, on in (("sahlin", want_sahlin), ("fast", want_fast)) if on])
         head, head_mode = (sah, "sahlin") if sah is not None else (fast, "fast")
         out = {
             "metric": f"reads/s clustered ({head_mode} mode, k=11 w=15)",

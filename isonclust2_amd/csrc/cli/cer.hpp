@@ -13,25 +13,116 @@
 #define IOC_CER_HPP
 
 #include <cstdint>
+#include <cstring>
+#include <initializer_list>
 #include <memory>
+#include <ostream>
 #include <string>
 #include <utility>
 #include <vector>
 
 namespace cer {
 
-struct Minimizer {
+// (packed: a view of the archive's mapping starts at whatever offset the record has in the file, so every access must be
+// compiled as an unaligned one)
+struct __attribute__((packed)) Minimizer {
     uint32_t Min, Pos, Index;
 };
 
+// The large fields of a record — bases, qualities, minimizer arrays: 150 kB per read, 460 MB per 3000-read batch — are IMMUTABLE
+// once written, so the in-memory record holds them as views: of the archive's read-only mapping (load_batch copies nothing; the
+// view keeps the mapping alive), or of a buffer of its own (records made by `sort`, consensus representatives).  A copy of a
+// record shares the bytes.  What a one-shot `cluster` process gains (profiles/r05_cli_breakdown.txt): no 460 MB of page faults on
+// load, none of the 150 kB deep copies per new representative, a writer that hands the kernel the mapped bytes (writev), and a
+// process exit that does not have to give 1.5 GB of anonymous memory back page by page.
+template <class T>
+class Span {
+    const T* p_ = nullptr;
+    size_t n_ = 0;
+    std::shared_ptr<const void> keep_;
+
+public:
+    Span() = default;
+    Span(const T* p, size_t n, std::shared_ptr<const void> keep) : p_(p), n_(n), keep_(std::move(keep)) {}
+    Span(std::vector<T>&& v) { *this = std::move(v); }
+    Span(const std::vector<T>& v) { *this = std::vector<T>(v); }
+    Span(std::initializer_list<T> l) { *this = std::vector<T>(l); }
+    Span& operator=(std::vector<T>&& v)
+    {
+        auto own = std::make_shared<std::vector<T>>(std::move(v));
+        p_ = own->data();
+        n_ = own->size();
+        keep_ = std::move(own);
+        return *this;
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    const T* data() const { return p_; }
+    T operator[](size_t i) const  // (by value through memcpy: a view of a mapped file is not aligned for T)
+    {
+        T v;
+        memcpy(&v, reinterpret_cast<const char*>(p_) + i * sizeof(T), sizeof(T));
+        return v;
+    }
+    void append_to(std::vector<T>& dst) const
+    {
+        const size_t at = dst.size();
+        dst.resize(at + n_);
+        if (n_) memcpy(static_cast<void*>(dst.data() + at), p_, n_ * sizeof(T));
+    }
+    bool operator==(const std::vector<T>& o) const { return n_ == o.size() && (n_ == 0 || memcmp(p_, o.data(), n_ * sizeof(T)) == 0); }
+    void clear()
+    {
+        p_ = nullptr;
+        n_ = 0;
+        keep_.reset();
+    }
+};
+
+class Bytes {
+    const char* p_ = "";
+    size_t n_ = 0;
+    std::shared_ptr<const void> keep_;
+
+public:
+    Bytes() = default;
+    Bytes(const char* p, size_t n, std::shared_ptr<const void> keep) : p_(p), n_(n), keep_(std::move(keep)) {}
+    Bytes(std::string&& s) { *this = std::move(s); }
+    Bytes(const std::string& s) { *this = std::string(s); }
+    Bytes(const char* z) { *this = std::string(z); }
+    Bytes& operator=(std::string&& s)
+    {
+        auto own = std::make_shared<std::string>(std::move(s));
+        p_ = own->data();
+        n_ = own->size();
+        keep_ = std::move(own);
+        return *this;
+    }
+    Bytes& assign(const char* p, size_t n) { return *this = std::string(p, n); }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    const char* data() const { return p_; }
+    const char* begin() const { return p_; }
+    const char* end() const { return p_ + n_; }
+    char operator[](size_t i) const { return p_[i]; }
+    std::string str() const { return std::string(p_, n_); }
+    bool operator==(const Bytes& o) const { return n_ == o.n_ && (n_ == 0 || memcmp(p_, o.p_, n_) == 0); }
+    bool operator==(const std::string& o) const { return n_ == o.size() && (n_ == 0 || memcmp(p_, o.data(), n_) == 0); }
+    bool operator==(const char* z) const { return n_ == strlen(z) && (n_ == 0 || memcmp(p_, z, n_) == 0); }
+    template <class U>
+    bool operator!=(const U& o) const { return !(*this == o); }
+    friend std::ostream& operator<<(std::ostream& os, const Bytes& b) { return os.write(b.p_, std::streamsize(b.n_)); }
+};
+
 struct Seq {  // src/seq.h:20-98
-    std::string name, seq, qual;
+    std::string name;
+    Bytes seq, qual;
     double score = 0, errorRate = 0;
 };
 
 struct ProcSeq {  // src/cluster_data.h:14-26
     std::unique_ptr<Seq> RawSeq, HpcSeq;
-    std::vector<Minimizer> Mins, RevMins;
+    Span<Minimizer> Mins, RevMins;
     int32_t MatchStrand = 0;
     std::string Id;
 };
@@ -50,7 +141,7 @@ struct CmdArgs {  // src/args.h:9-37
     int32_t Mode = Sahlin;
 };
 
-typedef std::vector<std::pair<uint32_t, std::vector<uint32_t>>> MinDB;  // kept sorted by key in memory
+typedef std::vector<std::pair<uint32_t, Span<uint32_t>>> MinDB;  // kept sorted by key in memory; posting lists are views (of the mapping, of one flat export)
 
 struct Batch {  // src/serialize.h:23-43
     int32_t BatchNr = 0;
@@ -66,6 +157,11 @@ struct Batch {  // src/serialize.h:23-43
     // written as unique_ptr flag + u64 length + the blob of ioc_poa_graph_save (empty vector entry = null pointer).
     std::vector<std::vector<uint8_t>> ConsGs;
 };
+
+// anonymous memory for the large flat host arrays, in transparent huge pages where the system grants them on madvise (a page
+// fault per 2 MB instead of per 4 KB: 29 against 90 ms for 460 MB on the MI355X hosts, tools/micro/file_write.cpp); never
+// shrinks, freed with the holder
+std::shared_ptr<void> huge_alloc(size_t bytes);
 
 bool save_batch(const Batch& b, const std::string& path, std::string& err);
 bool load_batch(Batch& b, const std::string& path, std::string& err);

@@ -6,8 +6,15 @@
 // tool exits with an error).  Host code here is I/O and bookkeeping only: FASTQ parsing, the batching
 // policy of `sort` (main.cpp:149-199), the member moves of `cluster` (cluster.cpp:177-261), the TSV /
 // FASTQ writers of `dump` (output.cpp:151-275).
+#include <dlfcn.h>
+#include <fcntl.h>
 #include <getopt.h>
+#include <poll.h>
+#include <sys/file.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/un.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -41,9 +48,17 @@ using std::string;
 static const char* VERSION = "2.4-hip-r1";
 static bool VERBOSE = false;
 
+// A served job (see "serve" below) must not take the resident process down with it: its error exits unwind to the server loop.
+struct JobExit {
+    int rc;
+};
+static bool g_served = false;
+static ioc_ctx* g_srv_ctx = nullptr;  // the resident process's context, made by its first job
+
 [[noreturn]] static void die(const string& m)
 {
     cerr << m << endl;
+    if (g_served) throw JobExit{1};
     // (no unwinding: `sort` calls this from a batch-writer thread while others still run, and the reference's own error exits
     // leave through exit(1) with nothing left to flush)
     fflush(nullptr);
@@ -185,8 +200,10 @@ static int main_sort(int argc, char** argv)
         Seq r;
         size_t sp = h.find_first_of(" \t");
         r.name = h.substr(1, sp == string::npos ? string::npos : sp - 1);
-        r.seq.swap(s);
-        r.qual.swap(q);
+        r.seq = std::move(s);
+        r.qual = std::move(q);
+        s.clear();
+        q.clear();
         reads.push_back(std::move(r));
     }
     const int n = int(reads.size());
@@ -278,9 +295,10 @@ static int main_sort(int argc, char** argv)
                 ps->HpcSeq->qual.assign(hq.data() + bo[size_t(i)], hlen[size_t(i)]);
                 ps->HpcSeq->score = r.score;
                 ps->HpcSeq->errorRate = herr[size_t(i)];
-                auto fill = [&](std::vector<Minimizer>& dst, int64_t b0, int64_t e0) {
-                    dst.resize(size_t(e0 - b0));
+                auto fill = [&](Span<Minimizer>& out, int64_t b0, int64_t e0) {
+                    std::vector<Minimizer> dst(size_t(e0 - b0));
                     for (int64_t t = b0; t < e0; ++t) dst[size_t(t - b0)] = Minimizer{mv[size_t(t)], mp[size_t(t)], uint32_t(t - b0)};
+                    out = std::move(dst);
                 };
                 fill(ps->Mins, of[size_t(i)], of[size_t(i) + 1]);
                 fill(ps->RevMins, orv[size_t(i)], orv[size_t(i) + 1]);
@@ -381,7 +399,8 @@ static int main_cluster(int argc, char** argv)
     // HIP initialisation (~80 ms) runs beside the archive load
     auto ctx_future = std::async(std::launch::async, [] {
         const auto t0 = std::chrono::steady_clock::now();
-        ioc_ctx* cc = make_ctx();
+        ioc_ctx* cc = g_srv_ctx ? g_srv_ctx : make_ctx();
+        if (g_served) g_srv_ctx = cc;
         return std::make_pair(cc, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     });
     Batch left, right;
@@ -413,6 +432,10 @@ static int main_cluster(int argc, char** argv)
         left.NrCls = 0;
         left.Db.clear();
     }
+    // An output file that exists is going to be replaced: giving its pages back (50 - 90 ms for a 460 MB file in the page cache,
+    // which O_TRUNC would spend between the last kernel and the first byte written) happens now, beside the GPU's start.  After
+    // the loads: the output may be one of the inputs, whose mapping keeps the old file alive.
+    auto unlink_old = std::async(std::launch::async, [out_path] { (void)unlink(out_path.c_str()); });
     left.SortArgs.Mode = mode;
     right.SortArgs.Mode = mode;
     if (min_cls > 0) left.SortArgs.MinClsSize = min_cls;
@@ -454,7 +477,10 @@ static int main_cluster(int argc, char** argv)
         if (ProcSeq* r = rep_of(i)) tot += int64_t(r->RevMins.size());
     }
     orv[size_t(n)] = tot;
-    std::unique_ptr<uint32_t[]> mv(new uint32_t[static_cast<size_t>(tot) + 1]), mp(new uint32_t[static_cast<size_t>(tot) + 1]);
+    // (huge pages: 191 MB of first touches on config 2's batch)
+    std::shared_ptr<void> mv_mem = huge_alloc((static_cast<size_t>(tot) + 1) * 4), mp_mem = huge_alloc((static_cast<size_t>(tot) + 1) * 4);
+    uint32_t* const mv = static_cast<uint32_t*>(mv_mem.get());
+    uint32_t* const mp = static_cast<uint32_t*>(mp_mem.get());
     // AoS (Min, Pos, Index) -> SoA, entries spread over the host cores
     {
         const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -465,26 +491,29 @@ static int main_cluster(int argc, char** argv)
                 for (int i = int(t0); i < n; i += int(nt)) {
                     ProcSeq* r = rep_of(i);
                     if (!r) continue;
-                    uint32_t* v = mv.get() + of[size_t(i)];
-                    uint32_t* q = mp.get() + of[size_t(i)];
-                    for (size_t t = 0; t < r->Mins.size(); ++t) {
-                        if (r->Mins[t].Index != t) bad = 1;
-                        v[t] = r->Mins[t].Min;
-                        q[t] = r->Mins[t].Pos;
+                    uint32_t* v = mv + of[size_t(i)];
+                    uint32_t* q = mp + of[size_t(i)];
+                    const Minimizer* m = r->Mins.data();  // (packed: read where the archive has them)
+                    unsigned wrong = 0;
+                    for (size_t t = 0, e = r->Mins.size(); t < e; ++t) {
+                        wrong |= m[t].Index ^ uint32_t(t);
+                        v[t] = m[t].Min;
+                        q[t] = m[t].Pos;
                     }
-                    v = mv.get() + orv[size_t(i)];
-                    q = mp.get() + orv[size_t(i)];
-                    for (size_t t = 0; t < r->RevMins.size(); ++t) {
-                        if (r->RevMins[t].Index != t) bad = 1;
-                        v[t] = r->RevMins[t].Min;
-                        q[t] = r->RevMins[t].Pos;
+                    v = mv + orv[size_t(i)];
+                    q = mp + orv[size_t(i)];
+                    m = r->RevMins.data();
+                    for (size_t t = 0, e = r->RevMins.size(); t < e; ++t) {
+                        wrong |= m[t].Index ^ uint32_t(t);
+                        v[t] = m[t].Min;
+                        q[t] = m[t].Pos;
                     }
+                    if (wrong) bad = 1;
                 }
             });
         for (auto& x : th) x.join();
         if (bad) die("Minimizer Index is not the ordinal");
     }
-    string rseq;
     for (int i = 0; i < n; ++i) {
         roff[size_t(i)] = rtot;
         ProcSeq* r = rep_of(i);
@@ -497,18 +526,28 @@ static int main_cluster(int argc, char** argv)
         score[size_t(i)] = r->RawSeq->score;
         raw_err[size_t(i)] = r->RawSeq->errorRate;
         hpc_err[size_t(i)] = r->HpcSeq->errorRate;
-        if (need_seq) {
-            rseq += r->RawSeq->seq;
-            rtot += int64_t(r->RawSeq->seq.size());
-        }
+        if (need_seq) rtot += int64_t(r->RawSeq->seq.size());
+    }
+    // the raw sequences side by side (alignment modes, consensus): one huge-page buffer, filled by a few threads
+    std::shared_ptr<void> rseq_mem = huge_alloc(size_t(rtot) + 1);
+    char* const rseq = static_cast<char*>(rseq_mem.get());
+    if (need_seq && rtot > 0) {
+        const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t0 = 0; t0 < nt; ++t0)
+            th.emplace_back([&, t0] {
+                for (int i = int(t0); i < n; i += int(nt))
+                    if (ProcSeq* r = rep_of(i)) memcpy(rseq + roff[size_t(i)], r->RawSeq->seq.data(), r->RawSeq->seq.size());
+            });
+        for (auto& x : th) x.join();
     }
     roff[size_t(n)] = rtot;
     ioc_batch_view rv{};
     rv.n = n;
     rv.off_fwd = of.data();
     rv.off_rev = orv.data();
-    rv.min_val = mv.get();
-    rv.min_pos = mp.get();
+    rv.min_val = mv;
+    rv.min_pos = mp;
     rv.total = tot;
     rv.raw_len = raw_len.data();
     rv.hpc_len = hpc_len.data();
@@ -517,7 +556,7 @@ static int main_cluster(int argc, char** argv)
     rv.hpc_err = hpc_err.data();
     rv.state = state.data();
     rv.min_qual = a.MinQual;
-    rv.raw_seq = need_seq ? rseq.data() : nullptr;
+    rv.raw_seq = need_seq ? rseq : nullptr;
     rv.raw_off = need_seq ? roff.data() : nullptr;
     rv.n_members = nmem.data();
     rv.depth = right.Depth;
@@ -535,14 +574,14 @@ static int main_cluster(int argc, char** argv)
         l_hpc_err[size_t(i)] = cl->at(0)->HpcSeq->errorRate;
         l_raw_err[size_t(i)] = cl->at(0)->RawSeq->errorRate;
         l_off[size_t(i)] = int64_t(lseq.size());
-        if (need_seq) lseq += cl->at(0)->RawSeq->seq;
+        if (need_seq) lseq.append(cl->at(0)->RawSeq->seq.data(), cl->at(0)->RawSeq->seq.size());
     }
     l_off[size_t(L)] = int64_t(lseq.size());
     k_offs.push_back(0);
     for (auto& kv : left.Db) {
         if (kv.second.empty()) continue;
         keys.push_back(kv.first);
-        post.insert(post.end(), kv.second.begin(), kv.second.end());
+        kv.second.append_to(post);
         k_offs.push_back(int64_t(post.size()));
     }
     ioc_left_view lv{};
@@ -576,6 +615,13 @@ static int main_cluster(int argc, char** argv)
     };
     std::map<int32_t, RepEvent> rep_events;
     ioc_poa* poa = nullptr;
+    struct PoaGuard {  // (a served job that leaves through die() must not leave its engine behind)
+        ioc_poa*& p;
+        ~PoaGuard()
+        {
+            if (p && g_served) ioc_poa_destroy(p);
+        }
+    } poa_guard{poa};
     if (cons_on) {
         if (mode == None) die("Invalid clustering mode: 3");
         check(c, ioc_poa_create(c, 4, -8, -8, -4, -20, -1, &poa), "consensus engine");  // src/main.cpp:285-290
@@ -598,7 +644,7 @@ static int main_cluster(int argc, char** argv)
             if (size_t(i) >= left.ConsGs.size() || left.ConsGs[size_t(i)].empty()) {
                 ioc_consensus_ops seed{};
                 ioc_poa_bind(poa, &seed);
-                const string& rs0 = left.Cls[size_t(i)]->at(0)->RawSeq->seq;
+                const Bytes& rs0 = left.Cls[size_t(i)]->at(0)->RawSeq->seq;
                 seed.create(seed.user, 0, i, rs0.data(), int(rs0.size()));
             }
         ioc_consensus_ops ops{};
@@ -639,8 +685,8 @@ static int main_cluster(int argc, char** argv)
     double core_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count();
 
     // ---- bookkeeping of the loop, cluster.cpp:115-310 ----
-    // representative copies of the fresh reads that open clusters (cluster.cpp:181-199): deep copies of
-    // ~150 kB each, made on the host cores beside each other; the loop below only links them in
+    // representative copies of the fresh reads that open clusters (cluster.cpp:181-199): the large fields are immutable views
+    // (cer.hpp), so a copy shares them — only the names are new
     std::vector<std::shared_ptr<ProcSeq>> rep_copy(static_cast<size_t>(n));
     {
         std::vector<int> fresh;
@@ -651,27 +697,20 @@ static int main_cluster(int argc, char** argv)
                 new_id[size_t(i)] = next_id++;
                 if (right.Cls[size_t(i)] && right.Cls[size_t(i)]->size() == 1 && rep_of(i)) fresh.push_back(i);
             }
-        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> th;
-        for (unsigned t0 = 0; t0 < nt; ++t0)
-            th.emplace_back([&, t0] {
-                for (size_t x = t0; x < fresh.size(); x += nt) {
-                    const int i = fresh[x];
-                    ProcSeq* r = rep_of(i);
-                    auto rep = std::make_shared<ProcSeq>();
-                    rep->RawSeq.reset(new Seq(*r->RawSeq));
-                    rep->HpcSeq.reset(new Seq(*r->HpcSeq));
-                    rep->Mins = r->Mins;
-                    rep->RevMins = r->RevMins;
-                    rep->MatchStrand = r->MatchStrand;
-                    rep->Id = r->Id;
-                    const string nm = "rep_" + std::to_string(left.BatchNr) + "_" + std::to_string(new_id[size_t(i)]);
-                    rep->RawSeq->name = nm;
-                    rep->HpcSeq->name = nm;
-                    rep_copy[size_t(i)] = rep;
-                }
-            });
-        for (auto& x : th) x.join();
+        for (const int i : fresh) {
+            ProcSeq* r = rep_of(i);
+            auto rep = std::make_shared<ProcSeq>();
+            rep->RawSeq.reset(new Seq(*r->RawSeq));
+            rep->HpcSeq.reset(new Seq(*r->HpcSeq));
+            rep->Mins = r->Mins;
+            rep->RevMins = r->RevMins;
+            rep->MatchStrand = r->MatchStrand;
+            rep->Id = r->Id;
+            const string nm = "rep_" + std::to_string(left.BatchNr) + "_" + std::to_string(new_id[size_t(i)]);
+            rep->RawSeq->name = nm;
+            rep->HpcSeq->name = nm;
+            rep_copy[size_t(i)] = rep;
+        }
     }
     for (int i = 0; i < n; ++i) {
         auto& entry = right.Cls[size_t(i)];
@@ -721,13 +760,14 @@ static int main_cluster(int argc, char** argv)
     {
         int64_t nk = 0, np = 0;
         check(c, ioc_index_export(c, &nk, &np, nullptr, nullptr, nullptr), "index export");
-        std::vector<uint32_t> ek(static_cast<size_t>(nk) + 1), ep(static_cast<size_t>(np) + 1);
+        std::vector<uint32_t> ek(static_cast<size_t>(nk) + 1);
+        auto ep = std::make_shared<std::vector<uint32_t>>(static_cast<size_t>(np) + 1);  // one flat array; the lists are views of it
         std::vector<int64_t> eo(static_cast<size_t>(nk) + 2);
-        check(c, ioc_index_export(c, &nk, &np, ek.data(), eo.data(), ep.data()), "index export");
+        check(c, ioc_index_export(c, &nk, &np, ek.data(), eo.data(), ep->data()), "index export");
         left.Db.clear();
         left.Db.reserve(size_t(nk));
         for (int64_t i = 0; i < nk; ++i)
-            left.Db.emplace_back(ek[size_t(i)], std::vector<uint32_t>(ep.begin() + eo[size_t(i)], ep.begin() + eo[size_t(i) + 1]));
+            left.Db.emplace_back(ek[size_t(i)], Span<uint32_t>(ep->data() + eo[size_t(i)], size_t(eo[size_t(i) + 1] - eo[size_t(i)]), ep));
     }
     if (VERBOSE) {
         cerr << "Finished clustering!" << endl;
@@ -779,6 +819,7 @@ static int main_cluster(int argc, char** argv)
         if (VERBOSE) cerr << "Consensus invocation count: " << st.n_cons_invoked << endl;
     }
     const double book_ms = ms_since(t_core) - core_ms;
+    unlink_old.wait();
     auto t_save = std::chrono::steady_clock::now();
     if (!save_batch(left, out_path, err)) die(err);
     const double save_ms = ms_since(t_save);
@@ -787,11 +828,16 @@ static int main_cluster(int argc, char** argv)
     if (getenv("ISONCLUST2_STATS_JSON"))
         fprintf(stderr,
                 "{\"entries\": %d, \"clusters\": %lld, \"core_ms\": %.3f, \"cli_ms\": %.3f, \"resolve_sweeps\": %d, "
-                "\"load_ms\": %.3f, \"flatten_ms\": %.3f, \"ctx_ms\": %.3f, \"bookkeeping_ms\": %.3f, \"save_ms\": %.3f}\n",
-                n, (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters, load_ms, flatten_ms, ctx_ms, book_ms, save_ms);
-    if (poa && getenv("IOC_TRACE")) ioc_poa_destroy(poa);  // (prints the engine's counters)
-    // the output is on disk: leave without unwinding a gigabyte of host structures and the HIP runtime
+                "\"load_ms\": %.3f, \"flatten_ms\": %.3f, \"ctx_ms\": %.3f, \"bookkeeping_ms\": %.3f, \"save_ms\": %.3f, "
+                "\"t_begin_mono_ms\": %.3f, \"t_end_mono_ms\": %.3f}\n",
+                n, (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters, load_ms, flatten_ms, ctx_ms, book_ms, save_ms,
+                // (CLOCK_MONOTONIC, the clock of Python's time.monotonic(): a harness can tell the time before main and after _exit)
+                std::chrono::duration<double, std::milli>(t_begin.time_since_epoch()).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());
+    if (poa && !g_served && getenv("IOC_TRACE")) ioc_poa_destroy(poa);  // (prints the engine's counters)
     fflush(nullptr);
+    if (g_served) return 0;  // (the resident process keeps its context; the batch records go with this frame)
+    // the output is on disk: leave without unwinding a gigabyte of host structures and the HIP runtime
     std::cout.flush();
     cerr.flush();
     if (getenv("IOC_CLI_CLEAN_EXIT")) exit(0);  // (profilers write their results from exit handlers)
@@ -871,7 +917,7 @@ static int main_dump(int argc, char** argv)
             auto& rep = b.Cls[i]->at(0);
             if (!rep->RawSeq) die("Null pointer instead of cluster rep sequence at index: " + std::to_string(i));
             if (rep->RawSeq->score < 0) continue;
-            string seq = rep->RawSeq->seq;
+            string seq = rep->RawSeq->seq.str();
             if (rep->MatchStrand == -1) seq = revcomp(seq);
             cons << "@cluster_" << i << " origin=" << rep->RawSeq->name << ":" << rep->MatchStrand << " length=" << seq.size()
                  << " size=" << b.Cls[i]->size() - 1 << "\n" << seq << "\n+\n" << rep->RawSeq->qual << "\n";
@@ -938,7 +984,7 @@ static void make_golden_batch(Batch& g)
     auto cl = std::make_shared<Cluster>();
     auto ps = std::make_shared<ProcSeq>();
     ps->RawSeq.reset(new Seq{"n", "AC", "II", 1.5, 0.25});
-    ps->Mins = {{1, 2, 3}};
+    ps->Mins = std::vector<Minimizer>{{1, 2, 3}};
     ps->MatchStrand = 1;
     ps->Id = "i";
     cl->push_back(ps);
@@ -973,8 +1019,8 @@ static int main_selftest(int argc, char** argv)
             if (m == 0) {
                 ps->RawSeq.reset(new Seq{ps->Id, "ACGTACGT", "IIIIIIII", 7.5, 0.01});
                 ps->HpcSeq.reset(new Seq{ps->Id, "ACGT", "IIII", 7.5, 0.02});
-                ps->Mins = {{1, 0, 0}, {5, 3, 1}};
-                ps->RevMins = {{3, 6, 0}};
+                ps->Mins = std::vector<Minimizer>{{1, 0, 0}, {5, 3, 1}};
+                ps->RevMins = std::vector<Minimizer>{{3, 6, 0}};
             }
             cl->push_back(ps);
         }
@@ -1096,6 +1142,380 @@ static int main_selftest(int argc, char** argv)
     return ok ? 0 : 1;
 }
 
+// ===================================================================================================
+// serve: the resident worker behind `cluster`
+//
+// A one-shot `cluster` process on config 2's batch spends 0.2 s starting the HIP runtime (0.06 s on a quiet card: a KFD process
+// created right after another one's exit first waits for that one's teardown — the steady state of a batch-and-merge
+// pipeline), 0.04 - 0.1 s in first-use costs (code objects, first allocations) and 0.1 s leaving, for 0.03 - 0.06 s of kernels
+// (profiles/r05_cli_breakdown.txt).  So `cluster` hands its job to a worker process that stays: the first call of a pipeline
+// starts it (fork + exec of this binary, before anything here has touched the GPU), later calls find it warm.  The command line,
+// the files and the messages are the one-shot command's: the client sends its arguments, its working directory, its
+// IOC_* / ISONCLUST2_* environment and its own stdout / stderr descriptors (SCM_RIGHTS), the worker runs main_cluster there on its
+// resident context and answers with the exit code.  A worker takes one job at a time; concurrent callers each get their own
+// (slots, chosen by a file lock the caller holds for the length of its job), a worker leaves after ISONCLUST2_SERVE_IDLE_S
+// seconds (default 15) without a job.  ISONCLUST2_SERVE=0, or any failure to reach or start a worker: the job runs in this
+// process, as before.  `isONclust2-hip serve stop` ends the callers' idle workers.
+// ===================================================================================================
+namespace serve {
+
+static const uint32_t MAGIC = 0x31435349u;  // "ISC1"
+
+static string dir_path()
+{
+    const char* base = getenv("ISONCLUST2_SERVE_DIR");
+    return base ? string(base) : "/tmp/isonclust2-hip-" + std::to_string(unsigned(getuid()));
+}
+static int device()
+{
+    const char* e = getenv("ISONCLUST2_DEVICE");
+    return e ? atoi(e) : 0;
+}
+// (a worker of another build — the binary or the library rebuilt since it started — must not answer for this one: the names
+// carry a stamp of both files, the old worker idles out)
+static string build_stamp()
+{
+    static string stamp;
+    if (!stamp.empty()) return stamp;
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const char* path) {
+        struct stat sb;
+        if (stat(path, &sb) != 0) return;
+        for (unsigned long long v : {(unsigned long long)sb.st_ino, (unsigned long long)sb.st_size, (unsigned long long)sb.st_mtim.tv_sec, (unsigned long long)sb.st_mtim.tv_nsec})
+            h = (h ^ v) * 1099511628211ull;
+    };
+    mix("/proc/self/exe");
+    Dl_info di;
+    if (dladdr(reinterpret_cast<void*>(&ioc_ctx_create), &di) && di.dli_fname) mix(di.dli_fname);
+    char buf[20];
+    snprintf(buf, sizeof(buf), "%08llx", h & 0xFFFFFFFFull);
+    return stamp = buf;
+}
+static string slot_base(int slot) { return dir_path() + "/" + build_stamp() + "d" + std::to_string(device()) + "s" + std::to_string(slot); }
+
+static bool write_all(int fd, const void* p, size_t n)
+{
+    const char* c = static_cast<const char*>(p);
+    while (n) {
+        const ssize_t w = ::send(fd, c, n, MSG_NOSIGNAL);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) return false;
+        c += w;
+        n -= size_t(w);
+    }
+    return true;
+}
+static bool read_all(int fd, void* p, size_t n)
+{
+    char* c = static_cast<char*>(p);
+    while (n) {
+        const ssize_t r = ::recv(fd, c, n, 0);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;
+        c += r;
+        n -= size_t(r);
+    }
+    return true;
+}
+static void put_str(string& b, const string& s)
+{
+    const uint32_t n = uint32_t(s.size());
+    b.append(reinterpret_cast<const char*>(&n), 4);
+    b += s;
+}
+
+// ---- the worker ----
+static int worker(int slot)
+{
+    const string base = slot_base(slot), sock = base + ".sock";
+    // one worker per slot: the lock lives as long as this process
+    const int lk = open((base + ".worker").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    if (lk < 0 || flock(lk, LOCK_EX | LOCK_NB) != 0) return 0;  // (another worker has the slot)
+    const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    sockaddr_un sa{};
+    sa.sun_family = AF_UNIX;
+    if (ls < 0 || sock.size() >= sizeof(sa.sun_path)) return 1;
+    memcpy(sa.sun_path, sock.c_str(), sock.size() + 1);
+    (void)unlink(sock.c_str());
+    if (bind(ls, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0 || listen(ls, 4) != 0) return 1;
+    double idle_s = 15.0;
+    if (const char* e = getenv("ISONCLUST2_SERVE_IDLE_S")) idle_s = std::max(0.1, atof(e));
+    g_served = true;
+    std::vector<string> applied;  // environment names the last job set here
+    for (;;) {
+        pollfd pf{ls, POLLIN, 0};
+        const int pr = poll(&pf, 1, int(idle_s * 1000.0));
+        if (pr < 0 && errno == EINTR) continue;
+        if (pr <= 0) break;  // idle: leave
+        const int cs = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+        if (cs < 0) continue;
+        // header + the caller's stdout / stderr
+        uint32_t hdr[2] = {0, 0};
+        int fds[2] = {-1, -1};
+        {
+            iovec io{hdr, sizeof(hdr)};
+            alignas(cmsghdr) char cbuf[CMSG_SPACE(sizeof(fds))];
+            msghdr mh{};
+            mh.msg_iov = &io;
+            mh.msg_iovlen = 1;
+            mh.msg_control = cbuf;
+            mh.msg_controllen = sizeof(cbuf);
+            ssize_t r;
+            do r = recvmsg(cs, &mh, MSG_CMSG_CLOEXEC); while (r < 0 && errno == EINTR);
+            if (r == ssize_t(sizeof(hdr)))
+                for (cmsghdr* cm = CMSG_FIRSTHDR(&mh); cm; cm = CMSG_NXTHDR(&mh, cm))
+                    if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS && cm->cmsg_len == CMSG_LEN(sizeof(fds))) memcpy(fds, CMSG_DATA(cm), sizeof(fds));
+        }
+        bool quit = false;
+        int rc = 1;
+        if (hdr[0] == MAGIC && hdr[1] == 0xFFFFFFFFu) {
+            quit = true;
+            rc = 0;
+        } else if (hdr[0] == MAGIC && hdr[1] <= (64u << 20) && fds[0] >= 0 && fds[1] >= 0) {
+            string body(hdr[1], '\0');
+            if (read_all(cs, &body[0], body.size())) {
+                std::vector<string> args, env;
+                size_t at = 0;
+                auto get = [&](std::vector<string>& dst) {
+                    uint32_t cnt = 0;
+                    if (at + 4 > body.size()) return false;
+                    memcpy(&cnt, body.data() + at, 4);
+                    at += 4;
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        uint32_t n = 0;
+                        if (at + 4 > body.size()) return false;
+                        memcpy(&n, body.data() + at, 4);
+                        at += 4;
+                        if (at + n > body.size()) return false;
+                        dst.emplace_back(body.data() + at, n);
+                        at += n;
+                    }
+                    return true;
+                };
+                uint32_t ncwd = 0;
+                if (get(args) && get(env) && at + 4 <= body.size() && (memcpy(&ncwd, body.data() + at, 4), at + 4 + ncwd <= body.size()) &&
+                    chdir(string(body.data() + at + 4, ncwd).c_str()) == 0) {
+                    for (auto& nm : applied) unsetenv(nm.c_str());
+                    applied.clear();
+                    for (auto& kv : env) {
+                        const size_t eq = kv.find('=');
+                        if (eq == string::npos) continue;
+                        setenv(kv.substr(0, eq).c_str(), kv.c_str() + eq + 1, 1);
+                        applied.push_back(kv.substr(0, eq));
+                    }
+                    // the job writes where its caller would have
+                    fflush(nullptr);
+                    const int keep1 = dup(1), keep2 = dup(2);
+                    dup2(fds[0], 1);
+                    dup2(fds[1], 2);
+                    std::vector<char*> av;
+                    for (auto& a : args) av.push_back(&a[0]);
+                    av.push_back(nullptr);
+                    optind = 0;  // (glibc: scan from the start again)
+                    VERBOSE = false;
+                    try {
+                        rc = main_cluster(int(args.size()), av.data());
+                    } catch (const JobExit& e) {
+                        rc = e.rc;
+                    } catch (const std::exception& e) {
+                        std::cerr << "isONclust2-hip: " << e.what() << std::endl;
+                        rc = 1;
+                    }
+                    std::cout.flush();
+                    std::cerr.flush();
+                    fflush(nullptr);
+                    dup2(keep1, 1);
+                    dup2(keep2, 2);
+                    close(keep1);
+                    close(keep2);
+                }
+            }
+        }
+        if (fds[0] >= 0) close(fds[0]);
+        if (fds[1] >= 0) close(fds[1]);
+        const int32_t out = rc;
+        (void)write_all(cs, &out, 4);
+        close(cs);
+        if (quit) break;
+    }
+    (void)unlink(sock.c_str());
+    close(ls);
+    fflush(nullptr);
+    _exit(0);  // (as the one-shot command: the driver takes the context back)
+}
+
+static int connect_to(const string& sock)
+{
+    const int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    sockaddr_un sa{};
+    sa.sun_family = AF_UNIX;
+    if (fd < 0 || sock.size() >= sizeof(sa.sun_path)) {
+        if (fd >= 0) close(fd);
+        return -1;
+    }
+    memcpy(sa.sun_path, sock.c_str(), sock.size() + 1);
+    if (connect(fd, reinterpret_cast<sockaddr*>(&sa), sizeof(sa)) != 0) {
+        close(fd);
+        return -1;
+    }
+    return fd;
+}
+
+static bool worker_alive(const string& base)
+{
+    const int lk = open((base + ".worker").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    if (lk < 0) return false;
+    const bool alive = flock(lk, LOCK_EX | LOCK_NB) != 0;
+    close(lk);  // (if we got the lock this gives it back)
+    return alive;
+}
+
+static bool spawn_worker(int slot)
+{
+    char exe[4096];
+    const ssize_t n = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+    if (n <= 0) return false;
+    exe[n] = 0;
+    const pid_t pid = fork();  // (nothing in this process has touched the GPU: the HIP runtime starts lazily)
+    if (pid < 0) return false;
+    if (pid == 0) {
+        if (fork() != 0) _exit(0);  // the worker is nobody's child
+        setsid();
+        const int dn = open("/dev/null", O_RDWR);
+        const string logp = slot_base(slot) + ".log";
+        const int lg = getenv("ISONCLUST2_SERVE_LOG") ? open(logp.c_str(), O_CREAT | O_WRONLY | O_APPEND, 0600) : -1;
+        dup2(dn, 0);
+        dup2(lg >= 0 ? lg : dn, 1);
+        dup2(lg >= 0 ? lg : dn, 2);
+        for (int fd = 3; fd < 256; ++fd) close(fd);
+        const string sl = std::to_string(slot);
+        execl(exe, exe, "serve", "worker", sl.c_str(), static_cast<char*>(nullptr));
+        _exit(127);
+    }
+    int st = 0;
+    (void)waitpid(pid, &st, 0);
+    return true;
+}
+
+// Hands `cluster` (argv as main_cluster takes it) to a worker.  Returns the job's exit code, or -1 when no worker could be
+// reached before anything was sent: the caller then runs the job itself.
+static int client(int argc, char** argv)
+{
+    const char* on = getenv("ISONCLUST2_SERVE");
+    if (on && atoi(on) == 0) return -1;
+    // (the help text leaves through exit(): answered here)
+    std::vector<string> args(argv, argv + argc);
+    for (size_t i = 1; i < args.size(); ++i)
+        if (args[i] == "-h" || args[i] == "--help") return -1;
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof(cwd))) return -1;
+    const string dir = dir_path();
+    if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return -1;
+    struct stat sb;
+    if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & 077) != 0) return -1;
+    int max_slots = 5;  // (a card takes few processes at once; each resident worker keeps its buffers)
+    if (const char* e = getenv("ISONCLUST2_SERVE_SLOTS")) max_slots = std::max(1, std::min(32, atoi(e)));
+    // a slot nobody is using: the caller's lock on it lasts for the job
+    int slot = -1, lk = -1;
+    for (int pass = 0; pass < 2 && slot < 0; ++pass)
+        for (int i = 0; i < max_slots; ++i) {
+            const int fd = open((slot_base(i) + ".lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+            if (fd < 0) return -1;
+            // first pass: a free slot whose worker is warm; second pass: any free slot; failing that, wait for slot 0
+            if (flock(fd, LOCK_EX | LOCK_NB) == 0 && (pass == 1 || worker_alive(slot_base(i)))) {
+                slot = i;
+                lk = fd;
+                break;
+            }
+            close(fd);
+        }
+    if (slot < 0) {
+        lk = open((slot_base(0) + ".lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (lk < 0 || flock(lk, LOCK_EX) != 0) return -1;
+        slot = 0;
+    }
+    const string base = slot_base(slot), sock = base + ".sock";
+    int cs = worker_alive(base) ? connect_to(sock) : -1;
+    if (cs < 0) {
+        if (!spawn_worker(slot)) {
+            close(lk);
+            return -1;
+        }
+        for (int tries = 0; tries < 5000 && cs < 0; ++tries) {  // (the worker binds its socket before it does anything else)
+            cs = connect_to(sock);
+            if (cs < 0) usleep(1000);
+        }
+        if (cs < 0) {
+            close(lk);
+            return -1;
+        }
+    }
+    string body;
+    {
+        const uint32_t na = uint32_t(args.size());
+        body.append(reinterpret_cast<const char*>(&na), 4);
+        for (auto& a : args) put_str(body, a);
+        std::vector<string> env;
+        for (char** e = environ; e && *e; ++e)
+            if (strncmp(*e, "IOC_", 4) == 0 || strncmp(*e, "ISONCLUST2_", 11) == 0) env.emplace_back(*e);
+        const uint32_t ne = uint32_t(env.size());
+        body.append(reinterpret_cast<const char*>(&ne), 4);
+        for (auto& e : env) put_str(body, e);
+        put_str(body, cwd);  // relative paths mean what they mean to the caller
+    }
+    uint32_t hdr[2] = {MAGIC, uint32_t(body.size())};
+    int fds[2] = {1, 2};
+    iovec io{hdr, sizeof(hdr)};
+    alignas(cmsghdr) char cbuf[CMSG_SPACE(sizeof(fds))];
+    memset(cbuf, 0, sizeof(cbuf));
+    msghdr mh{};
+    mh.msg_iov = &io;
+    mh.msg_iovlen = 1;
+    mh.msg_control = cbuf;
+    mh.msg_controllen = sizeof(cbuf);
+    cmsghdr* cm = CMSG_FIRSTHDR(&mh);
+    cm->cmsg_level = SOL_SOCKET;
+    cm->cmsg_type = SCM_RIGHTS;
+    cm->cmsg_len = CMSG_LEN(sizeof(fds));
+    memcpy(CMSG_DATA(cm), fds, sizeof(fds));
+    ssize_t w;
+    do w = sendmsg(cs, &mh, MSG_NOSIGNAL); while (w < 0 && errno == EINTR);
+    if (w != ssize_t(sizeof(hdr))) {
+        close(cs);
+        close(lk);
+        return -1;
+    }
+    int32_t rc = 1;
+    if (!write_all(cs, body.data(), body.size()) || !read_all(cs, &rc, 4)) {
+        // the job was handed over and the worker is gone (a crash takes its context with it): say so, do not run it twice
+        std::cerr << "isONclust2-hip: the resident worker ended before the job did (ISONCLUST2_SERVE=0 runs the job in the calling process)" << std::endl;
+        rc = 1;
+    }
+    close(cs);
+    close(lk);
+    return rc;
+}
+
+static int stop_all()
+{
+    int stopped = 0;
+    for (int i = 0; i < 32; ++i) {
+        const string base = slot_base(i);
+        if (!worker_alive(base)) continue;
+        const int cs = connect_to(base + ".sock");
+        if (cs < 0) continue;
+        uint32_t hdr[2] = {MAGIC, 0xFFFFFFFFu};
+        int32_t rc = 0;
+        if (write_all(cs, hdr, sizeof(hdr)) && read_all(cs, &rc, 4)) ++stopped;
+        close(cs);
+        for (int t = 0; t < 2000 && worker_alive(base); ++t) usleep(1000);  // (its context is gone when this returns)
+    }
+    std::cerr << "isONclust2-hip: " << stopped << " worker(s) stopped" << std::endl;
+    return 0;
+}
+
+}  // namespace serve
+
 int main(int argc, char** argv)
 {
     if (argc < 2) {
@@ -1114,7 +1534,18 @@ int main(int argc, char** argv)
         _exit(rc);
     };
     if (cmd == "sort") return leave(main_sort(argc - 1, argv + 1));
-    if (cmd == "cluster") return leave(main_cluster(argc - 1, argv + 1));
+    if (cmd == "cluster") {
+        const int served = serve::client(argc - 1, argv + 1);
+        if (served >= 0) return served;
+        return leave(main_cluster(argc - 1, argv + 1));
+    }
+    if (cmd == "serve") {
+        const string what = argc > 2 ? argv[2] : "";
+        if (what == "worker" && argc > 3) return serve::worker(atoi(argv[3]));
+        if (what == "stop") return serve::stop_all();
+        std::cerr << "isONclust2-hip serve stop    (workers are started by `cluster` itself; ISONCLUST2_SERVE=0 turns them off)" << endl;
+        return 0;
+    }
     if (cmd == "dump") return main_dump(argc - 1, argv + 1);
     if (cmd == "info") return main_info(argc - 1, argv + 1);
     if (cmd == "selftest") return main_selftest(argc - 1, argv + 1);

@@ -29,6 +29,18 @@ def pytest_sessionstart(session):
         pass
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """`cluster` hands its jobs to resident worker processes (csrc/cli/main.cpp, "serve"): end the idle ones this session
+    started instead of leaving them on the card for their idle time."""
+    import subprocess
+    cli = os.environ.get("IOC_CLI") or os.path.join(ROOT, "isonclust2_amd", "bin", "isONclust2-hip")
+    if os.path.exists(cli):
+        try:
+            subprocess.run([cli, "serve", "stop"], capture_output=True, timeout=60)
+        except Exception:
+            pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -32,6 +32,55 @@ def test_error_paths_exit_1(tmp_path):
     assert run("version").returncode == 0
 
 
+def test_large_archive_loads_as_views(tmp_path):
+    """A batch file above the 32 MB at which the loader pre-populates its mapping on several threads (the large fields of a
+    loaded record are views of that mapping, cer.hpp): `info` must load it and the round trip through `golden`-sized fields
+    must keep every byte — here a 2 x 17 MB record written by hand in the App. B layout."""
+    import struct
+    u64 = lambda v: struct.pack("<Q", v)
+    i32 = lambda v: struct.pack("<i", v)
+    u32 = lambda v: struct.pack("<I", v)
+    f64 = lambda v: struct.pack("<d", v)
+    st = lambda b: u64(len(b)) + b
+    n = 17 << 20
+    seq, qual = (b"ACGT" * (n // 4)), bytes([33 + (i % 40) for i in range(4096)]) * (n // 4096)
+    args = (b"\x00\x00" + st(b"") + b"".join(i32(v) for v in (11, 50000, 30000, 15, 5, 50, -150, 500, 3))
+            + b"".join(f64(v) for v in (7.0, 0.65, 0.2, 0.8, 0.1)) + st(b"out") + i32(1))
+    rec = (u32(0x80000002) + b"\x01" + st(b"r0") + st(seq) + st(qual) + f64(5.0) + f64(0.05)
+           + b"\x00" + u64(2) + b"".join(u32(v) for v in (7, 1, 0, 9, 5, 1)) + u64(0) + i32(1) + st(b"r0"))
+    img = (i32(0) + u64(0) + u64(0) + u64(n) + i32(1) + i32(1) + args + st(b"") + st(b"") + i32(-1) + u64(0)
+           + u64(1) + u32(0x80000001) + u64(1) + rec + u64(0))
+    p = tmp_path / "big.cer"
+    p.write_bytes(img)
+    r = run("info", str(p))
+    assert r.returncode == 0 and "Nr clusters: 1" in r.stderr, r.stderr
+    # a truncated copy is refused, not read past its end
+    (tmp_path / "cut.cer").write_bytes(img[:len(img) // 2])
+    r = run("info", str(tmp_path / "cut.cer"))
+    assert r.returncode == 1 and "truncated or corrupt" in r.stderr
+
+
+def test_served_cluster_reports_like_the_one_shot_command(tmp_path):
+    """`cluster` goes through a resident worker (serve): the caller's stderr and exit code must be the one-shot command's.
+    Without a GPU both end in the same error; the worker survives the failed job and `serve stop` ends it."""
+    env = dict(os.environ, ISONCLUST2_SERVE_DIR=str(tmp_path / "srv"), ISONCLUST2_SERVE_IDLE_S="20")
+    g = tmp_path / "g.cer"
+    assert run("golden", str(g)).returncode == 0
+    served = [run("cluster", "-l", str(g), "-o", str(tmp_path / "o.cer"), "-x", "fast", env=env) for _ in range(2)]
+    direct = run("cluster", "-l", str(g), "-o", str(tmp_path / "o2.cer"), "-x", "fast", env=dict(env, ISONCLUST2_SERVE="0"))
+    for r in served:
+        assert r.returncode == direct.returncode
+        assert direct.stderr.strip() in r.stderr          # (the one-shot process leaves at its first error exit, whichever thread hits it)
+    # relative paths are resolved against the CALLER's directory
+    r = subprocess.run([CLI, "cluster", "-l", "nope.cer", "-o", "o.cer", "-x", "fast"], capture_output=True, text=True, cwd=str(tmp_path), env=env)
+    assert r.returncode == 1 and "Failed to load batch nope.cer" in r.stderr
+    socks = [f for f in os.listdir(tmp_path / "srv") if f.endswith(".sock")]
+    assert len(socks) == 1, socks
+    r = run("serve", "stop", env=env)
+    assert "1 worker(s) stopped" in r.stderr
+    assert not [f for f in os.listdir(tmp_path / "srv") if f.endswith(".sock")]
+
+
 def _write_fastq(rs, path):
     with open(path, "wb") as f:
         for i in range(rs.n):
@@ -185,3 +234,57 @@ def test_sort_writes_the_same_batches_whatever_the_number_of_writer_threads(tmp_
         cmp = filecmp.dircmp(kept["1"] / sub, kept["4"] / sub)
         match, mismatch, errors = filecmp.cmpfiles(kept["1"] / sub, kept["4"] / sub, cmp.common_files, shallow=False)
         assert not mismatch and not errors and len(match) == len(cmp.common_files) and not cmp.left_only and not cmp.right_only
+
+
+@pytest.mark.gpu
+def test_resident_worker_writes_the_one_shot_commands_files(tmp_path):
+    """`cluster` through the resident worker (the default) and in the calling process (ISONCLUST2_SERVE=0) must leave the same
+    bytes: single batches in all three modes, a merge, a consensus-mode batch; the caller's environment (ISONCLUST2_STATS_JSON)
+    and its -v messages arrive; three callers at once each get a worker of their own; a failed job (a missing file) leaves the
+    worker usable; `serve stop` ends them."""
+    import concurrent.futures as cf
+    import filecmp
+    rs = synth.generate(240, 20, 600, 9, 21, seed=41)
+    fq = tmp_path / "reads.fq"
+    _write_fastq(rs, fq)
+    out = tmp_path / "sorted"
+    assert run("sort", "-B", "1000000", "-M", "120", "-o", str(out), str(fq)).returncode == 0
+    assert run("sort", "-B", "1000000", "-M", "120", "-g", "3", "-c", "8", "-P", "400", "-o", str(tmp_path / "sorted_c"), str(fq)).returncode == 0
+    b0, b1 = out / "batches" / "isONbatch_0.cer", out / "batches" / "isONbatch_1.cer"
+    env = dict(os.environ, ISONCLUST2_SERVE_DIR=str(tmp_path / "srv"), ISONCLUST2_SERVE_IDLE_S="60", ISONCLUST2_STATS_JSON="1")
+    off = dict(env, ISONCLUST2_SERVE="0")
+
+    def both(name, *args):
+        a, b = tmp_path / (name + "_served.cer"), tmp_path / (name + "_direct.cer")
+        r1 = run("cluster", *args, "-o", str(a), env=env)
+        r2 = run("cluster", *args, "-o", str(b), env=off)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+        assert "core_ms" in r1.stderr and "core_ms" in r2.stderr
+        strip = lambda t: [l for l in t.splitlines() if not l.startswith("{") and "Output batch written" not in l]
+        assert strip(r1.stderr) == strip(r2.stderr)
+        assert filecmp.cmp(a, b, shallow=False), name
+        return a
+
+    for mode in ("fast", "sahlin", "furious"):
+        c0 = both("c0_" + mode, "-v", "-l", str(b0), "-x", mode)
+        c1 = both("c1_" + mode, "-l", str(b1), "-x", mode)
+        both("m_" + mode, "-l", str(c0), "-r", str(c1), "-x", mode)
+    both("cons", "-v", "-l", str(tmp_path / "sorted_c" / "batches" / "isONbatch_0.cer"), "-x", "fast")
+    # a job that fails leaves its worker in place
+    r = run("cluster", "-l", str(tmp_path / "missing.cer"), "-o", str(tmp_path / "x.cer"), "-x", "fast", env=env)
+    assert r.returncode == 1 and "Failed to load batch" in r.stderr
+    both("after_failure", "-l", str(b0), "-x", "fast")
+    # three callers at once
+    def job(i):
+        o = tmp_path / f"par{i}.cer"
+        r = run("cluster", "-l", str(b0 if i % 2 == 0 else b1), "-o", str(o), "-x", "sahlin", env=env)
+        return r.returncode, o
+    with cf.ThreadPoolExecutor(3) as ex:
+        res = list(ex.map(job, range(3)))
+    assert all(rc == 0 for rc, _ in res)
+    assert filecmp.cmp(res[0][1], tmp_path / "c0_sahlin_direct.cer", shallow=False)
+    assert filecmp.cmp(res[1][1], tmp_path / "c1_sahlin_direct.cer", shallow=False)
+    assert filecmp.cmp(res[2][1], tmp_path / "c0_sahlin_direct.cer", shallow=False)
+    r = run("serve", "stop", env=env)
+    assert "worker(s) stopped" in r.stderr and not r.stderr.startswith("isONclust2-hip: 0 ")
+    assert not [f for f in os.listdir(tmp_path / "srv") if f.endswith(".sock")]
