@@ -48,7 +48,8 @@ struct AlnPairDev {
     uint32_t pad;
     // verdict mode (ioc_align_set_verdict_threshold): the traceback may stop once the count of good windows has reached stop_at
     // (the ratio is >= the threshold whatever follows) or can no longer reach it; 0 = walk to the end
-    uint32_t stop_at, pad2;
+    uint32_t stop_at;
+    float e_sum;         // (host side only) the pair's summed error rate e1 + e2 (ioc_aln_pair::e): what the corridor is planned from
 };
 
 struct AlnParams {
@@ -1825,7 +1826,35 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     // result the corridor cannot vouch for is run again with g_no_corridor set).  0.2: a pair of one transcript scores 1.62 - 1.8
     // per base at match 2 — it passes if 2 (1 - B / len) < 1.62 — and the tile grid of a 16.7 kb pair shrinks to about half.
     double corridor_frac = g_no_corridor ? 0.0 : 0.2;
-    if (const char* e = getenv("IOC_ALIGN_CORRIDOR")) corridor_frac = g_no_corridor ? 0.0 : std::max(0.0, std::min(1.0, atof(e)));
+    bool corridor_fixed = false;  // (IOC_ALIGN_CORRIDOR: one fraction for every couple, as in round 4)
+    if (const char* e = getenv("IOC_ALIGN_CORRIDOR")) {
+        corridor_frac = g_no_corridor ? 0.0 : std::max(0.0, std::min(1.0, atof(e)));
+        corridor_fixed = true;
+    }
+    // ROUND 5: the half width PER COUPLE, from the pairs' summed error rates.  A pair of one transcript scores
+    // rho = match - e x c per base, and passes the certificate iff B / length > 1 - rho / match.  Before anything has been aligned
+    // c comes from the error model behind setGapOpen's classes — a third each of substitutions (match - mismatch lost), insertions
+    // and deletions (gap open + the match) — plus 0.02 x length; once a gap-open class has 64 related pairs behind it (this
+    // context's earlier batches: ioc_ctx::aln_fit, fed in ioc_align_pairs) the line fitted to THEM, 4.5 standard deviations down.
+    // Config 3: mean width 0.157 x length (round 4: 0.2 for everybody — set by the least similar pair of the batch).  A wrong
+    // guess costs time (the probe widens, or the pair is refuted and run again), never a result.
+    const bool fit_ok = c->aln_fit_sig[0] == P.match && c->aln_fit_sig[1] == P.mismatch && c->aln_fit_sig[2] == P.gap_extend && !getenv("IOC_ALIGN_CORRIDOR_NO_FIT");
+    auto pair_frac = [&](const AlnPairDev& d) -> double {
+        if (corridor_fixed || !(P.match > 0)) return corridor_frac;
+        const double e = double(d.e_sum);
+        if (!(e > 0.0) || !(e < 1.0)) return corridor_frac;
+        const int go = std::max(2, std::min(5, d.gap_open));
+        double rho = double(P.match) - e * (double(P.match - P.mismatch) / 3.0 + 2.0 / 3.0 * double(go + P.match)), margin = 0.02;
+        const ioc_ctx::CorridorFit& f = c->aln_fit[go - 2];
+        if (fit_ok && f.n >= 64.0 && e >= f.e_lo - 0.02 && e <= f.e_hi + 0.02) {
+            const double me = f.se / f.n, mr = f.sr / f.n, vee = f.see / f.n - me * me, ver = f.ser / f.n - me * mr, vrr = f.srr / f.n - mr * mr;
+            const double slope = vee > 1e-9 ? ver / vee : 0.0;
+            const double sd = std::sqrt(std::max(0.0, vrr - slope * ver));
+            rho = mr + slope * (e - me) - 4.5 * std::max(sd, 0.004);
+            margin = 0.003;
+        }
+        return std::max(0.03, std::min(0.45, 1.0 - rho / double(P.match) + margin));
+    };
     // Bands per couple.  A full batch (config 3: 811 couples) is bound by throughput: 11 bands of 1536 rows (66.8 ms; 7 of 2560:
     // 69.2; 17 of 1024: worse again).  A small one (a merge aligns a few hundred representatives) is bound by ONE couple's
     // critical path, (bands + strips - 1) tiles of rows / (4 bands) + 63 steps: more, shorter bands shorten it as long as the
@@ -1912,7 +1941,12 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                 cp.phi[b] = uint16_t(std::min<uint32_t>(65535u, cp.nstrips - 1u));  // (V2Item::strip is 16 bits wide)
             }
             const uint32_t strip_cols = 64u * FW_C;
-            const uint32_t B = uint32_t(corridor_frac * double(std::max(nmax, mmax)));
+            double frac = 0.0;
+            for (int h = 0; h < 2; ++h)
+                if (cp.pid[h] != 0xFFFFFFFFu) frac = std::max(frac, pair_frac(dp[cp.pid[h]]));
+            if (corridor_frac <= 0.0) frac = 0.0;
+            const uint32_t B = uint32_t(frac * double(std::max(nmax, mmax)));
+            cp.b0 = B;
             int64_t beff = INT64_MAX;
             uint32_t skipped = 0;
             uint16_t lo[V2_MAX_BANDS], hi[V2_MAX_BANDS];
@@ -2157,7 +2191,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
                                d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), few_couples ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr));
             ACHK(c, hipGetLastError());
             hipLaunchKernelGGL(k_fwd2_probe, dim3(slices[si].second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first, d_pend,
-                               static_cast<const uint32_t*>(c->a_ck.p), P, float(corridor_frac));
+                               static_cast<const uint32_t*>(c->a_ck.p), P);
             ACHK(c, hipGetLastError());
             ACHK(c, hipMemsetAsync(d_ctl, 0, 4, s));  // (the queue's counter; the flags of the probe's tiles stay)
         }
@@ -2228,6 +2262,16 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             memcpy(&t[2], &pg[10], 8);
             fprintf(stderr, "[ioc] v2 marks: waiting %.3e cycles of %.3e wave-cycles alive (%.1f %%), longest wave %.3e cycles, %u workgroups\n", double(t[0]), double(t[1]),
                     100.0 * double(t[0]) / std::max(1.0, double(t[1])), double(t[2]), n_wg);
+        }
+        if (getenv("IOC_V2_TRACE_RATES")) {  // developer aid: score per base against the summed error rate, pair by pair (the corridor's calibration)
+            std::vector<int4> he(np);
+            ACHK(c, hipMemcpy(he.data(), c->a_ends2.p, size_t(np) * sizeof(int4), hipMemcpyDeviceToHost));
+            for (uint32_t x = 0; x < n_pairs; ++x) {
+                const uint32_t pid = order[first_pair + x];
+                const AlnPairDev& d = dp[pid];
+                fprintf(stderr, "[rate] e %.5f n %u m %u score %d per_base %.5f go %d flags %d corridor %u\n", double(d.e_sum), d.n, d.m, he[pid].x,
+                        double(he[pid].x) / double(std::max(d.n, d.m)), d.gap_open, he[pid].w, cps[pend[pid].couple].corridor);
+            }
         }
         if (getenv("IOC_V2_TRACE_TIMES")) {  // developer aid: the slowest walks of the slice (k_trace2 ends when its slowest wave does)
             std::vector<uint32_t> rw(size_t(np) * V2_RESUME_WORDS);
@@ -2379,6 +2423,7 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
         d.r_off = uint32_t(c->aln_offs[size_t(a.ref)]);
         d.m = uint32_t(m);
         d.gap_open = ioc_host_gap_open(a.e);
+        d.e_sum = float(a.e);
         d.ilimit = il;
         d.rc = a.ref_revcomp ? 1u : 0u;
         d.stop_at = 0;
@@ -2408,6 +2453,18 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         return uint64_t(dp[x].n) * dp[x].m > uint64_t(dp[y].n) * dp[y].m;
     });
+    // Pairs with the same tile grid (coarse rows x strips) in the order of their summed error rates: a couple's corridor is as wide as
+    // its less similar pair needs (align_v2_run), so like goes with like.  Order only.
+    if (!getenv("IOC_ALIGN_NO_ESORT")) {
+        auto rows = [&](uint32_t x) { return uint64_t((dp[x].n + 511u) / 512u); };
+        auto cols = [&](uint32_t x) { return uint64_t((dp[x].m + 511u) / 512u); };
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const uint64_t tx = rows(x) * cols(x), ty = rows(y) * cols(y);
+            if (tx != ty) return tx > ty;  // (heaviest first, as before — by tiles)
+            if (rows(x) != rows(y)) return rows(x) > rows(y);
+            return dp[x].e_sum > dp[y].e_sum;
+        });
+    }
     // The caller's similarity hints (ioc_aln_pair::reserved, 0 = none): pairs hinted far below the batch's median — a quarter of
     // it — are taken for unrelated and sorted behind the others, so that version 2 couples them with each other: a couple with
     // an unrelated pair gets no corridor, and a pair of one transcript coupled with it pays for every tile too (config 3: 19 %
@@ -2753,6 +2810,24 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     ACHK(c, hipMemcpyAsync(hs.data(), d_score, size_t(np) * 4, hipMemcpyDeviceToHost, s));
     ACHK(c, hipMemcpyAsync(hc.data(), d_count, size_t(np) * 4, hipMemcpyDeviceToHost, s));
     ACHK(c, hipStreamSynchronize(s));
+    if (v2 && !g_no_corridor) {
+        // what the corridor model learns from this batch (ioc_ctx::aln_fit): related pairs long enough to have had a corridor
+        if (c->aln_fit_sig[0] != match || c->aln_fit_sig[1] != mismatch || c->aln_fit_sig[2] != gap_extend) {
+            for (auto& f : c->aln_fit) f = ioc_ctx::CorridorFit();
+            c->aln_fit_sig[0] = match, c->aln_fit_sig[1] = mismatch, c->aln_fit_sig[2] = gap_extend;
+        }
+        for (uint32_t x = 0; x < np; ++x) {
+            const AlnPairDev& d = dp[x];
+            const uint32_t len = std::max(d.n, d.m);
+            if (hc[x] == 0xFFFFFFFFu || len < 4096u || !(d.e_sum > 0.0f) || std::min(d.n, d.m) * 10u < len * 9u) continue;
+            const double rho = double(hs[x]) / double(len), e = double(d.e_sum);
+            if (rho * 2.0 < double(match)) continue;  // (not a pair of one transcript)
+            ioc_ctx::CorridorFit& f = c->aln_fit[std::max(2, std::min(5, d.gap_open)) - 2];
+            if (f.n >= 1e6) continue;  // (enough)
+            f.n += 1.0, f.se += e, f.sr += rho, f.see += e * e, f.ser += e * rho, f.srr += rho * rho;
+            f.e_lo = std::min(f.e_lo, e), f.e_hi = std::max(f.e_hi, e);
+        }
+    }
     std::vector<int32_t> again;  // pairs the packed kernel flagged: scores outside its 16-bit window
     std::vector<int32_t> again_full;  // pairs whose result the corridor cannot vouch for (V2Couple): every tile this time
     for (uint32_t x = 0; x < np; ++x) {

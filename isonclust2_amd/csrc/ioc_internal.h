@@ -162,6 +162,14 @@ struct ioc_ctx {
     int64_t shard_aln_pairs = 0;  // pairs THIS rank aligned in sharded alignment rounds since ioc_set_shard
     DevBuf b_shard_stage;
     double aln_verdict_thr = -1.0;  // ioc_align_set_verdict_threshold (<= 0: exact counts)
+    // The aligner's corridor model (ioc_align_gpu.hip, align_v2_run): score per base of the pairs aligned so far against their summed
+    // error rate, one straight line per gap-open class (setGapOpen: 2..5).  Decides how wide a couple's corridor is PLANNED — which
+    // tiles are computed, never what comes out (the certificate and the re-run see to that).
+    struct CorridorFit {
+        double n = 0, se = 0, sr = 0, see = 0, ser = 0, srr = 0, e_lo = 1e9, e_hi = -1e9;
+    };
+    CorridorFit aln_fit[4];
+    int32_t aln_fit_sig[3] = {0, 0, 0};  // (match, mismatch, gap_extend) the sums belong to
     uint32_t* h_pin = nullptr;     // 256 bytes of pinned host memory: the read-backs of the resolve's sweeps
     DevBuf b_bsort;                // the sorted index build's arena (ioc_build_sort.hip)
     DevBuf b_gap_bound, b_keep_q;  // k_gap_bounds' table of the current queries; the per-query compaction threshold (fast mode)
