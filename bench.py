@@ -813,7 +813,7 @@ def main():
             stuck = 1.0
     if stuck:
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)   # (the line is out; the exit code says that a leg of the merge never came back)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

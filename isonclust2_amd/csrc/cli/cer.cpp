@@ -398,7 +398,13 @@ bool load_batch(Batch& b, const std::string& path, std::string& err)
         }
         // a non-null graph must be this build's blob: the reference writes spoa's own members here, without a length
         // prefix (spoa's cereal layout is not in the reference tree) — such a file cannot be exchanged in consensus mode
-        if (n < 8 || memcmp(r.p, "IOCPOA1", 8) != 0) {
+        if (n >= 8 && memcmp(r.p, "IOCPOA1", 8) == 0) {
+            err = "Failed to load batch " + path + ": consensus graph " + std::to_string(i) +
+                  " was written by an earlier build (IOCPOA1: its edge weights and node order are not this build's; a consensus "
+                  "grown on it would be neither build's) — cluster the batch again with this build";
+            return false;
+        }
+        if (n < 8 || memcmp(r.p, "IOCPOA2", 8) != 0) {
             err = "Failed to load batch " + path + ": consensus graph " + std::to_string(i) +
                   " is not in this build's format (spoa-serialized graphs of the reference are not readable here; "
                   "files written with consensus off exchange fine)";

@@ -1136,6 +1136,16 @@ static int main_selftest(int argc, char** argv)
             cerr << "selftest: foreign graph blob not refused: " << e2 << endl;
             ok = false;
         }
+        // ... and so is a graph of the builds before the edge weights changed (IOCPOA1)
+        v.replace(v.size() - 8, 8, string("IOCPOA1\0", 8));
+        {
+            std::ofstream out(path, std::ios::binary);
+            out.write(v.data(), std::streamsize(v.size()));
+        }
+        if (load_batch(t, path, e2) || e2.find("earlier build") == string::npos) {
+            cerr << "selftest: graph blob of an earlier build not refused: " << e2 << endl;
+            ok = false;
+        }
     }
     remove(path.c_str());
     cerr << (ok ? "selftest ok" : "selftest FAILED") << endl;

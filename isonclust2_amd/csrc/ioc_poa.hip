@@ -1635,7 +1635,9 @@ int ioc_poa_graph_export(ioc_poa* p, int side, int idx, int32_t* n_nodes, int32_
 }
 
 // ---- persistence (the .cer batch files carry one graph per cluster, src/serialize.h:21,37) ----------------------
-// blob: "IOCPOA1\0" | i32 nseq | i32 n_nodes | i32 n_edges | n_nodes x (u8 base, i32 n_aligned, n_aligned x i32) |
+// blob: "IOCPOA2\0" (round 4 changed what an edge weighs — w[i - 1] + w[i], spoa's — and the order nodes are created in: a graph of
+// the "IOCPOA1" builds would take later reads' edges at twice the weight of its own and give a consensus neither build would; it is
+// refused by name) | i32 nseq | i32 n_nodes | i32 n_edges | n_nodes x (u8 base, i32 n_aligned, n_aligned x i32) |
 // n_edges x (i32 from, i32 to, i64 weight).  The layout is this build's own (spoa's cereal layout is not in the tree).
 int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t cap)
 {
@@ -1658,7 +1660,7 @@ int64_t ioc_poa_graph_save(ioc_poa* p, int side, int idx, uint8_t* out, int64_t 
         w += n;
     };
     auto put32 = [&](int32_t v) { put(&v, 4); };
-    put("IOCPOA1", 8);
+    put("IOCPOA2", 8);
     put32(G.nseq);
     put32(int32_t(G.n_nodes()));
     put32(int32_t(G.n_edges()));
@@ -1702,7 +1704,8 @@ static int parse_graph_blob(const uint8_t* in, int64_t len, PGraph& G)
     };
     char magic[8];
     get(magic, 8);
-    if (!ok || memcmp(magic, "IOCPOA1", 8) != 0) return 1;
+    if (ok && memcmp(magic, "IOCPOA1", 8) == 0) return 4;
+    if (!ok || memcmp(magic, "IOCPOA2", 8) != 0) return 1;
     G.nseq = get32();
     const int32_t nn = get32(), ne = get32();
     if (!ok || nn < 0 || ne < 0) return 2;
@@ -1738,7 +1741,10 @@ static int parse_graph_blob(const uint8_t* in, int64_t len, PGraph& G)
 }
 static int graph_blob_error(ioc_poa* p, int code)
 {
-    return ioc_fail(p->ctx, IOC_ERR_INPUT, code == 1 ? "not a graph written by this build" : code == 3 ? "graph with a cycle" : "corrupt graph");
+    return ioc_fail(p->ctx, IOC_ERR_INPUT, code == 1   ? "not a graph written by this build"
+                                           : code == 3 ? "graph with a cycle"
+                                           : code == 4 ? "consensus graph of an earlier build (IOCPOA1: other edge weights and node order); cluster the batch again with this build"
+                                                       : "corrupt graph");
 }
 
 int ioc_poa_graph_load(ioc_poa* p, int side, int idx, const uint8_t* in, int64_t len)

@@ -236,3 +236,30 @@ def test_sharded_score_and_resolve_two_ranks():
         for rec in out:
             assert rec[1], (rank, rec)
     assert all(p.exitcode == 0 for p in ps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sahlin", "fast"])
+def test_scale_command_path(mode):
+    """The command the driver's scaling run issues — `python bench.py --gpus N` — end to end with two ranks sharing this card over
+    gloo (RCCL refuses two ranks on one device): the launcher that touches no GPU, torch.distributed.run, the ranks' batches,
+    the timed region with its barrier, the merge of the ranks' representatives with its work shared out, rank 0's one JSON line.
+    (the path's first execution must not be the first 8-GPU lease.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-cli", "--no-core", "--mode", mode], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["reads_per_gpu"] == 3000 and j["config"]["identical_batches"] is False
+    assert j["golden_parity"] and all(v.startswith("every rank") for v in j["golden_parity"].values()), j["golden_parity"]
+    m = j["merge"]
+    assert "error" not in m, m
+    assert m["mode"] == mode and m["replicated"] is False, m
+    assert m["golden"]["clusters_match"] is True, m["golden"]
+    assert abs(j["value"] - 2 * 3000 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]

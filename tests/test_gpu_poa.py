@@ -356,5 +356,11 @@ def test_graphs_travel_as_blobs_one_by_one_and_many_at_once(ctx):
     assert L.ioc_poa_graph_load_many(none.h, 0, 6, ids, ptrs, lens_bad) != 0
     assert all(none.size(g) < 0 for g in range(6))
     assert L.ioc_poa_graph_load_many(none.h, 0, 0, None, None, None) == 0
+    # a graph of the builds before round 4's edge weights ("IOCPOA1") is refused by name, not grown further
+    assert bytes(blobs[0][:8]) == b"IOCPOA2\x00"
+    old = (C.c_uint8 * len(blobs[0]))(*bytes(blobs[0]))
+    old[6] = ord("1")
+    assert L.ioc_poa_graph_load(none.h, 0, 0, old, len(old)) != 0
+    assert b"earlier build" in L.ioc_last_error(ctx.h)
     for p in (src, one, many, none):
         p.close()
