@@ -384,7 +384,12 @@ int ioc_cluster_batch(ioc_ctx* ctx, const ioc_params* p, const char* table_path,
  * out_strand[i] = +1 / -1 (-1: every member's MatchStrand flips, :235-246).  left == NULL is
  * ioc_cluster_batch.  ioc_index_export afterwards returns the merged MinDB.  (The arrays of `right`
  * are read until the call returns: a large batch's reverse lists and positions are still being
- * uploaded, by a thread of the library, while the first kernels run.) */
+ * uploaded, by a thread of the library, while the first kernels run.)
+ * A right batch of more than 131 072 entries (one device pass: the all-pairs candidate tables grow with the square of the
+ * entries) runs in chunks of that many, in order, each against the left state the chunks before it left behind — the
+ * reference's one loop; the results are those of one pass.  After such a call the context's resident queries are the last
+ * chunk's (ioc_gather_records_device refuses).  No limit on a read's length: queries of more than 8192 forward minimizers
+ * are sorted in global memory instead of LDS (src/minimizer.cpp:78-123 has plain vectors). */
 int ioc_cluster_merge(ioc_ctx* ctx, const ioc_params* p, const char* table_path, const ioc_left_view* left,
                       const ioc_batch_view* right, int32_t* out_cls, int8_t* out_strand,
                       ioc_cluster_stats* stats);

@@ -180,7 +180,7 @@ void ioc_ctx_destroy(ioc_ctx* c)
                       &c->b_rows, &c->b_post, &c->b_dvals, &c->b_dcount, &c->b_dslot, &c->b_scan,
                       &c->b_cand_key, &c->b_cand_size, &c->b_cand_mapped, &c->b_cand_count, &c->b_valid0,
                       &c->b_valid1, &c->b_dec_target, &c->b_dec_strand, &c->b_flags, &c->b_forced_t,
-                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_keep_q, &c->b_bsort, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->a_prof, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
+                      &c->b_forced_s, &c->b_misc, &c->b_glim, &c->b_queue, &c->b_cut, &c->b_qinfo, &c->b_exp_cid, &c->b_exp_cnt, &c->b_exp_off, &c->b_exp_out, &c->b_exp_work, &c->b_dlong, &c->b_part, &c->b_shard_stage, &c->b_gap_bound, &c->b_keep_q, &c->b_bsort, &c->b_diag, &c->b_top_all, &c->b_pmins, &c->b_pbnd, &c->a_pool, &c->a_pairs, &c->a_order, &c->a_out, &c->a_bnd, &c->a_lrow, &c->a_ck, &c->a_cko, &c->a_ends, &c->a_ends2, &c->a_xflags, &c->a_prof, &c->b_aln_t, &c->b_aln_s, &c->b_tie_count, &c->b_tie_keys, &c->b_qhist, &c->b_qfirst, &c->b_qout, &c->b_qlist, &c->x_min, &c->x_pos, &c->x_off_fwd, &c->x_off_rev,
                       &c->x_hpc_len, &c->x_hseq, &c->x_hqual, &c->b_dist_min, &c->b_dist_pos};
     for (auto b : bufs) dev_free(*b);
     for (auto& e : c->ev)
@@ -395,6 +395,7 @@ int64_t ioc_gather_records_device(ioc_ctx* c, int32_t n_idx, const int32_t* entr
     if (!c || n_idx < 0 || (n_idx > 0 && (!entries || !off_fwd || !off_rev))) return IOC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->h_off_fwd.size() != size_t(c->n) + 1 || !c->d_min || !c->d_pos) return ioc_fail(c, IOC_ERR_STATE, "no queries on the device");
+    if (c->chunked_call) return ioc_fail(c, IOC_ERR_STATE, "the last clustering call ran its batch in chunks: only the last chunk's entries are on the device");
     {
         const int rw = ioc_wait_uploads(c, 2);
         if (rw != IOC_OK) return rw;
@@ -558,10 +559,12 @@ int ioc_index_build(ioc_ctx* c)
     const int64_t ub_entries = nfwd_total + c->n_left_post;
     if (ub_entries >= (int64_t(1) << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 index postings");
     if (uint64_t(c->L) + uint64_t(n) >= (1ull << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "too many targets");
-    if (uint32_t(n) > 131072u) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 131072 queries per call");
+    if (uint32_t(n) > 131072u) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 131072 queries per device pass (ioc_cluster_merge runs a larger batch in chunks)");
     uint32_t pmax = 1;
     while (pmax < uint32_t(c->max_fwd)) pmax <<= 1;
-    if (pmax > 32768) return ioc_fail(c, IOC_ERR_CAPACITY, "a query has more than 32768 forward minimizers");
+    // (a query of more than IOC_DISTINCT_LDS_MAX forward minimizers takes the long way round below; IOC_DISTINCT_BITONIC=1, the
+    // round-1 network kept for comparison, sorts up to 32768 in LDS)
+    if (pmax > 32768 && env_u32("IOC_DISTINCT_BITONIC", 0) == 1) return ioc_fail(c, IOC_ERR_CAPACITY, "IOC_DISTINCT_BITONIC=1: a query has more than 32768 forward minimizers");
     hipStream_t s = c->stream;
     c->tm.ms_align_fwd = c->tm.ms_align_trace = 0.f;
     c->tm.n_align_pairs = c->tm.n_align_cells = c->tm.n_align_refused = c->tm.n_align_cells_computed = 0;
@@ -640,6 +643,31 @@ int ioc_index_build(ioc_ctx* c)
         HIPCHK(c, iock_distinct(s, n, c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals), P<uint32_t>(c->b_dcount), pmax,
                                 value_bits, qk, qv, c->post16, uint32_t(c->L), sentinel, &written));
         a.pairs_done = written;
+        if (pmax > IOC_DISTINCT_LDS_MAX && env_u32("IOC_DISTINCT_BITONIC", 0) != 1) {
+            // the queries that kernel left out: sorted in global memory (ioc_sort.hip)
+            std::vector<int32_t> qid;
+            std::vector<unsigned long long> seg(1, 0ull);
+            for (int j = 0; j < n; ++j) {
+                const int64_t m = c->h_off_fwd[size_t(j) + 1] - c->h_off_fwd[size_t(j)];
+                if (m > int64_t(IOC_DISTINCT_LDS_MAX)) {
+                    qid.push_back(j);
+                    seg.push_back(seg.back() + (unsigned long long)m);
+                }
+            }
+            const size_t total = size_t(seg.back()), nl = qid.size();
+            if (total >= (size_t(1) << 31)) return ioc_fail(c, IOC_ERR_CAPACITY, "more than 2^31 forward minimizers in the batch's long queries");
+            const size_t tmpb = iock_distinct_long_temp(total, uint32_t(nl), value_bits);
+            const size_t o_seg = (nl * 4 + 255) & ~size_t(255), o_work = o_seg + (((nl + 1) * 8 + 255) & ~size_t(255)), o_tmp = o_work + ((2 * total * 4 + 255) & ~size_t(255));
+            RESERVE(c, c->b_dlong, o_tmp + tmpb);
+            uint8_t* w = P<uint8_t>(c->b_dlong);
+            HIPCHK(c, hipMemcpyAsync(w, qid.data(), nl * 4, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(w + o_seg, seg.data(), (nl + 1) * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(c, iock_distinct_long(s, uint32_t(nl), total, reinterpret_cast<const int32_t*>(w), reinterpret_cast<const unsigned long long*>(w + o_seg),
+                                         c->d_off_fwd, c->d_min, P<int64_t>(c->b_doff), P<uint32_t>(c->b_dvals), P<uint32_t>(c->b_dcount), value_bits,
+                                         reinterpret_cast<uint32_t*>(w + o_work), w + o_tmp, tmpb, written ? qk : nullptr, written ? qv : nullptr, c->post16,
+                                         uint32_t(c->L), sentinel));
+            HIPCHK(c, hipStreamSynchronize(s));  // (qid / seg are this frame's)
+        }
     }
     if (sorted_build) {
         // Everything whose size does not hang on the sort's outcome is queued BEFORE the one read-back: the table at the capacity

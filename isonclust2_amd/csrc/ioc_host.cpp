@@ -887,10 +887,116 @@ int ioc_cluster_batch(ioc_ctx* c, const ioc_params* p, const char* table_path, c
     return ioc_cluster_merge(c, p, table_path, nullptr, rb, out_cls, out_strand, stats);
 }
 
+static int cluster_merge_one(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_left_view* left,
+                             const ioc_batch_view* rb, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats);
+
+// A right batch of more entries than one device pass takes (131 072: the all-pairs candidate tables grow with the square of the
+// entries) is the reference's loop all the same (cluster.cpp:115: one entry after the other against whatever clusters exist by
+// then): the entries go through in CHUNKS, in order, each against the left state the chunks before it have left behind — the
+// MinDB exported after a chunk (ioc_index_export: AddMinimizers of every representative so far) and the representatives'
+// error rates and sequences become the next chunk's left batch, exactly what `cluster -l L -r R` does between two processes.
+// Cluster ids need no translation: a chunk numbers its new clusters from the count it was given.  IOC_MERGE_CHUNK (entries).
+static int cluster_merge_chunked(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_left_view* left, const ioc_batch_view* rb,
+                                 int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats, int32_t chunk)
+{
+    const int n = rb->n;
+    const bool seqs = p->mode == IOC_MODE_SAHLIN || p->mode == IOC_MODE_FURIOUS;
+    if (left && left->n_keys == -1 && !left->keys) return ioc_fail(c, IOC_ERR_CAPACITY, "a resident left state cannot be combined with a right batch that runs in chunks");
+    if (seqs && (!rb->raw_seq || !rb->raw_off)) return ioc_fail(c, IOC_ERR_ARG, "sahlin / furious mode needs the raw sequences");
+    // the left state as it grows: owned copies from the second chunk on
+    int32_t L = left ? left->n_clusters : 0;
+    std::vector<double> l_hpc, l_raw;
+    std::vector<uint32_t> keys, post;
+    std::vector<int64_t> offs, l_off(1, 0);
+    std::string l_seq;
+    if (L > 0) {
+        l_hpc.assign(left->cls_hpc_err, left->cls_hpc_err + L);
+        if (seqs) {
+            if (!left->rep_seq || !left->rep_off || !left->cls_raw_err) return ioc_fail(c, IOC_ERR_ARG, "sahlin / furious mode needs the left representatives' sequences");
+            l_raw.assign(left->cls_raw_err, left->cls_raw_err + L);
+            l_off.assign(left->rep_off, left->rep_off + L + 1);
+            l_seq.assign(left->rep_seq + l_off[0], size_t(l_off[size_t(L)] - l_off[0]));
+            for (auto& o : l_off) o -= left->rep_off[0];
+        }
+    }
+    ioc_cluster_stats total{};
+    ioc_left_view lv{};
+    const ioc_left_view* cur = left;
+    for (int a = 0; a < n; a += chunk) {
+        const int m = std::min<int>(chunk, n - a);
+        ioc_batch_view sub = *rb;  // (the minimizer arrays and their absolute offsets stay: a chunk is a window of the per-entry arrays)
+        sub.n = m;
+        sub.off_fwd = rb->off_fwd + a;
+        sub.off_rev = rb->off_rev + a;
+        sub.raw_len = rb->raw_len + a;
+        sub.hpc_len = rb->hpc_len + a;
+        sub.score = rb->score + a;
+        sub.raw_err = rb->raw_err + a;
+        sub.hpc_err = rb->hpc_err + a;
+        sub.state = rb->state ? rb->state + a : nullptr;
+        sub.raw_off = rb->raw_off ? rb->raw_off + a : nullptr;
+        sub.n_members = rb->n_members ? rb->n_members + a : nullptr;
+        sub.is_cluster = rb->is_cluster ? rb->is_cluster + a : nullptr;
+        ioc_cluster_stats st{};
+        int r = cluster_merge_one(c, p, table_path, cur, &sub, out_cls + a, out_strand + a, &st);
+        if (r != IOC_OK) return r;
+        total.n_joined += st.n_joined, total.n_gated += st.n_gated, total.n_tie_replays += st.n_tie_replays, total.n_aln_invoked += st.n_aln_invoked;
+        total.n_aln_pairs += st.n_aln_pairs, total.n_aln_order_dep += st.n_aln_order_dep, total.aln_rounds += st.aln_rounds;
+        total.resolve_iters = std::max(total.resolve_iters, st.resolve_iters);
+        total.n_clusters = st.n_clusters;
+        if (a + m >= n) break;
+        // ---- the next chunk's left batch ----
+        for (int i = 0; i < m; ++i)
+            if (out_cls[a + i] == L) {  // (opened a cluster: ids are handed out in entry order)
+                ++L;
+                l_hpc.push_back(rb->hpc_err[a + i]);
+                if (seqs) {
+                    l_raw.push_back(rb->raw_err[a + i]);
+                    l_seq.append(rb->raw_seq + rb->raw_off[a + i], size_t(rb->raw_off[a + i + 1] - rb->raw_off[a + i]));
+                    l_off.push_back(int64_t(l_seq.size()));
+                }
+            }
+        if (int64_t(L) != st.n_clusters) return ioc_fail(c, IOC_ERR_STATE, "chunked clustering: cluster count out of step");
+        int64_t nk = 0, np = 0;
+        if ((r = ioc_index_export(c, &nk, &np, nullptr, nullptr, nullptr)) != IOC_OK) return r;
+        keys.assign(size_t(nk) + 1, 0);
+        post.assign(size_t(np) + 1, 0);
+        offs.assign(size_t(nk) + 2, 0);
+        if ((r = ioc_index_export(c, &nk, &np, keys.data(), offs.data(), post.data())) != IOC_OK) return r;
+        lv = ioc_left_view{};
+        lv.n_clusters = L;
+        lv.cls_hpc_err = l_hpc.data();
+        lv.n_keys = nk;
+        lv.keys = keys.data();
+        lv.offs = offs.data();
+        lv.postings = post.data();
+        lv.rep_seq = seqs ? l_seq.data() : nullptr;
+        lv.rep_off = seqs ? l_off.data() : nullptr;
+        lv.cls_raw_err = seqs ? l_raw.data() : nullptr;
+        cur = L > 0 ? &lv : nullptr;
+    }
+    if (stats) *stats = total;
+    return IOC_OK;
+}
+
 int ioc_cluster_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_left_view* left,
                       const ioc_batch_view* rb, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
 {
     if (!c || !p || !table_path || !rb || !out_cls || !out_strand) return IOC_ERR_ARG;
+    int32_t chunk = 131072;
+    if (const char* e = getenv("IOC_MERGE_CHUNK")) chunk = std::max(1, std::min(131072, atoi(e)));
+    c->chunked_call = false;
+    if (rb->n > chunk && p->mode != IOC_MODE_NONE) {
+        const int r = cluster_merge_chunked(c, p, table_path, left, rb, out_cls, out_strand, stats, chunk);
+        c->chunked_call = true;  // (the context's queries are the LAST chunk's: ioc_gather_records_device says so)
+        return r;
+    }
+    return cluster_merge_one(c, p, table_path, left, rb, out_cls, out_strand, stats);
+}
+
+static int cluster_merge_one(ioc_ctx* c, const ioc_params* p, const char* table_path, const ioc_left_view* left,
+                             const ioc_batch_view* rb, int32_t* out_cls, int8_t* out_strand, ioc_cluster_stats* stats)
+{
     const int32_t L = left ? left->n_clusters : 0;
     if (L < 0) return ioc_fail(c, IOC_ERR_ARG, "negative left cluster count");
     const int n = rb->n;

@@ -82,6 +82,7 @@ struct ioc_ctx {
     // ---- scoring ----
     bool scored = false;
     DevBuf b_cand_key, b_cand_size, b_cand_mapped, b_cand_count, b_qinfo, b_part, b_diag, b_top_all, b_pmins, b_pbnd;
+    DevBuf b_dlong;  // ioc_index_build: the long queries' values gathered / sorted (iock_distinct_long)
     DevBuf b_exp_cid, b_exp_cnt, b_exp_off, b_exp_out, b_exp_work;  // ioc_index_export: final ids, per-slot counts / offsets, compact postings
     bool have_guess = false;
     int64_t cand_capacity = 0;
@@ -161,6 +162,7 @@ struct ioc_ctx {
     int shard_exchanges = 0;
     int64_t shard_aln_pairs = 0;  // pairs THIS rank aligned in sharded alignment rounds since ioc_set_shard
     DevBuf b_shard_stage;
+    bool chunked_call = false;  // the last ioc_cluster_merge ran its right batch in chunks: the resident queries are the last chunk's
     double aln_verdict_thr = -1.0;  // ioc_align_set_verdict_threshold (<= 0: exact counts)
     // The aligner's corridor model (ioc_align_gpu.hip, align_v2_run): score per base of the pairs aligned so far against their summed
     // error rate, one straight line per gap-open class (setGapOpen: 2..5).  Decides how wide a couple's corridor is PLANNED — which

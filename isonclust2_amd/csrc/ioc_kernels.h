@@ -79,6 +79,12 @@ extern "C" {
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
                          uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits, uint32_t* pk = nullptr, void* pv = nullptr,
                          int pv16 = 0, uint32_t target0 = 0, uint32_t sentinel = 0, int* pairs_written = nullptr);
+// queries of more than IOC_DISTINCT_LDS_MAX forward minimizers (k_distinct_radix skips them): ioc_sort.hip
+#define IOC_DISTINCT_LDS_MAX 8192u
+size_t iock_distinct_long_temp(size_t total, uint32_t nlong, int value_bits);
+hipError_t iock_distinct_long(hipStream_t st, uint32_t nlong, size_t total, const int32_t* d_qid, const unsigned long long* d_seg, const int64_t* off_fwd,
+                              const uint32_t* mins, const int64_t* doff, uint32_t* dvals, uint32_t* dcount, int value_bits, uint32_t* work, void* temp,
+                              size_t temp_bytes, uint32_t* pk, void* pv, int pv16, uint32_t target0, uint32_t sentinel);
 hipError_t iock_hash_insert_queries(hipStream_t st, int n, const int64_t* doff, const uint32_t* dvals,
                                     const uint32_t* dcount, uint32_t* keys, uint32_t cap, uint32_t shift,
                                     uint32_t* cnt, uint32_t* dslot, uint32_t* dpos, uint32_t* err);

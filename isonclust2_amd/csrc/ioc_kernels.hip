@@ -99,9 +99,10 @@ k_distinct_radix(int n, const int64_t* __restrict__ off_fwd, const uint32_t* __r
         if (threadIdx.x == 0) dcount[j] = 0;
         return;
     }
+    if (m > pmax) return;  // (beyond this kernel's LDS: the host sends such a query through iock_distinct_long)
     uint32_t P = IOC_BLOCK;
     while (P < m) P <<= 1;
-    if (P > pmax) P = pmax;  // host guarantees m <= pmax <= IOC_BLOCK * IOC_DR_PER
+    if (P > pmax) P = pmax;  // (pmax <= IOC_BLOCK * IOC_DR_PER)
     const uint32_t per = P / IOC_BLOCK;  // keys per thread = 64-key chunks per wave
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6));
@@ -551,8 +552,9 @@ hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const ui
     if (n <= 0) return hipSuccess;
     size_t lds = size_t(pmax) * 4;
     const bool radix = !(getenv("IOC_DISTINCT_BITONIC") && atoi(getenv("IOC_DISTINCT_BITONIC")) == 1);  // (=1: round 1's bitonic network, for comparison)
-    if (radix && pmax <= IOC_BLOCK * IOC_DR_PER && IOC_BLOCK == 256) {
-        const uint32_t pm = pmax < IOC_BLOCK ? IOC_BLOCK : pmax;
+    if (radix && IOC_BLOCK == 256) {
+        // (a batch with a query beyond IOC_BLOCK * IOC_DR_PER values: this kernel takes the others, iock_distinct_long that one)
+        const uint32_t pm = pmax < IOC_BLOCK ? IOC_BLOCK : std::min<uint32_t>(pmax, IOC_BLOCK * IOC_DR_PER);
         lds = size_t(pm) * 4;
         const int bits = value_bits < 1 ? 32 : (value_bits > 32 ? 32 : value_bits);
         if (lds > 48 * 1024) CK(hipFuncSetAttribute((const void*)k_distinct_radix, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));

@@ -200,3 +200,37 @@ def test_device_resident_records_merge_equals_the_oracle_fold(ctx, cfg, seed, nb
     assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
     assert merged.n_clusters == left_o.n_clusters()
     _same_index(merged, left_o)
+
+
+@pytest.mark.parametrize("cfg,seed,mode,chunk", [("config1", 5, "fast", "37"), ("short_dup", 5, "fast", "200"), ("config1", 6, "sahlin", "61"),
+                                                 ("short_dup", 6, "furious", "150")])
+def test_a_batch_beyond_one_device_pass_runs_in_chunks(ctx, monkeypatch, cfg, seed, mode, chunk):
+    """More entries than one device pass takes (131 072; IOC_MERGE_CHUNK forces it small here): ioc_cluster_merge runs the right
+    batch chunk by chunk, each chunk against the clusters the chunks before it left — the reference's one loop (cluster.cpp:115).
+    Single batches and a left fold whose right batches are chunked too: assignments and the exported MinDB equal the oracle's."""
+    rs = synth.generate_config(cfg, seed=seed)
+    obs, sbs = _batches(rs, 2)
+    for sb, B in zip(sbs, obs):
+        info = B.entry_info()
+        seqs = [rs.read(int(i))[0] for i in info["orig"]]
+        off = np.zeros(len(seqs) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in seqs])
+        sb.view.update(raw_seq=b"".join(seqs), raw_off=off)
+    p = api.default_params(11, 15, mode)
+    for B in obs:
+        B.cluster(mode=mode)
+    monkeypatch.setenv("IOC_MERGE_CHUNK", chunk)
+    cbs = [pipeline.cluster_single(ctx, p, sb) for sb in sbs]
+    for cb, B in zip(cbs, obs):
+        assert cb.n_clusters == B.n_clusters()
+        _same_index(cb, B)
+    obs[0].cluster(right=obs[1], mode=mode)
+    assert obs[1].n_clusters() > int(chunk) // 4
+    monkeypatch.setenv("IOC_MERGE_CHUNK", str(max(7, int(chunk) // 4)))
+    merged = pipeline.cluster_merge(ctx, p, cbs[0], cbs[1])
+    ocl, ost = obs[0].assignments(rs.n)
+    cls, strand = merged.assignments(rs.n)
+    bad = np.nonzero((cls != ocl) | (strand != ost))[0]
+    assert len(bad) == 0, (len(bad), bad[:5], cls[bad[:5]], ocl[bad[:5]])
+    assert merged.n_clusters == obs[0].n_clusters()
+    _same_index(merged, obs[0])

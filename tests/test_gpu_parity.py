@@ -124,3 +124,38 @@ def test_every_prefix_of_a_batch(ctx):
         assert np.array_equal(cls, ocl) and np.array_equal(strand, ost), m
         joins_at_end += int(m > 1 and cls[m - 1] < cls[:m].max())
     assert joins_at_end > 20
+
+
+def _concat(a, b):
+    return synth.ReadSet(seq=np.concatenate([a.seq, b.seq]), qual=np.concatenate([a.qual, b.qual]),
+                         offs=np.concatenate([a.offs, a.offs[-1] + b.offs[1:]]), transcript=np.concatenate([a.transcript, a.transcript.max() + 1 + b.transcript]),
+                         strand=np.concatenate([a.strand, b.strand]), tag=a.tag + "+" + b.tag)
+
+
+@pytest.mark.parametrize("mode", ["fast", "sahlin"])
+def test_ultra_long_read(ctx, mode):
+    """A read of 200 kb (50 000 forward minimizers: beyond every in-LDS structure of the index build) among 200 ordinary ones must
+    not stop the batch — the reference has no such limit (plain vectors, minimizer.cpp:78-123; round 4 returned IOC_ERR_CAPACITY
+    above 32 768 forward minimizers).  Fast mode: two reads of one 200 kb transcript (the second is evaluated against the first
+    one's 45 000-value set); sahlin: one (the oracle's scalar aligner would need minutes for a 200 kb x 200 kb pair).  The GPU
+    sort stage must extract the long read's minimizers like the oracle's, too."""
+    from isonclust2_amd import pipeline
+    rs = _concat(synth.generate(200, 20, 1500, 10, 21, seed=71), synth.generate(2 if mode == "fast" else 1, 1, 200000, 12, 18, seed=72))
+    B, view = oracle_sorted_batch(rs)
+    assert int(np.diff(view["off_fwd"]).max()) > 40000
+    ocl, ost, _ = oracle_entry_assignments(B, view, mode=mode)
+    v = dict(view)
+    if mode != "fast":
+        seqs = [rs.read(int(i))[0] for i in view["orig"]]
+        off = np.zeros(len(seqs) + 1, np.int64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        v.update(raw_seq=b"".join(seqs), raw_off=off)
+    cls, strand, st = ctx.cluster_batch(api.default_params(11, 15, mode), v)
+    assert np.array_equal(cls, ocl) and np.array_equal(strand, ost)
+    if mode == "fast":
+        long_entries = np.nonzero(np.diff(view["off_fwd"]) > 40000)[0]
+        assert len(long_entries) == 2 and cls[long_entries[0]] == cls[long_entries[1]]   # (the second long read joined the first)
+    sb, order = pipeline.sort_stage(ctx, rs, 11, 15)
+    assert np.array_equal(order, view["orig"])
+    for key in ("off_fwd", "off_rev", "min_val", "min_pos", "hpc_len"):
+        assert np.array_equal(np.asarray(sb.view[key]), np.asarray(view[key])), key
