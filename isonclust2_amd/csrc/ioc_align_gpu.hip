@@ -2196,7 +2196,27 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             ACHK(c, hipMemsetAsync(d_ctl, 0, 4, s));  // (the queue's counter; the flags of the probe's tiles stay)
         }
         const uint32_t n_main = n_items - n_probe[si];
-        const uint32_t n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_main + V2_WAVES - 1) / V2_WAVES));
+        // Workgroups per compute unit.  A tile waits for the tile above and the tile to its left, so a couple's grid offers only
+        // its current anti-diagonal — with the corridor 2 - 3 tiles of a 16.7 kb pair — and a tile takes 0.5 - 0.9 ms: the pass is
+        // bound by tiles in flight as much as by throughput (config 3: 37 ms for a critical path of ~18).  Waves beyond the tiles
+        // that can run sit on a tile whose neighbours are still being computed, and they sit unevenly: a SIMD with three busy
+        // waves next to one with a single busy wave and two waiting.  So: as many workgroups per CU as the list's tiles per
+        // anti-diagonal keep busy, the same number on every CU (config 3 with the corridor: 2 per CU 37.2 ms, 3 per CU 39.8,
+        // 2.25 per CU 40.6; every tile: 3 per CU 67.6, 2 per CU 72.7; a quarter of the batch: 1 per CU 22.7, 3 per CU 25.1).
+        uint32_t per_cu = uint32_t(occ);
+        {
+            uint64_t tiles = 0;
+            uint32_t diags = 1;
+            for (uint32_t k2 = slices[si].first; k2 < slices[si].first + slices[si].second; ++k2) {
+                const V2Couple& cp = cps[k2];
+                for (uint32_t b = 0; b < cp.nbands; ++b) tiles += uint32_t(cp.phi[b]) - uint32_t(cp.plo[b]) + 1u;
+                diags = std::max(diags, cp.nbands + cp.nstrips - 1u);
+            }
+            const double x = double(tiles) / double(diags) / double(uint32_t(n_cu) * uint32_t(V2_WAVES));
+            if (!few_couples) per_cu = x < 1.0 ? 1u : x < 2.75 ? std::min(2u, uint32_t(occ)) : uint32_t(occ);
+        }
+        uint32_t n_wg = std::max(1u, std::min(per_cu * uint32_t(n_cu), (n_main + V2_WAVES - 1) / V2_WAVES));
+        if (const char* e = getenv("IOC_ALIGN_V2_WGS")) n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), uint32_t(atoi(e))));  // (experiments)
         hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items + n_probe[si], n_main,
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
                                d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), few_couples ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr));

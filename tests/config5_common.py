@@ -50,3 +50,37 @@ def mindb_sha(keys, offs, post):
     for a, t in ((keys, np.uint32), (offs, np.int64), (post, np.uint32)):
         h.update(np.ascontiguousarray(a, t).tobytes())
     return h.hexdigest()[:32]
+
+
+# ---- the same branch with REAL partial-order graphs -------------------------------------------------------
+# One leaf pair and their merge at a scale the oracle's scalar POA finishes in minutes in the build container: REAL_NB batches of
+# REAL_PER reads x 2 kb over REAL_G transcripts (50 reads per cluster: every join between ConsMinSize 20 and ConsMaxSize 150 takes
+# a consensus), sahlin, the graphs = the oracle's POA (oracle/poa_oracle.cpp) on the golden's side, the product's engine
+# (ioc_poa.hip) on the test's.  Beyond the toy-graph record's digests: the consensus strings IN EVENT ORDER (cluster id + sha256
+# of the string, one entry per consensus event), and at the end every cluster's graph (letters, topological ranks, weighted
+# edges) and consensus.  spoa itself stays unpinned: this is parity with the oracle's restatement of it.
+REAL_NB, REAL_PER, REAL_G = 2, 3000, 60
+
+
+def real_reads(nb=REAL_NB, per=REAL_PER, g=REAL_G):
+    return concat_readsets([synth.generate(per, g, LEN, 10, 21, seed=2000 + c, tr_seed=TR_SEED + 1) for c in range(nb)])
+
+
+def events_sha(events):
+    """events: [(cluster id, consensus bytes)] in event order."""
+    h = hashlib.sha256()
+    for c, s in events:
+        h.update(f"{int(c)}:".encode() + hashlib.sha256(s).digest())
+    return h.hexdigest()[:32]
+
+
+def graphs_sha(store, n_clusters, side=0):
+    """Every cluster's graph and consensus at the end: store.graph(c) -> (bases, rank, edge_from, edge_to, edge_w), store.consensus(c)."""
+    hg, hc = hashlib.sha256(), hashlib.sha256()
+    for c in range(n_clusters):
+        bases, rank, ef, et, ew = store.graph(c, side)[:5]
+        hg.update(bytes(bases) + np.asarray(rank, np.int32).tobytes())
+        e = sorted(zip(np.asarray(ef).tolist(), np.asarray(et).tolist(), np.asarray(ew).tolist()))
+        hg.update(np.asarray(e, np.int64).tobytes())
+        hc.update(hashlib.sha256(store.consensus(c, side)).digest())
+    return hg.hexdigest()[:32], hc.hexdigest()[:32]

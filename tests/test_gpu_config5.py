@@ -111,3 +111,95 @@ def test_config5_tree_merge(full):
     for s in range(len(full.gold["merges"])):
         cb = full.merge(s)
     assert cb.batch_start == 0 and cb.batch_end == full.n_total - 1
+
+
+# ---- REAL partial-order graphs: the product's engine against the oracle's POA goldens -----------------------
+class PoaStore:
+    """The product's POA engine (ioc_poa.hip) as the graph store of ioc_cluster_consensus, with what the pipeline needs around
+    it: the replaced representatives' records (rep_changed: the consensus strings arrive there in event order) and the transfer of
+    graphs between engines (ioc_poa_graph_save / load: what the `.cer` files carry from a leaf to a merge)."""
+
+    def __init__(self, ctx):
+        import ctypes as C
+        from isonclust2_amd import _lib
+        from tests.test_gpu_poa import Poa
+        self.C, self.poa = C, Poa(ctx)
+        self.rep_records, self.events = [], []
+
+        def rep_changed(user, cls, rec):
+            r = rec.contents
+            take = lambda ptr, n: np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+            raw = C.string_at(r.raw_seq, r.raw_len)
+            self.events.append((int(cls), raw))
+            self.rep_records.append((int(cls), dict(raw_seq=raw, raw_len=int(r.raw_len), raw_err=float(r.raw_err), score=float(r.raw_score),
+                                                    hpc_len=int(r.hpc_len), hpc_err=float(r.hpc_err), fwd_min=take(r.fwd_min, r.n_fwd),
+                                                    fwd_pos=take(r.fwd_pos, r.n_fwd), rev_min=take(r.rev_min, r.n_rev), rev_pos=take(r.rev_pos, r.n_rev),
+                                                    entry=int(r.entry))))
+
+        self._keep = _lib.CONS_REP_CHANGED(rep_changed)
+        self.ops = self.poa.ops
+        self.ops.rep_changed = self._keep
+
+    def graph(self, c, side=0):
+        return self.poa.graph(c, side)
+
+    def consensus(self, c, side=0):
+        return self.poa.consensus(c, side)
+
+    def copy_graph_to(self, idx, other, to_side, to_idx):
+        C, L = self.C, self.poa.L
+        L.ioc_poa_graph_save.restype = C.c_int64
+        n = L.ioc_poa_graph_save(self.poa.h, 0, idx, None, C.c_int64(0))
+        assert n > 0
+        buf = (C.c_uint8 * n)()
+        assert L.ioc_poa_graph_save(self.poa.h, 0, idx, buf, C.c_int64(n)) == n
+        assert L.ioc_poa_graph_load(other.poa.h, to_side, to_idx, buf, C.c_int64(n)) == 0
+
+    def close(self):
+        self.poa.close()
+
+
+def _check_real(tag, cb, store, g, n_total):
+    acl, ast = cb.assignments(n_total)
+    gs, cs = c5.graphs_sha(store, cb.n_clusters)
+    got = {"clusters": cb.n_clusters, "assigned": int(np.count_nonzero(acl >= 0)), "fnv1a": f"{fnv1a(acl, ast):016x}",
+           "cons_invoked": int(cb.stats["n_cons_invoked"]), "aln_invoked": int(cb.stats["n_aln_invoked"]), "events": len(store.events),
+           "events_sha": c5.events_sha(store.events), "graphs_sha": gs, "consensus_sha": cs, "mindb_keys": int(len(cb.mindb[0])),
+           "mindb_postings": int(len(cb.mindb[2])), "mindb_sha": c5.mindb_sha(*cb.mindb)}
+    want = {k: g[k] for k in got}
+    assert got == want, (tag, {k: (got[k], want[k]) for k in got if got[k] != want[k]})
+
+
+@pytest.mark.parametrize("per", [200, c5.REAL_PER])
+def test_config5_real_graphs(ctx, per):
+    """Two leaves of `per` reads x 2 kb (sahlin, -c 150, ConsMinSize 20) and their merge with the product's POA engine behind the
+    consensus, against the goldens the ORACLE computed with its own scalar POA behind its hook (tools/gen_golden_config5.py
+    --real-graphs): assignments, event counts, the consensus strings in event order, every cluster's final graph (letters,
+    ranks, weighted edges) and consensus, the MinDB.  (src/consensus.cpp:34-126, src/cluster.cpp:263-309; spoa itself: unpinned.)"""
+    gold = GOLD[f"real{per}"]
+    nb = c5.REAL_NB
+    rs = c5.real_reads(nb, per)
+    p = api.default_params(c5.K, c5.W, c5.MODE)
+    srt, _ = pipeline.sort_stage(ctx, rs, c5.K, c5.W)
+    cbs, stores = [], []
+    try:
+        for b in range(nb):
+            sb = pipeline.slice_sorted(srt, b * per, (b + 1) * per, batch_nr=b)
+            store = PoaStore(ctx)
+            stores.append(store)
+            cb = pipeline.cluster_consensus_single(ctx, p, sb, CONS, store)
+            _check_real(f"leaf {b}", cb, store, gold["leaves"][b], rs.n)
+            cbs.append(cb)
+        if per == c5.REAL_PER:
+            assert gold["leaves"][0]["cons_invoked"] > 500      # the leaves really take consensus events
+        gm = PoaStore(ctx)
+        stores.append(gm)
+        for src, side in ((stores[0], 0), (stores[1], 1)):
+            for c_id in range(cbs[side].n_clusters):
+                src.copy_graph_to(c_id, gm, side, c_id)
+        merged = pipeline.cluster_consensus_merge(ctx, p, cbs[0], cbs[1], CONS, gm)
+        _check_real("merge 0+1", merged, gm, gold["merges"][0], rs.n)
+        assert gold["merges"][0]["cons_invoked"] > 20
+    finally:
+        for s in stores:
+            s.close()

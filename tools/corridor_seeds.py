@@ -9,9 +9,10 @@ import bench  # noqa: E402
 from isonclust2_amd import api, pipeline, synth  # noqa: E402
 
 first, n = int(sys.argv[1]), int(sys.argv[2])
+config = sys.argv[3] if len(sys.argv) > 3 else "config2"
 for seed in range(first, first + n):
     ctx = api.Context(0)
-    rs, sb, order = bench.prepare(ctx, api, pipeline, synth, "config2", seed, 11, 15, 0)
+    rs, sb, order = bench.prepare(ctx, api, pipeline, synth, config, seed, 11, 15, 0)
     cls, strand, st = ctx.cluster_resident()
     cls, strand, st = ctx.cluster_resident()
     tm = ctx.timings()

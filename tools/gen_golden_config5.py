@@ -26,7 +26,12 @@ from tests.helpers import ToyGraphs, fnv1a  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--per", type=int, default=c5.PER)
 ap.add_argument("--nb", type=int, default=c5.NB)
+ap.add_argument("--real-graphs", action="store_true", help="the record `real<PER>`: REAL_NB leaves + their merge with the oracle's own POA behind the consensus hook "
+                                                            "(tests/config5_common.py, VERDICT r4 item 4)")
 a = ap.parse_args()
+if a.real_graphs:
+    import subprocess
+    sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_golden_config5_real.py")] + (["--per", str(a.per)] if a.per != c5.PER else [])))
 PATH = os.path.join(ROOT, "tests", "golden", "config5.json")
 out = json.load(open(PATH)) if os.path.exists(PATH) else {}
 rec = {"workload": f"{a.nb} x {a.per} reads of {c5.LEN} b, G={c5.G}, chunk seeds 1000.., transcript seed {c5.TR_SEED}, global sort; "
