@@ -2172,6 +2172,10 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         const uint32_t n_items = uint32_t(items[si].size());
         // (few couples: bound by ONE grid's critical path — tiles follow their left neighbours row by row, v2_wait_rows)
         const bool few_couples = slices[si].second <= few_limit;
+        // (experiment: every launch lets a tile follow its left neighbour, which publishes its progress every IOC_ALIGN_V2_PROG_ALL blocks of 64 rows)
+        const uint32_t prog_all = getenv("IOC_ALIGN_V2_PROG_ALL") ? uint32_t(std::max(1, atoi(getenv("IOC_ALIGN_V2_PROG_ALL")))) : 0u;
+        const bool use_prog = few_couples || prog_all != 0;
+        const uint32_t prog_every = few_couples ? 1u : prog_all;
         ACHK(c, hipMemcpyAsync(d_items, items[si].data(), size_t(n_items) * sizeof(V2Item), hipMemcpyHostToDevice, s));
         ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
         ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
@@ -2188,7 +2192,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             const uint32_t n_wg0 = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), (n_probe[si] + V2_WAVES - 1) / V2_WAVES));
             hipLaunchKernelGGL(k_fwd2, dim3(n_wg0), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items, n_probe[si],
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                               d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), few_couples ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr));
+                               d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), use_prog ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr), prog_every);
             ACHK(c, hipGetLastError());
             hipLaunchKernelGGL(k_fwd2_probe, dim3(slices[si].second), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first, d_pend,
                                static_cast<const uint32_t*>(c->a_ck.p), P);
@@ -2217,9 +2221,11 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         }
         uint32_t n_wg = std::max(1u, std::min(per_cu * uint32_t(n_cu), (n_main + V2_WAVES - 1) / V2_WAVES));
         if (const char* e = getenv("IOC_ALIGN_V2_WGS")) n_wg = std::max(1u, std::min(uint32_t(occ) * uint32_t(n_cu), uint32_t(atoi(e))));  // (experiments)
-        hipLaunchKernelGGL(k_fwd2, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items + n_probe[si], n_main,
+        // (two workgroups per CU: the build of the kernel that may use the registers of the third)
+        auto* fwd_kernel = (per_cu <= 2 && !getenv("IOC_ALIGN_V2_NO_W2")) ? k_fwd2_w2 : k_fwd2;
+        hipLaunchKernelGGL(fwd_kernel, dim3(n_wg), dim3(64 * V2_WAVES), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_items + n_probe[si], n_main,
                                d_ctl, d_ctl + 16, d_ctl + 1, static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint32_t*>(c->a_ck.p), d_lrow,
-                               d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), few_couples ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr));
+                               d_best, d_ctl + 16 + 2 * max_flags, guard, static_cast<const uint4*>(c->a_prof.p), reinterpret_cast<unsigned long long*>(d_ctl + ctl_words - 2), use_prog ? d_ctl + 16 + max_flags : static_cast<uint32_t*>(nullptr), prog_every);
         ACHK(c, hipGetLastError());
         hipLaunchKernelGGL(k_fwd2_ends, dim3(n_pairs), dim3(64), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps, d_order + first_pair, n_pairs,
                            d_pend, d_lrow, d_best, d_ctl + 16 + 2 * max_flags, static_cast<int4*>(c->a_ends2.p), d_resume, d_early, route ? int(P.match) : 0,
