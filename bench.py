@@ -170,7 +170,7 @@ def cli_region(rs, modes, runs=3):
     if not os.path.exists(cli):
         return None
     d = tempfile.mkdtemp(prefix="ioc_bench_")
-    keys = ("process_wall_ms", "cli_ms", "core_ms", "load_ms", "ctx_ms", "bookkeeping_ms", "save_ms", "before_main_ms", "after_exit_ms")
+    keys = ("process_wall_ms", "cli_ms", "core_ms", "load_ms", "ctx_ms", "trim_ms", "bookkeeping_ms", "save_ms", "before_main_ms", "after_exit_ms")
     try:
         fq = os.path.join(d, "reads.fq")
         with open(fq, "wb") as f:
@@ -195,6 +195,9 @@ def cli_region(rs, modes, runs=3):
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
             j = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+            if os.environ.get("IOC_BENCH_CLI_TRACE"):   # (developer aid, with IOC_TRACE=1: where a child spent its time)
+                sys.stderr.write(f"--- cluster -x {mode} {'served' if env.get('ISONCLUST2_SERVE') != '0' else 'one-shot'}: wall {wall:.1f} ms\n" +
+                                 "\n".join(l for l in r.stderr.splitlines() if l.startswith("[ioc]")) + "\n")
             j["process_wall_ms"] = wall
             if "t_begin_mono_ms" in j:   # (one-shot: time before main and after _exit; served: before the worker had the job / after it answered)
                 j["before_main_ms"], j["after_exit_ms"] = j["t_begin_mono_ms"] - m0, m1 - j["t_end_mono_ms"]
@@ -218,8 +221,12 @@ def cli_region(rs, modes, runs=3):
                 if first:
                     res[kind]["first_call_starting_the_worker"] = {k: round(first[k], 1) for k in keys if k in first}
                     subprocess.run([cli, "serve", "stop"], capture_output=True, env=env)
-            # (the keys of earlier rounds' lines: the one-shot process)
-            out[mode] = dict(res.get("one_shot", {}), served=res.get("served"))
+            # `cli.<mode>` = the command as a user runs it (its default: the job goes to the resident worker), the process that
+            # does the job itself (ISONCLUST2_SERVE=0, what rounds 1 - 4 reported under these keys) beside it
+            out[mode] = dict(res.get("served", {}), how="`isONclust2-hip cluster` as installed: the calling process hands the job to the resident "
+                                                       "worker that the first call of a pipeline starts (`first_call_starting_the_worker`); "
+                                                       "`one_shot` = ISONCLUST2_SERVE=0, the job runs in the calling process",
+                             one_shot=res.get("one_shot"))
         return out
     finally:
         subprocess.call(["rm", "-rf", d])

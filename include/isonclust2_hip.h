@@ -63,6 +63,11 @@ typedef struct {
 /* ---- context -------------------------------------------------------------------------------- */
 int ioc_ctx_create(int device, ioc_ctx** out);
 void ioc_ctx_destroy(ioc_ctx* ctx);
+/* Gives the aligner's scratch (the checkpoint arena: gigabytes after an alignment-mode batch) back to the driver; the next call
+ * that needs it allocates again.  A one-shot process calls this as soon as its clustering call has returned: the driver wipes
+ * released VRAM before it hands it out again (8 GB: ~0.4 s), and a process that starts right after this one would otherwise
+ * wait for that inside its own first large hipMalloc (profiles/r05_cli_breakdown.txt). */
+int ioc_ctx_trim(ioc_ctx* ctx);
 const char* ioc_last_error(const ioc_ctx* ctx);
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
 int ioc_set_stream(ioc_ctx* ctx, void* hip_stream);

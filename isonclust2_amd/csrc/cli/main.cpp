@@ -683,6 +683,11 @@ static int main_cluster(int argc, char** argv)
               "clustering");
     }
     double core_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count();
+    // a one-shot process gives the aligner's arena back NOW, beside its own bookkeeping and writing: the driver wipes released
+    // VRAM before anybody gets it again, and the next `cluster` process of a pipeline would wait for that in its own first
+    // large allocation (0.27 ms or 400 ms for the same 8 GB hipMalloc: profiles/r05_cli_breakdown.txt)
+    if (!g_served && (mode == Sahlin || mode == Furious)) (void)ioc_ctx_trim(c);
+    const double trim_ms = ms_since(t_core) - core_ms;
 
     // ---- bookkeeping of the loop, cluster.cpp:115-310 ----
     // representative copies of the fresh reads that open clusters (cluster.cpp:181-199): the large fields are immutable views
@@ -818,7 +823,7 @@ static int main_cluster(int argc, char** argv)
         }
         if (VERBOSE) cerr << "Consensus invocation count: " << st.n_cons_invoked << endl;
     }
-    const double book_ms = ms_since(t_core) - core_ms;
+    const double book_ms = ms_since(t_core) - core_ms - trim_ms;
     unlink_old.wait();
     auto t_save = std::chrono::steady_clock::now();
     if (!save_batch(left, out_path, err)) die(err);
@@ -828,9 +833,9 @@ static int main_cluster(int argc, char** argv)
     if (getenv("ISONCLUST2_STATS_JSON"))
         fprintf(stderr,
                 "{\"entries\": %d, \"clusters\": %lld, \"core_ms\": %.3f, \"cli_ms\": %.3f, \"resolve_sweeps\": %d, "
-                "\"load_ms\": %.3f, \"flatten_ms\": %.3f, \"ctx_ms\": %.3f, \"bookkeeping_ms\": %.3f, \"save_ms\": %.3f, "
+                "\"load_ms\": %.3f, \"flatten_ms\": %.3f, \"ctx_ms\": %.3f, \"trim_ms\": %.3f, \"bookkeeping_ms\": %.3f, \"save_ms\": %.3f, "
                 "\"t_begin_mono_ms\": %.3f, \"t_end_mono_ms\": %.3f}\n",
-                n, (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters, load_ms, flatten_ms, ctx_ms, book_ms, save_ms,
+                n, (long long)st.n_clusters, core_ms, cli_ms, st.resolve_iters, load_ms, flatten_ms, ctx_ms, trim_ms, book_ms, save_ms,
                 // (CLOCK_MONOTONIC, the clock of Python's time.monotonic(): a harness can tell the time before main and after _exit)
                 std::chrono::duration<double, std::milli>(t_begin.time_since_epoch()).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count());

@@ -191,6 +191,18 @@ void ioc_ctx_destroy(ioc_ctx* c)
     delete c;
 }
 
+int ioc_ctx_trim(ioc_ctx* c)
+{
+    if (!c) return IOC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->side_stream) HIPCHK(c, hipStreamSynchronize(c->side_stream));
+    // the aligner's arenas: checkpoints (8 GB for config 3's batch), tables, profiles, traceback scratch
+    DevBuf* bufs[] = {&c->a_ck, &c->a_cko, &c->a_prof, &c->a_bnd, &c->a_lrow, &c->a_xflags, &c->a_ends, &c->a_ends2};
+    for (auto b : bufs) dev_free(*b);
+    return IOC_OK;
+}
+
 const char* ioc_last_error(const ioc_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int ioc_set_stream(ioc_ctx* c, void* s)
