@@ -2011,8 +2011,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         cp.cbase = w;
         w += up4(ncc * uint64_t(cp.nq) * 2u);
         cwords[k2] = w;
-        cp.prof = prof_total;  // (uint4 entries)
-        prof_total += uint64_t(cp.nstrips) * 2u * 5u * 64u;
+        cp.prof = 0;  // (uint4 entries; placed per slice below: the profiles of a slice's couples count against the budget with its checkpoints)
         max_strips = std::max(max_strips, cp.nstrips);
         for (int h = 0; h < 2; ++h) {
             cp.lrow0[h] = lrow_total;
@@ -2031,8 +2030,13 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     for (uint32_t first = 0; first < ncouples;) {
         uint64_t used = 0;
         uint32_t k2 = first;
-        while (k2 < ncouples && (k2 == first || (used + cwords[k2]) * 4ull <= budget)) {
+        uint64_t prof_used = 0;  // uint4 entries of query profiles in this slice (they used to be made for every couple of the call at once)
+        while (k2 < ncouples) {
+            const uint64_t prof_k = uint64_t(cps[k2].nstrips) * 2u * 5u * 64u;
+            if (k2 != first && (used + cwords[k2]) * 4ull + (prof_used + prof_k) * sizeof(uint4) > budget) break;
             V2Couple& cp = cps[k2];
+            cp.prof = prof_used;
+            prof_used += prof_k;
             cp.rdat += used;
             cp.rbase += used;
             cp.cdat += used;
@@ -2043,6 +2047,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
             ++k2;
         }
         arena_words = std::max(arena_words, used);
+        prof_total = std::max(prof_total, prof_used);
         slices.emplace_back(first, k2 - first);
         first = k2;
     }
@@ -2110,9 +2115,7 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
     ACHK(c, hipMemcpyAsync(d_pend, pend.data(), size_t(np) * sizeof(V2PairEnd), hipMemcpyHostToDevice, s));
     // the query profiles of every (couple, strip), once per batch
     if ((r = reserve(c, c->a_prof, size_t(prof_total) * sizeof(uint4) + 256)) != IOC_OK) return r;
-    hipLaunchKernelGGL(k_fwd2_prof, dim3(ncouples, max_strips), dim3(128), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps,
-                       static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint4*>(c->a_prof.p));
-    ACHK(c, hipGetLastError());
+    // (the profiles themselves are made slice by slice, in front of the slice's forward pass)
     if ((r = reserve(c, c->a_ends2, size_t(np) * sizeof(int4))) != IOC_OK) return r;
     if ((r = reserve(c, c->a_lrow, (size_t(lrow_total) + best_total + 16) * sizeof(int2))) != IOC_OK) return r;
     int2* d_lrow = static_cast<int2*>(c->a_lrow.p);
@@ -2178,6 +2181,9 @@ int align_v2_run(ioc_ctx* c, const std::vector<AlnPairDev>& dp, const uint32_t* 
         const uint32_t prog_every = few_couples ? 1u : prog_all;
         ACHK(c, hipMemcpyAsync(d_items, items[si].data(), size_t(n_items) * sizeof(V2Item), hipMemcpyHostToDevice, s));
         ACHK(c, hipMemcpyAsync(d_cps + slices[si].first, cps.data() + slices[si].first, size_t(slices[si].second) * sizeof(V2Couple), hipMemcpyHostToDevice, s));  // (flag0)
+        hipLaunchKernelGGL(k_fwd2_prof, dim3(slices[si].second, max_strips), dim3(128), 0, s, static_cast<const AlnPairDev*>(c->a_pairs.p), d_cps + slices[si].first,
+                           static_cast<const uint8_t*>(c->a_pool.p), P, static_cast<uint4*>(c->a_prof.p));
+        ACHK(c, hipGetLastError());
         ACHK(c, hipMemsetAsync(d_ctl, 0, ctl_words * 4, s));
         ACHK(c, hipMemsetAsync(d_resume, 0, resume_words * 4, s));  // (parked state and the two lists of walks; k_fwd2_ends writes into them)
         if (tiles_skipped)  // (the bests of the last row and the last column that a skipped tile does not write: far below any score)

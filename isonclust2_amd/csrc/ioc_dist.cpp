@@ -282,7 +282,9 @@ int ioc_dist_allgatherv_device(ioc_ctx* c, const void* d_send, void* d_recv, con
         ncclResult_t e = rccl()->Broadcast(r == d->rank ? d_send : dst, dst, size_t(counts[r]) * size_t(esize), ncclUint8, r, d->comm, c->stream);
         if (e != ncclSuccess) {
             (void)rccl()->GroupEnd();
-            return ioc_fail(c, IOC_ERR_HIP, std::string("RCCL: ncclBroadcast: ") + rccl()->GetErrorString(e));
+            const std::string why = std::string("RCCL: ncclBroadcast: ") + rccl()->GetErrorString(e);
+            dist_abort(d);  // (as NCK does: later calls must fail at once instead of entering collectives on a half-used communicator)
+            return ioc_fail(c, IOC_ERR_HIP, why);
         }
     }
     NCK(c, rccl()->GroupEnd());
@@ -419,117 +421,134 @@ int ioc_dist_merge(ioc_ctx* c, const ioc_params* p, const char* table_path, cons
     if (local == IOC_OK) local = reserve(c, c->b_dist_pos, size_t(FW + RW) * 4 + 256);
     if (agree(d, local) != 0)
         return local != IOC_OK ? local : ioc_fail(c, IOC_ERR_STATE, "ioc_dist_merge: another rank could not start the exchange (its own error says why)");
-    HCK(c, hipEventRecord(e0, c->stream));
-    uint32_t* gmin = static_cast<uint32_t*>(c->b_dist_min.p);
-    uint32_t* gpos = static_cast<uint32_t*>(c->b_dist_pos.p);
-    std::vector<int64_t> dF(static_cast<size_t>(W)), dR(static_cast<size_t>(W));
-    {
-        int64_t a = 0, b = FW;
-        for (int r = 0; r < W; ++r) {
-            dF[size_t(r)] = a;
-            dR[size_t(r)] = b;
-            a += fws[size_t(r)];
-            b += rws[size_t(r)];
-        }
-    }
-    const hipMemcpyKind kind = reps->minimizers_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (fw) {
-        HCK(c, hipMemcpyAsync(gmin + dF[size_t(d->rank)], reps->min_val + f0, size_t(fw) * 4, kind, c->stream));
-        HCK(c, hipMemcpyAsync(gpos + dF[size_t(d->rank)], reps->min_pos + f0, size_t(fw) * 4, kind, c->stream));
-    }
-    if (rw) {
-        HCK(c, hipMemcpyAsync(gmin + dR[size_t(d->rank)], reps->min_val + r0, size_t(rw) * 4, kind, c->stream));
-        HCK(c, hipMemcpyAsync(gpos + dR[size_t(d->rank)], reps->min_pos + r0, size_t(rw) * 4, kind, c->stream));
-    }
-    if (int rc = ioc_dist_allgatherv_device(c, gmin + dF[size_t(d->rank)], gmin, fws.data(), dF.data(), 4)) return rc;
-    if (int rc = ioc_dist_allgatherv_device(c, gmin + dR[size_t(d->rank)], gmin, rws.data(), dR.data(), 4)) return rc;
-    if (int rc = ioc_dist_allgatherv_device(c, gpos + dF[size_t(d->rank)], gpos, fws.data(), dF.data(), 4)) return rc;
-    if (int rc = ioc_dist_allgatherv_device(c, gpos + dR[size_t(d->rank)], gpos, rws.data(), dR.data(), 4)) return rc;
-    HCK(c, hipEventRecord(e1, c->stream));
-    // 3. the per-representative host records (and the raw sequences)
-    std::vector<RepMeta> mine(static_cast<size_t>(n)), all(static_cast<size_t>(N));
-    for (int32_t i = 0; i < n; ++i) {
-        RepMeta& m = mine[size_t(i)];
-        m.raw_len = reps->raw_len[i];
-        m.hpc_len = reps->hpc_len[i];
-        m.n_fwd = uint32_t(reps->off_fwd[i + 1] - reps->off_fwd[i]);
-        m.n_rev = uint32_t(reps->off_rev[i + 1] - reps->off_rev[i]);
-        m.state = reps->state[i];
-        m.pad = 0;
-        m.score = reps->score[i];
-        m.raw_err = reps->raw_err[i];
-        m.hpc_err = reps->hpc_err[i];
-    }
-    std::vector<int64_t> sz(static_cast<size_t>(W));
-    if (int rc = ioc_dist_allgatherv_host(c, mine.data(), int64_t(mine.size() * sizeof(RepMeta)), all.data(), sz.data())) return rc;
-    std::string seq_all;
-    std::vector<int64_t> seq_off;
-    if (all_seq) {
-        seq_all.resize(size_t(SB));
-        std::vector<int64_t> ssz(static_cast<size_t>(W));
-        if (int rc = ioc_dist_allgatherv_host(c, have_seq && n ? reps->raw_seq + reps->raw_off[0] : nullptr, sb, seq_all.data(), ssz.data()))
-            return rc;
-        // the sequence lengths are raw_len (RawSeq->Str().length())
-        seq_off.resize(size_t(N) + 1);
-        seq_off[0] = 0;
-        for (int64_t i = 0; i < N; ++i) seq_off[size_t(i) + 1] = seq_off[size_t(i)] + all[size_t(i)].raw_len;
-        if (seq_off[size_t(N)] != SB) return ioc_fail(c, IOC_ERR_INPUT, "ioc_dist_merge: raw_len does not add up to the sequences gathered");
-    }
+    // Everything between the opening agreement and the closing one runs inside `exchange_and_merge`: whatever way it ends — a HIP call
+    // that fails, a host allocation, an inconsistent record — this rank still reaches the closing agreement and says so there, where
+    // the peers' next agreement meets it (the early returns of this stretch used to leave them waiting).
     float ms_comm = 0;
-    HCK(c, hipEventSynchronize(e1));
-    (void)hipEventElapsedTime(&ms_comm, e0, e1);
-    // 4. the combined view: rank 0's representatives are clusters from the start (the left fold ((b0 + b1) + b2) ... of freshly
-    //    clustered batches makes the decisions of one loop over all representatives in rank order: ioc_batch_view::is_cluster)
-    std::vector<int64_t> off_f(static_cast<size_t>(N) + 1), off_r(static_cast<size_t>(N) + 1);
-    std::vector<uint32_t> raw_len(static_cast<size_t>(N)), hpc_len(static_cast<size_t>(N));
-    std::vector<double> score(static_cast<size_t>(N)), raw_err(static_cast<size_t>(N)), hpc_err(static_cast<size_t>(N));
-    std::vector<uint8_t> state(static_cast<size_t>(N)), is_cluster(static_cast<size_t>(N), 0);
-    off_f[0] = 0;
-    off_r[0] = FW;
-    for (int64_t i = 0; i < N; ++i) {
-        const RepMeta& m = all[size_t(i)];
-        off_f[size_t(i) + 1] = off_f[size_t(i)] + m.n_fwd;
-        off_r[size_t(i) + 1] = off_r[size_t(i)] + m.n_rev;
-        raw_len[size_t(i)] = m.raw_len;
-        hpc_len[size_t(i)] = m.hpc_len;
-        score[size_t(i)] = m.score;
-        raw_err[size_t(i)] = m.raw_err;
-        hpc_err[size_t(i)] = m.hpc_err;
-        state[size_t(i)] = uint8_t(m.state);
-        is_cluster[size_t(i)] = i < cnt[0] ? 1 : 0;
-    }
-    if (off_f[size_t(N)] != FW || off_r[size_t(N)] != FW + RW) return ioc_fail(c, IOC_ERR_INPUT, "ioc_dist_merge: list lengths do not add up");
-    ioc_batch_view v{};
-    v.n = int32_t(N);
-    v.off_fwd = off_f.data();
-    v.off_rev = off_r.data();
-    v.min_val = gmin;
-    v.min_pos = gpos;
-    v.total = FW + RW;
-    v.raw_len = raw_len.data();
-    v.hpc_len = hpc_len.data();
-    v.score = score.data();
-    v.raw_err = raw_err.data();
-    v.hpc_err = hpc_err.data();
-    v.state = state.data();
-    v.min_qual = reps->min_qual;
-    v.raw_seq = all_seq ? seq_all.data() : nullptr;
-    v.raw_off = all_seq ? seq_off.data() : nullptr;
-    v.n_members = nullptr;
-    v.depth = 0;
-    v.min_cls_size = min_cls_size;
-    v.is_cluster = is_cluster.data();
-    v.minimizers_on_device = 1;
-    HCK(c, hipStreamSynchronize(c->stream));
-    const auto t0 = std::chrono::steady_clock::now();
-    // fast mode: score + resolve sharded over the ranks (query j on rank j % W), `valid` all-reduced after every sweep;
-    // sahlin / furious: the alignment rounds sharded by owner of the query, their verdicts summed over the ranks (ioc_host.cpp)
-    const char* es = getenv("IOC_DIST_SHARD");
-    const bool shard = W > 1 && !(es && es[0] == '0');
+    std::vector<RepMeta> mine(static_cast<size_t>(n));
+    int exchanges = 0;
+    bool shard = false;
+    auto t0 = std::chrono::steady_clock::now();
+    auto exchange_and_merge = [&]() -> int {
+        HCK(c, hipEventRecord(e0, c->stream));
+        uint32_t* gmin = static_cast<uint32_t*>(c->b_dist_min.p);
+        uint32_t* gpos = static_cast<uint32_t*>(c->b_dist_pos.p);
+        std::vector<int64_t> dF(static_cast<size_t>(W)), dR(static_cast<size_t>(W));
+        {
+            int64_t a = 0, b = FW;
+            for (int r = 0; r < W; ++r) {
+                dF[size_t(r)] = a;
+                dR[size_t(r)] = b;
+                a += fws[size_t(r)];
+                b += rws[size_t(r)];
+            }
+        }
+        const hipMemcpyKind kind = reps->minimizers_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (fw) {
+            HCK(c, hipMemcpyAsync(gmin + dF[size_t(d->rank)], reps->min_val + f0, size_t(fw) * 4, kind, c->stream));
+            HCK(c, hipMemcpyAsync(gpos + dF[size_t(d->rank)], reps->min_pos + f0, size_t(fw) * 4, kind, c->stream));
+        }
+        if (rw) {
+            HCK(c, hipMemcpyAsync(gmin + dR[size_t(d->rank)], reps->min_val + r0, size_t(rw) * 4, kind, c->stream));
+            HCK(c, hipMemcpyAsync(gpos + dR[size_t(d->rank)], reps->min_pos + r0, size_t(rw) * 4, kind, c->stream));
+        }
+        if (int rc = ioc_dist_allgatherv_device(c, gmin + dF[size_t(d->rank)], gmin, fws.data(), dF.data(), 4)) return rc;
+        if (int rc = ioc_dist_allgatherv_device(c, gmin + dR[size_t(d->rank)], gmin, rws.data(), dR.data(), 4)) return rc;
+        if (int rc = ioc_dist_allgatherv_device(c, gpos + dF[size_t(d->rank)], gpos, fws.data(), dF.data(), 4)) return rc;
+        if (int rc = ioc_dist_allgatherv_device(c, gpos + dR[size_t(d->rank)], gpos, rws.data(), dR.data(), 4)) return rc;
+        HCK(c, hipEventRecord(e1, c->stream));
+        // 3. the per-representative host records (and the raw sequences)
+        std::vector<RepMeta> all(static_cast<size_t>(N));
+        for (int32_t i = 0; i < n; ++i) {
+            RepMeta& m = mine[size_t(i)];
+            m.raw_len = reps->raw_len[i];
+            m.hpc_len = reps->hpc_len[i];
+            m.n_fwd = uint32_t(reps->off_fwd[i + 1] - reps->off_fwd[i]);
+            m.n_rev = uint32_t(reps->off_rev[i + 1] - reps->off_rev[i]);
+            m.state = reps->state[i];
+            m.pad = 0;
+            m.score = reps->score[i];
+            m.raw_err = reps->raw_err[i];
+            m.hpc_err = reps->hpc_err[i];
+        }
+        std::vector<int64_t> sz(static_cast<size_t>(W));
+        if (int rc = ioc_dist_allgatherv_host(c, mine.data(), int64_t(mine.size() * sizeof(RepMeta)), all.data(), sz.data())) return rc;
+        std::string seq_all;
+        std::vector<int64_t> seq_off;
+        if (all_seq) {
+            seq_all.resize(size_t(SB));
+            std::vector<int64_t> ssz(static_cast<size_t>(W));
+            if (int rc = ioc_dist_allgatherv_host(c, have_seq && n ? reps->raw_seq + reps->raw_off[0] : nullptr, sb, seq_all.data(), ssz.data()))
+                return rc;
+            // the sequence lengths are raw_len (RawSeq->Str().length())
+            seq_off.resize(size_t(N) + 1);
+            seq_off[0] = 0;
+            for (int64_t i = 0; i < N; ++i) seq_off[size_t(i) + 1] = seq_off[size_t(i)] + all[size_t(i)].raw_len;
+            if (seq_off[size_t(N)] != SB) return ioc_fail(c, IOC_ERR_INPUT, "ioc_dist_merge: raw_len does not add up to the sequences gathered");
+        }
+        HCK(c, hipEventSynchronize(e1));
+        (void)hipEventElapsedTime(&ms_comm, e0, e1);
+        // 4. the combined view: rank 0's representatives are clusters from the start (the left fold ((b0 + b1) + b2) ... of freshly
+        //    clustered batches makes the decisions of one loop over all representatives in rank order: ioc_batch_view::is_cluster)
+        std::vector<int64_t> off_f(static_cast<size_t>(N) + 1), off_r(static_cast<size_t>(N) + 1);
+        std::vector<uint32_t> raw_len(static_cast<size_t>(N)), hpc_len(static_cast<size_t>(N));
+        std::vector<double> score(static_cast<size_t>(N)), raw_err(static_cast<size_t>(N)), hpc_err(static_cast<size_t>(N));
+        std::vector<uint8_t> state(static_cast<size_t>(N)), is_cluster(static_cast<size_t>(N), 0);
+        off_f[0] = 0;
+        off_r[0] = FW;
+        for (int64_t i = 0; i < N; ++i) {
+            const RepMeta& m = all[size_t(i)];
+            off_f[size_t(i) + 1] = off_f[size_t(i)] + m.n_fwd;
+            off_r[size_t(i) + 1] = off_r[size_t(i)] + m.n_rev;
+            raw_len[size_t(i)] = m.raw_len;
+            hpc_len[size_t(i)] = m.hpc_len;
+            score[size_t(i)] = m.score;
+            raw_err[size_t(i)] = m.raw_err;
+            hpc_err[size_t(i)] = m.hpc_err;
+            state[size_t(i)] = uint8_t(m.state);
+            is_cluster[size_t(i)] = i < cnt[0] ? 1 : 0;
+        }
+        if (off_f[size_t(N)] != FW || off_r[size_t(N)] != FW + RW) return ioc_fail(c, IOC_ERR_INPUT, "ioc_dist_merge: list lengths do not add up");
+        ioc_batch_view v{};
+        v.n = int32_t(N);
+        v.off_fwd = off_f.data();
+        v.off_rev = off_r.data();
+        v.min_val = gmin;
+        v.min_pos = gpos;
+        v.total = FW + RW;
+        v.raw_len = raw_len.data();
+        v.hpc_len = hpc_len.data();
+        v.score = score.data();
+        v.raw_err = raw_err.data();
+        v.hpc_err = hpc_err.data();
+        v.state = state.data();
+        v.min_qual = reps->min_qual;
+        v.raw_seq = all_seq ? seq_all.data() : nullptr;
+        v.raw_off = all_seq ? seq_off.data() : nullptr;
+        v.n_members = nullptr;
+        v.depth = 0;
+        v.min_cls_size = min_cls_size;
+        v.is_cluster = is_cluster.data();
+        v.minimizers_on_device = 1;
+        HCK(c, hipStreamSynchronize(c->stream));
+        t0 = std::chrono::steady_clock::now();
+        // fast mode: score + resolve sharded over the ranks (query j on rank j % W), `valid` all-reduced after every sweep;
+        // sahlin / furious: the alignment rounds sharded by owner of the query, their verdicts summed over the ranks (ioc_host.cpp)
+        const char* es = getenv("IOC_DIST_SHARD");
+        shard = W > 1 && !(es && es[0] == '0');
+        int rc = IOC_OK;
+        if (shard && ioc_dist_set_shard(c, 1) != IOC_OK) rc = IOC_ERR_STATE;
+        if (rc == IOC_OK) rc = ioc_cluster_merge(c, p, table_path, nullptr, &v, out_cls, out_strand, stats);
+        exchanges = ioc_shard_exchanges(c);
+        if (shard) (void)ioc_dist_set_shard(c, 0);
+        return rc;
+    };
     int rc = IOC_OK;
-    if (shard && ioc_dist_set_shard(c, 1) != IOC_OK) rc = IOC_ERR_STATE;
-    if (rc == IOC_OK) rc = ioc_cluster_merge(c, p, table_path, nullptr, &v, out_cls, out_strand, stats);
-    const int exchanges = ioc_shard_exchanges(c);
+    try {
+        rc = exchange_and_merge();
+    } catch (const std::exception& e) {
+        rc = ioc_fail(c, IOC_ERR_STATE, std::string("ioc_dist_merge: ") + e.what());
+    }
     if (shard) (void)ioc_dist_set_shard(c, 0);
     // the closing agreement: a rank that failed since the last exchange (or in a merge without exchanges: the alignment modes)
     // says so here; it pairs with the agreement in front of the peers' next exchange or with their closing one
