@@ -780,7 +780,9 @@ def main():
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "value_region": "resident: one pass of the hot path (ioc_cluster_resident: index build, gap-bound table, scoring, resolve, "
-                            "alignment rounds) over a sorted batch already in HBM, nothing kept from one step to the next; "
+                            "alignment rounds) over a sorted batch already in HBM; nothing computed is kept from one step to the next — "
+                            "the aligner's corridor MODEL is (six sums per gap-open class over the pairs the context has aligned before: it "
+                            "plans which tiles a step computes, the certificate decides what stands; the first step of a context plans from an error-model prior); "
                             "`core` = host arrays -> host results incl. PCIe, `cli` = whole cluster process incl. .cer I/O",
             "config": {"workload": f"{a.config} = BASELINE.json configs[{2 if head_mode == 'sahlin' else 1}]: {rs.tag}; one sorted "
                                    "3000-read / 50 Mb batch per GPU, minimizer SoA and sequences resident in HBM",

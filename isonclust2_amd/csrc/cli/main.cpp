@@ -1450,6 +1450,10 @@ static int client(int argc, char** argv)
         slot = 0;
     }
     const string base = slot_base(slot), sock = base + ".sock";
+    if (sock.size() >= sizeof(sockaddr_un{}.sun_path)) {  // (a directory too deep for a socket's name: the job runs here)
+        close(lk);
+        return -1;
+    }
     int cs = worker_alive(base) ? connect_to(sock) : -1;
     if (cs < 0) {
         if (!spawn_worker(slot)) {
@@ -1459,6 +1463,7 @@ static int client(int argc, char** argv)
         for (int tries = 0; tries < 5000 && cs < 0; ++tries) {  // (the worker binds its socket before it does anything else)
             cs = connect_to(sock);
             if (cs < 0) usleep(1000);
+            if (cs < 0 && tries > 200 && !worker_alive(base)) break;  // (it could not start: no point in waiting)
         }
         if (cs < 0) {
             close(lk);

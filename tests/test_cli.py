@@ -60,10 +60,16 @@ def test_large_archive_loads_as_views(tmp_path):
     assert r.returncode == 1 and "truncated or corrupt" in r.stderr
 
 
+def _short_dir():
+    import tempfile
+    return tempfile.mkdtemp(prefix="iocs", dir="/tmp")
+
+
 def test_served_cluster_reports_like_the_one_shot_command(tmp_path):
     """`cluster` goes through a resident worker (serve): the caller's stderr and exit code must be the one-shot command's.
     Without a GPU both end in the same error; the worker survives the failed job and `serve stop` ends it."""
-    env = dict(os.environ, ISONCLUST2_SERVE_DIR=str(tmp_path / "srv"), ISONCLUST2_SERVE_IDLE_S="20")
+    srv = _short_dir()   # (a unix socket's path holds 107 characters: pytest's tmp_path can be longer than that)
+    env = dict(os.environ, ISONCLUST2_SERVE_DIR=srv, ISONCLUST2_SERVE_IDLE_S="20")
     g = tmp_path / "g.cer"
     assert run("golden", str(g)).returncode == 0
     served = [run("cluster", "-l", str(g), "-o", str(tmp_path / "o.cer"), "-x", "fast", env=env) for _ in range(2)]
@@ -74,11 +80,13 @@ def test_served_cluster_reports_like_the_one_shot_command(tmp_path):
     # relative paths are resolved against the CALLER's directory
     r = subprocess.run([CLI, "cluster", "-l", "nope.cer", "-o", "o.cer", "-x", "fast"], capture_output=True, text=True, cwd=str(tmp_path), env=env)
     assert r.returncode == 1 and "Failed to load batch nope.cer" in r.stderr
-    socks = [f for f in os.listdir(tmp_path / "srv") if f.endswith(".sock")]
+    socks = [f for f in os.listdir(srv) if f.endswith(".sock")]
     assert len(socks) == 1, socks
     r = run("serve", "stop", env=env)
     assert "1 worker(s) stopped" in r.stderr
-    assert not [f for f in os.listdir(tmp_path / "srv") if f.endswith(".sock")]
+    assert not [f for f in os.listdir(srv) if f.endswith(".sock")]
+    import shutil
+    shutil.rmtree(srv, ignore_errors=True)
 
 
 def _write_fastq(rs, path):
@@ -251,7 +259,8 @@ def test_resident_worker_writes_the_one_shot_commands_files(tmp_path):
     assert run("sort", "-B", "1000000", "-M", "120", "-o", str(out), str(fq)).returncode == 0
     assert run("sort", "-B", "1000000", "-M", "120", "-g", "3", "-c", "8", "-P", "400", "-o", str(tmp_path / "sorted_c"), str(fq)).returncode == 0
     b0, b1 = out / "batches" / "isONbatch_0.cer", out / "batches" / "isONbatch_1.cer"
-    env = dict(os.environ, ISONCLUST2_SERVE_DIR=str(tmp_path / "srv"), ISONCLUST2_SERVE_IDLE_S="60", ISONCLUST2_STATS_JSON="1")
+    srv = _short_dir()
+    env = dict(os.environ, ISONCLUST2_SERVE_DIR=srv, ISONCLUST2_SERVE_IDLE_S="60", ISONCLUST2_STATS_JSON="1")
     off = dict(env, ISONCLUST2_SERVE="0")
 
     def both(name, *args):
@@ -287,4 +296,6 @@ def test_resident_worker_writes_the_one_shot_commands_files(tmp_path):
     assert filecmp.cmp(res[2][1], tmp_path / "c0_sahlin_direct.cer", shallow=False)
     r = run("serve", "stop", env=env)
     assert "worker(s) stopped" in r.stderr and not r.stderr.startswith("isONclust2-hip: 0 ")
-    assert not [f for f in os.listdir(tmp_path / "srv") if f.endswith(".sock")]
+    assert not [f for f in os.listdir(srv) if f.endswith(".sock")]
+    import shutil
+    shutil.rmtree(srv, ignore_errors=True)
