@@ -1202,6 +1202,12 @@ static string build_stamp()
     mix("/proc/self/exe");
     Dl_info di;
     if (dladdr(reinterpret_cast<void*>(&ioc_ctx_create), &di) && di.dli_fname) mix(di.dli_fname);
+    // (... nor a worker that sees other devices than the caller: the runtime reads these once, when the worker starts)
+    for (const char* nm : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"}) {
+        const char* v = getenv(nm);
+        for (const char* q = v ? v : "\x01"; *q; ++q) h = (h ^ (unsigned long long)(unsigned char)*q) * 1099511628211ull;
+        h = (h ^ 0xFFull) * 1099511628211ull;
+    }
     char buf[20];
     snprintf(buf, sizeof(buf), "%08llx", h & 0xFFFFFFFFull);
     return stamp = buf;
@@ -1343,6 +1349,7 @@ static int worker(int slot)
                     dup2(keep2, 2);
                     close(keep1);
                     close(keep2);
+                    (void)!chdir("/");  // (the caller's directory is the caller's again)
                 }
             }
         }

@@ -278,7 +278,10 @@ def test_resident_worker_writes_the_one_shot_commands_files(tmp_path):
         c0 = both("c0_" + mode, "-v", "-l", str(b0), "-x", mode)
         c1 = both("c1_" + mode, "-l", str(b1), "-x", mode)
         both("m_" + mode, "-l", str(c0), "-r", str(c1), "-x", mode)
-    both("cons", "-v", "-l", str(tmp_path / "sorted_c" / "batches" / "isONbatch_0.cer"), "-x", "fast")
+    # consensus mode: two different batches through the same worker one after the other, then their merge (graphs in the files)
+    k0 = both("cons0", "-v", "-l", str(tmp_path / "sorted_c" / "batches" / "isONbatch_0.cer"), "-x", "fast")
+    k1 = both("cons1", "-l", str(tmp_path / "sorted_c" / "batches" / "isONbatch_1.cer"), "-x", "sahlin")
+    both("consm", "-l", str(k0), "-r", str(k1), "-x", "sahlin")
     # a job that fails leaves its worker in place
     r = run("cluster", "-l", str(tmp_path / "missing.cer"), "-o", str(tmp_path / "x.cer"), "-x", "fast", env=env)
     assert r.returncode == 1 and "Failed to load batch" in r.stderr
