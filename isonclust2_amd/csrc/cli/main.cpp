@@ -1263,6 +1263,13 @@ static int worker(int slot)
     if (const char* e = getenv("ISONCLUST2_SERVE_IDLE_S")) idle_s = std::max(0.1, atof(e));
     g_served = true;
     std::vector<string> applied;  // environment names the last job set here
+    // (what the process that happened to start this worker had in ITS environment is not the next caller's: a job runs under
+    // the IOC_* / ISONCLUST2_* variables its own caller sends, nothing else of that kind)
+    for (char** e = environ; e && *e; ++e)
+        if ((strncmp(*e, "IOC_", 4) == 0 || strncmp(*e, "ISONCLUST2_", 11) == 0) && strncmp(*e, "ISONCLUST2_SERVE_", 17) != 0) {
+            const char* eq = strchr(*e, '=');
+            if (eq) applied.emplace_back(*e, size_t(eq - *e));
+        }
     for (;;) {
         pollfd pf{ls, POLLIN, 0};
         const int pr = poll(&pf, 1, int(idle_s * 1000.0));

@@ -282,6 +282,10 @@ def test_resident_worker_writes_the_one_shot_commands_files(tmp_path):
     k0 = both("cons0", "-v", "-l", str(tmp_path / "sorted_c" / "batches" / "isONbatch_0.cer"), "-x", "fast")
     k1 = both("cons1", "-l", str(tmp_path / "sorted_c" / "batches" / "isONbatch_1.cer"), "-x", "sahlin")
     both("consm", "-l", str(k0), "-r", str(k1), "-x", "sahlin")
+    # a job runs under ITS caller's IOC_* / ISONCLUST2_* environment, not under an earlier caller's or the worker's own
+    quiet = {k: v for k, v in env.items() if k != "ISONCLUST2_STATS_JSON"}
+    r = run("cluster", "-l", str(b0), "-o", str(tmp_path / "quiet.cer"), "-x", "fast", env=quiet)
+    assert r.returncode == 0 and "core_ms" not in r.stderr, r.stderr
     # a job that fails leaves its worker in place
     r = run("cluster", "-l", str(tmp_path / "missing.cer"), "-o", str(tmp_path / "x.cer"), "-x", "fast", env=env)
     assert r.returncode == 1 and "Failed to load batch" in r.stderr
