@@ -253,6 +253,7 @@ int ioc_set_params(ioc_ctx* c, const ioc_params* p, const int32_t gap_limit[225]
 static int queries_common(ioc_ctx* c, int32_t n, const int64_t* off_fwd, const int64_t* off_rev, int64_t total)
 {
     if (n < 0 || total < 0 || (n > 0 && (!off_fwd || !off_rev))) return ioc_fail(c, IOC_ERR_ARG, "bad query shape");
+    c->chunked_call = false;  // (new queries: whatever a chunked ioc_cluster_merge left is gone; it sets the flag again when it returns)
     c->h_off_fwd.assign(off_fwd, off_fwd + n + 1);
     c->h_off_rev.assign(off_rev, off_rev + n + 1);
     c->h_doff.assign(size_t(n) + 1, 0);

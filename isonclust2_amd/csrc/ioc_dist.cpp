@@ -370,7 +370,10 @@ int ioc_dist_exchange(ioc_ctx* c, void* d_buf, int64_t count, int32_t kind)
 int ioc_dist_set_shard(ioc_ctx* c, int32_t on)
 {
     if (int rc = need_dist(c)) return rc;
-    if (on && c->dist->world > 1) return ioc_set_shard(c, c->dist->world, c->dist->rank, rccl_exchange, c->dist);
+    if (on && c->dist->world > 1) {
+        c->dist->informed = false;  // (a failure a peer announced during an earlier sharded call is that call's: ADVICE r4)
+        return ioc_set_shard(c, c->dist->world, c->dist->rank, rccl_exchange, c->dist);
+    }
     return ioc_set_shard(c, 1, 0, nullptr, nullptr);
 }
 
