@@ -50,6 +50,7 @@ CONFIGS = {
     "config2_clean": (3000, 150, 16667, 16.0, 25.0),
     "config2_half": (1500, 75, 16667, 10.0, 21.0),   # (half of config 2's batch: an alignment round of ~400 couples)
     "config2_quarter": (750, 38, 16667, 10.0, 21.0),
+    "config2_eighth": (375, 19, 16667, 10.0, 21.0),   # (an alignment round of ~100 couples: the few-couples launches)
     "tiny": (64, 8, 600, 10.0, 21.0),
     "short_dup": (1200, 120, 300, 10.0, 21.0),    # short reads, tie-prone
 }
