@@ -68,6 +68,10 @@ void ioc_ctx_destroy(ioc_ctx* ctx);
  * released VRAM before it hands it out again (8 GB: ~0.4 s), and a process that starts right after this one would otherwise
  * wait for that inside its own first large hipMalloc (profiles/r05_cli_breakdown.txt). */
 int ioc_ctx_trim(ioc_ctx* ctx);
+/* Optional, for a process that runs ONE batch: has the code objects of the clustering path (and of the aligner, if
+ * alignment_mode != 0) loaded by background threads now, beside the caller's own preparation, instead of at each file's first
+ * launch.  Returns at once; nothing depends on it. */
+int ioc_ctx_prewarm(ioc_ctx* ctx, int32_t alignment_mode);
 const char* ioc_last_error(const ioc_ctx* ctx);
 /* Run on a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
 int ioc_set_stream(ioc_ctx* ctx, void* hip_stream);

@@ -112,7 +112,7 @@ class Timings(C.Structure):
 
 # every symbol include/isonclust2_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "ioc_ctx_create", "ioc_ctx_destroy", "ioc_ctx_trim", "ioc_last_error", "ioc_set_stream", "ioc_synchronize",
+    "ioc_ctx_create", "ioc_ctx_destroy", "ioc_ctx_trim", "ioc_ctx_prewarm", "ioc_last_error", "ioc_set_stream", "ioc_synchronize",
     "ioc_set_params", "ioc_queries_upload", "ioc_queries_bind_device", "ioc_left_load",
     "ioc_index_build", "ioc_score", "ioc_resolve", "ioc_get_decisions", "ioc_get_cuts", "ioc_force_decision",
     "ioc_clear_forced", "ioc_query_candidates", "ioc_index_export", "ioc_qual_scores",

@@ -399,8 +399,10 @@ static int main_cluster(int argc, char** argv)
     // HIP initialisation (~80 ms) runs beside the archive load
     auto ctx_future = std::async(std::launch::async, [] {
         const auto t0 = std::chrono::steady_clock::now();
+        const bool fresh = g_srv_ctx == nullptr;
         ioc_ctx* cc = g_srv_ctx ? g_srv_ctx : make_ctx();
         if (g_served) g_srv_ctx = cc;
+        if (fresh && !getenv("IOC_NO_PREWARM")) (void)ioc_ctx_prewarm(cc, 1);  // (code objects load beside the flattening and the uploads)
         return std::make_pair(cc, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     });
     Batch left, right;

@@ -2916,4 +2916,11 @@ int ioc_align_pairs(ioc_ctx* c, int32_t n_pairs, const ioc_aln_pair* pairs, int3
     return IOC_OK;
 }
 
+// (ioc_ctx_prewarm)
+hipError_t iock_warm_align()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_fwd2_ends));
+}
+
 }  // extern "C"

@@ -350,3 +350,10 @@ hipError_t iock_build_sort_phase2(hipStream_t st, const IocBuildSort* a, uint32_
                            off, static_cast<uint32_t*>(post));
     return hipGetLastError();
 }
+
+// (ioc_ctx_prewarm: makes the runtime load this file's code object now instead of at its first launch)
+extern "C" hipError_t iock_warm_build_sort()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_bs_pairs_queries<uint16_t>));
+}

@@ -191,6 +191,31 @@ void ioc_ctx_destroy(ioc_ctx* c)
     delete c;
 }
 
+int ioc_ctx_prewarm(ioc_ctx* c, int32_t alignment_mode)
+{
+    if (!c) return IOC_ERR_ARG;
+    // A code object is loaded when one of its kernels is first launched: 2 - 25 ms each for the six files of the clustering path,
+    // in the middle of a one-shot process's critical path.  Here they are loaded by threads of their own, beside the caller's
+    // uploads (IOC_TRACE prints what each took).  Nothing depends on it: a launch that comes first loads its file itself.
+    const int dev = c->device;
+    const bool trace = getenv("IOC_TRACE") != nullptr;
+    auto go = [dev, trace](const char* what, hipError_t (*fn)()) {
+        std::thread([=] {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hipSetDevice(dev) == hipSuccess) (void)fn();
+            if (trace)
+                fprintf(stderr, "[ioc] prewarm: %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }).detach();
+    };
+    go("kernels", iock_warm_kernels);
+    go("build_sort", iock_warm_build_sort);
+    go("score", iock_warm_score);
+    go("resolve", iock_warm_resolve);
+    go("sort", iock_warm_sort);
+    if (alignment_mode) go("align", iock_warm_align);
+    return IOC_OK;
+}
+
 int ioc_ctx_trim(ioc_ctx* c)
 {
     if (!c) return IOC_ERR_ARG;
@@ -657,7 +682,7 @@ int ioc_index_build(ioc_ctx* c)
                                 value_bits, qk, qv, c->post16, uint32_t(c->L), sentinel, &written));
         a.pairs_done = written;
         if (pmax > IOC_DISTINCT_LDS_MAX && env_u32("IOC_DISTINCT_BITONIC", 0) != 1) {
-            // the queries that kernel left out: sorted in global memory (ioc_sort.hip)
+            // the queries that kernel left out: sorted in global memory (ioc_sort_long.hip)
             std::vector<int32_t> qid;
             std::vector<unsigned long long> seg(1, 0ull);
             for (int j = 0; j < n; ++j) {

@@ -79,7 +79,14 @@ extern "C" {
 hipError_t iock_distinct(hipStream_t st, int n, const int64_t* off_fwd, const uint32_t* mins, const int64_t* doff,
                          uint32_t* dvals, uint32_t* dcount, uint32_t pmax, int value_bits, uint32_t* pk = nullptr, void* pv = nullptr,
                          int pv16 = 0, uint32_t target0 = 0, uint32_t sentinel = 0, int* pairs_written = nullptr);
-// queries of more than IOC_DISTINCT_LDS_MAX forward minimizers (k_distinct_radix skips them): ioc_sort.hip
+// one per kernel file: loads the file's code object (ioc_ctx_prewarm)
+hipError_t iock_warm_kernels();
+hipError_t iock_warm_build_sort();
+hipError_t iock_warm_score();
+hipError_t iock_warm_resolve();
+hipError_t iock_warm_sort();
+hipError_t iock_warm_align();
+// queries of more than IOC_DISTINCT_LDS_MAX forward minimizers (k_distinct_radix skips them): ioc_sort_long.hip
 #define IOC_DISTINCT_LDS_MAX 8192u
 size_t iock_distinct_long_temp(size_t total, uint32_t nlong, int value_bits);
 hipError_t iock_distinct_long(hipStream_t st, uint32_t nlong, size_t total, const int32_t* d_qid, const unsigned long long* d_seg, const int64_t* off_fwd,

@@ -764,3 +764,10 @@ hipError_t iock_pack_rows(hipStream_t st, uint32_t nslots, const uint32_t* keys,
 
 
 }  // extern "C"
+
+// (ioc_ctx_prewarm: makes the runtime load this file's code object now instead of at its first launch)
+extern "C" hipError_t iock_warm_kernels()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_distinct_radix));
+}

@@ -1044,3 +1044,10 @@ size_t iock_decide_args_size() { return sizeof(DecideArgs); }
 
 
 }  // extern "C"
+
+// (ioc_ctx_prewarm: makes the runtime load this file's code object now instead of at its first launch)
+extern "C" hipError_t iock_warm_resolve()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_copy_prefix_valid));
+}

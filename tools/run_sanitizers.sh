@@ -27,7 +27,7 @@ echo "-- build: libisonclust2_hip.so host code with clang -fsanitize=address,und
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -pthread -ffp-contract=off -Wno-unused-result -Wno-option-ignored \
     -fsanitize=address,undefined -fno-omit-frame-pointer -shared-libsan -Iinclude -I$SRC -shared -o $OUT/libisonclust2_hip.so \
     $SRC/ioc_kernels.hip $SRC/ioc_score.hip $SRC/ioc_resolve.hip $SRC/ioc_extract.hip $SRC/ioc_capi.cpp $SRC/ioc_host.cpp $SRC/ioc_align.cpp $SRC/ioc_align_gpu.hip \
-    $SRC/ioc_update.hip $SRC/ioc_consensus.cpp $SRC/ioc_poa.hip $SRC/ioc_sort.hip $SRC/ioc_dist.cpp $SRC/ioc_build_sort.hip -L/opt/rocm/lib -lrccl || exit 1
+    $SRC/ioc_update.hip $SRC/ioc_consensus.cpp $SRC/ioc_poa.hip $SRC/ioc_sort.hip $SRC/ioc_sort_long.hip $SRC/ioc_dist.cpp $SRC/ioc_build_sort.hip -L/opt/rocm/lib -lrccl || exit 1
 echo "-- build: command line (main.cpp, cer.cpp) with the same runtime"
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -shared-libsan -Iinclude \
     -o $OUT/isONclust2-hip $SRC/cli/main.cpp $SRC/cli/cer.cpp -L$OUT -lisonclust2_hip -L/opt/rocm/lib -lamdhip64 \
