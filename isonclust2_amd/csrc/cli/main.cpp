@@ -1253,7 +1253,16 @@ static int worker(int slot)
     const string base = slot_base(slot), sock = base + ".sock";
     // one worker per slot: the lock lives as long as this process
     const int lk = open((base + ".worker").c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
-    if (lk < 0 || flock(lk, LOCK_EX | LOCK_NB) != 0) return 0;  // (another worker has the slot)
+    if (lk < 0) return 0;
+    {   // (a caller probing whether a worker is alive holds this lock for an instant: try a few times before concluding that
+        // another worker has the slot)
+        int got = -1;
+        for (int t = 0; t < 40 && got != 0; ++t) {
+            got = flock(lk, LOCK_EX | LOCK_NB);
+            if (got != 0) usleep(500);
+        }
+        if (got != 0) return 0;
+    }
     const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     sockaddr_un sa{};
     sa.sun_family = AF_UNIX;
