@@ -89,6 +89,25 @@ def test_served_cluster_reports_like_the_one_shot_command(tmp_path):
     shutil.rmtree(srv, ignore_errors=True)
 
 
+def test_idle_worker_leaves_by_itself(tmp_path):
+    """A worker without a job for ISONCLUST2_SERVE_IDLE_S seconds ends and takes its socket with it (no GPU needed: the job
+    fails at the context, the worker is up all the same)."""
+    import shutil
+    import time
+    srv = _short_dir()
+    env = dict(os.environ, ISONCLUST2_SERVE_DIR=srv, ISONCLUST2_SERVE_IDLE_S="0.3")
+    g = tmp_path / "g.cer"
+    assert run("golden", str(g)).returncode == 0
+    run("cluster", "-l", str(g), "-o", str(tmp_path / "o.cer"), "-x", "fast", env=env)
+    assert [f for f in os.listdir(srv) if f.endswith(".sock")]
+    t0 = time.time()
+    while [f for f in os.listdir(srv) if f.endswith(".sock")] and time.time() - t0 < 10:
+        time.sleep(0.1)
+    assert not [f for f in os.listdir(srv) if f.endswith(".sock")]
+    assert "0 worker(s) stopped" in run("serve", "stop", env=env).stderr
+    shutil.rmtree(srv, ignore_errors=True)
+
+
 def _write_fastq(rs, path):
     with open(path, "wb") as f:
         for i in range(rs.n):
@@ -306,3 +325,38 @@ def test_resident_worker_writes_the_one_shot_commands_files(tmp_path):
     assert not [f for f in os.listdir(srv) if f.endswith(".sock")]
     import shutil
     shutil.rmtree(srv, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_a_200_kb_read_goes_through_sort_and_cluster(tmp_path):
+    """The command line on a FASTQ with one 200 kb read among ordinary ones (round 4 stopped such a batch with a capacity error):
+    `sort` extracts its 50 000 minimizers on the GPU, `cluster` takes it through the long-query path of the index build; the
+    partition equals the oracle's."""
+    from oracle import pyoracle as po
+    a, b = synth.generate(150, 15, 1200, 10, 21, seed=81), synth.generate(2, 1, 200000, 12, 18, seed=82)
+    rs = synth.ReadSet(seq=np.concatenate([a.seq, b.seq]), qual=np.concatenate([a.qual, b.qual]), offs=np.concatenate([a.offs, a.offs[-1] + b.offs[1:]]),
+                       transcript=np.concatenate([a.transcript, 100 + b.transcript]), strand=np.concatenate([a.strand, b.strand]), tag="long")
+    fq = tmp_path / "reads.fq"
+    _write_fastq(rs, fq)
+    out = tmp_path / "sorted"
+    assert run("sort", "-B", "10000000", "-M", str(rs.n), "-o", str(out), str(fq)).returncode == 0
+    r = run("cluster", "-l", str(out / "batches" / "isONbatch_0.cer"), "-o", str(tmp_path / "c.cer"), "-x", "fast")
+    assert r.returncode == 0, r.stderr
+    assert run("dump", "-i", str(out / "sorted_reads_idx.cer"), "-o", str(tmp_path / "dump"), str(tmp_path / "c.cer")).returncode == 0
+    R = po.ReadSet.from_flat(rs.seq, rs.qual, rs.offs)
+    R.score_sort(11, 15)
+    B = po.Batch(R, 0, rs.n - 1, po.default_params(11, 15), 0)
+    B.cluster(mode="fast")
+    ocl, ost = B.assignments(rs.n)
+    got = {}
+    for line in open(tmp_path / "dump" / "clusters.tsv").read().splitlines()[1:]:
+        c, st, name = line.split("\t")
+        got[int(name[1:])] = (int(c), int(st))
+    assigned = np.nonzero(ocl >= 0)[0]
+    assert sorted(got) == assigned.tolist()
+    m = {}
+    for i in assigned:
+        assert got[int(i)][1] == ost[i]
+        assert m.setdefault(int(ocl[i]), got[int(i)][0]) == got[int(i)][0]
+    assert len(set(m.values())) == len(m)
+    assert got[rs.n - 1][0] == got[rs.n - 2][0]      # (the two reads of the 200 kb transcript share a cluster)
