@@ -420,6 +420,77 @@ bool load_batch(Batch& b, const std::string& path, std::string& err)
     return true;
 }
 
+bool map_file(const std::string& path, MappedFile& out, std::string& err)
+{
+    auto mh = std::make_shared<Mapping>();
+    mh->fd = open(path.c_str(), O_RDONLY);
+    if (mh->fd < 0) {
+        err = "Failed to open " + path + "!";
+        return false;
+    }
+    struct stat sb;
+    if (fstat(mh->fd, &sb) != 0) {
+        err = "Failed to stat " + path + "!";
+        return false;
+    }
+    mh->n = size_t(sb.st_size);
+    out = MappedFile();
+    if (mh->n == 0) return true;
+    mh->p = mmap(nullptr, mh->n, PROT_READ, MAP_PRIVATE, mh->fd, 0);
+    if (mh->p == MAP_FAILED) {
+        err = "Failed to map " + path + "!";
+        return false;
+    }
+    if (mh->n >= (size_t(32) << 20)) {  // (page tables now, on a few threads: see load_batch)
+        const size_t nt = 4, step = ((mh->n / nt) + 4095) & ~size_t(4095);
+        char* const at = static_cast<char*>(mh->p);
+        const size_t total = mh->n;
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; ++t) {
+            const size_t a0 = std::min(total, t * step), a1 = std::min(total, (t + 1) * step);
+            if (a1 > a0) th.emplace_back([at, a0, a1] { (void)madvise(at + a0, a1 - a0, 22 /* MADV_POPULATE_READ */); });
+        }
+        for (auto& x : th) x.join();
+    }
+    out.data = static_cast<const char*>(mh->p);
+    out.size = mh->n;
+    out.keep = mh;
+    return true;
+}
+
+struct GatherFile::Impl {
+    int fd = -1;
+    Writer* w = nullptr;
+};
+GatherFile::GatherFile() : p_(new Impl) {}
+GatherFile::~GatherFile()
+{
+    (void)close();
+    delete p_;
+}
+bool GatherFile::open(const std::string& path)
+{
+    (void)close();
+    p_->fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (p_->fd < 0) return false;
+    p_->w = new Writer(p_->fd);
+    return true;
+}
+void GatherFile::put(const void* data, size_t n)
+{
+    if (p_->w) p_->w->raw(data, n);
+}
+bool GatherFile::close()
+{
+    if (!p_->w) return true;
+    p_->w->flush();
+    const bool ok = ::close(p_->fd) == 0 && p_->w->ok;
+    delete p_->w;
+    p_->w = nullptr;
+    p_->fd = -1;
+    return ok;
+}
+
 std::shared_ptr<void> huge_alloc(size_t bytes)
 {
     const size_t n = (std::max<size_t>(bytes, 1) + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);

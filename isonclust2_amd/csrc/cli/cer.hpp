@@ -163,6 +163,31 @@ struct Batch {  // src/serialize.h:23-43
 // shrinks, freed with the holder
 std::shared_ptr<void> huge_alloc(size_t bytes);
 
+// a file mapped read-only as a whole (what load_batch reads from; `sort` parses its FASTQ out of one: the reads' bases and
+// qualities are views of it); nullptr + err when it cannot be had.  size 0: an empty file (data() is then a valid empty string).
+struct MappedFile {
+    const char* data = "";
+    size_t size = 0;
+    std::shared_ptr<const void> keep;  // what the views of it hold
+};
+bool map_file(const std::string& path, MappedFile& out, std::string& err);
+
+// a file written as a gather of pieces that stay where they are until flush() / close() (writev, 1024 pieces a call): small pieces
+// may be passed with copy = true (staged), large ones — views of a mapping — are handed to the kernel in place
+class GatherFile {
+    struct Impl;
+    Impl* p_;
+
+public:
+    GatherFile();
+    ~GatherFile();
+    GatherFile(const GatherFile&) = delete;
+    GatherFile& operator=(const GatherFile&) = delete;
+    bool open(const std::string& path);
+    void put(const void* data, size_t n);  // (pieces below 2 KB are staged: the caller's copy may go)
+    bool close();                          // false: some write failed
+};
+
 bool save_batch(const Batch& b, const std::string& path, std::string& err);
 bool load_batch(Batch& b, const std::string& path, std::string& err);
 bool save_sorted_idx(const std::string& fastq_path, const std::string& path);  // SortedIdx, src/output.h:15-23

@@ -188,91 +188,158 @@ static int main_sort(int argc, char** argv)
     a.InFastq = argv[optind];
     VERBOSE = a.Verbose;
 
+    const bool trace = getenv("IOC_TRACE") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ioc] sort: %-44s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_lap).count());
+        t_lap = t1;
+    };
     // ---- FASTQ (whole file in RAM, like bioparser Parse(-1), main.cpp:109-112) ----
-    std::ifstream in(a.InFastq);
-    if (!in.is_open()) die("Failed to open " + a.InFastq + "!");
+    auto ctx_future = std::async(std::launch::async, [] { return make_ctx(); });  // (the runtime starts beside the parsing)
+    // (parsed out of a read-only mapping: a read's bases and qualities are views of it — nothing of an 8 GB file is copied)
+    MappedFile fqmap;
+    {
+        string merr;
+        if (!map_file(a.InFastq, fqmap, merr)) die("Failed to open " + a.InFastq + "!");
+    }
     std::vector<Seq> reads;
-    string h, s, p, q;
-    while (std::getline(in, h)) {
-        if (h.empty()) continue;
-        if (!std::getline(in, s) || !std::getline(in, p) || !std::getline(in, q)) die("Truncated fastq record: " + h);
-        if (h[0] != '@' || s.size() != q.size()) die("Malformed fastq record: " + h);
-        Seq r;
-        size_t sp = h.find_first_of(" \t");
-        r.name = h.substr(1, sp == string::npos ? string::npos : sp - 1);
-        r.seq = std::move(s);
-        r.qual = std::move(q);
-        s.clear();
-        q.clear();
-        reads.push_back(std::move(r));
+    {
+        const char* p = fqmap.data;
+        const char* const e = fqmap.data + fqmap.size;
+        // the next line [b, l) without its newline; false at the end of the file (std::getline's rules: a last line without a
+        // newline counts, an empty remainder does not)
+        auto line = [&](const char*& b0, const char*& l0) {
+            if (p >= e) return false;
+            const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(e - p)));
+            b0 = p;
+            l0 = nl ? nl : e;
+            p = nl ? nl + 1 : e;
+            return true;
+        };
+        const char *hb, *he, *sb, *se, *pb, *pe, *qb, *qe;
+        while (line(hb, he)) {
+            if (he == hb) continue;
+            const string h(hb, size_t(he - hb));
+            if (!line(sb, se) || !line(pb, pe) || !line(qb, qe)) die("Truncated fastq record: " + h);
+            if (hb[0] != '@' || se - sb != qe - qb) die("Malformed fastq record: " + h);
+            Seq r;
+            const size_t sp = h.find_first_of(" \t");
+            r.name = h.substr(1, sp == string::npos ? string::npos : sp - 1);
+            r.seq = Bytes(sb, size_t(se - sb), fqmap.keep);
+            r.qual = Bytes(qb, size_t(qe - qb), fqmap.keep);
+            reads.push_back(std::move(r));
+        }
     }
     const int n = int(reads.size());
     if (VERBOSE) cerr << "Parsed " << n << " sequences." << endl;
+    lap("fastq parsed");
 
-    ioc_ctx* c = make_ctx();
+    ioc_ctx* c = ctx_future.get();
+    lap("context (started beside the parsing)");
     // ---- FillQualScores on the device, SortByQualScores on the host ----
     std::vector<int64_t> offs(static_cast<size_t>(n) + 1, 0);
     for (int i = 0; i < n; ++i) offs[size_t(i) + 1] = offs[size_t(i)] + int64_t(reads[size_t(i)].qual.size());
     {
-        std::vector<uint8_t> qual(static_cast<size_t>(offs[size_t(n)]));
-        for (int i = 0; i < n; ++i) memcpy(qual.data() + offs[size_t(i)], reads[size_t(i)].qual.data(), reads[size_t(i)].qual.size());
+        std::shared_ptr<void> qual_mem = huge_alloc(static_cast<size_t>(offs[size_t(n)]) + 1);
+        uint8_t* const qual = static_cast<uint8_t*>(qual_mem.get());
+        {
+            const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> th;
+            for (unsigned t0 = 0; t0 < nt; ++t0)
+                th.emplace_back([&, t0] {
+                    for (int i = int(t0); i < n; i += int(nt)) memcpy(qual + offs[size_t(i)], reads[size_t(i)].qual.data(), reads[size_t(i)].qual.size());
+                });
+            for (auto& x : th) x.join();
+        }
         std::vector<double> score(static_cast<size_t>(n)), err(static_cast<size_t>(n));
-        check(c, ioc_qual_scores(c, n, offs.data(), qual.data(), a.KmerSize, score.data(), err.data()), "quality scores");
+        check(c, ioc_qual_scores(c, n, offs.data(), qual, a.KmerSize, score.data(), err.data()), "quality scores");
         for (int i = 0; i < n; ++i) {
             reads[size_t(i)].score = score[size_t(i)];
             reads[size_t(i)].errorRate = err[size_t(i)];
         }
     }
+    lap("quality scores (GPU)");
     std::stable_sort(reads.begin(), reads.end(), [](const Seq& x, const Seq& y) { return x.score > y.score; });
+    lap("stable sort");
 
     const string batch_dir = a.BatchOutFolder + "/batches";
     create_outdir(a.BatchOutFolder);
     create_outdir(batch_dir);
     {
-        std::ofstream fq, tsv, sc;
+        std::ofstream tsv, sc;
         const string sorted = a.BatchOutFolder + "/sorted_reads.fastq";
-        create_file(sorted, fq);
+        GatherFile fq;  // (the bases and qualities go from the input's mapping to the page cache in one gather per 1024 pieces)
+        if (!fq.open(sorted)) die("Failed to open " + sorted + "!");
         create_file(a.BatchOutFolder + "/sorted_reads_idx.tsv", tsv);
         tsv << "Id\tPos" << endl;
         unsigned long long seek = 0;
         for (auto& r : reads) {
             if (r.score < 0) continue;
             tsv << r.name << "\t" << seek << "\n";  // (the same bytes as endl, without a write() per read)
-            fq << "@" << r.name << "\n" << r.seq << "\n+\n" << r.qual << "\n";
+            fq.put("@", 1);
+            fq.put(r.name.data(), r.name.size());
+            fq.put("\n", 1);
+            fq.put(r.seq.data(), r.seq.size());
+            fq.put("\n+\n", 3);
+            fq.put(r.qual.data(), r.qual.size());
+            fq.put("\n", 1);
             seek += r.name.size() + r.seq.size() + r.qual.size() + 6;
         }
+        if (!fq.close()) die("Failed to write " + sorted + "!");
         save_sorted_idx(sorted, a.BatchOutFolder + "/sorted_reads_idx.cer");
         create_file(a.BatchOutFolder + "/scores.tsv", sc);
         for (auto& r : reads) sc << r.name << "\t" << r.score << "\n";
     }
 
+    lap("sorted fastq, index, scores written");
     // ---- batches (main.cpp:149-199) ----
     // The batches are independent once the reads are sorted: the extraction of a batch runs on the one context (a mutex around
     // the three calls), the assembly of its records and its file are built by worker threads side by side (IOC_SORT_THREADS,
     // default 6: the 64 batches of a 2 M-read file took 29 s one after the other).
     std::mutex ctx_mu, log_mu;
+    std::atomic<long long> us_dev{0}, us_asm{0}, us_save{0};  // (IOC_TRACE: summed over the batches' threads)
+    auto us_now = [] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto write_batch = [&](int start, int end, unsigned long bases, int nr) {
-        std::unique_lock<std::mutex> dev(ctx_mu);
+        // (every large buffer of a batch comes in huge pages — 0.9 GB of first touches per 31 250-read batch otherwise, six threads at
+        // once — and the records are views of them: nothing is copied per read, cer.hpp)
         const int m = end - start + 1;
         std::vector<int64_t> bo(static_cast<size_t>(m) + 1, 0);
         for (int i = 0; i < m; ++i) bo[size_t(i) + 1] = bo[size_t(i)] + int64_t(reads[size_t(start + i)].seq.size());
-        std::vector<uint8_t> seq(static_cast<size_t>(bo[size_t(m)])), qual(static_cast<size_t>(bo[size_t(m)]));
+        const size_t nb = static_cast<size_t>(bo[size_t(m)]);
+        std::shared_ptr<void> seq_mem = huge_alloc(nb + 1), qual_mem = huge_alloc(nb + 1);
+        uint8_t* const seq = static_cast<uint8_t*>(seq_mem.get());
+        uint8_t* const qual = static_cast<uint8_t*>(qual_mem.get());
         for (int i = 0; i < m; ++i) {
-            memcpy(seq.data() + bo[size_t(i)], reads[size_t(start + i)].seq.data(), reads[size_t(start + i)].seq.size());
-            memcpy(qual.data() + bo[size_t(i)], reads[size_t(start + i)].qual.data(), reads[size_t(start + i)].qual.size());
+            memcpy(seq + bo[size_t(i)], reads[size_t(start + i)].seq.data(), reads[size_t(start + i)].seq.size());
+            memcpy(qual + bo[size_t(i)], reads[size_t(start + i)].qual.data(), reads[size_t(start + i)].qual.size());
         }
         std::vector<uint32_t> hlen(static_cast<size_t>(m));
         std::vector<double> herr(static_cast<size_t>(m));
         std::vector<int64_t> of(static_cast<size_t>(m) + 1), orv(static_cast<size_t>(m) + 1);
         std::vector<int32_t> status(static_cast<size_t>(m));
-        check(c, ioc_extract_minimizers(c, m, bo.data(), seq.data(), qual.data(), a.KmerSize, a.WindowSize, hlen.data(),
+        std::shared_ptr<void> hs_mem = huge_alloc(nb + 1), hq_mem = huge_alloc(nb + 1);
+        char* const hs = static_cast<char*>(hs_mem.get());
+        char* const hq = static_cast<char*>(hq_mem.get());
+        std::unique_lock<std::mutex> dev(ctx_mu);  // ---- the one context: extraction and its downloads, one batch at a time ----
+        const long long t_dev = us_now();
+        check(c, ioc_extract_minimizers(c, m, bo.data(), seq, qual, a.KmerSize, a.WindowSize, hlen.data(),
                                         herr.data(), of.data(), orv.data(), status.data()), "minimizer extraction");
         const int64_t tot = orv[size_t(m)];
-        std::vector<uint32_t> mv(static_cast<size_t>(tot) + 1), mp(static_cast<size_t>(tot) + 1);
-        check(c, ioc_extracted_download(c, mv.data(), mp.data(), tot + 1), "minimizer download");
-        std::vector<char> hs(static_cast<size_t>(bo[size_t(m)]) + 1), hq(static_cast<size_t>(bo[size_t(m)]) + 1);
-        check(c, ioc_extracted_hpc_download(c, hs.data(), hq.data(), int64_t(hs.size())), "hpc download");
+        std::shared_ptr<void> mv_mem = huge_alloc((static_cast<size_t>(tot) + 1) * 4), mp_mem = huge_alloc((static_cast<size_t>(tot) + 1) * 4);
+        uint32_t* const mv = static_cast<uint32_t*>(mv_mem.get());
+        uint32_t* const mp = static_cast<uint32_t*>(mp_mem.get());
+        check(c, ioc_extracted_download(c, mv, mp, tot + 1), "minimizer download");
+        check(c, ioc_extracted_hpc_download(c, hs, hq, int64_t(nb + 1)), "hpc download");
         dev.unlock();
+        const long long t_asm = us_now();
+        us_dev += t_asm - t_dev;
+        seq_mem.reset();
+        qual_mem.reset();
+        // the minimizers as the records hold them (Min, Pos, Index): one array for the batch
+        std::shared_ptr<void> aos_mem = huge_alloc((static_cast<size_t>(tot) + 1) * sizeof(Minimizer));
+        Minimizer* const aos = static_cast<Minimizer*>(aos_mem.get());
         Batch b;
         b.Cls.resize(size_t(m));
         for (int i = 0; i < m; ++i) {
@@ -291,14 +358,13 @@ static int main_sort(int argc, char** argv)
                 ps->RawSeq.reset(new Seq(r));
                 ps->HpcSeq.reset(new Seq);
                 ps->HpcSeq->name = r.name;
-                ps->HpcSeq->seq.assign(hs.data() + bo[size_t(i)], hlen[size_t(i)]);
-                ps->HpcSeq->qual.assign(hq.data() + bo[size_t(i)], hlen[size_t(i)]);
+                ps->HpcSeq->seq = Bytes(hs + bo[size_t(i)], hlen[size_t(i)], hs_mem);
+                ps->HpcSeq->qual = Bytes(hq + bo[size_t(i)], hlen[size_t(i)], hq_mem);
                 ps->HpcSeq->score = r.score;
                 ps->HpcSeq->errorRate = herr[size_t(i)];
                 auto fill = [&](Span<Minimizer>& out, int64_t b0, int64_t e0) {
-                    std::vector<Minimizer> dst(size_t(e0 - b0));
-                    for (int64_t t = b0; t < e0; ++t) dst[size_t(t - b0)] = Minimizer{mv[size_t(t)], mp[size_t(t)], uint32_t(t - b0)};
-                    out = std::move(dst);
+                    for (int64_t t = b0; t < e0; ++t) aos[size_t(t)] = Minimizer{mv[size_t(t)], mp[size_t(t)], uint32_t(t - b0)};
+                    out = Span<Minimizer>(aos + b0, size_t(e0 - b0), aos_mem);
                 };
                 fill(ps->Mins, of[size_t(i)], of[size_t(i) + 1]);
                 fill(ps->RevMins, orv[size_t(i)], orv[size_t(i) + 1]);
@@ -315,7 +381,10 @@ static int main_sort(int argc, char** argv)
         b.BatchBases = bases;
         b.SortArgs = a;
         string err;
+        const long long t_save = us_now();
+        us_asm += t_save - t_asm;
         if (!save_batch(b, batch_dir + "/isONbatch_" + std::to_string(nr) + ".cer", err)) die(err);
+        us_save += us_now() - t_save;
         if (VERBOSE) {
             std::lock_guard<std::mutex> lk(log_mu);
             cerr << "\tWritten batch " << nr << " with " << m << " sequences and " << int(double(bases) / 1000.0) << " kilobases." << endl;
@@ -357,6 +426,10 @@ static int main_sort(int argc, char** argv)
             for (auto& t : th) t.join();
         }
     }
+    lap("batches extracted and written");
+    if (trace)
+        fprintf(stderr, "[ioc] sort:   of it, summed over the batches: device section (one at a time) %.1f ms, record assembly %.1f ms, file %.1f ms\n", us_dev.load() / 1e3,
+                us_asm.load() / 1e3, us_save.load() / 1e3);
     ioc_ctx_destroy(c);
     return 0;
 }
@@ -930,28 +1003,92 @@ static int main_dump(int argc, char** argv)
                  << " size=" << b.Cls[i]->size() - 1 << "\n" << seq << "\n+\n" << rep->RawSeq->qual << "\n";
         }
     }
-    std::ifstream fq(fastq);
-    if (!fq.is_open()) die("Failed to open " + fastq + "!");
+    // The sorted FASTQ is read out of a mapping; a read that keeps its strand goes into its cluster's file as the four lines it
+    // is in the mapping (one piece of a gather), a read of the other strand as a reverse-complemented copy; the cluster files
+    // are written side by side by a few threads.  (src/output.cpp:225-275 reads and writes record by record; the per-cluster
+    // strings of round 4 held the whole 8 GB of configs[4] in anonymous memory.)
+    MappedFile fqmap;
+    {
+        string merr;
+        if (!map_file(fastq, fqmap, merr)) die("Failed to open " + fastq + "!");
+    }
     std::ofstream tsv;
     create_file(outdir + "/clusters.tsv", tsv);
     tsv << "ClusterId\tStrand\tRead" << endl;
-    std::unordered_map<unsigned, string> per_cluster;
-    string h, s, p, q;
-    while (std::getline(fq, h) && std::getline(fq, s) && std::getline(fq, p) && std::getline(fq, q)) {
-        const string id = h.substr(1);
-        auto it = id2cls.find(id);
-        if (it == id2cls.end()) continue;
-        if (it->second.strand == -1) {
-            s = revcomp(s);
-            std::reverse(q.begin(), q.end());
+    struct Piece {
+        const char* p;  // the record in the mapping (strand +), or nullptr: `own`
+        size_t n;
+        string own;
+    };
+    std::unordered_map<unsigned, std::vector<Piece>> per_cluster;
+    {
+        const char* p = fqmap.data;
+        const char* const e = fqmap.data + fqmap.size;
+        auto line = [&](const char*& b0, const char*& l0) {
+            if (p >= e) return false;
+            const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(e - p)));
+            b0 = p;
+            l0 = nl ? nl : e;
+            p = nl ? nl + 1 : e;
+            return true;
+        };
+        const char *hb, *he, *sb, *se, *pb, *pe, *qb, *qe;
+        while (line(hb, he) && line(sb, se) && line(pb, pe) && line(qb, qe)) {
+            if (he == hb) continue;  // (std::string::substr(1) of an empty header throws in the reference's reader; nothing to keep here)
+            const string id(hb + 1, size_t(he - hb - 1));
+            auto it = id2cls.find(id);
+            if (it == id2cls.end()) continue;
+            tsv << it->second.cls << "\t" << it->second.strand << "\t" << id << "\n";
+            auto& dst = per_cluster[it->second.cls];
+            if (it->second.strand == -1 || p != qe + 1) {  // (the other strand, or a last record without its newline: a copy)
+                string rec;
+                rec.reserve(size_t(qe - hb) + 2);
+                rec.append(hb, size_t(he - hb));
+                rec += '\n';
+                if (it->second.strand == -1) {
+                    rec += revcomp(string(sb, size_t(se - sb)));
+                    rec += '\n';
+                    rec.append(pb, size_t(pe - pb));
+                    rec += '\n';
+                    rec.append(std::reverse_iterator<const char*>(qe), std::reverse_iterator<const char*>(qb));
+                } else {
+                    rec.append(sb, size_t(se - sb));
+                    rec += '\n';
+                    rec.append(pb, size_t(pe - pb));
+                    rec += '\n';
+                    rec.append(qb, size_t(qe - qb));
+                }
+                rec += '\n';
+                dst.push_back(Piece{nullptr, 0, std::move(rec)});
+            } else {
+                dst.push_back(Piece{hb, size_t(qe + 1 - hb), string()});
+            }
         }
-        tsv << it->second.cls << "\t" << it->second.strand << "\t" << id << "\n";
-        per_cluster[it->second.cls] += h + "\n" + s + "\n" + p + "\n" + q + "\n";
     }
-    for (auto& kv : per_cluster) {
-        std::ofstream f;
-        create_file(outdir + "/cluster_fastq/" + std::to_string(kv.first) + ".fq", f);
-        f << kv.second;
+    {
+        std::vector<const std::pair<const unsigned, std::vector<Piece>>*> jobs;
+        for (auto& kv : per_cluster) jobs.push_back(&kv);
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t0 = 0; t0 < nt; ++t0)
+            th.emplace_back([&] {
+                for (size_t x = next.fetch_add(1); x < jobs.size(); x = next.fetch_add(1)) {
+                    GatherFile f;
+                    if (!f.open(outdir + "/cluster_fastq/" + std::to_string(jobs[x]->first) + ".fq")) {
+                        failed = 1;
+                        continue;
+                    }
+                    for (auto& pc : jobs[x]->second) {
+                        if (pc.p) f.put(pc.p, pc.n);
+                        else f.put(pc.own.data(), pc.own.size());
+                    }
+                    if (!f.close()) failed = 1;
+                }
+            });
+        for (auto& x : th) x.join();
+        if (failed) die("Failed to write the cluster FASTQ files!");
     }
     if (VERBOSE) cerr << "Dump complete." << endl;
     return 0;

@@ -165,6 +165,25 @@ def test_sort_cluster_merge_dump_matches_oracle(tmp_path, mode):
     assert names == [f"r{i}" for i, s in zip(order, score) if s >= 0]
     info = open(tmp_path / "dump" / "clusters_info.tsv").read().splitlines()
     assert len(info) - 1 == A.n_clusters()
+    # cluster_fastq/<id>.fq: every read of the cluster once, in the order of the sorted FASTQ, on the cluster's strand
+    # (src/output.cpp:225-275: sequence reverse-complemented and qualities reversed for MatchStrand -1)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    pos = {nm: k for k, nm in enumerate(names)}
+    seen = 0
+    for c_id in set(c for c, _ in got.values()):
+        lines = open(tmp_path / "dump" / "cluster_fastq" / f"{c_id}.fq", "rb").read().split(b"\n")
+        assert lines[-1] == b"" and (len(lines) - 1) % 4 == 0
+        recs = [lines[k:k + 4] for k in range(0, len(lines) - 1, 4)]
+        ids = [int(r[0][2:]) for r in recs]
+        assert sorted(ids) == sorted(i for i, (c, _) in got.items() if c == c_id)
+        assert [pos[f"r{i}"] for i in ids] == sorted(pos[f"r{i}"] for i in ids)
+        for r, i in zip(recs, ids):
+            sq, ql = rs.read(i)
+            if got[i][1] == -1:
+                sq, ql = sq.translate(comp)[::-1], ql[::-1]
+            assert r[1] == sq and r[3] == ql and r[2] == b"+"
+            seen += 1
+    assert seen == len(got)
 
 
 @pytest.mark.gpu
