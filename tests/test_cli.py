@@ -89,6 +89,24 @@ def test_served_cluster_reports_like_the_one_shot_command(tmp_path):
     shutil.rmtree(srv, ignore_errors=True)
 
 
+def test_dump_reads_the_fastq_out_of_a_mapping(tmp_path):
+    """`dump` without a GPU: the golden batch (one cluster whose record carries the read id "i"), a hand-written sorted_reads_idx.cer
+    and a FASTQ with that read, another one, a record of the other kind of line ending at the end: the cluster's file holds the
+    read's four lines (src/output.cpp:225-275).  Runs under the sanitizer pass too (mapping + gather writer)."""
+    import struct
+    g = tmp_path / "g.cer"
+    assert run("golden", str(g)).returncode == 0
+    fq = tmp_path / "sorted_reads.fastq"
+    fq.write_bytes(b"@other\nACGT\n+\nIIII\n@i\nGATTACA\n+\nABCDEFG\n@last\nAC\n+\nII")
+    idx = tmp_path / "sorted_reads_idx.cer"
+    idx.write_bytes(struct.pack("<Q", len(str(fq))) + str(fq).encode())
+    r = run("dump", "-i", str(idx), "-o", str(tmp_path / "dump"), str(g))
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "dump" / "cluster_fastq" / "0.fq").read_bytes() == b"@i\nGATTACA\n+\nABCDEFG\n"
+    assert (tmp_path / "dump" / "clusters.tsv").read_text().splitlines() == ["ClusterId\tStrand\tRead", "0\t1\ti"]
+    assert "@cluster_0 origin=n:1 length=2 size=0" in (tmp_path / "dump" / "cluster_cons.fq").read_text()
+
+
 def test_idle_worker_leaves_by_itself(tmp_path):
     """A worker without a job for ISONCLUST2_SERVE_IDLE_S seconds ends and takes its socket with it (no GPU needed: the job
     fails at the context, the worker is up all the same)."""
