@@ -1015,10 +1015,10 @@ static int main_dump(int argc, char** argv)
     std::ofstream tsv;
     create_file(outdir + "/clusters.tsv", tsv);
     tsv << "ClusterId\tStrand\tRead" << endl;
-    struct Piece {
-        const char* p;  // the record in the mapping (strand +), or nullptr: `own`
-        size_t n;
-        string own;
+    struct Piece {  // a read's four lines in the mapping
+        const char *hb, *sb, *pb, *qb, *qe;  // header, sequence, separator, qualities; he = sb - 1, se = pb - 1, pe = qb - 1
+        bool flip;      // MatchStrand -1: sequence reverse-complemented, qualities reversed
+        bool whole;     // the record ends with its newline: it can go out as it lies
     };
     std::unordered_map<unsigned, std::vector<Piece>> per_cluster;
     {
@@ -1039,30 +1039,7 @@ static int main_dump(int argc, char** argv)
             auto it = id2cls.find(id);
             if (it == id2cls.end()) continue;
             tsv << it->second.cls << "\t" << it->second.strand << "\t" << id << "\n";
-            auto& dst = per_cluster[it->second.cls];
-            if (it->second.strand == -1 || p != qe + 1) {  // (the other strand, or a last record without its newline: a copy)
-                string rec;
-                rec.reserve(size_t(qe - hb) + 2);
-                rec.append(hb, size_t(he - hb));
-                rec += '\n';
-                if (it->second.strand == -1) {
-                    rec += revcomp(string(sb, size_t(se - sb)));
-                    rec += '\n';
-                    rec.append(pb, size_t(pe - pb));
-                    rec += '\n';
-                    rec.append(std::reverse_iterator<const char*>(qe), std::reverse_iterator<const char*>(qb));
-                } else {
-                    rec.append(sb, size_t(se - sb));
-                    rec += '\n';
-                    rec.append(pb, size_t(pe - pb));
-                    rec += '\n';
-                    rec.append(qb, size_t(qe - qb));
-                }
-                rec += '\n';
-                dst.push_back(Piece{nullptr, 0, std::move(rec)});
-            } else {
-                dst.push_back(Piece{hb, size_t(qe + 1 - hb), string()});
-            }
+            per_cluster[it->second.cls].push_back(Piece{hb, sb, pb, qb, qe, it->second.strand == -1, p == qe + 1});
         }
     }
     {
@@ -1074,15 +1051,39 @@ static int main_dump(int argc, char** argv)
         std::vector<std::thread> th;
         for (unsigned t0 = 0; t0 < nt; ++t0)
             th.emplace_back([&] {
+                char comp[256];
+                for (int x = 0; x < 256; ++x) comp[x] = char(x);
+                comp[int('A')] = 'T', comp[int('C')] = 'G', comp[int('G')] = 'C', comp[int('T')] = 'A';
+                string stage;  // the flipped records of ONE cluster (and a last record without its newline), built by this thread
                 for (size_t x = next.fetch_add(1); x < jobs.size(); x = next.fetch_add(1)) {
                     GatherFile f;
                     if (!f.open(outdir + "/cluster_fastq/" + std::to_string(jobs[x]->first) + ".fq")) {
                         failed = 1;
                         continue;
                     }
+                    size_t need = 0;
+                    for (auto& pc : jobs[x]->second)
+                        if (pc.flip || !pc.whole) need += size_t(pc.qe - pc.hb) + 2;
+                    stage.clear();
+                    stage.reserve(need);  // (the gather points into it: it must not move before close())
                     for (auto& pc : jobs[x]->second) {
-                        if (pc.p) f.put(pc.p, pc.n);
-                        else f.put(pc.own.data(), pc.own.size());
+                        if (!pc.flip && pc.whole) {
+                            f.put(pc.hb, size_t(pc.qe + 1 - pc.hb));
+                            continue;
+                        }
+                        const size_t at = stage.size();
+                        stage.append(pc.hb, size_t(pc.sb - pc.hb));            // header line with its newline
+                        const char* se = pc.pb - 1;
+                        if (pc.flip) {
+                            for (const char* c = se; c != pc.sb;) stage += comp[(unsigned char)*--c];
+                            stage += '\n';
+                            stage.append(pc.pb, size_t(pc.qb - pc.pb));        // separator line with its newline
+                            stage.append(std::reverse_iterator<const char*>(pc.qe), std::reverse_iterator<const char*>(pc.qb));
+                        } else {
+                            stage.append(pc.sb, size_t(pc.qe - pc.sb));
+                        }
+                        stage += '\n';
+                        f.put(stage.data() + at, stage.size() - at);
                     }
                     if (!f.close()) failed = 1;
                 }
