@@ -397,3 +397,34 @@ def test_a_200_kb_read_goes_through_sort_and_cluster(tmp_path):
         assert m.setdefault(int(ocl[i]), got[int(i)][0]) == got[int(i)][0]
     assert len(set(m.values())) == len(m)
     assert got[rs.n - 1][0] == got[rs.n - 2][0]      # (the two reads of the 200 kb transcript share a cluster)
+
+
+@pytest.mark.gpu
+def test_sort_reads_fastq_like_getline(tmp_path):
+    """`sort` parses its FASTQ out of a mapping: the rules are those of the line reader it replaced (src/main.cpp:109-112 reads with
+    bioparser; this build always took '@name rest' / sequence / '+...' / qualities, blank lines between records skipped) — a last
+    record without its newline, blank lines, descriptions behind the name all give the files of the plain input; a record whose
+    qualities and bases differ in length, or that ends early, stops the command with a message."""
+    import filecmp
+    rs = synth.generate(60, 6, 500, 10, 21, seed=91)
+    # (a batch file records the input's and the output folder's names as given: the same relative names in two directories)
+    for d in ("a", "b"):
+        os.mkdir(tmp_path / d)
+    plain, odd = tmp_path / "a" / "reads.fq", tmp_path / "b" / "reads.fq"
+    _write_fastq(rs, plain)
+    with open(odd, "wb") as f:
+        for i in range(rs.n):
+            s, q = rs.read(i)
+            f.write((b"\n\n" if i % 7 == 3 else b"") + b"@r%d\tanother description\n" % i + s + b"\n+r%d\n" % i + q + (b"\n" if i + 1 < rs.n else b""))
+    for d in ("a", "b"):
+        r = subprocess.run([CLI, "sort", "-B", "1000000", "-M", "1000", "-o", "sorted", "reads.fq"], capture_output=True, text=True, cwd=str(tmp_path / d))
+        assert r.returncode == 0, r.stderr
+    for name in ("sorted_reads.fastq", "sorted_reads_idx.tsv", "scores.tsv", "batches/isONbatch_0.cer"):
+        assert filecmp.cmp(tmp_path / "a" / "sorted" / name, tmp_path / "b" / "sorted" / name, shallow=False), name
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@x\nACGTACGTACGTACGTACGTACGTAC\n+\nIIII\n")
+    r = run("sort", "-o", str(tmp_path / "s2"), str(bad))
+    assert r.returncode == 1 and "Malformed fastq record: @x" in r.stderr
+    bad.write_bytes(b"@x\nACGT\n+\n")
+    r = run("sort", "-o", str(tmp_path / "s3"), str(bad))
+    assert r.returncode == 1 and "Truncated fastq record: @x" in r.stderr
