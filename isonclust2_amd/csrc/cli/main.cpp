@@ -947,7 +947,16 @@ static int main_dump(int argc, char** argv)
     if (index.empty()) die("Specifying the sorted read index is mandatory!");
     Batch b;
     string err, fastq;
+    const bool trace = getenv("IOC_TRACE") != nullptr;
+    auto t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ioc] dump: %-44s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_lap).count());
+        t_lap = t1;
+    };
     if (!load_batch(b, argv[optind], err)) die(err);
+    lap("batch loaded");
     if (!load_sorted_idx(fastq, index)) die("Failed to load index " + index);
     create_outdir(outdir);
     b.Db.clear();
@@ -1007,11 +1016,13 @@ static int main_dump(int argc, char** argv)
     // is in the mapping (one piece of a gather), a read of the other strand as a reverse-complemented copy; the cluster files
     // are written side by side by a few threads.  (src/output.cpp:225-275 reads and writes record by record; the per-cluster
     // strings of round 4 held the whole 8 GB of configs[4] in anonymous memory.)
+    lap("read ids, info files, consensus fastq");
     MappedFile fqmap;
     {
         string merr;
         if (!map_file(fastq, fqmap, merr)) die("Failed to open " + fastq + "!");
     }
+    lap("sorted fastq mapped");
     std::ofstream tsv;
     create_file(outdir + "/clusters.tsv", tsv);
     tsv << "ClusterId\tStrand\tRead" << endl;
@@ -1042,6 +1053,7 @@ static int main_dump(int argc, char** argv)
             per_cluster[it->second.cls].push_back(Piece{hb, sb, pb, qb, qe, it->second.strand == -1, p == qe + 1});
         }
     }
+    lap("sorted fastq walked, clusters.tsv");
     {
         std::vector<const std::pair<const unsigned, std::vector<Piece>>*> jobs;
         for (auto& kv : per_cluster) jobs.push_back(&kv);
@@ -1091,6 +1103,7 @@ static int main_dump(int argc, char** argv)
         for (auto& x : th) x.join();
         if (failed) die("Failed to write the cluster FASTQ files!");
     }
+    lap("cluster fastq files written");
     if (VERBOSE) cerr << "Dump complete." << endl;
     return 0;
 }
