@@ -250,7 +250,7 @@ def test_scale_command_path(mode):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
-                        "--no-cpu-baseline", "--no-cli", "--no-core", "--mode", mode], capture_output=True, text=True, timeout=900, cwd=root)
+                        "--no-cpu-baseline", "--no-cli", "--no-core", "--strict", "--mode", mode], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
